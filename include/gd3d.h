@@ -1,0 +1,140 @@
+/*
+ * gd3d.h — C ABI of libgd3d.so: the MI355X (gfx950) hot path of mmdet3d-gaussian.
+ *
+ * Drop-in boundary.  The reference has NO native entry point on
+ * this path: the losses are ~110-145 ATen ops per call in
+ *   /root/reference/mmdet3d_gaussian/models/losses/gaussian_distance_loss.py:8-310
+ * and the NMS is the third-party mmdet3d `iou3d_cuda.nms_gpu` pybind call reached from
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_centerpoint_head.py:9,340-345
+ *   /root/reference/mmdet3d_gaussian/models/roi_heads/bbox_heads/pvrcnn_bbox_head.py:12,463-464
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types; every pointer is DEVICE memory of the
+ *     current HIP device unless the name says `_host`;
+ *   - the caller allocates everything, including the workspace (size from the
+ *     *_workspace_bytes query); the library keeps no global state and frees nothing;
+ *   - every call is asynchronous and stream-ordered on `stream` (a hipStream_t passed
+ *     as void*; NULL = the null stream); no hipDeviceSynchronize / hipMalloc inside,
+ *     so calls may be captured in a hipGraph;
+ *   - return value: 0 on success, otherwise a hipError_t value or one of the
+ *     GD3D_E_* codes below; nothing throws, nothing calls exit().
+ *   - float arrays must be 4-byte aligned; 16-byte aligned (N,7) arrays take the fast
+ *     LDS-DMA path, others a slower scalar path with identical results.
+ */
+#ifndef GD3D_H_
+#define GD3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD3D_ABI_VERSION 1
+
+/* error codes outside the hipError_t range */
+#define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
+#define GD3D_E_TOOLARGE 10002 /* n exceeds what the launch geometry supports */
+
+/* loss_type: keys of GDLoss.BAG_GD_LOSS (gaussian_distance_loss.py:253-259) */
+enum {
+  GD3D_GWD3D = 0,        /* gwd3d_loss        :42-106  */
+  GD3D_KLD3D = 1,        /* kld3d_loss        :109-141 */
+  GD3D_BD3D = 2,         /* bd3d_loss         :144-186 */
+  GD3D_JD3D = 3,         /* jd3d_loss         :189-198 */
+  GD3D_KLD3D_SYMMAX = 4, /* kld3d_symmax_loss :201-211 */
+  GD3D_KLD3D_SYMMIN = 5, /* kld3d_symmin_loss :214-224 */
+  GD3D_KFIOU3D = 6,      /* kfiou3d_loss      :227-248 */
+  GD3D_NUM_LOSS_TYPES = 7
+};
+
+/* fun: postprocess non-linearity (gaussian_distance_loss.py:24-39) */
+enum { GD3D_FUN_NONE = 0, GD3D_FUN_LOG1P = 1, GD3D_FUN_EXPM1 = 2, GD3D_FUN_NLOG = 3 };
+
+/* GDLoss hyper-parameters that reach the arithmetic (gaussian_distance_loss.py:261-278). */
+typedef struct gd3d_params {
+  int32_t loss_type;      /* GD3D_* above */
+  int32_t fun;            /* GD3D_FUN_* */
+  float tau;              /* tau >= 1 -> 1 - tau/(tau+d); else identity (:36-39) */
+  float alpha;            /* xyz vs whlr balance */
+  float center_offset[3]; /* gravity-centre offset, default (0,0,0.5) (:12) */
+  int32_t flag;           /* gwd3d: `normalize`; all others: `sqrt` (kwargs at :42,:109,...) */
+} gd3d_params;
+
+/* ------------------------------------------------------------------------------------
+ * Gaussian-distance loss, fused forward + gradient.
+ * Replaces: preprocess x2 + one BAG_GD_LOSS function + postprocess + mmdet
+ * weight_reduce_loss + `* loss_weight`, and the autograd backward of all of it
+ * (gaussian_distance_loss.py:8-39, :42-248, :280-310).
+ *
+ * For pair i (rows pred[i,:], target[i,:] = (x,y,z,w,h,l,r), fp32, row-major, stride 7):
+ *     L_i            = BAG_GD_LOSS[loss_type](preprocess(pred_i), preprocess(target_i))
+ *     loss[i]        = scale * w_i * L_i                       (if loss != NULL)
+ *     *loss_sum      = scale * sum_i w_i * L_i                 (if loss_sum != NULL; fp32,
+ *                      deterministic: fixed-order two-stage reduction, no float atomics)
+ *     grad_pred[i,:] = scale * w_i * dL_i/dpred_i              (if grad_pred != NULL)
+ *     grad_target[i,:] = scale * w_i * dL_i/dtarget_i          (if grad_target != NULL)
+ * with w_i = row_weight[i] (1 if row_weight == NULL).  `scale` carries
+ * loss_weight / (avg_factor | N | 1) so that the kernel writes final gradients.
+ * n == 0 is legal (loss_sum = 0).  workspace: gd3d_loss_workspace_bytes(n) bytes,
+ * 16-byte aligned, needed only when loss_sum != NULL.
+ * ---------------------------------------------------------------------------------- */
+size_t gd3d_loss_workspace_bytes(int64_t n);
+
+int gd3d_loss_fused(const gd3d_params* params, const float* pred, const float* target,
+                    const float* row_weight, int64_t n, float scale, float* loss,
+                    float* loss_sum, float* grad_pred, float* grad_target, void* workspace,
+                    void* stream);
+
+/* In-place row scaling used by autograd backward when the upstream gradient is not 1:
+ *   grad[i,:] *= (per_row ? g[i] : g[0]),  grad is (n,7) fp32, g is DEVICE memory.
+ * With per_row == 0 the kernel reads g[0] first and exits without touching grad when it is
+ * exactly 1.0f, so the common `loss.backward()` costs one empty launch and no HBM traffic
+ * and no host sync.  (Replaces the autograd mul nodes of `* self.loss_weight`, :310.) */
+int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Rotated BEV NMS.  Replaces mmdet3d `iou3d_cuda.nms_gpu(boxes, keep, thresh, device)`
+ * behind `nms_gpu(boxes, scores, thresh, pre_max_size, post_max_size)`
+ * (call sites gd_centerpoint_head.py:340-345, pvrcnn_bbox_head.py:463-464).
+ *   boxes_sorted : (n,5) fp32 [x1,y1,x2,y2,ry], ALREADY sorted by descending score
+ *   keep         : (n) int64, receives indices into boxes_sorted, ascending
+ *   num_keep     : (1) int64
+ * Greedy: box i is kept iff no kept j < i has IoU_bev(j,i) > thresh.  The suppression
+ * bit-mask (n x ceil(n/64) uint64) and the greedy scan both stay on the device.
+ * rnms_normal_bev: same with axis-aligned IoU (mmdet3d nms_normal_gpu; angle ignored).
+ * ---------------------------------------------------------------------------------- */
+size_t rnms_workspace_bytes(int64_t n);
+
+int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
+             int64_t* num_keep, void* workspace, void* stream);
+
+int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
+                    int64_t* num_keep, void* workspace, void* stream);
+
+/* Pairwise rotated BEV IoU in the NMS box format (mmdet3d `boxes_iou_bev`):
+ *   a (na,5), b (nb,5) [x1,y1,x2,y2,ry] -> iou (na,nb) fp32 row-major. */
+int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou,
+                   void* stream);
+
+/* Pairwise rotated IoU of 7-dof boxes (x,y,z,w,h,l,yaw), the reference's CPU eval helpers
+ *   /root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:8-49  (iou_3d, z_offset)
+ *   /root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:51-81 (iou_bev)
+ * built on rotated_boxes_intersection (ops/eval/rbox_utils.hpp:280-302).
+ *   det (nd,7), gt (ng,7) -> iou (nd,ng) fp32 row-major. */
+int riou_eval_bev(const float* det, int64_t nd, const float* gt, int64_t ng, float* iou,
+                  void* stream);
+
+int riou_eval_3d(const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset,
+                 float* iou, void* stream);
+
+/* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
+ * string naming the code-object target, e.g. "gfx950". */
+int gd3d_abi_version(const char** arch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GD3D_H_ */

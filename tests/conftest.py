@@ -1,0 +1,22 @@
+"""pytest configuration: `gpu` marker + repo root on sys.path.
+
+`-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI symbol check, gloo world_size-2.
+`-m gpu`      : parity tests proper — HIP path through the C ABI vs the oracle / golden vectors.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return os.path.join(ROOT, 'tests', 'golden')

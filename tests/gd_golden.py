@@ -1,0 +1,97 @@
+"""Shared access to the golden vectors generated from the real reference
+(tests/golden/make_golden_gd.py) and the tolerance policy used against them."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+_index = None
+_pairs = None
+_module = None
+
+
+def index():
+    global _index
+    if _index is None:
+        with open(os.path.join(GOLD, 'gd_index.json')) as f:
+            _index = json.load(f)
+    return _index
+
+
+def pairs():
+    global _pairs
+    if _pairs is None:
+        _pairs = dict(np.load(os.path.join(GOLD, 'gd_pairs.npz')))
+    return _pairs
+
+
+def module():
+    global _module
+    if _module is None:
+        _module = dict(np.load(os.path.join(GOLD, 'gd_module.npz')))
+    return _module
+
+
+def pair_case_names():
+    return sorted(index()['pairs']['cases'])
+
+
+def families(with_ident=True):
+    f = list(index()['pairs']['families'])
+    return f if with_ident else [x for x in f if x != 'ident']
+
+
+# ---------------------------------------------------------------- tolerance policy
+# north_star: "outputs match the reference within 1e-5 fp32".  The reference's own fp32
+# result differs from its fp64 result by up to ~2e-4 (loss) / O(0.1) (grad) on near-identical
+# boxes (catastrophic cancellation in whlr_distance, then sqrt), so a fixed 1e-5
+# is only meaningful where the reference itself is that accurate.  Policy, per element i of one
+# (case, input family):
+#     |ours_i - ref64_i| <= (TOL + YARD * max_j relerr_ref32_j) * (1 + scale_i)
+# with scale_i = |ref64_i| for losses and the row's max |grad| for gradients, and
+# relerr_ref32_j = |ref32_j - ref64_j| / (1 + scale_j) the reference's OWN fp32 error on that
+# family.  I.e. 1e-5 relative wherever the reference's fp32 is trustworthy (kitti / large / delta
+# families: max relerr_ref32 ~1e-6), and never asked to be more than YARD x closer to the truth
+# than the reference's own worst fp32 evaluation on the same inputs (near-identical family).
+LOSS_TOL = 1e-5
+GRAD_TOL = 1e-5
+YARD = 3.0
+
+
+def _scale(ref64, rowwise):
+    a = np.where(np.isfinite(ref64), np.abs(ref64), 0)
+    return a.max(axis=-1, keepdims=True) if rowwise else a
+
+
+def _bound(ref64, ref32, tol, rowwise):
+    ref64 = np.asarray(ref64, np.float64)
+    ref32 = np.asarray(ref32, np.float64)
+    sc = 1 + _scale(ref64, rowwise)
+    with np.errstate(all='ignore'):
+        rel = np.abs(ref32 - ref64) / sc
+    fin = np.isfinite(rel)
+    yard = rel[fin].max() if fin.any() else 0.0
+    return (tol + YARD * yard) * sc * np.ones_like(ref64)
+
+
+def loss_bound(l64, l32, tol=LOSS_TOL):
+    return _bound(l64, l32, tol, rowwise=False)
+
+
+def grad_bound(g64, g32, tol=GRAD_TOL):
+    return _bound(g64, g32, tol, rowwise=True)
+
+
+def check_close(name, ours, ref64, bound):
+    ours = np.asarray(ours, np.float64)
+    ref64 = np.asarray(ref64, np.float64)
+    fin = np.isfinite(ref64) & np.isfinite(bound)
+    assert np.isfinite(ours[fin]).all(), f'{name}: non-finite where the reference is finite'
+    err = np.abs(ours - ref64)
+    bad = fin & (err > bound)
+    if bad.any():
+        k = np.argmax(np.where(bad, err / np.maximum(bound, 1e-300), 0))
+        raise AssertionError(f'{name}: {bad.sum()} of {bad.size} outside tolerance; worst flat index {k}: '
+                             f'ours={ours.flat[k]!r} ref64={ref64.flat[k]!r} bound={bound.flat[k]!r}')
