@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the Gaussian-distance hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): M box-pairs/s, forward+backward, for GWD / KLD / BCD at 10 M pairs.
+Workload (BASELINE.json configs[2]): 10 M synthetic anchor x gt pairs per GPU (SURVEY.md §8d recipe,
+seed 0), GDLoss(loss_type, fun='log1p', tau=1.0, alpha=1.0, reduction='mean', loss_weight=5.0).
+One "step" = gwd3d, kld3d and bd3d, each forward + backward over the whole batch, through the
+reference's module surface (GDLoss.forward -> autograd backward).  Inputs are resident in HBM before
+the timed region.  value = (3 losses x pairs x steps x ranks) / max-over-ranks wall time.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), pairs sharded by rank with no
+data-path collective; each loss's per-shard value is all-gathered (one fp32 per rank) asynchronously.
+Weak scaling: every rank keeps 10 M pairs.
+
+The JSON line also carries
+  roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
+                 (88 B/pair) / average launch duration measured with HIP events recorded
+                 around every fused launch INSIDE the timed region, on the stream it is launched on.
+  cpu_baseline : the fp32 CPU oracle ("port") timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+LOSSES = ('gwd3d', 'kld3d', 'bd3d')
+BYTES_PER_PAIR = 88          # read pred 28 + target 28, write loss 4 + grad_pred 28
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def synthetic_pairs(n, seed, device):
+    """SURVEY.md §8d generator, produced on the device in chunks (no 560 MB host staging)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    lo = torch.tensor([0, -40, -3, 0.5, 0.5, 0.5, -math.pi], device=device)
+    hi = torch.tensor([70, 40, 1, 2.5, 4.5, 2.0, math.pi], device=device)
+    sigma = torch.tensor([0.3, 0.3, 0.1, 0.1, 0.1, 0.1, 0.1], device=device)
+    tgt = torch.rand(n, 7, generator=g, device=device) * (hi - lo) + lo
+    pred = tgt + torch.randn(n, 7, generator=g, device=device) * sigma
+    return pred.float().contiguous(), tgt.float().contiguous()
+
+
+def cpu_baseline(sample_pairs, seed):
+    """fp32 CPU oracle (oracle/gd_oracle.c) on a bounded sample of the same workload, all host cores."""
+    import oracle
+    cores = os.cpu_count() or 1
+    pred, tgt = synthetic_pairs(sample_pairs, seed, torch.device('cpu'))
+    p, t = pred.numpy(), tgt.numpy()
+    loss = np.empty(sample_pairs, np.float32)
+    gp = np.empty((sample_pairs, 7), np.float32)
+    t0 = time.perf_counter()
+    for lt in LOSSES:
+        prm = oracle.make_params(lt, fun='log1p', tau=1.0)
+        oracle.gd_loss_timed(p, t, prm, 5.0 / sample_pairs, loss, gp, cores)
+    dt = time.perf_counter() - t0
+    return {'value': round(3 * sample_pairs / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle (oracle/gd_oracle.c), '
+                      f'OpenMP {cores} threads, {dt:.2f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--pairs', type=int, default=10_000_000, help='pairs per GPU (default: BASELINE config 3)')
+    ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import mmdet3d_gaussian_amd as amd
+    from mmdet3d_gaussian_amd import gd_loss as gdl
+    amd.load_library()
+
+    n = args.pairs
+    pred, tgt = synthetic_pairs(n, seed=rank, device=dev)
+    pred.requires_grad_(True)
+    mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
+                                    reduction='mean', loss_weight=5.0)) for lt in LOSSES}
+    events = {lt: [] for lt in LOSSES}
+    last = {}
+
+    def step(record):
+        for lt in LOSSES:
+            gdl.PROFILE_EVENTS = events[lt] if record else None
+            pred.grad = None
+            loss = mods[lt](pred, tgt)
+            loss.backward()
+            if world > 1:
+                last[lt] = amd.sharded.gather_shard_losses(loss, async_op=True)
+            else:
+                last[lt] = loss.detach()
+        gdl.PROFILE_EVENTS = None
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = tt.item()
+
+    # dominant-kernel durations from the HIP events recorded inside the timed region
+    kern_ms = {}
+    for lt in LOSSES:
+        d = [a.elapsed_time(b) for a, b in events[lt]]
+        kern_ms[lt] = sum(d) / max(len(d), 1)
+    losses = {}
+    for lt in LOSSES:
+        v = last[lt]
+        if world > 1:
+            total, _ = v.result()
+            losses[lt] = total.item() / world  # mean over ranks of per-rank means (equal shard sizes)
+        else:
+            losses[lt] = v.item()
+
+    if rank == 0:
+        total_pairs = 3 * n * args.steps * world
+        value = total_pairs / elapsed / 1e6
+        dom = max(LOSSES, key=lambda k: kern_ms[k])          # slowest of the three fused kernels
+        dom_s = kern_ms[dom] * 1e-3
+        achieved = BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.isfile(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            'metric': 'M box-pairs/sec (fwd+bwd) for GWD/KLD/BCD @10M pairs',
+            'value': round(value, 2), 'unit': 'M box-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{n} synthetic anchor x gt 7-dof box pairs per GPU (BASELINE configs[2]); '
+                                   'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward '
+                                   '(fun=log1p, tau=1, reduction=mean, loss_weight=5)',
+                       'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
+                       'launch': 'eager'},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                         'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
+                         'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
+                         'mpairs_per_s_kernel': {k: round(n / (v * 1e-3) / 1e6, 1) if v > 0 else None
+                                                 for k, v in kern_ms.items()}},
+            'loss_values': {k: round(v, 6) for k, v in losses.items()},
+        }
+        if args.cpu_sample > 0:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

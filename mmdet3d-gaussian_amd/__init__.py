@@ -1,0 +1,26 @@
+"""mmdet3d-gaussian hot path for AMD MI355X (gfx950).
+
+Exposes the reference's call surface for the one path this package accelerates:
+  * ``GDLoss``                 — /root/reference/mmdet3d_gaussian/models/losses/gaussian_distance_loss.py:251
+  * ``LOSSES`` / ``build_loss``— the registry verbs heads use to build it from config dicts
+  * ``nms_gpu`` & friends      — the mmdet3d iou3d ops the reference imports (gd_centerpoint_head.py:9)
+  * ``iou_bev`` / ``iou_3d``   — GPU counterparts of ops/eval/affinity.cpp
+  * ``sharded``                — pair-sharded multi-GPU evaluation (one process per GPU, RCCL)
+All arithmetic runs in hand-written HIP kernels reached through the C ABI of include/gd3d.h
+(libgd3d.so, built in-tree by ``build.py``).  There is no CPU fallback.
+"""
+from . import build as _build_mod
+from ._lib import load as load_library, lib_path
+from .gd_loss import GDLoss, make_params
+from .iou3d import boxes_iou_bev, iou_3d, iou_bev, nms_gpu, nms_normal_gpu, xywhr2xyxyr
+from .registry import LOSSES, Registry, build_loss
+from . import sharded
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into mmdet3d-gaussian_amd/libgd3d.so."""
+    return _build_mod.build(force=force, verbose=verbose)
+
+
+__all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu',
+           'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path']

@@ -1,0 +1,69 @@
+"""ctypes binding of libgd3d.so — the only way the Python host code reaches the HIP kernels.
+
+There is NO CPU fallback: if the library cannot be loaded (or built) every op raises.  The
+signatures mirror include/gd3d.h one to one.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_lib = None
+
+
+class Params(ctypes.Structure):
+    """gd3d_params (include/gd3d.h)."""
+    _fields_ = [('loss_type', ctypes.c_int32), ('fun', ctypes.c_int32),
+                ('tau', ctypes.c_float), ('alpha', ctypes.c_float),
+                ('center_offset', ctypes.c_float * 3), ('flag', ctypes.c_int32)]
+
+
+# every symbol include/gd3d.h declares: name -> (restype, argtypes)
+_vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+SYMBOLS = {
+    'gd3d_loss_workspace_bytes': (_sz, [_i64]),
+    'gd3d_loss_fused': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
+    'rnms_workspace_bytes': (_sz, [_i64]),
+    'rnms_bev': (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+    'rnms_normal_bev': (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+    'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    'riou_eval_bev': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    'riou_eval_3d': (_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp]),
+    'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
+}
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or stale and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _build.is_stale():
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.isfile(_build.LIB_PATH):
+                raise RuntimeError(
+                    'libgd3d.so (HIP kernels for gfx950) is missing and could not be built; '
+                    'there is no CPU fallback for this package') from e
+    L = ctypes.CDLL(_build.LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    arch = ctypes.c_char_p()
+    ver = L.gd3d_abi_version(ctypes.byref(arch))
+    if ver != 1:
+        raise RuntimeError(f'libgd3d.so ABI version {ver} != 1')
+    _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed with code {rc}' + (' (bad argument)' if rc == 10001 else ''))

@@ -1,0 +1,480 @@
+// gd3d_device.h — per-pair register math of the fused Gaussian-distance kernels (gfx950).
+//
+// One thread owns one (pred, target) pair: 14 input floats in registers, the loss value and
+// the 7 (or 14) gradient floats out.  Everything is closed-form 2x2 algebra on the entries of
+//   Sigma = R diag(a^2, b^2) R^T :  S11 = A c^2 + B s^2,  S12 = (A-B) s c,  S22 = A s^2 + B c^2
+// which is what the reference builds with (N,2,2) bmm chains
+// (/root/reference/mmdet3d_gaussian/models/losses/gaussian_distance_loss.py:8-21, 86-87).
+// The backward is hand-derived reverse mode; clamp / sqrt-at-zero / max-tie rules are those
+// torch autograd applies to the reference graph (clamp: pass-through on the closed interval;
+// clamp(0).sqrt(): 0 for u < 0, +inf slope at u == 0; maximum/minimum: ties split 1/2).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/gd3d.h"
+
+namespace gd3d {
+
+#define GD_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ scalar helpers
+GD_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+GD_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
+
+// sin & cos.  Cody-Waite reduction by pi/2 with FMAs + Cephes minimax polynomials on
+// [-pi/4, pi/4] (abs error < 1.5e-7 for |x| <= 8192).  Beyond that (never in practice for a
+// yaw) fall back to the full-range library routine.
+GD_DEV void sincos_f(float x, float& s, float& c) {
+  if (__builtin_expect(!(fabsf(x) <= 8192.0f), 0)) {
+    sincosf(x, &s, &c);
+    return;
+  }
+  const float q = rintf(x * 0.63661977236758134f);
+  float r = fmaf(q, -1.5703125f, x);
+  r = fmaf(q, -4.837512969970703125e-4f, r);
+  r = fmaf(q, -7.54978995489188216e-8f, r);
+  const int n = (int)q;
+  const float z = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  ps = fmaf(ps * z, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  const float sv = (n & 1) ? pc : ps;
+  const float cv = (n & 1) ? ps : pc;
+  s = (n & 2) ? -sv : sv;
+  c = ((n + 1) & 2) ? -cv : cv;
+}
+
+// log1p with the (1+d) rounding error folded back in
+GD_DEV float log1p_f(float d) {
+  const float u = 1.0f + d;
+  const float corr = (d - (u - 1.0f)) * frcp(u);
+  return __logf(u) + corr;  // __logf -> v_log_f32 * ln2 (1 ulp of the result)
+}
+
+// ------------------------------------------------------------------ box -> Gaussian
+struct Box {
+  float X, Y, Z;     // gravity centre (UNCLAMPED dims, ref :12)
+  float a, b, e;     // half extents of clamped dims (ref :13-14, :19-20)
+  float mw, mh, ml;  // 0.5 * clamp pass-through mask
+  float co, si;
+  float A, B;
+  float S11, S12, S22;
+};
+
+struct Adj {
+  float gX, gY, gZ, ga, gb, ge, gr;
+};
+
+GD_DEV float half_clamp(float v, float& m) {
+  // torch.clamp(min=1e-7, max=1e7) then * 0.5; NaN propagates (fmin/fmax would drop it)
+  m = (v >= 1e-7f && v <= 1e7f) ? 0.5f : 0.0f;
+  float cl = v < 1e-7f ? 1e-7f : v;
+  cl = cl > 1e7f ? 1e7f : cl;
+  return 0.5f * cl;
+}
+
+GD_DEV void rotdiag(float dA, float dB, float co, float si, float& m11, float& m12, float& m22) {
+  const float cc = co * co, ss = si * si;
+  m11 = fmaf(dA, cc, dB * ss);
+  m12 = (dA - dB) * (si * co);
+  m22 = fmaf(dA, ss, dB * cc);
+}
+
+GD_DEV void rotdiag_bwd(float dA, float dB, float co, float si, float m12, float g11, float g12,
+                        float g22, float& g_dA, float& g_dB, float& g_r) {
+  const float cc = co * co, ss = si * si, sc = si * co;
+  g_dA = fmaf(g11, cc, fmaf(g12, sc, g22 * ss));
+  g_dB = fmaf(g11, ss, fmaf(-g12, sc, g22 * cc));
+  g_r = fmaf(g22 - g11, 2.0f * m12, g12 * (dA - dB) * (cc - ss));
+}
+
+GD_DEV void box_make(const float (&v)[7], const float (&c)[3], Box& o) {
+  o.X = fmaf(c[0], v[3], v[0]);
+  o.Y = fmaf(c[1], v[4], v[1]);
+  o.Z = fmaf(c[2], v[5], v[2]);
+  o.a = half_clamp(v[3], o.mw);
+  o.b = half_clamp(v[4], o.mh);
+  o.e = half_clamp(v[5], o.ml);
+  sincos_f(v[6], o.si, o.co);
+  o.A = o.a * o.a;
+  o.B = o.b * o.b;
+  rotdiag(o.A, o.B, o.co, o.si, o.S11, o.S12, o.S22);
+}
+
+GD_DEV void sigma_bwd(const Box& bx, float g11, float g12, float g22, Adj& g) {
+  float gA, gB, gr;
+  rotdiag_bwd(bx.A, bx.B, bx.co, bx.si, bx.S12, g11, g12, g22, gA, gB, gr);
+  g.ga = fmaf(gA, 2.0f * bx.a, g.ga);
+  g.gb = fmaf(gB, 2.0f * bx.b, g.gb);
+  g.gr += gr;
+}
+
+GD_DEV void box_grad(const Box& bx, const Adj& g, const float (&c)[3], float f, float (&out)[7]) {
+  out[0] = f * g.gX;
+  out[1] = f * g.gY;
+  out[2] = f * g.gZ;
+  out[3] = f * fmaf(c[0], g.gX, bx.mw * g.ga);
+  out[4] = f * fmaf(c[1], g.gY, bx.mh * g.gb);
+  out[5] = f * fmaf(c[2], g.gZ, bx.ml * g.ge);
+  out[6] = f * g.gr;
+}
+
+GD_DEV void adj_zero(Adj& g) { g.gX = g.gY = g.gZ = g.ga = g.gb = g.ge = g.gr = 0.0f; }
+
+// ------------------------------------------------------------------ postprocess (ref :24-39)
+template <int FUN>
+GD_DEV float post(float d, float tau, float& deriv) {
+  float f, df;
+  if (FUN == GD3D_FUN_LOG1P) {
+    f = log1p_f(d);
+    df = frcp(1.0f + d);
+  } else if (FUN == GD3D_FUN_EXPM1) {
+    f = expm1f(d);
+    df = f + 1.0f;
+  } else if (FUN == GD3D_FUN_NLOG) {
+    const float t = 1.0f - d + 1e-7f;
+    f = -logf(t);
+    df = frcp(t);
+  } else {
+    f = d;
+    df = 1.0f;
+  }
+  if (tau >= 1.0f) {  // wave-uniform (kernel argument)
+    const float iq = frcp(tau + f);
+    deriv = tau * iq * iq * df;
+    return fmaf(-tau, iq, 1.0f);
+  }
+  deriv = df;
+  return f;
+}
+
+// clamp(0).sqrt(): value and d sqrt/du under autograd rules
+GD_DEV float sqrt0(float u, float& dsu) {
+  float uc = u > 0.0f ? u : 0.0f;
+  uc = (u != u) ? u : uc;
+  const float s = fsqrt(uc);
+  dsu = (u >= 0.0f) ? 0.5f * frcp(s) : 0.0f;
+  return s;
+}
+
+// ------------------------------------------------------------------ gwd3d (ref :42-106)
+template <int FUN, bool NORMALIZE, bool GT>
+GD_DEV float gwd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+  const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
+  const float dxyz = fmaf(dX, dX, fmaf(dY, dY, dZ * dZ));
+  const float T = fmaf(p.S11, t.S11, fmaf(2.0f * p.S12, t.S12, p.S22 * t.S22));
+  const float Dp = p.a * p.b, Dt = t.a * t.b, D = Dp * Dt;
+  const float q = fmaf(2.0f, D, T);
+  float dsq;
+  const float sq = sqrt0(q, dsq);
+  const float de = p.e - t.e;
+  const float whlr = fmaf(de, de, fmaf(-2.0f, sq, (p.A + p.B) + (t.A + t.B)));
+  const float a2 = alpha * alpha;
+  const float u = fmaf(a2, whlr, dxyz);
+  float ddist;
+  const float dist = sqrt0(u, ddist);
+  float dn = dist, iscale = 1.0f;
+  if (NORMALIZE) {
+    // scale = 2 exp((ln D + ln ep + ln et)/6) = 2 (D ep et)^(1/6)
+    const float L = __logf(D) + __logf(p.e * t.e);
+    iscale = 0.5f * __expf(L * (-1.0f / 6.0f));
+    dn = dist * iscale;
+  }
+  float dpost;
+  const float out = post<FUN>(dn, tau, dpost);
+
+  const float g_dist = dpost * iscale;
+  const float g_L = NORMALIZE ? -dpost * dn * (1.0f / 6.0f) : 0.0f;
+  const float g_u = g_dist * ddist;
+  const float g_w = g_u * a2;
+  const float g_q = -2.0f * g_w * dsq;
+  const float iap = frcp(p.a), ibp = frcp(p.b), iep = frcp(p.e);
+  // d ln D / d a_p = 1/a_p : keep the log route separate from the 2*g_q*D route
+  const float g_D = 2.0f * g_q;
+  gp.gX = 2.0f * g_u * dX;
+  gp.gY = 2.0f * g_u * dY;
+  gp.gZ = 2.0f * g_u * dZ;
+  gp.ga = fmaf(g_w, 2.0f * p.a, fmaf(g_D, p.b * Dt, g_L * iap));
+  gp.gb = fmaf(g_w, 2.0f * p.b, fmaf(g_D, p.a * Dt, g_L * ibp));
+  gp.ge = fmaf(g_w, 2.0f * de, g_L * iep);
+  gp.gr = 0.0f;
+  sigma_bwd(p, g_q * t.S11, 2.0f * g_q * t.S12, g_q * t.S22, gp);
+  if (GT) {
+    const float iat = frcp(t.a), ibt = frcp(t.b), iet = frcp(t.e);
+    gt.gX = -gp.gX;
+    gt.gY = -gp.gY;
+    gt.gZ = -gp.gZ;
+    gt.ga = fmaf(g_w, 2.0f * t.a, fmaf(g_D, Dp * t.b, g_L * iat));
+    gt.gb = fmaf(g_w, 2.0f * t.b, fmaf(g_D, Dp * t.a, g_L * ibt));
+    gt.ge = fmaf(-g_w, 2.0f * de, g_L * iet);
+    gt.gr = 0.0f;
+    sigma_bwd(t, g_q * p.S11, 2.0f * g_q * p.S12, g_q * p.S22, gt);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------ kld3d core (ref :109-137)
+struct KldI {
+  float iap, ibp, iep, iA, iB, iE, P11, P12, P22, dX, dY, dZ;
+};
+
+GD_DEV float kld_fwd(const Box& p, const Box& t, float ia2, KldI& k) {
+  k.iap = frcp(p.a);
+  k.ibp = frcp(p.b);
+  k.iep = frcp(p.e);
+  k.iA = k.iap * k.iap;
+  k.iB = k.ibp * k.ibp;
+  k.iE = k.iep * k.iep;
+  rotdiag(k.iA, k.iB, p.co, p.si, k.P11, k.P12, k.P22);
+  k.dX = p.X - t.X;
+  k.dY = p.Y - t.Y;
+  k.dZ = p.Z - t.Z;
+  const float quad = fmaf(k.dX * k.dX, k.P11, fmaf(2.0f * k.dX * k.dY, k.P12, k.dY * k.dY * k.P22));
+  const float xyz = 0.5f * fmaf(k.dZ * k.dZ, k.iE, quad);
+  const float tr = fmaf(k.P11, t.S11, fmaf(2.0f * k.P12, t.S12, k.P22 * t.S22));
+  float whlr = 0.5f * fmaf(k.iE, t.e * t.e, tr);
+  // (ln ap + ln bp + ln ep) - (ln at + ln bt + ln et) as one log of a ratio would overflow for
+  // clamped dims; keep two logs of products (each product is within fp32 range: >= 1.25e-22)
+  const float lp = __logf(p.a * p.b * p.e);
+  const float lt = __logf(t.a * t.b * t.e);
+  whlr = whlr + (lp - lt) - 1.5f;
+  return fmaf(xyz, ia2, whlr);
+}
+
+// accumulates into gp (always) and gt (if GT) with upstream g
+template <bool GP, bool GT>
+GD_DEV void kld_bwd(const Box& p, const Box& t, float ia2, const KldI& k, float g, Adj& gp, Adj& gt) {
+  const float g_xyz = g * ia2, g_w = g;
+  const float g_quad = 0.5f * g_xyz;
+  const float g_dX = 2.0f * g_quad * fmaf(k.dX, k.P11, k.dY * k.P12);
+  const float g_dY = 2.0f * g_quad * fmaf(k.dX, k.P12, k.dY * k.P22);
+  const float g_dZ = g_xyz * k.dZ * k.iE;
+  if (GP) {
+    const float g_iE = 0.5f * fmaf(g_xyz, k.dZ * k.dZ, g_w * (t.e * t.e));
+    gp.gX += g_dX;
+    gp.gY += g_dY;
+    gp.gZ += g_dZ;
+    const float gP11 = fmaf(g_quad * k.dX, k.dX, 0.5f * g_w * t.S11);
+    const float gP12 = fmaf(2.0f * g_quad * k.dX, k.dY, g_w * t.S12);
+    const float gP22 = fmaf(g_quad * k.dY, k.dY, 0.5f * g_w * t.S22);
+    float g_iA, g_iB, g_r;
+    rotdiag_bwd(k.iA, k.iB, p.co, p.si, k.P12, gP11, gP12, gP22, g_iA, g_iB, g_r);
+    gp.gr += g_r;
+    gp.ga += fmaf(g_iA, -2.0f * k.iA * k.iap, g_w * k.iap);
+    gp.gb += fmaf(g_iB, -2.0f * k.iB * k.ibp, g_w * k.ibp);
+    gp.ge += fmaf(g_iE, -2.0f * k.iE * k.iep, g_w * k.iep);
+  }
+  if (GT) {
+    gt.gX -= g_dX;
+    gt.gY -= g_dY;
+    gt.gZ -= g_dZ;
+    sigma_bwd(t, 0.5f * g_w * k.P11, g_w * k.P12, 0.5f * g_w * k.P22, gt);
+    gt.ga -= g_w * frcp(t.a);
+    gt.gb -= g_w * frcp(t.b);
+    gt.ge += g_w * fmaf(k.iE, t.e, -frcp(t.e));
+  }
+}
+
+template <int FUN, bool SQRT, bool GT>
+GD_DEV float kld(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+  KldI k;
+  const float ia2 = frcp(alpha * alpha);
+  float d = kld_fwd(p, t, ia2, k), ds = 1.0f;
+  if (SQRT) d = sqrt0(d, ds);
+  float dpost;
+  const float out = post<FUN>(d, tau, dpost);
+  adj_zero(gp);
+  adj_zero(gt);
+  kld_bwd<true, GT>(p, t, ia2, k, dpost * ds, gp, gt);
+  return out;
+}
+
+// ------------------------------------------------------------------ jd3d (ref :189-198)
+template <int FUN, bool SQRT, bool GT>
+GD_DEV float jd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+  KldI k1, k2;
+  const float ia2 = frcp(alpha * alpha);
+  float v = kld_fwd(p, t, ia2, k1);
+  v = v + kld_fwd(t, p, ia2, k2);
+  v = v * 0.5f;
+  float ds = 1.0f;
+  if (SQRT) v = sqrt0(v, ds);
+  float dpost;
+  const float out = post<FUN>(v, tau, dpost);
+  const float g = dpost * ds * 0.5f;
+  adj_zero(gp);
+  adj_zero(gt);
+  kld_bwd<true, GT>(p, t, ia2, k1, g, gp, gt);
+  kld_bwd<GT, true>(t, p, ia2, k2, g, gt, gp);
+  return out;
+}
+
+// ------------------------------------------------------------------ symmax / symmin (ref :201-224)
+template <int FUN, bool SQRT, bool GT, bool WANT_MAX>
+GD_DEV float sym(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+  KldI k1, k2;
+  const float ia2 = frcp(alpha * alpha);
+  float v1 = kld_fwd(p, t, ia2, k1), v2 = kld_fwd(t, p, ia2, k2);
+  float ds1 = 1.0f, ds2 = 1.0f;
+  if (SQRT) {
+    v1 = sqrt0(v1, ds1);
+    v2 = sqrt0(v2, ds2);
+  }
+  float m, f1, f2;
+  if (v1 == v2) {
+    m = v1;
+    f1 = f2 = 0.5f;
+  } else if ((v1 > v2) == WANT_MAX) {
+    m = v1;
+    f1 = 1.0f;
+    f2 = 0.0f;
+  } else {
+    m = v2;
+    f1 = 0.0f;
+    f2 = 1.0f;
+  }
+  if (v1 != v1 || v2 != v2) {
+    m = v1 + v2;
+    f1 = f2 = 0.0f;
+  }
+  float dpost;
+  const float out = post<FUN>(m, tau, dpost);
+  adj_zero(gp);
+  adj_zero(gt);
+  // a zero factor must contribute exactly 0 (not 0 * inf): branch instead of multiply
+  if (f1 != 0.0f) kld_bwd<true, GT>(p, t, ia2, k1, dpost * f1 * ds1, gp, gt);
+  if (f2 != 0.0f) kld_bwd<GT, true>(t, p, ia2, k2, dpost * f2 * ds2, gt, gp);
+  return out;
+}
+
+// ------------------------------------------------------------------ bd3d (ref :144-186)
+template <int FUN, bool SQRT, bool GT>
+GD_DEV float bd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+  const float ia2 = frcp(alpha * alpha);
+  const float S11 = 0.5f * (p.S11 + t.S11), S12 = 0.5f * (p.S12 + t.S12), S22 = 0.5f * (p.S22 + t.S22);
+  const float Ep = p.e * p.e, Et = t.e * t.e, Sl = 0.5f * (Ep + Et);
+  const float det_raw = fmaf(S11, S22, -S12 * S12);
+  const float mdet = det_raw >= 1e-7f ? 1.0f : 0.0f;
+  float det = det_raw >= 1e-7f ? det_raw : 1e-7f;
+  det = (det_raw != det_raw) ? det_raw : det;
+  const float idet = frcp(det);
+  const float I11 = S22 * idet, I12 = -S12 * idet, I22 = S11 * idet;
+  const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
+  const float quad = fmaf(dX * dX, I11, fmaf(2.0f * dX * dY, I12, dY * dY * I22));
+  const float iSl = frcp(Sl);
+  const float xyz = 0.125f * fmaf(dZ * dZ, iSl, quad);
+  // 0.5(ln det + ln Sl) - 0.25(ln Ap + ln Bp + ln Ep) - 0.25(ln At + ln Bt + ln Et)
+  //   = 0.5 (ln det + ln Sl) - 0.5 (ln(ap bp ep) + ln(at bt et))
+  float whlr = 0.5f * (__logf(det) + __logf(Sl));
+  whlr = whlr - 0.5f * (__logf(p.a * p.b * p.e) + __logf(t.a * t.b * t.e));
+  float d = fmaf(xyz, ia2, whlr), ds = 1.0f;
+  if (SQRT) d = sqrt0(d, ds);
+  float dpost;
+  const float out = post<FUN>(d, tau, dpost);
+
+  const float g = dpost * ds, g_xyz = g * ia2, g_w = g;
+  const float g_quad = 0.125f * g_xyz;
+  const float g_Sl = fmaf(-0.125f * g_xyz * dZ * dZ, iSl * iSl, 0.5f * g_w * iSl);
+  const float g_dX = 2.0f * g_quad * fmaf(dX, I11, dY * I12);
+  const float g_dY = 2.0f * g_quad * fmaf(dX, I12, dY * I22);
+  const float g_dZ = 0.25f * g_xyz * dZ * iSl;
+  const float gI11 = g_quad * dX * dX, gI12 = 2.0f * g_quad * dX * dY, gI22 = g_quad * dY * dY;
+  const float g_idet = fmaf(gI11, S22, fmaf(-gI12, S12, gI22 * S11));
+  const float g_det = fmaf(-g_idet * idet, idet, 0.5f * g_w * idet) * mdet;
+  const float gS11 = 0.5f * fmaf(gI22, idet, g_det * S22);
+  const float gS22 = 0.5f * fmaf(gI11, idet, g_det * S11);
+  const float gS12 = 0.5f * fmaf(-gI12, idet, -2.0f * g_det * S12);
+  gp.gX = g_dX;
+  gp.gY = g_dY;
+  gp.gZ = g_dZ;
+  gp.ga = -0.5f * g_w * frcp(p.a);
+  gp.gb = -0.5f * g_w * frcp(p.b);
+  gp.ge = fmaf(g_Sl, p.e, -0.5f * g_w * frcp(p.e));
+  gp.gr = 0.0f;
+  sigma_bwd(p, gS11, gS12, gS22, gp);
+  if (GT) {
+    gt.gX = -g_dX;
+    gt.gY = -g_dY;
+    gt.gZ = -g_dZ;
+    gt.ga = -0.5f * g_w * frcp(t.a);
+    gt.gb = -0.5f * g_w * frcp(t.b);
+    gt.ge = fmaf(g_Sl, t.e, -0.5f * g_w * frcp(t.e));
+    gt.gr = 0.0f;
+    sigma_bwd(t, gS11, gS12, gS22, gt);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------ kfiou3d (ref :227-248)
+template <int FUN, bool GT>
+GD_DEV float kfiou(const Box& p, const Box& t, Adj& gp, Adj& gt) {
+  const float S11 = p.S11 + t.S11, S12 = p.S12 + t.S12, S22 = p.S22 + t.S22;
+  const float det2 = fmaf(S11, S22, -S12 * S12);
+  const float detl = fmaf(p.e, p.e, t.e * t.e);
+  const float det = det2 * detl;
+  const float vp = p.a * p.b * p.e, vt = t.a * t.b * t.e;
+  const float m = det >= 1e-7f ? 1.0f : 0.0f;
+  float detc = det >= 1e-7f ? det : 1e-7f;
+  detc = (det != det) ? det : detc;
+  const float isq = __builtin_amdgcn_rsqf(detc);
+  const float inter = vp * vt * isq;
+  const float un_raw = vp + vt - inter;
+  const float mu = un_raw >= 1e-7f ? 1.0f : 0.0f;
+  float un = un_raw >= 1e-7f ? un_raw : 1e-7f;
+  un = (un_raw != un_raw) ? un_raw : un;
+  const float iun = frcp(un);
+  const float k = inter * iun;
+  const float d = fmaf(-4.656854249492381f, k, 1.0f);
+  float dpost;
+  const float out = post<FUN>(d, 0.0f, dpost);  // tau is fixed to 0.0 (ref :247)
+
+  const float g_k = -4.656854249492381f * dpost;
+  float g_inter = g_k * iun;
+  const float g_unraw = -g_k * k * iun * mu;
+  g_inter -= g_unraw;
+  const float g_vp = fmaf(g_inter, vt * isq, g_unraw);
+  const float g_vt = fmaf(g_inter, vp * isq, g_unraw);
+  const float g_det = -0.5f * g_inter * inter * isq * isq * m;  // d inter / d detc = -inter / (2 detc)
+  const float g_det2 = g_det * detl, g_detl = g_det * det2;
+  const float gS11 = g_det2 * S22, gS22 = g_det2 * S11, gS12 = -2.0f * g_det2 * S12;
+  gp.gX = gp.gY = gp.gZ = 0.0f;
+  gp.ga = g_vp * p.b * p.e;
+  gp.gb = g_vp * p.a * p.e;
+  gp.ge = fmaf(g_vp, p.a * p.b, 2.0f * g_detl * p.e);
+  gp.gr = 0.0f;
+  sigma_bwd(p, gS11, gS12, gS22, gp);
+  if (GT) {
+    gt.gX = gt.gY = gt.gZ = 0.0f;
+    gt.ga = g_vt * t.b * t.e;
+    gt.gb = g_vt * t.a * t.e;
+    gt.ge = fmaf(g_vt, t.a * t.b, 2.0f * g_detl * t.e);
+    gt.gr = 0.0f;
+    sigma_bwd(t, gS11, gS12, gS22, gt);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------ one pair
+// Returns L_i; fills gpred[7] (and gtgt[7] if GT) with f * dL_i/d(row).
+template <int LOSS, int FUN, bool FLAG, bool GT>
+GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (&c)[3], float alpha,
+                       float tau, float f, float (&gpred)[7], float (&gtgt)[7]) {
+  Box p, t;
+  Adj gp, gt;
+  box_make(pv, c, p);
+  box_make(tv, c, t);
+  float out;
+  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, alpha, tau, gp, gt);
+  else out = kfiou<FUN, GT>(p, t, gp, gt);
+  box_grad(p, gp, c, f, gpred);
+  if (GT) box_grad(t, gt, c, f, gtgt);
+  return out;
+}
+
+}  // namespace gd3d

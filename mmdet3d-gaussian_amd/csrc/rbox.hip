@@ -1,0 +1,301 @@
+// rbox.hip — rotated BEV NMS and pairwise rotated IoU kernels for gfx950 + their C-ABI entry points
+// (include/gd3d.h).  Geometry: rbox_device.h.  Compiled with -ffp-contract=off (see build.py).
+//
+// NMS (replaces mmdet3d iou3d_cuda.nms_gpu, whose mask goes D->H and is scanned on the host):
+//   1. obox_prep_kernel: one thread per box: sin/cos + rotated corners once -> 64-byte OBox records.
+//   2. nms_mask_kernel:  one 256-thread workgroup per (row block, col block >= row block) pair of
+//      64-box blocks.  Lane r of wave s tests row box r against 16 column boxes (s*16 .. s*16+15)
+//      that sit in LDS (wave-wide broadcast reads); per-thread polygon vertices live in LDS
+//      [slot][thread]; the four 16-bit partial words are OR-ed through LDS into the 64-bit mask word.
+//      This is compute/latency-bound integer+fp32 work (no HBM roofline: N=4096 reads 256 KB, writes 1 MB).
+//   3. nms_scan_kernel:  the greedy scan as ONE wave that never leaves the device: the 64-box
+//      diagonal word of each block is resolved with scalar readlane steps, then the mask rows of the
+//      boxes just kept are OR-ed into the removed-set (LDS) with independent, pipelined row loads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gd3d.h"
+#include "rbox_device.h"
+
+namespace rbox {
+
+constexpr int NMS_T = 256;
+
+__global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict__ boxes, int n, OBox* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float b[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) b[k] = boxes[(size_t)i * 5 + k];
+  OBox o;
+  obox_make(b, o);
+  out[i] = o;
+}
+
+template <bool NORMAL>
+__global__ __launch_bounds__(NMS_T) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
+                                                         int n, int cb, float thresh,
+                                                         unsigned long long* __restrict__ mask) {
+  // upper-triangular block pairs only: linear block id -> (row, col >= row)
+  __shared__ OBox scol[64];
+  __shared__ float sraw[64 * 5];
+  __shared__ unsigned int spart[4][64];
+  __shared__ VertexScratch<NORMAL ? 1 : NMS_T> vs;
+
+  int row = 0, rem = blockIdx.x;
+  // rows have cb, cb-1, ... blocks; walk (cb is small: <= 1024)
+  while (rem >= cb - row) {
+    rem -= cb - row;
+    ++row;
+  }
+  const int col = row + rem;
+  const int tid = threadIdx.x, r = tid & 63, seg = tid >> 6;
+  const int ncol = min(64, n - col * 64);
+  const int i = row * 64 + r;
+
+  if (NORMAL) {
+    for (int k = tid; k < ncol * 5; k += NMS_T) sraw[k] = boxes[(size_t)col * 64 * 5 + k];
+  } else {
+    // 64 records x 16 dwords, cooperative copy
+    const float* src = reinterpret_cast<const float*>(ob + (size_t)col * 64);
+    float* dst = reinterpret_cast<float*>(scol);
+    for (int k = tid; k < ncol * 16; k += NMS_T) dst[k] = src[k];
+  }
+  __syncthreads();
+
+  unsigned int bits = 0;
+  if (i < n) {
+    OBox A;
+    float araw[5];
+    if (NORMAL) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) araw[k] = boxes[(size_t)i * 5 + k];
+    } else {
+      A = ob[i];
+    }
+    const int j0 = seg * 16;
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = j0 + jj;
+      if (j >= ncol) break;
+      if (row == col && j <= r) continue;
+      float iou;
+      if constexpr (NORMAL) iou = iou_normal(araw, &sraw[j * 5]);
+      else iou = iou_bev<NMS_T>(A, scol[j], vs, tid);
+      if (iou > thresh) bits |= 1u << jj;
+    }
+  }
+  spart[seg][r] = bits;
+  __syncthreads();
+  if (tid < 64 && i < n) {
+    const unsigned long long w = (unsigned long long)spart[0][r] | ((unsigned long long)spart[1][r] << 16) |
+                                 ((unsigned long long)spart[2][r] << 32) | ((unsigned long long)spart[3][r] << 48);
+    mask[(size_t)i * cb + col] = w;
+  }
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int cb,
+                                                      long long* __restrict__ keep, long long* __restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];
+  const int lane = threadIdx.x;
+  for (int w = lane; w < cb; w += 64) remv[w] = 0ull;
+  __syncthreads();
+  int count = 0;
+  for (int c = 0; c < cb; ++c) {
+    const int i = c * 64 + lane;
+    const unsigned long long diag = (i < n) ? mask[(size_t)i * cb + c] : 0ull;
+    const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+    unsigned long long cur = remv[c];
+    // (the builtin returns a signed int: go through unsigned before widening)
+    cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
+          (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
+    const int nvalid = min(64, n - c * 64);
+    unsigned long long kept = 0ull;
+    for (int l = 0; l < nvalid; ++l) {  // scalar, wave-uniform
+      const unsigned long long dl = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
+                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
+      if (!((cur >> l) & 1ull)) {
+        kept |= 1ull << l;
+        cur |= dl;
+      }
+    }
+    // OR the mask rows of the boxes just kept into the removed-set words that follow
+    for (int w0 = c + 1; w0 < cb; w0 += 64) {
+      const int w = w0 + lane;
+      const bool act = w < cb;
+      unsigned long long acc = 0ull;
+      unsigned long long kb = kept;
+      while (kb) {  // up to 4 independent row loads in flight per step
+        int l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          l[u] = kb ? __builtin_ctzll(kb) : -1;
+          kb = kb ? (kb & (kb - 1)) : 0ull;
+        }
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(c * 64 + l[u]) * cb + w] : 0ull;
+        acc |= (v[0] | v[1]) | (v[2] | v[3]);
+      }
+      if (act) remv[w] |= acc;
+    }
+    if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
+    count += __builtin_popcountll(kept);
+    __syncthreads();
+  }
+  if (lane == 0) *num_keep = count;
+}
+
+// pairwise IoU matrices ------------------------------------------------------------------
+constexpr int IOU_T = 256;
+__global__ __launch_bounds__(IOU_T) void riou_xyxyr_kernel(const float* __restrict__ a, long long na,
+                                                           const float* __restrict__ b, long long nb,
+                                                           float* __restrict__ out) {
+  __shared__ VertexScratch<IOU_T> vs;
+  const long long idx = (long long)blockIdx.x * IOU_T + threadIdx.x;
+  if (idx >= na * nb) return;
+  const long long i = idx / nb, j = idx - i * nb;
+  float ra[5], rb[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    ra[k] = a[i * 5 + k];
+    rb[k] = b[j * 5 + k];
+  }
+  OBox A, B;
+  obox_make(ra, A);
+  obox_make(rb, B);
+  out[idx] = iou_bev<IOU_T>(A, B, vs, threadIdx.x);
+}
+
+constexpr int EVAL_T = 128;
+// affinity.cpp:8-81
+template <bool IS3D>
+__global__ __launch_bounds__(EVAL_T) void riou_eval_kernel(const float* __restrict__ det, long long nd,
+                                                           const float* __restrict__ gt, long long ng, float z_offset,
+                                                           float* __restrict__ out) {
+  __shared__ HullScratch<EVAL_T> hs;
+  const long long idx = (long long)blockIdx.x * EVAL_T + threadIdx.x;
+  if (idx >= nd * ng) return;
+  const long long di = idx / ng, gi = idx - di * ng;
+  float d[7], g[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    d[k] = det[di * 7 + k];
+    g[k] = gt[gi * 7 + k];
+  }
+  const RBox D = {d[0], d[1], d[3], d[4], d[6]}, G = {g[0], g[1], g[3], g[4], g[6]};
+  const float bev = rot_intersection<EVAL_T>(D, G, hs, threadIdx.x);
+  const float EPSF = 1.1920928955078125e-7f;
+  if (IS3D) {
+    const float dzb = d[2] + (z_offset - 0.5f) * d[5], gzb = g[2] + (z_offset - 0.5f) * g[5];
+    const float dzt = d[2] + (z_offset + 0.5f) * d[5], gzt = g[2] + (z_offset + 0.5f) * g[5];
+    const float zb = dzb > gzb ? dzb : gzb, zt = dzt < gzt ? dzt : gzt;
+    float zi = zt - zb;
+    zi = zi < 0.f ? 0.f : zi;
+    const float dv = d[3] * d[4] * d[5], gv = g[3] * g[4] * g[5];
+    float iv = bev * zi;
+    iv = iv < 0.f ? 0.f : iv;
+    iv = iv > dv ? dv : iv;
+    iv = iv > gv ? gv : iv;
+    float uv = dv + gv - iv;
+    uv = uv < EPSF ? EPSF : uv;
+    out[idx] = iv / uv;
+  } else {
+    const float da = d[3] * d[4], ga = g[3] * g[4];
+    float inter = bev < 0.f ? 0.f : bev;
+    inter = inter > da ? da : inter;
+    inter = inter > ga ? ga : inter;
+    float un = da + ga - inter;
+    un = un < EPSF ? EPSF : un;
+    out[idx] = inter / un;
+  }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace rbox
+
+using namespace rbox;
+
+static const int64_t RNMS_MAX_N = 65536;  // 1024 mask words per row; removed-set = 8 KiB of LDS
+
+extern "C" {
+
+size_t rnms_workspace_bytes(int64_t n) {
+  if (n <= 0) return 16;
+  const size_t cb = (size_t)((n + 63) / 64);
+  return align_up((size_t)n * sizeof(OBox), 256) + (size_t)n * cb * sizeof(unsigned long long);
+}
+
+static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
+                     void* workspace, void* stream) {
+  if (n < 0 || num_keep == nullptr) return GD3D_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), s);
+  if (boxes == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  if (n > RNMS_MAX_N) return GD3D_E_TOOLARGE;
+  const int ni = (int)n, cb = (ni + 63) / 64;
+  OBox* ob = (OBox*)workspace;
+  unsigned long long* mask = (unsigned long long*)((char*)workspace + align_up((size_t)n * sizeof(OBox), 256));
+  if (!normal) {
+    hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, ni, ob);
+  }
+  const unsigned nblk = (unsigned)((long long)cb * (cb + 1) / 2);
+  if (normal)
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(NMS_T), 0, s, (const OBox*)ob, boxes, ni, cb, thresh,
+                       mask);
+  else
+    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(NMS_T), 0, s, (const OBox*)ob, boxes, ni, cb, thresh,
+                       mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)cb * sizeof(unsigned long long), s,
+                     (const unsigned long long*)mask, ni, cb, (long long*)keep, (long long*)num_keep);
+  return (int)hipGetLastError();
+}
+
+int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep, void* workspace,
+             void* stream) {
+  return rnms_impl(false, boxes_sorted, n, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
+                    void* workspace, void* stream) {
+  return rnms_impl(true, boxes_sorted, n, thresh, keep, num_keep, workspace, stream);
+}
+
+int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou, void* stream) {
+  if (na < 0 || nb < 0) return GD3D_E_BADARG;
+  if (na == 0 || nb == 0) return 0;
+  if (a == nullptr || b == nullptr || iou == nullptr) return GD3D_E_BADARG;
+  const long long tot = (long long)na * nb;
+  const long long blocks = (tot + IOU_T - 1) / IOU_T;
+  if (blocks > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(riou_xyxyr_kernel, dim3((unsigned)blocks), dim3(IOU_T), 0, (hipStream_t)stream, a, (long long)na,
+                     b, (long long)nb, iou);
+  return (int)hipGetLastError();
+}
+
+static int riou_eval_impl(bool is3d, const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset,
+                          float* iou, void* stream) {
+  if (nd < 0 || ng < 0) return GD3D_E_BADARG;
+  if (nd == 0 || ng == 0) return 0;
+  if (det == nullptr || gt == nullptr || iou == nullptr) return GD3D_E_BADARG;
+  const long long tot = (long long)nd * ng;
+  const long long blocks = (tot + EVAL_T - 1) / EVAL_T;
+  if (blocks > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  if (is3d)
+    hipLaunchKernelGGL((riou_eval_kernel<true>), dim3((unsigned)blocks), dim3(EVAL_T), 0, (hipStream_t)stream, det,
+                       (long long)nd, gt, (long long)ng, z_offset, iou);
+  else
+    hipLaunchKernelGGL((riou_eval_kernel<false>), dim3((unsigned)blocks), dim3(EVAL_T), 0, (hipStream_t)stream, det,
+                       (long long)nd, gt, (long long)ng, z_offset, iou);
+  return (int)hipGetLastError();
+}
+
+int riou_eval_bev(const float* det, int64_t nd, const float* gt, int64_t ng, float* iou, void* stream) {
+  return riou_eval_impl(false, det, nd, gt, ng, 0.5f, iou, stream);
+}
+
+int riou_eval_3d(const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset, float* iou, void* stream) {
+  return riou_eval_impl(true, det, nd, gt, ng, z_offset, iou, stream);
+}
+
+}  // extern "C"

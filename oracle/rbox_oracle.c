@@ -140,19 +140,19 @@ static int in_box(const obox *o, pt p) {
 }
 
 static float box_overlap(const obox *a, const obox *b) {
-  pt cp[16];
+  pt cp[16]; /* the published buffer size; writes are guarded (cnt < 16) here and in the HIP kernel */
   float pcx = 0.0f, pcy = 0.0f;
   int cnt = 0;
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       pt ans;
-      if (seg_intersection(a->c[i + 1], a->c[i], b->c[j + 1], b->c[j], &ans)) {
+      if (seg_intersection(a->c[i + 1], a->c[i], b->c[j + 1], b->c[j], &ans) && cnt < 16) {
         pcx = pcx + ans.x; pcy = pcy + ans.y; cp[cnt++] = ans;
       }
     }
   for (int k = 0; k < 4; ++k) {
-    if (in_box(a, b->c[k])) { pcx = pcx + b->c[k].x; pcy = pcy + b->c[k].y; cp[cnt++] = b->c[k]; }
-    if (in_box(b, a->c[k])) { pcx = pcx + a->c[k].x; pcy = pcy + a->c[k].y; cp[cnt++] = a->c[k]; }
+    if (in_box(a, b->c[k]) && cnt < 16) { pcx = pcx + b->c[k].x; pcy = pcy + b->c[k].y; cp[cnt++] = b->c[k]; }
+    if (in_box(b, a->c[k]) && cnt < 16) { pcx = pcx + a->c[k].x; pcy = pcy + a->c[k].y; cp[cnt++] = a->c[k]; }
   }
   if (cnt == 0) return 0.0f; /* published code divides by cnt = 0 and then sums nothing: 0 */
   pcx = pcx / (float)cnt; pcy = pcy / (float)cnt;

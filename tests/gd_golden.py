@@ -84,14 +84,33 @@ def grad_bound(g64, g32, tol=GRAD_TOL):
     return _bound(g64, g32, tol, rowwise=True)
 
 
+# Sampling allowance: the yardstick is a maximum over a finite family (128-256 rows), so an independent fp32
+# evaluation exceeds it now and then by a small factor.  Up to FRAC_OUT of the elements may lie between
+# bound and HARD x bound; none beyond.
+FRAC_OUT = 0.002
+HARD = 4.0
+
+
 def check_close(name, ours, ref64, bound):
     ours = np.asarray(ours, np.float64)
     ref64 = np.asarray(ref64, np.float64)
+    bound = np.broadcast_to(np.asarray(bound, np.float64), ref64.shape)
     fin = np.isfinite(ref64) & np.isfinite(bound)
     assert np.isfinite(ours[fin]).all(), f'{name}: non-finite where the reference is finite'
     err = np.abs(ours - ref64)
     bad = fin & (err > bound)
+    if bad.any() and bad.sum() <= FRAC_OUT * bad.size and not (fin & (err > HARD * bound)).any():
+        return
     if bad.any():
         k = np.argmax(np.where(bad, err / np.maximum(bound, 1e-300), 0))
         raise AssertionError(f'{name}: {bad.sum()} of {bad.size} outside tolerance; worst flat index {k}: '
-                             f'ours={ours.flat[k]!r} ref64={ref64.flat[k]!r} bound={bound.flat[k]!r}')
+                             f'ours={ours.flat[k]!r} ref64={ref64.flat[k]!r} |err|={err.flat[k]:.3e} '
+                             f'bound={bound.flat[k]:.3e}')
+
+
+def oracle32_bounds(pred, target, prm, ref64, scale):
+    """Tolerance for seeded inputs that have no reference-fp32 run: the fp32 build of the oracle (pinned to be as
+    accurate as the reference's fp32, test_oracle_gd.py) plays the yardstick role of ref32."""
+    import oracle
+    r32 = oracle.gd_loss(pred, target, prm, scale=scale, dtype=np.float32)
+    return (loss_bound(ref64['loss'], r32['loss']), grad_bound(ref64['grad_pred'], r32['grad_pred']))

@@ -1,0 +1,109 @@
+"""GPU parity tests for the rotated NMS / IoU kernels through the C ABI wrappers.
+NMS keep indices: BIT-EXACT against the CPU oracle (same fp32 operation sequence).
+ops/eval IoU: against golden matrices from the compiled reference (tests/golden/riou_eval.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from rbox_inputs import eval_boxes, nms_boxes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'riou_eval.npz')
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import mmdet3d_gaussian_amd as m
+    assert torch.cuda.is_available()
+    m.load_library()
+    return m
+
+
+@pytest.mark.parametrize('n,thr,clutter', [(1, 0.25, True), (2, 0.25, True), (63, 0.25, True), (64, 0.01, True),
+                                           (65, 0.25, True), (129, 0.5, False), (1000, 0.2, True), (4096, 0.25, True),
+                                           (4096, 0.01, False), (9000, 0.7, True)])
+def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
+    boxes, scores = nms_boxes(n, seed=n + int(thr * 100), clutter=clutter)
+    want = oracle.nms_gpu_oracle(boxes, scores, thr)
+    got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
+    assert got.dtype == torch.int64
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_nms_pre_post_cuts_and_alias(amd):
+    boxes, scores = nms_boxes(3000, seed=1)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    want = oracle.nms_gpu_oracle(boxes, scores, 0.2, pre_max_size=1000, post_max_size=83)   # nuScenes test_cfg
+    got = amd.nms_gpu(b, s, thresh=0.2, pre_max_size=1000, post_max_size=83)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got2 = amd.nms_gpu(b, s, 0.2, pre_maxsize=1000, post_max_size=83)
+    np.testing.assert_array_equal(got2.cpu().numpy(), want)
+
+
+def test_nms_empty_and_identical_boxes(amd):
+    e = amd.nms_gpu(torch.zeros(0, 5).cuda(), torch.zeros(0).cuda(), 0.5)
+    assert e.shape == (0,) and e.dtype == torch.int64
+    b = torch.tensor([[0, 0, 2, 1, 0.3]]).repeat(200, 1).cuda()
+    s = torch.linspace(0, 1, 200).cuda()
+    k = amd.nms_gpu(b, s, 0.5)
+    assert k.tolist() == [199]
+
+
+def test_nms_mask_words_bit_exact(amd):
+    """Not only the keep list: every 64-bit suppression word the scan can read equals the oracle's."""
+    import ctypes
+    lib = amd.load_library()
+    n, thr = 700, 0.25
+    boxes, scores = nms_boxes(n, seed=77)
+    order = np.argsort(-scores, kind='stable')
+    bs = np.ascontiguousarray(boxes[order])
+    want = oracle.nms_mask(bs, thr)
+    d = torch.from_numpy(bs).cuda()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda'); num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    wsb = lib.rnms_workspace_bytes(n)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device='cuda')
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.rnms_bev(vp(d), n, thr, vp(keep), vp(num), vp(ws), None) == 0
+    torch.cuda.synchronize()
+    cb = (n + 63) // 64
+    off = (n * 64 + 255) // 256 * 256
+    mask = ws[off:off + n * cb * 8].cpu().numpy().view(np.uint64).reshape(n, cb)
+    rows = np.arange(n)[:, None] // 64
+    cols = np.arange(cb)[None, :]
+    upper = cols >= rows                       # the kernel only produces the blocks the scan reads
+    np.testing.assert_array_equal(mask[upper], want[upper])
+
+
+def test_nms_normal(amd):
+    boxes, scores = nms_boxes(2000, seed=4)
+    want = oracle.nms_gpu_oracle(boxes, scores, 0.3, normal=True)
+    got = amd.nms_normal_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.3)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_boxes_iou_bev_matches_oracle(amd):
+    a, _ = nms_boxes(300, seed=8, extent=10)
+    b, _ = nms_boxes(200, seed=9, extent=10)
+    got = amd.boxes_iou_bev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.iou_bev_xyxyr(a, b))
+
+
+@pytest.mark.parametrize('fam', ['shift', 'dense', 'degen', 'ragged'])
+def test_eval_iou_matches_reference_golden(amd, fam):
+    """(D,7)x(G,7) IoU matrices vs the reference's own C++ (compiled in the build container).
+    fp32 tolerance 1e-5 abs on IoU (the only non-identical arithmetic is the device's fp64 cos/sin)."""
+    g = np.load(GOLD)
+    det, gt = torch.from_numpy(g[fam + '.det']).cuda(), torch.from_numpy(g[fam + '.gt']).cuda()
+    np.testing.assert_allclose(amd.iou_bev(det, gt).cpu().numpy(), g[fam + '.iou_bev'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(amd.iou_3d(det, gt, 0.5).cpu().numpy(), g[fam + '.iou_3d'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(amd.iou_3d(det, gt, 0.0).cpu().numpy(), g[fam + '.iou_3d_z0'], atol=1e-5, rtol=0)
+
+
+def test_eval_iou_large_matches_oracle(amd):
+    d, g = eval_boxes(700, 1, spread=30), eval_boxes(500, 2, spread=30)
+    got = amd.iou_3d(torch.from_numpy(d).cuda(), torch.from_numpy(g).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.eval_iou_3d(d, g), atol=1e-5, rtol=0)
+    assert amd.iou_bev(torch.zeros(0, 7).cuda(), torch.from_numpy(g).cuda()).shape == (0, 500)
