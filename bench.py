@@ -130,6 +130,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU-bound iff this < elapsed)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -176,7 +177,7 @@ def main():
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward '
                                    '(fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
-                       'launch': 'eager'},
+                       'launch': 'eager', 'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,

@@ -79,7 +79,8 @@ typedef struct gd3d_params {
  * with w_i = row_weight[i] (1 if row_weight == NULL).  `scale` carries
  * loss_weight / (avg_factor | N | 1) so that the kernel writes final gradients.
  * n == 0 is legal (loss_sum = 0).  workspace: gd3d_loss_workspace_bytes(n) bytes,
- * 16-byte aligned, needed only when loss_sum != NULL.
+ * 16-byte aligned; required when loss_sum != NULL; whenever it is given the kernel leaves one
+ * fp32 partial sum per 256-pair tile in it.
  * ---------------------------------------------------------------------------------- */
 size_t gd3d_loss_workspace_bytes(int64_t n);
 
@@ -87,6 +88,12 @@ int gd3d_loss_fused(const gd3d_params* params, const float* pred, const float* t
                     const float* row_weight, int64_t n, float scale, float* loss,
                     float* loss_sum, float* grad_pred, float* grad_target, void* workspace,
                     void* stream);
+
+/* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
+ * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
+ * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can
+ * bracket the fused kernel alone with events (bench.py) or defer the scalar. */
+int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* stream);
 
 /* In-place row scaling used by autograd backward when the upstream gradient is not 1:
  *   grad[i,:] *= (per_row ? g[i] : g[0]),  grad is (n,7) fp32, g is DEVICE memory.

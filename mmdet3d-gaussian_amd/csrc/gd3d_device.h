@@ -67,10 +67,11 @@ struct Adj {
 };
 
 GD_DEV float half_clamp(float v, float& m) {
-  // torch.clamp(min=1e-7, max=1e7) then * 0.5; NaN propagates (fmin/fmax would drop it)
-  m = (v >= 1e-7f && v <= 1e7f) ? 0.5f : 0.0f;
-  float cl = v < 1e-7f ? 1e-7f : v;
-  cl = cl > 1e7f ? 1e7f : cl;
+  // 0.5 * torch.clamp(v, 1e-7, 1e7) in one v_med3_f32; the clamp passes gradient iff it changed nothing.
+  // A NaN dim: med3 returns a bound and m = 0; the NaN still reaches the loss through the gravity
+  // centre (X = x + c*w uses the raw dim, even for c = 0) except in kfiou3d, which re-injects it.
+  const float cl = __builtin_amdgcn_fmed3f(v, 1e-7f, 1e7f);
+  m = (cl == v) ? 0.5f : 0.0f;
   return 0.5f * cl;
 }
 
@@ -149,11 +150,11 @@ GD_DEV float post(float d, float tau, float& deriv) {
   return f;
 }
 
-// clamp(0).sqrt(): value and d sqrt/du under autograd rules
+// clamp(0).sqrt(): value and d sqrt/du under autograd rules (slope 0 for u < 0, +inf at u == 0).
+// u * 0 keeps a NaN a NaN where clamp(0) would (torch.clamp propagates NaN) and is 0 otherwise.
 GD_DEV float sqrt0(float u, float& dsu) {
-  float uc = u > 0.0f ? u : 0.0f;
-  uc = (u != u) ? u : uc;
-  const float s = fsqrt(uc);
+  const bool pos = u > 0.0f;
+  const float s = pos ? fsqrt(u) : u * 0.0f;
   dsu = (u >= 0.0f) ? 0.5f * frcp(s) : 0.0f;
   return s;
 }
@@ -413,7 +414,9 @@ GD_DEV float kfiou(const Box& p, const Box& t, Adj& gp, Adj& gt) {
   const float det2 = fmaf(S11, S22, -S12 * S12);
   const float detl = fmaf(p.e, p.e, t.e * t.e);
   const float det = det2 * detl;
-  const float vp = p.a * p.b * p.e, vt = t.a * t.b * t.e;
+  // kfiou3d never touches the centre, so a NaN dim must be re-injected here (see half_clamp); X,Y,Z carry it
+  const float nanp = (p.X + p.Y + p.Z) * 0.0f + (t.X + t.Y + t.Z) * 0.0f;  // 0, or NaN if any input is NaN/inf
+  const float vp = p.a * p.b * p.e + nanp, vt = t.a * t.b * t.e;
   const float m = det >= 1e-7f ? 1.0f : 0.0f;
   float detc = det >= 1e-7f ? det : 1e-7f;
   detc = (det != det) ? det : detc;

@@ -31,6 +31,41 @@ constexpr int TILE_V4 = TILE_F / 4;  // 16-byte vectors per tensor tile (448)
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void gbl_cptr_t;
 
+// ---- tuning switches (A/B-tested with tools/build_variants.py + tools/kernel_time.py) ----
+#ifndef GD_NT_LOAD
+#define GD_NT_LOAD 1   // LDS-DMA loads with the nt cache policy: every input byte is read exactly once
+                       // (measured r01, 10 M pairs: nt loads + nt stores 129 us vs 151 us plain; a persistent
+                       //  double-buffered grid-stride variant was 143-160 us and was dropped)
+#endif
+#ifndef GD_NT_STORE
+#define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
+#endif
+constexpr int DMA_AUX = GD_NT_LOAD ? 2 : 0;
+constexpr int NUM_CU = 256;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+GD_DEV void store_v4(float* dst, const float* src_lds, int idx) {
+  const v4f v = reinterpret_cast<const v4f*>(src_lds)[idx];
+  if (GD_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst) + idx);
+  else reinterpret_cast<v4f*>(dst)[idx] = v;
+}
+
+// 14 LDS-DMA pieces of 1 KiB bring one 256-pair tile of pred and target into LDS; wave w issues
+// pieces w, w+4, w+8, w+12.
+GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, float* st, int wave, int lane) {
+#pragma unroll
+  for (int j0 = 0; j0 < 16; j0 += 4) {
+    const int j = j0 + wave;  // wave-uniform
+    if (j < 7) {
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gpred + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, DMA_AUX);
+    } else if (j < 14) {
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - 7) * 256 + lane * 4), (lds_ptr_t*)(st + (j - 7) * 256), 16, 0,
+                                       DMA_AUX);
+    }
+  }
+}
+
 struct LossArgs {
   const float* pred;
   const float* target;
@@ -45,10 +80,21 @@ struct LossArgs {
   int vec_ok;        // all (N,7) pointers 16-byte aligned
 };
 
+// wave64 sum with DPP adds (no LDS crossbar): inclusive scan inside each 16-lane row (row_shr 1,2,4,8 with
+// zero fill), then row_bcast:15 / row_bcast:31 carry the row totals; lane 63 holds the total.  Fixed order.
+template <int CTRL, int ROW_MASK>
+GD_DEV float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
 GD_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
@@ -59,7 +105,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
   const long long base = (long long)blockIdx.x * TILE;
   const long long rows_left = a.n - base;
   const bool full = rows_left >= TILE;
@@ -72,17 +118,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   if (a.w != nullptr && valid) wi = a.w[base + tid];
 
   if (fast) {
-    // 14 DMA pieces of 1 KiB; wave w issues pieces w, w+4, w+8, w+12
-#pragma unroll
-    for (int j0 = 0; j0 < 16; j0 += 4) {
-      const int j = j0 + wave;  // wave-uniform
-      if (j < 7) {
-        __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gpred + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, 0);
-      } else if (j < 14) {
-        __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - 7) * 256 + lane * 4), (lds_ptr_t*)(st + (j - 7) * 256), 16, 0,
-                                         0);
-      }
-    }
+    issue_tile_dma(gpred, gtarget, sp, st, wave, lane);
   } else {
     const long long fl = (rows_left < TILE ? rows_left : TILE) * 7;
     for (int i = tid; i < TILE_F; i += TILE) {
@@ -117,7 +153,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
 
   float bsum = 0.0f;
   if (a.partials != nullptr) {
-    const float ws = wave_sum(fl);
+    const float ws = wave_sum(fl);  // uniform (readlane 63)
     if (lane == 0) swave[wave] = ws;
   }
   __syncthreads();
@@ -128,16 +164,12 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
 
   if (fast) {
     if (a.gp != nullptr) {
-      float4* dst = reinterpret_cast<float4*>(a.gp + base * 7);
-      const float4* src = reinterpret_cast<const float4*>(sp);
-      dst[tid] = src[tid];
-      if (tid < TILE_V4 - TILE) dst[tid + TILE] = src[tid + TILE];
+      store_v4(a.gp + base * 7, sp, tid);
+      if (tid < TILE_V4 - TILE) store_v4(a.gp + base * 7, sp, tid + TILE);
     }
     if (GT) {
-      float4* dst = reinterpret_cast<float4*>(a.gt + base * 7);
-      const float4* src = reinterpret_cast<const float4*>(st);
-      dst[tid] = src[tid];
-      if (tid < TILE_V4 - TILE) dst[tid + TILE] = src[tid + TILE];
+      store_v4(a.gt + base * 7, st, tid);
+      if (tid < TILE_V4 - TILE) store_v4(a.gt + base * 7, st, tid + TILE);
     }
   } else {
     const long long fl7 = (rows_left < TILE ? rows_left : TILE) * 7;
@@ -148,13 +180,27 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   }
 }
 
-// second stage: fixed-order fp64 sum of the per-block partials -> one fp32
+// second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; every thread
+// issues all of its 16-B loads before the first add (the kernel is pure latency: 39 K floats at 10 M pairs).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, long long nb,
                                                                float* __restrict__ out) {
   __shared__ double sd[1024];
   const int tid = threadIdx.x;
+  const long long nv = nb >> 2;  // whole float4s (the workspace is 16-byte aligned)
+  const float4* p4 = reinterpret_cast<const float4*>(partials);
   double acc = 0.0;
-  for (long long i = tid; i < nb; i += 1024) acc += (double)partials[i];
+  for (long long i0 = 0; i0 < nv; i0 += 1024 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = i0 + (long long)u * 1024 + tid;
+      v[u] = i < nv ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+  }
+  const long long tail = (nv << 2) + tid;
+  if (tail < nb) acc += (double)partials[tail];
   sd[tid] = acc;
   __syncthreads();
 #pragma unroll
@@ -165,7 +211,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   if (tid == 0) *out = (float)sd[0];
 }
 
-// grad[i,:] *= g  (scalar g: early exit when g == 1)
+// grad[i,:] *= g  (scalar g: the whole grid exits after one scalar load when g == 1)
 __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ grad, const float* __restrict__ g,
                                                          int per_row, long long nflt) {
   float gs = 1.0f;
@@ -174,31 +220,44 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ gra
     if (gs == 1.0f) return;  // uniform across the grid
   }
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nflt; i += stride) {
-    const float m = per_row ? g[i / 7] : gs;
-    grad[i] *= m;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!per_row && (((uintptr_t)grad & 15) == 0)) {
+    v4f* g4 = reinterpret_cast<v4f*>(grad);
+    const long long nv = nflt >> 2;
+    for (long long i = i0; i < nv; i += stride) g4[i] = g4[i] * gs;
+    for (long long i = (nv << 2) + i0; i < nflt; i += stride) grad[i] *= gs;
+    return;
   }
+  for (long long i = i0; i < nflt; i += stride) grad[i] *= per_row ? g[i / 7] : gs;
+}
+
+struct Geometry {
+  unsigned tgrid;  // one workgroup per 256-pair tile
+};
+
+template <int LOSS, int FUN, bool FLAG, bool GT>
+static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
+  hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), 0, s, a);
 }
 
 template <int LOSS, int FUN>
-static hipError_t launch_flag_gt(bool flag, bool gt, dim3 grid, hipStream_t s, const LossArgs& a) {
-  const dim3 blk(TILE);
+static hipError_t launch_flag_gt(bool flag, bool gt, const Geometry& grid, hipStream_t s, const LossArgs& a) {
   switch ((flag ? 2 : 0) | (gt ? 1 : 0)) {
-    case 0: hipLaunchKernelGGL((fused_kernel<LOSS, FUN, false, false>), grid, blk, 0, s, a); break;
-    case 1: hipLaunchKernelGGL((fused_kernel<LOSS, FUN, false, true>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((fused_kernel<LOSS, FUN, true, false>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((fused_kernel<LOSS, FUN, true, true>), grid, blk, 0, s, a); break;
+    case 0: launch_one<LOSS, FUN, false, false>(grid, s, a); break;
+    case 1: launch_one<LOSS, FUN, false, true>(grid, s, a); break;
+    case 2: launch_one<LOSS, FUN, true, false>(grid, s, a); break;
+    default: launch_one<LOSS, FUN, true, true>(grid, s, a); break;
   }
   return hipGetLastError();
 }
 
 template <int LOSS>
-static hipError_t launch_fun(int fun, bool flag, bool gt, dim3 grid, hipStream_t s, const LossArgs& a) {
+static hipError_t launch_fun(int fun, bool flag, bool gt, const Geometry& grid, hipStream_t s, const LossArgs& a) {
   if (fun == GD3D_FUN_LOG1P) return launch_flag_gt<LOSS, GD3D_FUN_LOG1P>(flag, gt, grid, s, a);
   return launch_flag_gt<LOSS, GD3D_FUN_NONE>(flag, gt, grid, s, a);
 }
 
-static hipError_t launch_kfiou(int fun, bool gt, dim3 grid, hipStream_t s, const LossArgs& a) {
+static hipError_t launch_kfiou(int fun, bool gt, const Geometry& grid, hipStream_t s, const LossArgs& a) {
   // `sqrt` is accepted and ignored by kfiou3d_loss (ref :228), so FLAG is pinned to false
   switch (fun) {
     case GD3D_FUN_EXPM1: return launch_flag_gt<GD3D_KFIOU3D, GD3D_FUN_EXPM1>(false, gt, grid, s, a);
@@ -214,9 +273,10 @@ using namespace gd3d;
 extern "C" {
 
 size_t gd3d_loss_workspace_bytes(int64_t n) {
+  // one fp32 partial per workgroup; sized for the one-tile-per-workgroup geometry (the largest one)
   if (n <= 0) return 16;
   const int64_t nb = (n + TILE - 1) / TILE;
-  return (size_t)((nb * 4 + 15) / 16 * 16);
+  return (size_t)(((nb + 1) * 4 + 15) / 16 * 16);
 }
 
 int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
@@ -232,6 +292,7 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
     return GD3D_E_BADARG;
   }
   if (loss_sum != nullptr && workspace == nullptr) return GD3D_E_BADARG;
+  if (workspace != nullptr && ((uintptr_t)workspace & 15) != 0) return GD3D_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nb = (n + TILE - 1) / TILE;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
@@ -239,6 +300,8 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
     if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
     return 0;
   }
+  if (loss_sum == nullptr && loss == nullptr && grad_pred == nullptr && grad_target == nullptr && workspace == nullptr)
+    return 0;  // nothing requested
   LossArgs a;
   a.pred = pred;
   a.target = target;
@@ -246,7 +309,7 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
   a.loss = loss;
   a.gp = grad_pred;
   a.gt = grad_target;
-  a.partials = loss_sum != nullptr ? (float*)workspace : nullptr;
+  a.partials = (float*)workspace;  // per-workgroup partial sums are produced whenever a workspace is given
   a.n = n;
   a.scale = scale;
   a.alpha = p->alpha;
@@ -258,7 +321,9 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
   a.vec_ok = (bits & 15) == 0;
   const bool gt = grad_target != nullptr;
   const bool flag = p->flag != 0;
-  const dim3 grid((unsigned)nb);
+  Geometry grid;
+  grid.tgrid = (unsigned)nb;
+  const long long nparts = nb;
   hipError_t e;
   switch (p->loss_type) {
     case GD3D_GWD3D: e = launch_fun<GD3D_GWD3D>(p->fun, flag, gt, grid, s, a); break;
@@ -270,12 +335,19 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
     default: e = launch_kfiou(p->fun, gt, grid, s, a); break;
   }
   if (e != hipSuccess) return (int)e;
-  if (loss_sum != nullptr) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, (long long)nb,
-                       loss_sum);
-    e = hipGetLastError();
-  }
-  return (int)e;
+  (void)nparts;
+  if (loss_sum != nullptr) return gd3d_loss_reduce(workspace, n, loss_sum, stream);
+  return 0;
+}
+
+int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* stream) {
+  if (n < 0 || loss_sum == nullptr) return GD3D_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+  if (workspace == nullptr) return GD3D_E_BADARG;
+  const long long nparts = (n + TILE - 1) / TILE;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nparts, loss_sum);
+  return (int)hipGetLastError();
 }
 
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream) {
@@ -283,7 +355,7 @@ int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* s
   if (n == 0) return 0;
   const long long nflt = (long long)n * 7;
   long long blocks = (nflt + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;  // grid-stride; small so that the g == 1 early exit costs ~2 us
   hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, g, per_row,
                      nflt);
   return (int)hipGetLastError();

@@ -52,11 +52,17 @@ def make_params(loss_type, fun, tau, alpha, center_offset, kwargs):
 
 
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
-def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+_LIB = None
+
+
+def _library():
+    global _LIB
+    if _LIB is None:
+        _LIB = _lib.load()
+    return _LIB
 
 
 def _rows(t):
@@ -67,30 +73,47 @@ def _rows(t):
     t = t.reshape(-1, 7)
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt):
-    """One launch of gd3d_loss_fused.  Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None)."""
-    lib = _lib.load()
+    """One launch of gd3d_loss_fused on the current stream of pred's device.
+    Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None)."""
+    lib = _library()
     n = pred.shape[0]
     dev = pred.device
-    with torch.cuda.device(dev):
+    switch = torch.cuda.current_device() != dev.index
+    if switch:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+    try:
         loss = torch.empty(n, dtype=torch.float32, device=dev) if want_loss else None
-        total = torch.empty((), dtype=torch.float32, device=dev) if want_sum else None
         gp = torch.empty_like(pred) if want_gp else None
         gt = torch.empty_like(target) if want_gt else None
-        ws = torch.empty(lib.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev) if want_sum else None
+        total = ws = None
+        if want_sum:
+            # one allocation: [0] = the fp32 result, [4:] = the per-workgroup partials (16-byte aligned)
+            buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(n) // 4, dtype=torch.float32, device=dev)
+            total, ws = buf[0], buf[4:]
         ev = PROFILE_EVENTS
-        if ev is not None:
+        stream = torch.cuda.current_stream().cuda_stream
+        if ev is None:
+            rc = lib.gd3d_loss_fused(params, _ptr(pred), _ptr(target), _ptr(row_weight), n, scale,
+                                     _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
+        else:  # profiling: HIP events around the fused kernel alone; the reduce stage is launched separately
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = lib.gd3d_loss_fused(ctypes.byref(params), _ptr(pred), _ptr(target), _ptr(row_weight), n, float(scale),
-                                 _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), _stream(dev))
-        if ev is not None:
+            rc = lib.gd3d_loss_fused(params, _ptr(pred), _ptr(target), _ptr(row_weight), n, scale,
+                                     _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
             e1.record()
             ev.append((e0, e1))
-    _lib.check(rc, 'gd3d_loss_fused')
+            if rc == 0 and want_sum:
+                rc = lib.gd3d_loss_reduce(_ptr(ws), n, _ptr(total), stream)
+    finally:
+        if switch:
+            torch.cuda.set_device(prev)
+    if rc != 0:
+        _lib.check(rc, 'gd3d_loss_fused')
     return loss, total, gp, gt
 
 
@@ -109,7 +132,7 @@ class _GDReduced(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
-        lib = _lib.load()
+        lib = _library()
         pred = ctx.replay[0]
         if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
             r_pred, r_target, r_w, r_params, r_scale = ctx.replay
@@ -118,13 +141,23 @@ class _GDReduced(torch.autograd.Function):
         else:
             gp, gt = ctx.gp, ctx.gt
             ctx.used = True
-        g = grad_out.reshape(1).to(torch.float32).contiguous()
-        with torch.cuda.device(pred.device):
+        g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
+        dev = pred.device
+        switch = torch.cuda.current_device() != dev.index
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(dev)
+        try:
+            stream = torch.cuda.current_stream().cuda_stream
             for buf in (gp, gt):
                 if buf is not None:
                     # reads g on the device, exits without touching memory when g == 1 (no host sync)
-                    _lib.check(lib.gd3d_scale_rows(_ptr(buf), _ptr(g), 0, buf.shape[0], _stream(pred.device)),
-                               'gd3d_scale_rows')
+                    rc = lib.gd3d_scale_rows(buf.data_ptr(), g.data_ptr(), 0, buf.shape[0], stream)
+                    if rc != 0:
+                        _lib.check(rc, 'gd3d_scale_rows')
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
         return gp, gt, None, None, None
 
 
@@ -174,19 +207,30 @@ class GDLoss(nn.Module):
         self.reduction = reduction
         self.loss_weight = loss_weight
         self.kwargs = kwargs
+        self._params_cache = None  # (key, gd3d_params) for calls without per-call kwargs
+
+    def _params(self, call_kwargs):
+        # kfiou3d ignores tau (ref :247) — the kernel is told tau = 0
+        tau = 0.0 if self.loss_type == 'kfiou3d' else self.tau
+        if call_kwargs:
+            _kwargs = deepcopy(self.kwargs)
+            _kwargs.update(call_kwargs)  # ref :293-294
+            return make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset, _kwargs)
+        co = self.center_offset
+        key = (self.loss_type, self.fun, tau, self.alpha,
+               tuple(co.tolist()) if isinstance(co, torch.Tensor) else tuple(co), tuple(sorted(self.kwargs.items())))
+        if self._params_cache is None or self._params_cache[0] != key:
+            self._params_cache = (key, make_params(self.loss_type, self.fun, tau, self.alpha, co, self.kwargs))
+        return self._params_cache[1]
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
             return (pred * weight).sum()  # ref :290-292 (keeps the graph; raises for an (N,) weight, as there)
-        _kwargs = deepcopy(self.kwargs)
-        _kwargs.update(kwargs)
+        params = self._params(kwargs)
         if weight is not None and weight.shape == pred.shape:
             weight = weight.mean(dim=-1)
-        # kfiou3d ignores tau (ref :247) — the kernel is told tau = 0
-        tau = 0.0 if self.loss_type == 'kfiou3d' else self.tau
-        params = make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset, _kwargs)
 
         out_dtype = pred.dtype
         p = _rows(pred)

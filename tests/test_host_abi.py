@@ -1,0 +1,122 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports exactly what
+include/gd3d.h declares (no compute calls), and the host logic of GDLoss / registry mirrors the
+reference module's constructor and argument handling.  No GPU needed."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import mmdet3d_gaussian_amd as amd
+from mmdet3d_gaussian_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|size_t)\s+((?:gd3d|rnms|riou)_\w+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 10, names
+    lib = ctypes.CDLL(amd.lib_path())           # built by __graft_entry__.build() / first import
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/gd3d.h but not exported by libgd3d.so'
+    assert sorted(_lib.SYMBOLS) == names, 'ctypes table and header disagree'
+
+
+def test_abi_version_and_queries_without_gpu():
+    lib = amd.load_library()
+    arch = ctypes.c_char_p()
+    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 1
+    assert arch.value == b'gfx950'
+    assert lib.gd3d_loss_workspace_bytes(0) >= 16
+    assert lib.gd3d_loss_workspace_bytes(10_000_000) >= 4 * ((10_000_000 + 255) // 256)
+    assert lib.gd3d_loss_workspace_bytes(10_000_000) % 16 == 0
+    n = 4096
+    assert lib.rnms_workspace_bytes(n) >= n * 64 + n * (n // 64) * 8
+
+
+def test_params_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.Params) == 32
+    assert _lib.Params.center_offset.offset == 16 and _lib.Params.flag.offset == 28
+
+
+def test_gdloss_ctor_mirrors_reference_asserts():
+    amd.GDLoss('gwd3d'); amd.GDLoss('kfiou3d', fun='expm1'); amd.GDLoss('kfiou3d', fun='nlog')
+    with pytest.raises(AssertionError):
+        amd.GDLoss('gwd3d', fun='expm1')          # ref :267-268
+    with pytest.raises(AssertionError):
+        amd.GDLoss('kfiou3d', fun='log1p')        # ref :269-270
+    with pytest.raises(AssertionError):
+        amd.GDLoss('nope')
+    with pytest.raises(AssertionError):
+        amd.GDLoss('gwd3d', reduction='avg')
+    m = amd.GDLoss('bd3d', center_offset=(0, 0, 0.5), fun='log1p', tau=1.0, alpha=1.0, reduction='mean',
+                   loss_weight=5.0, sqrt=False)
+    assert m.kwargs == {'sqrt': False} and m.loss_weight == 5.0
+
+
+def test_registry_builds_reference_config_dicts():
+    """The dict the reference's KITTI configs carry (configs/kitti/*tau1*.py:7-8) builds unchanged."""
+    cfg = dict(type='GDLoss', loss_type='kld3d', fun='log1p', tau=1.0, alpha=1.0, loss_weight=5.0)
+    m = amd.build_loss(cfg)
+    assert isinstance(m, amd.GDLoss) and m.loss_type == 'kld3d' and 'GDLoss' in amd.LOSSES
+    with pytest.raises(KeyError):
+        amd.build_loss(dict(type='SmoothL1Loss'))
+    with pytest.raises(KeyError):
+        amd.LOSSES.register_module()(amd.GDLoss)   # duplicate without force
+
+
+def test_make_params_flags_and_unknown_kwargs():
+    p = amd.make_params('gwd3d', 'log1p', 1.0, 2.0, (0.1, 0.2, 0.3), {'normalize': False})
+    assert (p.loss_type, p.fun, p.flag) == (0, 1, 0) and abs(p.alpha - 2.0) < 1e-7
+    assert [round(c, 3) for c in p.center_offset] == [0.1, 0.2, 0.3]
+    assert amd.make_params('kld3d', 'none', 0.0, 1.0, (0, 0, 0.5), {}).flag == 1          # sqrt default True
+    assert amd.make_params('kfiou3d', 'expm1', 0.0, 1.0, (0, 0, 0.5), {}).flag == 0       # sqrt default False
+    with pytest.raises(TypeError):
+        amd.make_params('kld3d', 'none', 0.0, 1.0, (0, 0, 0.5), {'normalize': True})      # ref: unexpected kwarg
+
+
+def test_no_cpu_fallback():
+    m = amd.GDLoss('gwd3d')
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m(torch.rand(4, 7), torch.rand(4, 7))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.nms_gpu(torch.rand(4, 5), torch.rand(4), 0.5)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.iou_3d(torch.rand(4, 7), torch.rand(4, 7))
+    with pytest.raises(ValueError):
+        # avg_factor with reduction='sum' is rejected before any device work (mmdet weight_reduce_loss)
+        amd.GDLoss('gwd3d', reduction='sum')(torch.rand(4, 7).to('meta') if False else _FakeCuda(4), _FakeCuda(4),
+                                             avg_factor=2.0)
+
+
+class _FakeCuda(torch.Tensor):
+    """A CPU tensor that claims to be on the GPU, to reach host-side argument checks without a device."""
+    @staticmethod
+    def __new__(cls, n):
+        return torch.Tensor._make_subclass(cls, torch.rand(n, 7))
+
+    @property
+    def is_cuda(self):
+        return True
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no file of the product package may mention it."""
+    pkg = os.path.join(ROOT, 'mmdet3d-gaussian_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt and 'oracle/' not in txt, f
+
+
+def test_xywhr2xyxyr():
+    b = torch.tensor([[1.0, 2.0, 4.0, 2.0, 0.3]])
+    assert torch.allclose(amd.xywhr2xyxyr(b), torch.tensor([[-1.0, 1.0, 3.0, 3.0, 0.3]]))

@@ -1,0 +1,125 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the pair-sharding + tiny-collective path used at N > 1.
+The product's fused op needs a GPU, so each rank's LOCAL loss is produced by an oracle-backed stand-in with
+GDLoss's forward signature; everything around it (shard ranges, global normaliser, all_gather of per-shard
+losses, rank-ordered sum, local gradients, async join) is the product code of mmdet3d-gaussian_amd/sharded.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from mmdet3d_gaussian_amd import sharded
+
+
+class _OracleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, lt, scale):
+        r = oracle.gd_loss(pred.detach().numpy(), target.numpy(), oracle.make_params(lt),
+                           row_weight=None if weight is None else weight.numpy(), scale=scale)
+        ctx.gp = torch.from_numpy(r['grad_pred'])
+        return torch.tensor(r['loss_sum'], dtype=torch.float64)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.gp * g, None, None, None, None
+
+
+class OracleGDLoss(torch.nn.Module):
+    """GDLoss.forward signature on CPU tensors (reduction mean|sum), for the collective-path tests only."""
+
+    def __init__(self, loss_type, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.loss_type, self.reduction, self.loss_weight = loss_type, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        n = pred.shape[0]
+        den = 1.0 if self.reduction == 'sum' else (avg_factor if avg_factor is not None else n)
+        return _OracleLoss.apply(pred, target, weight, self.loss_type, self.loss_weight / den)
+
+
+def _pairs(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.stack([rng.uniform(0, 70, n), rng.uniform(-40, 40, n), rng.uniform(-3, 1, n), rng.uniform(.5, 2.5, n),
+                  rng.uniform(.5, 4.5, n), rng.uniform(.5, 2, n), rng.uniform(-3, 3, n)], -1)
+    p = t + rng.normal(0, 0.1, (n, 7))
+    return torch.from_numpy(p), torch.from_numpy(t)
+
+
+def _worker(rank, world, port, n, lt, reduction, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pred, tgt = _pairs(n, 0)
+        w = torch.linspace(0.5, 1.5, n, dtype=torch.float64)
+        lo, hi = sharded.shard_range(n, rank, world)
+        p = pred[lo:hi].clone().requires_grad_(True)
+        mod = sharded.ShardedGDLoss(OracleGDLoss(lt, reduction=reduction, loss_weight=5.0))
+        out = mod(p, tgt[lo:hi], w[lo:hi])           # total_pairs discovered with one all_reduce
+        out.backward()
+        # async path used by bench.py
+        pend = sharded.gather_shard_losses(mod.local_loss(p.detach(), tgt[lo:hi], w[lo:hi], total_pairs=n))
+        total, parts = pend.result()
+        q.put((rank, lo, hi, out.item(), p.grad.numpy(), total.item(), parts.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.parametrize('lt,reduction,n', [('gwd3d', 'mean', 1001), ('bd3d', 'sum', 64), ('kld3d', 'mean', 3)])
+def test_two_rank_sharded_loss_matches_single_process(lt, reduction, n):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, lt, reduction, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pred, tgt = _pairs(n, 0)
+    w = np.linspace(0.5, 1.5, n)
+    scale = 5.0 / n if reduction == 'mean' else 5.0
+    ref = oracle.gd_loss(pred.numpy(), tgt.numpy(), oracle.make_params(lt), row_weight=w, scale=scale)
+    assert res[0][1] == 0 and res[-1][2] == n and res[0][2] == res[1][1]        # contiguous cover
+    for rank, lo, hi, out, grad, total, parts in res:
+        assert abs(out - ref['loss_sum']) < 1e-12 * max(1, abs(ref['loss_sum']))
+        assert abs(total - ref['loss_sum']) < 1e-12 * max(1, abs(ref['loss_sum']))
+        assert parts.shape == (world,)
+        np.testing.assert_allclose(grad, ref['grad_pred'][lo:hi], rtol=1e-12, atol=1e-15)
+    # every rank holds the identical global value (rank-ordered sum)
+    assert res[0][3] == res[1][3] and res[0][5] == res[1][5]
+
+
+def test_shard_range_properties():
+    for n in (0, 1, 7, 10_000_000):
+        for world in (1, 2, 3, 8):
+            cover = [sharded.shard_range(n, r, world) for r in range(world)]
+            assert cover[0][0] == 0 and cover[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+            sizes = [hi - lo for lo, hi in cover]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharded.shard_range(10, 2, 2)
+
+
+def test_single_process_passthrough():
+    pred, tgt = _pairs(50, 1)
+    p = pred.clone().requires_grad_(True)
+    mod = sharded.ShardedGDLoss(OracleGDLoss('kld3d'))
+    out = mod(p, tgt)
+    out.backward()
+    ref = oracle.gd_loss(pred.numpy(), tgt.numpy(), oracle.make_params('kld3d'), scale=1 / 50)
+    assert abs(out.item() - ref['loss_sum']) < 1e-12
+    total, parts = sharded.gather_shard_losses(out).result()
+    assert total.item() == out.item() and parts.shape == (1,)
