@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence for the round into gpurun_out/<round>/.
+#   tools/collect_profiles.sh r01
+# kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
+# and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+set -u
+R=${1:-r01}
+export TMPDIR=/tmp
+OUT=gpurun_out/$R
+mkdir -p $OUT
+BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-sample 0"
+SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_kernel_trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SHORT > $OUT/pmc_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+  --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE \
+  --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
+python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+python3 tools/profile_summary.py $OUT $R
+ls -la $OUT
