@@ -11,8 +11,14 @@ reference's module surface (GDLoss.forward -> autograd backward).  Inputs are re
 the timed region.  value = (3 losses x pairs x steps x ranks) / max-over-ranks wall time.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), pairs sharded by rank with no
-data-path collective; each loss's per-shard value is all-gathered (one fp32 per rank) asynchronously.
-Weak scaling: every rank keeps 10 M pairs.
+data-path collective; once per step the three per-shard loss values are all-gathered (3 fp32 per rank),
+asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs.
+
+Launch mode.  N = 1 launches eagerly (the GPU, not the host, is the limit: 440 us of host work per 451 us step) so
+that every fused launch inside the timed region is bracketed by HIP events.  N > 1 replays a hipGraph of the step
+(torch.cuda.CUDAGraph; host cost 16 us/step) so that the per-step collective call does not make the host the
+limit; HIP events cannot be recorded inside a captured graph on ROCm, so there the kernel durations come from an
+eager pass run right after the timed region (`roofline.timing` says which).  `--graph` / `--no-graph` override.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
@@ -76,7 +82,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--pairs', type=int, default=10_000_000, help='pairs per GPU (default: BASELINE config 3)')
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,9 +97,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)  # torchrun, even with 1 rank
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    use_graph = (args.graph or world > 1) and not args.no_graph
 
     import mmdet3d_gaussian_amd as amd
     from mmdet3d_gaussian_amd import gd_loss as gdl
@@ -106,21 +115,41 @@ def main():
     events = {lt: [] for lt in LOSSES}
     last = {}
 
-    def step(record):
+    def compute(record):
+        """gwd3d, kld3d, bd3d: GDLoss forward + autograd backward each.  Returns the 3 detached loss scalars."""
+        outs = []
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if record else None
             pred.grad = None
             loss = mods[lt](pred, tgt)
             loss.backward()
-            if world > 1:
-                last[lt] = amd.sharded.gather_shard_losses(loss, async_op=True)
-            else:
-                last[lt] = loss.detach()
+            outs.append(loss.detach())
         gdl.PROFILE_EVENTS = None
+        return outs
+
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                compute(False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_outs = compute(False)
+
+    def step(record):
+        outs = compute(record) if graph is None else (graph.replay() or graph_outs)
+        if use_dist:  # one tiny collective per step: (3,) shard losses -> (world, 3)
+            last['pending'] = amd.sharded.gather_shard_losses(torch.stack(outs), async_op=True)
+        else:
+            last['outs'] = outs
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -129,30 +158,34 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(graph is None)
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU-bound iff this < elapsed)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = tt.item()
+    timing = 'HIP events around every fused launch inside the timed region'
+    if graph is not None:  # events cannot be recorded inside a captured graph on ROCm: eager pass right after
+        for _ in range(min(args.steps, 10)):
+            compute(True)
+        torch.cuda.synchronize(dev)
+        timing = 'HIP events around every fused launch, eager pass run right after the graph-replayed timed region'
 
     # dominant-kernel durations from the HIP events recorded inside the timed region
     kern_ms = {}
     for lt in LOSSES:
         d = [a.elapsed_time(b) for a, b in events[lt]]
         kern_ms[lt] = sum(d) / max(len(d), 1)
-    losses = {}
-    for lt in LOSSES:
-        v = last[lt]
-        if world > 1:
-            total, _ = v.result()
-            losses[lt] = total.item() / world  # mean over ranks of per-rank means (equal shard sizes)
-        else:
-            losses[lt] = v.item()
+    if use_dist:
+        total, per_rank = last['pending'].result()   # (3,), (world, 3)
+        vals = (total / world).tolist()               # mean over ranks of per-rank means (equal shard sizes)
+    else:
+        vals = [v.item() for v in last['outs']]
+    losses = dict(zip(LOSSES, vals))
 
     if rank == 0:
         total_pairs = 3 * n * args.steps * world
@@ -177,10 +210,12 @@ def main():
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward '
                                    '(fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
-                       'launch': 'eager', 'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4)},
+                       'launch': 'hipGraph replay' if graph is not None else 'eager',
+                       'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
+                       'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
-                         'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
+                         'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR, 'timing': timing,
                          'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
                          'mpairs_per_s_kernel': {k: round(n / (v * 1e-3) / 1e6, 1) if v > 0 else None
                                                  for k, v in kern_ms.items()}},
@@ -189,7 +224,7 @@ def main():
         if args.cpu_sample > 0:
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,10 @@ def _ptr(t):
 
 
 _LIB = None
+# raw-handle accessors (no Python-level device bookkeeping on the per-call path)
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_get_device = torch._C._cuda_getDevice
+_set_device = torch._C._cuda_setDevice
 
 
 def _library():
@@ -82,10 +86,10 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
     lib = _library()
     n = pred.shape[0]
     dev = pred.device
-    switch = torch.cuda.current_device() != dev.index
+    prev = _get_device()
+    switch = prev != dev.index
     if switch:
-        prev = torch.cuda.current_device()
-        torch.cuda.set_device(dev)
+        _set_device(dev.index)
     try:
         loss = torch.empty(n, dtype=torch.float32, device=dev) if want_loss else None
         gp = torch.empty_like(pred) if want_gp else None
@@ -96,7 +100,7 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
             buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(n) // 4, dtype=torch.float32, device=dev)
             total, ws = buf[0], buf[4:]
         ev = PROFILE_EVENTS
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _raw_stream(dev.index)
         if ev is None:
             rc = lib.gd3d_loss_fused(params, _ptr(pred), _ptr(target), _ptr(row_weight), n, scale,
                                      _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
@@ -111,7 +115,7 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
                 rc = lib.gd3d_loss_reduce(_ptr(ws), n, _ptr(total), stream)
     finally:
         if switch:
-            torch.cuda.set_device(prev)
+            _set_device(prev)
     if rc != 0:
         _lib.check(rc, 'gd3d_loss_fused')
     return loss, total, gp, gt
@@ -143,12 +147,12 @@ class _GDReduced(torch.autograd.Function):
             ctx.used = True
         g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         dev = pred.device
-        switch = torch.cuda.current_device() != dev.index
+        prev = _get_device()
+        switch = prev != dev.index
         if switch:
-            prev = torch.cuda.current_device()
-            torch.cuda.set_device(dev)
+            _set_device(dev.index)
         try:
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream(dev.index)
             for buf in (gp, gt):
                 if buf is not None:
                     # reads g on the device, exits without touching memory when g == 1 (no host sync)
@@ -157,7 +161,7 @@ class _GDReduced(torch.autograd.Function):
                         _lib.check(rc, 'gd3d_scale_rows')
         finally:
             if switch:
-                torch.cuda.set_device(prev)
+                _set_device(prev)
         return gp, gt, None, None, None
 
 

@@ -62,11 +62,12 @@ class PendingGather:
 
 
 def gather_shard_losses(local_loss, group=None, async_op=True):
-    """Start the all_gather of the per-shard (detached) loss scalars.  Returns a PendingGather."""
+    """Start the all_gather of this rank's (detached) shard loss — a scalar, or a small vector when several losses
+    share one collective.  Returns a PendingGather whose result() is (sum over ranks, per-rank stack)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return PendingGather([local_loss.detach().reshape(())], None)
+        return PendingGather([local_loss.detach().clone()], None)
     world = dist.get_world_size(group)
-    local = local_loss.detach().reshape(()).contiguous()
+    local = local_loss.detach().contiguous()
     parts = [torch.empty_like(local) for _ in range(world)]
     work = dist.all_gather(parts, local, group=group, async_op=async_op)
     return PendingGather(parts, work if async_op else None)
