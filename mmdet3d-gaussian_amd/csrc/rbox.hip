@@ -93,56 +93,84 @@ __global__ __launch_bounds__(NMS_T) void nms_mask_kernel(const OBox* __restrict_
   }
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int cb,
-                                                      long long* __restrict__ keep, long long* __restrict__ num_keep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];
-  const int lane = threadIdx.x;
-  for (int w = lane; w < cb; w += 64) remv[w] = 0ull;
+constexpr int SCAN_T = 256;
+__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int cb,
+                                                          long long* __restrict__ keep, long long* __restrict__ num_keep) {
+  // One workgroup of 4 waves walks the 64-box blocks in order.
+  //   resolve  (wave 0): the block's diagonal mask word per lane; a scalar loop visits only the boxes that are still
+  //            alive (s_ff1 over the complement of the removed word), v_readlane fetches the kept box's word.
+  //   propagate (all waves): the mask rows of the boxes just kept are OR-ed into the LDS-resident removed-set;
+  //            wave v takes every 4th kept row, 8 independent 8-byte loads in flight per lane, ds_or_b64 to merge.
+  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cb words
+  __shared__ unsigned long long skept;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int w = tid; w < cb; w += SCAN_T) remv[w] = 0ull;
   __syncthreads();
   int count = 0;
   for (int c = 0; c < cb; ++c) {
-    const int i = c * 64 + lane;
-    const unsigned long long diag = (i < n) ? mask[(size_t)i * cb + c] : 0ull;
-    const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-    unsigned long long cur = remv[c];
-    // (the builtin returns a signed int: go through unsigned before widening)
-    cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
-          (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
-    const int nvalid = min(64, n - c * 64);
-    unsigned long long kept = 0ull;
-    for (int l = 0; l < nvalid; ++l) {  // scalar, wave-uniform
-      const unsigned long long dl = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
-                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
-      if (!((cur >> l) & 1ull)) {
+    if (wave == 0) {
+      const int i = c * 64 + lane;
+      const unsigned long long diag = (i < n) ? mask[(size_t)i * cb + c] : 0ull;
+      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+      unsigned long long cur = remv[c];
+      // (the builtin returns a signed int: go through unsigned before widening)
+      cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
+      const int nvalid = min(64, n - c * 64);
+      if (nvalid < 64) cur |= ~0ull << nvalid;
+      unsigned long long kept = 0ull;
+      unsigned long long cand = ~cur;
+      while (cand) {  // scalar, wave-uniform: one iteration per KEPT box
+        const int l = __builtin_ctzll(cand);
+        const unsigned long long dl =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
         kept |= 1ull << l;
-        cur |= dl;
+        cur |= dl;                        // dl only has bits above l
+        cand = (cand & (cand - 1)) & ~cur;
       }
+      if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
+      if (lane == 0) skept = kept;
     }
-    // OR the mask rows of the boxes just kept into the removed-set words that follow
-    for (int w0 = c + 1; w0 < cb; w0 += 64) {
-      const int w = w0 + lane;
-      const bool act = w < cb;
-      unsigned long long acc = 0ull;
-      unsigned long long kb = kept;
-      while (kb) {  // up to 4 independent row loads in flight per step
-        int l[4];
+    __syncthreads();
+    unsigned long long kb = skept;
+    kb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kb >> 32)) << 32) |
+         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)kb);
+    count += __builtin_popcountll(kb);
+    if (c + 1 < cb && kb) {
+      // drop the kept rows this wave does not own: keep bit #k of kb iff k % 4 == wave
+      unsigned long long mine = 0ull, t = kb;
+      int k = 0;
+      while (t) {
+        const unsigned long long low = t & (~t + 1ull);
+        if ((k & 3) == wave) mine |= low;
+        t ^= low;
+        ++k;
+      }
+      for (int w0 = c + 1; w0 < cb; w0 += 64) {
+        const int w = w0 + lane;
+        const bool act = w < cb;
+        unsigned long long acc = 0ull;
+        unsigned long long mb = mine;
+        while (mb) {
+          int l[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          l[u] = kb ? __builtin_ctzll(kb) : -1;
-          kb = kb ? (kb & (kb - 1)) : 0ull;
+          for (int u = 0; u < 8; ++u) {
+            l[u] = mb ? __builtin_ctzll(mb) : -1;
+            mb = mb ? (mb & (mb - 1)) : 0ull;
+          }
+          unsigned long long v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(c * 64 + l[u]) * cb + w] : 0ull;
+          acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
         }
-        unsigned long long v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(c * 64 + l[u]) * cb + w] : 0ull;
-        acc |= (v[0] | v[1]) | (v[2] | v[3]);
+        if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: four waves merge into the same words
       }
-      if (act) remv[w] |= acc;
     }
-    if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
-    count += __builtin_popcountll(kept);
     __syncthreads();
   }
-  if (lane == 0) *num_keep = count;
+  if (tid == 0) *num_keep = count;
 }
 
 // pairwise IoU matrices ------------------------------------------------------------------
@@ -246,7 +274,7 @@ static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, i
   else
     hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(NMS_T), 0, s, (const OBox*)ob, boxes, ni, cb, thresh,
                        mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)cb * sizeof(unsigned long long), s,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_T), (size_t)cb * sizeof(unsigned long long), s,
                      (const unsigned long long*)mask, ni, cb, (long long*)keep, (long long*)num_keep);
   return (int)hipGetLastError();
 }
