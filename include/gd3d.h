@@ -89,6 +89,15 @@ int gd3d_loss_fused(const gd3d_params* params, const float* pred, const float* t
                     float* loss_sum, float* grad_pred, float* grad_target, void* workspace,
                     void* stream);
 
+/* Same, with the per-row weight given as an (n,7) fp32 array whose row mean is taken inside the kernel:
+ *   w_i = mean(weight7[i,:])   (GDLoss.forward: `if weight.shape == pred.shape: weight = weight.mean(dim=-1)`,
+ * gaussian_distance_loss.py:295-296; the heads pass decode_weight of shape (P,7), gd_anchor3d_head.py:129-141).
+ * Saves the separate mean pass.  row_weight and weight7 are mutually exclusive (GD3D_E_BADARG if both). */
+int gd3d_loss_fused_w7(const gd3d_params* params, const float* pred, const float* target,
+                       const float* row_weight, const float* weight7, int64_t n, float scale,
+                       float* loss, float* loss_sum, float* grad_pred, float* grad_target,
+                       void* workspace, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

@@ -23,6 +23,7 @@ _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ct
 SYMBOLS = {
     'gd3d_loss_workspace_bytes': (_sz, [_i64]),
     'gd3d_loss_fused': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_loss_fused_w7': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),

@@ -53,14 +53,19 @@ GD_DEV void store_v4(float* dst, const float* src_lds, int idx) {
 
 // 14 LDS-DMA pieces of 1 KiB bring one 256-pair tile of pred and target into LDS; wave w issues
 // pieces w, w+4, w+8, w+12.
-GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, float* st, int wave, int lane) {
+// (an optional third tile, the (256,7) weights, adds pieces 14..20)
+GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, float* st, int wave, int lane,
+                           const float* gw7, float* sw7) {
 #pragma unroll
-  for (int j0 = 0; j0 < 16; j0 += 4) {
+  for (int j0 = 0; j0 < 24; j0 += 4) {
     const int j = j0 + wave;  // wave-uniform
     if (j < 7) {
       __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gpred + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, DMA_AUX);
     } else if (j < 14) {
       __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - 7) * 256 + lane * 4), (lds_ptr_t*)(st + (j - 7) * 256), 16, 0,
+                                       DMA_AUX);
+    } else if (j < 21 && gw7 != nullptr) {
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gw7 + (j - 14) * 256 + lane * 4), (lds_ptr_t*)(sw7 + (j - 14) * 256), 16, 0,
                                        DMA_AUX);
     }
   }
@@ -69,7 +74,8 @@ GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, 
 struct LossArgs {
   const float* pred;
   const float* target;
-  const float* w;    // nullable
+  const float* w;    // nullable: (N,) row weights
+  const float* w7;   // nullable: (N,7) weights, row mean taken in the kernel (GDLoss.forward :295-296)
   float* loss;       // nullable
   float* gp;         // nullable
   float* gt;         // nullable (only read when the kernel is instantiated with GT)
@@ -101,6 +107,7 @@ template <int LOSS, int FUN, bool FLAG, bool GT>
 __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   __shared__ __attribute__((aligned(16))) float sp[TILE_F];
   __shared__ __attribute__((aligned(16))) float st[TILE_F];
+  __shared__ __attribute__((aligned(16))) float sw7[TILE_F];
   __shared__ float swave[TILE / 64];
 
   const int tid = threadIdx.x;
@@ -117,16 +124,25 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   float wi = 1.0f;
   if (a.w != nullptr && valid) wi = a.w[base + tid];
 
+  const float* gw7 = a.w7 != nullptr ? a.w7 + base * 7 : nullptr;
   if (fast) {
-    issue_tile_dma(gpred, gtarget, sp, st, wave, lane);
+    issue_tile_dma(gpred, gtarget, sp, st, wave, lane, gw7, sw7);
   } else {
     const long long fl = (rows_left < TILE ? rows_left : TILE) * 7;
     for (int i = tid; i < TILE_F; i += TILE) {
       sp[i] = i < fl ? gpred[i] : 1.0f;
       st[i] = i < fl ? gtarget[i] : 1.0f;
+      if (gw7 != nullptr) sw7[i] = i < fl ? gw7[i] : 0.0f;
     }
   }
   __syncthreads();  // s_waitcnt vmcnt(0) + barrier: every wave's pieces have landed
+
+  if (a.w7 != nullptr) {  // weight.mean(dim=-1): sum of the 7 entries in index order, then / 7
+    float sum = sw7[tid * 7];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) sum += sw7[tid * 7 + k];
+    wi = sum / 7.0f;
+  }
 
   float pv[7], tv[7];
 #pragma unroll
@@ -282,6 +298,14 @@ size_t gd3d_loss_workspace_bytes(int64_t n) {
 int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
                     int64_t n, float scale, float* loss, float* loss_sum, float* grad_pred, float* grad_target,
                     void* workspace, void* stream) {
+  return gd3d_loss_fused_w7(p, pred, target, row_weight, nullptr, n, scale, loss, loss_sum, grad_pred, grad_target,
+                            workspace, stream);
+}
+
+int gd3d_loss_fused_w7(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
+                       const float* weight7, int64_t n, float scale, float* loss, float* loss_sum, float* grad_pred,
+                       float* grad_target, void* workspace, void* stream) {
+  if (row_weight != nullptr && weight7 != nullptr) return GD3D_E_BADARG;
   if (p == nullptr || n < 0) return GD3D_E_BADARG;
   if (n > 0 && (pred == nullptr || target == nullptr)) return GD3D_E_BADARG;
   if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
@@ -306,6 +330,7 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
   a.pred = pred;
   a.target = target;
   a.w = row_weight;
+  a.w7 = weight7;
   a.loss = loss;
   a.gp = grad_pred;
   a.gt = grad_target;
@@ -317,7 +342,8 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];
   a.c2 = p->center_offset[2];
-  const uintptr_t bits = (uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad_pred | (uintptr_t)grad_target;
+  const uintptr_t bits = (uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad_pred | (uintptr_t)grad_target |
+                         (uintptr_t)weight7;
   a.vec_ok = (bits & 15) == 0;
   const bool gt = grad_target != nullptr;
   const bool flag = p->flag != 0;

@@ -101,14 +101,20 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
             total, ws = buf[0], buf[4:]
         ev = PROFILE_EVENTS
         stream = _raw_stream(dev.index)
+        w1 = w7 = None
+        if row_weight is not None:  # (N,) row weights, or (N,7) whose row mean the kernel takes itself
+            if row_weight.dim() == 2:
+                w7 = row_weight.data_ptr()
+            else:
+                w1 = row_weight.data_ptr()
         if ev is None:
-            rc = lib.gd3d_loss_fused(params, _ptr(pred), _ptr(target), _ptr(row_weight), n, scale,
-                                     _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
+            rc = lib.gd3d_loss_fused_w7(params, _ptr(pred), _ptr(target), w1, w7, n, scale,
+                                        _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
         else:  # profiling: HIP events around the fused kernel alone; the reduce stage is launched separately
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = lib.gd3d_loss_fused(params, _ptr(pred), _ptr(target), _ptr(row_weight), n, scale,
-                                     _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
+            rc = lib.gd3d_loss_fused_w7(params, _ptr(pred), _ptr(target), w1, w7, n, scale,
+                                        _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
             e1.record()
             ev.append((e0, e1))
             if rc == 0 and want_sum:
@@ -180,7 +186,7 @@ class _GDPerPair(torch.autograd.Function):
         pred, target, row_weight, params, scale = ctx.replay
         rw = grad_out.reshape(-1).to(torch.float32)
         if row_weight is not None:
-            rw = rw * row_weight
+            rw = rw * (row_weight.mean(dim=-1) if row_weight.dim() == 2 else row_weight)
         rw = rw.contiguous()
         _, _, gp, gt = fused_call(params, pred, target, rw, scale, False, False, ctx.needs_input_grad[0],
                                   ctx.needs_input_grad[1])
@@ -233,8 +239,8 @@ class GDLoss(nn.Module):
         if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
             return (pred * weight).sum()  # ref :290-292 (keeps the graph; raises for an (N,) weight, as there)
         params = self._params(kwargs)
-        if weight is not None and weight.shape == pred.shape:
-            weight = weight.mean(dim=-1)
+        # ref :295-296 `weight.mean(dim=-1)` for an (N,7) weight: done inside the kernel (gd3d_loss_fused_w7)
+        weight7 = weight is not None and weight.shape == pred.shape
 
         out_dtype = pred.dtype
         p = _rows(pred)
@@ -244,9 +250,10 @@ class GDLoss(nn.Module):
         n = p.shape[0]
         w = None
         if weight is not None:
-            w = weight.reshape(-1).to(device=p.device, dtype=torch.float32).contiguous()
-            if w.numel() != n:
-                raise RuntimeError(f'weight has {w.numel()} elements for {n} boxes')
+            w = weight.reshape(-1, 7) if weight7 else weight.reshape(-1)
+            w = w.to(device=p.device, dtype=torch.float32).contiguous()
+            if w.shape[0] != n:
+                raise RuntimeError(f'weight has {w.shape[0]} rows for {n} boxes')
 
         # mmdet weight_reduce_loss folded into one scalar for the kernel
         post_div = None
