@@ -98,6 +98,38 @@ int gd3d_loss_fused_w7(const gd3d_params* params, const float* pred, const float
                        float* loss, float* loss_sum, float* grad_pred, float* grad_target,
                        void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Head-level fusion: the bbox-coder decode that the dense heads run
+ * immediately before GDLoss is applied inside the kernel prologue, and the gradient is chained back
+ * to the ENCODED prediction, so `pred`/`grad_pred` are the raw head outputs of the positives.
+ *   kind = GD3D_PRO_ANCHOR_DELTA: mmdet3d DeltaXYZWLHRBBoxCoder.decode(anchors, deltas) applied to BOTH
+ *          pred and target (gd_anchor3d_head.py:133-136).  aux = anchors (n,7) [xa,ya,za,wa,la,ha,ra]:
+ *            diag = sqrt(la^2+wa^2); x = xt*diag+xa; y = yt*diag+ya; w = exp(wt)*wa; l = exp(lt)*la;
+ *            h = exp(ht)*ha; z = zt*ha + (za + ha/2) - h/2; r = rt + ra
+ *   kind = GD3D_PRO_CENTER: CenterPointBBoxYawCoder.decode(locs, pred, correct_yaw=False)[..., :7] applied to
+ *          pred only (core/bbox/coders/centerpoint_bbox_yaw_coders.py:32-42, gd_centerpoint_head.py:422-423);
+ *          target rows are the annotated boxes as they are.  aux = locs (n,2) fp32 grid coordinates:
+ *            x = (p0 + loc0) * out_size_factor * voxel_size[0] + pc_range[0]; y likewise; z = p2;
+ *            dims = exp(p3..p5) if norm_bbox else p3..p5; yaw = p6
+ * ---------------------------------------------------------------------------------- */
+enum { GD3D_PRO_NONE = 0, GD3D_PRO_ANCHOR_DELTA = 1, GD3D_PRO_CENTER = 2 };
+
+typedef struct gd3d_prologue {
+  int32_t kind;           /* GD3D_PRO_* */
+  int32_t norm_bbox;      /* GD3D_PRO_CENTER: dims are predicted as logs */
+  const float* aux;       /* anchors (n,7) or locs (n,2), device memory */
+  float out_size_factor;  /* GD3D_PRO_CENTER */
+  float voxel_size[2];
+  float pc_range[2];
+  float reserved;
+} gd3d_prologue;
+
+int gd3d_loss_fused_decoded(const gd3d_params* params, const gd3d_prologue* prologue,
+                            const float* pred, const float* target, const float* row_weight,
+                            const float* weight7, int64_t n, float scale, float* loss,
+                            float* loss_sum, float* grad_pred, float* grad_target,
+                            void* workspace, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

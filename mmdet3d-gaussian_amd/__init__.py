@@ -6,6 +6,8 @@ Exposes the reference's call surface for the one path this package accelerates:
   * ``nms_gpu`` & friends      — the mmdet3d iou3d ops the reference imports (gd_centerpoint_head.py:9)
   * ``iou_bev`` / ``iou_3d``   — GPU counterparts of ops/eval/affinity.cpp
   * ``sharded``                — pair-sharded multi-GPU evaluation (one process per GPU, RCCL)
+  * ``coders`` / ``head_loss`` — the bbox coders either side of the loss and the two head-level loss slices with the
+                                 decode fused into the kernel (gd_anchor3d_head.py:95-141, gd_centerpoint_head.py:413-434)
 All arithmetic runs in hand-written HIP kernels reached through the C ABI of include/gd3d.h
 (libgd3d.so, built in-tree by ``build.py``).  There is no CPU fallback.
 """
@@ -15,6 +17,8 @@ from .gd_loss import GDLoss, make_params
 from .iou3d import boxes_iou_bev, iou_3d, iou_bev, nms_gpu, nms_normal_gpu, xywhr2xyxyr
 from .registry import LOSSES, Registry, build_loss
 from . import sharded
+from .coders import CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
+from .head_loss import anchor_decoded_gd_loss, anchor_head_decoded_loss, center_head_gd_loss
 
 
 def build(force=False, verbose=False):
@@ -23,4 +27,6 @@ def build(force=False, verbose=False):
 
 
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu',
-           'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path']
+           'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
+           'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
+           'center_head_gd_loss']

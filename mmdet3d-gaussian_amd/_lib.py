@@ -18,12 +18,21 @@ class Params(ctypes.Structure):
                 ('center_offset', ctypes.c_float * 3), ('flag', ctypes.c_int32)]
 
 
+class Prologue(ctypes.Structure):
+    """gd3d_prologue (include/gd3d.h)."""
+    _fields_ = [('kind', ctypes.c_int32), ('norm_bbox', ctypes.c_int32), ('aux', ctypes.c_void_p),
+                ('out_size_factor', ctypes.c_float), ('voxel_size', ctypes.c_float * 2),
+                ('pc_range', ctypes.c_float * 2), ('reserved', ctypes.c_float)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
     'gd3d_loss_workspace_bytes': (_sz, [_i64]),
     'gd3d_loss_fused': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_fused_w7': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_loss_fused_decoded': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32,
+                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),

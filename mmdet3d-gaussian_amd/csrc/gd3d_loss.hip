@@ -84,7 +84,53 @@ struct LossArgs {
   float scale, alpha, tau;
   float c0, c1, c2;
   int vec_ok;        // all (N,7) pointers 16-byte aligned
+  // bbox-coder decode fused into the prologue (include/gd3d.h gd3d_prologue)
+  int pro;
+  int norm_bbox;
+  const float* aux;
+  float osf, vs0, vs1, pc0, pc1;
 };
+
+// Decode the encoded rows in registers and remember what the chain rule needs.
+//   ANCHOR_DELTA: j = (diag, diag, ha, w, l, h, 1) with the z/h cross term handled in encode_grad()
+struct DecodeJac {
+  float j[7];
+};
+
+GD_DEV void decode_anchor(const float (&enc)[7], const float (&an)[7], float (&dec)[7], DecodeJac& J) {
+  const float diag = fsqrt(fmaf(an[4], an[4], an[3] * an[3]));
+  const float w = expf(enc[3]) * an[3], l = expf(enc[4]) * an[4], h = expf(enc[5]) * an[5];
+  dec[0] = fmaf(enc[0], diag, an[0]);
+  dec[1] = fmaf(enc[1], diag, an[1]);
+  dec[2] = fmaf(enc[2], an[5], an[2] + an[5] * 0.5f) - h * 0.5f;
+  dec[3] = w;
+  dec[4] = l;
+  dec[5] = h;
+  dec[6] = enc[6] + an[6];
+  J.j[0] = diag; J.j[1] = diag; J.j[2] = an[5]; J.j[3] = w; J.j[4] = l; J.j[5] = h; J.j[6] = 1.0f;
+}
+
+GD_DEV void decode_center(const float (&enc)[7], float loc0, float loc1, const LossArgs& a, float (&dec)[7],
+                          DecodeJac& J) {
+  dec[0] = (enc[0] + loc0) * a.osf * a.vs0 + a.pc0;
+  dec[1] = (enc[1] + loc1) * a.osf * a.vs1 + a.pc1;
+  dec[2] = enc[2];
+#pragma unroll
+  for (int k = 3; k < 6; ++k) {
+    dec[k] = a.norm_bbox ? expf(enc[k]) : enc[k];
+    J.j[k] = a.norm_bbox ? dec[k] : 1.0f;
+  }
+  dec[6] = enc[6];
+  J.j[0] = a.osf * a.vs0; J.j[1] = a.osf * a.vs1; J.j[2] = 1.0f; J.j[6] = 1.0f;
+}
+
+// gradient wrt the decoded row -> gradient wrt the encoded row (in place)
+GD_DEV void encode_grad(float (&g)[7], const DecodeJac& J, bool anchor_kind) {
+  const float gz = g[2];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) g[k] *= J.j[k];
+  if (anchor_kind) g[5] = fmaf(-0.5f * gz, J.j[5], g[5]);  // z = ... - h/2 with h = exp(ht)*ha
+}
 
 // wave64 sum with DPP adds (no LDS crossbar): inclusive scan inside each 16-lane row (row_shr 1,2,4,8 with
 // zero fill), then row_bcast:15 / row_bcast:31 carry the row totals; lane 63 holds the total.  Fixed order.
@@ -105,10 +151,13 @@ GD_DEV float wave_sum(float v) {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
-  __shared__ __attribute__((aligned(16))) float sp[TILE_F];
-  __shared__ __attribute__((aligned(16))) float st[TILE_F];
-  __shared__ __attribute__((aligned(16))) float sw7[TILE_F];
-  __shared__ float swave[TILE / 64];
+  // dynamic LDS (16-byte aligned base, every carve offset a multiple of 16): two tiles + 4 wave sums, plus a
+  // third tile only when (N,7) weights are given, so that the common launch keeps 8 workgroups per CU
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const sp = smem;
+  float* const st = smem + TILE_F;
+  float* const swave = smem + 2 * TILE_F;
+  float* const sw7 = smem + 2 * TILE_F + 4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -153,8 +202,36 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   const float c[3] = {a.c0, a.c1, a.c2};
   const float f = a.scale * wi;
   float g1[7], g2[7];
+  DecodeJac Jp, Jt;
+  if (a.pro != GD3D_PRO_NONE) {  // workgroup-uniform; head-level calls are small (P <~ 1e4), aux is read directly
+    if (a.pro == GD3D_PRO_ANCHOR_DELTA) {
+      float an[7], dp[7], dt[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) an[k] = valid ? a.aux[(base + tid) * 7 + k] : 1.0f;
+      decode_anchor(pv, an, dp, Jp);
+      decode_anchor(tv, an, dt, Jt);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        pv[k] = dp[k];
+        tv[k] = dt[k];
+      }
+    } else {
+      float dp[7];
+      const float l0 = valid ? a.aux[(base + tid) * 2] : 0.0f, l1 = valid ? a.aux[(base + tid) * 2 + 1] : 0.0f;
+      decode_center(pv, l0, l1, a, dp, Jp);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        pv[k] = dp[k];
+        Jt.j[k] = 1.0f;
+      }
+    }
+  }
   const float L = pair_loss<LOSS, FUN, FLAG, GT>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
   const float fl = valid ? f * L : 0.0f;
+  if (a.pro != GD3D_PRO_NONE) {
+    encode_grad(g1, Jp, a.pro == GD3D_PRO_ANCHOR_DELTA);
+    if (GT) encode_grad(g2, Jt, a.pro == GD3D_PRO_ANCHOR_DELTA);
+  }
 
   if (a.loss != nullptr && valid) a.loss[base + tid] = fl;
 
@@ -253,7 +330,8 @@ struct Geometry {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
-  hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), 0, s, a);
+  const size_t lds = (size_t)(2 * TILE_F + 4 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+  hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), lds, s, a);
 }
 
 template <int LOSS, int FUN>
@@ -305,7 +383,18 @@ int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target
 int gd3d_loss_fused_w7(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
                        const float* weight7, int64_t n, float scale, float* loss, float* loss_sum, float* grad_pred,
                        float* grad_target, void* workspace, void* stream) {
+  return gd3d_loss_fused_decoded(p, nullptr, pred, target, row_weight, weight7, n, scale, loss, loss_sum, grad_pred,
+                                 grad_target, workspace, stream);
+}
+
+int gd3d_loss_fused_decoded(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
+                            const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
+                            float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream) {
   if (row_weight != nullptr && weight7 != nullptr) return GD3D_E_BADARG;
+  if (pro != nullptr && pro->kind != GD3D_PRO_NONE) {
+    if (pro->kind != GD3D_PRO_ANCHOR_DELTA && pro->kind != GD3D_PRO_CENTER) return GD3D_E_BADARG;
+    if (n > 0 && pro->aux == nullptr) return GD3D_E_BADARG;
+  }
   if (p == nullptr || n < 0) return GD3D_E_BADARG;
   if (n > 0 && (pred == nullptr || target == nullptr)) return GD3D_E_BADARG;
   if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
@@ -342,6 +431,14 @@ int gd3d_loss_fused_w7(const gd3d_params* p, const float* pred, const float* tar
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];
   a.c2 = p->center_offset[2];
+  a.pro = (pro != nullptr) ? pro->kind : GD3D_PRO_NONE;
+  a.norm_bbox = (pro != nullptr) ? pro->norm_bbox : 0;
+  a.aux = (pro != nullptr) ? pro->aux : nullptr;
+  a.osf = (pro != nullptr) ? pro->out_size_factor : 1.0f;
+  a.vs0 = (pro != nullptr) ? pro->voxel_size[0] : 1.0f;
+  a.vs1 = (pro != nullptr) ? pro->voxel_size[1] : 1.0f;
+  a.pc0 = (pro != nullptr) ? pro->pc_range[0] : 0.0f;
+  a.pc1 = (pro != nullptr) ? pro->pc_range[1] : 0.0f;
   const uintptr_t bits = (uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad_pred | (uintptr_t)grad_target |
                          (uintptr_t)weight7;
   a.vec_ok = (bits & 15) == 0;

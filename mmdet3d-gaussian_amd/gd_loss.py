@@ -80,8 +80,9 @@ def _rows(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt):
-    """One launch of gd3d_loss_fused on the current stream of pred's device.
+def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None):
+    """One launch of gd3d_loss_fused(_decoded) on the current stream of pred's device.
+    `prologue`: None or a _lib.Prologue (bbox-coder decode fused into the kernel, head_loss.py).
     Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None)."""
     lib = _library()
     n = pred.shape[0]
@@ -108,13 +109,13 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
             else:
                 w1 = row_weight.data_ptr()
         if ev is None:
-            rc = lib.gd3d_loss_fused_w7(params, _ptr(pred), _ptr(target), w1, w7, n, scale,
-                                        _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
+            rc = lib.gd3d_loss_fused_decoded(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
+                                             _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
         else:  # profiling: HIP events around the fused kernel alone; the reduce stage is launched separately
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = lib.gd3d_loss_fused_w7(params, _ptr(pred), _ptr(target), w1, w7, n, scale,
-                                        _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
+            rc = lib.gd3d_loss_fused_decoded(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
+                                             _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
             e1.record()
             ev.append((e0, e1))
             if rc == 0 and want_sum:
@@ -131,12 +132,12 @@ class _GDReduced(torch.autograd.Function):
     """scale * sum_i w_i L_i  with the final gradients produced by the SAME launch."""
 
     @staticmethod
-    def forward(ctx, pred, target, row_weight, params, scale):
+    def forward(ctx, pred, target, row_weight, params, scale, prologue=None):
         need_gp, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        _, total, gp, gt = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt)
+        _, total, gp, gt = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt, prologue)
         ctx.gp, ctx.gt = gp, gt
         ctx.used = False
-        ctx.replay = (pred, target, row_weight, params, scale)
+        ctx.replay = (pred, target, row_weight, params, scale, prologue)
         return total
 
     @staticmethod
@@ -145,9 +146,9 @@ class _GDReduced(torch.autograd.Function):
         lib = _library()
         pred = ctx.replay[0]
         if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
-            r_pred, r_target, r_w, r_params, r_scale = ctx.replay
+            r_pred, r_target, r_w, r_params, r_scale, r_pro = ctx.replay
             _, _, gp, gt = fused_call(r_params, r_pred, r_target, r_w, r_scale, False, False, ctx.gp is not None,
-                                      ctx.gt is not None)
+                                      ctx.gt is not None, r_pro)
         else:
             gp, gt = ctx.gp, ctx.gt
             ctx.used = True
@@ -168,29 +169,29 @@ class _GDReduced(torch.autograd.Function):
         finally:
             if switch:
                 _set_device(prev)
-        return gp, gt, None, None, None
+        return gp, gt, None, None, None, None
 
 
 class _GDPerPair(torch.autograd.Function):
     """(scale * w_i * L_i)_i ; backward re-runs the fused kernel with the upstream row gradient folded in."""
 
     @staticmethod
-    def forward(ctx, pred, target, row_weight, params, scale):
-        loss, _, _, _ = fused_call(params, pred, target, row_weight, scale, True, False, False, False)
-        ctx.replay = (pred, target, row_weight, params, scale)
+    def forward(ctx, pred, target, row_weight, params, scale, prologue=None):
+        loss, _, _, _ = fused_call(params, pred, target, row_weight, scale, True, False, False, False, prologue)
+        ctx.replay = (pred, target, row_weight, params, scale, prologue)
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
-        pred, target, row_weight, params, scale = ctx.replay
+        pred, target, row_weight, params, scale, prologue = ctx.replay
         rw = grad_out.reshape(-1).to(torch.float32)
         if row_weight is not None:
             rw = rw * (row_weight.mean(dim=-1) if row_weight.dim() == 2 else row_weight)
         rw = rw.contiguous()
         _, _, gp, gt = fused_call(params, pred, target, rw, scale, False, False, ctx.needs_input_grad[0],
-                                  ctx.needs_input_grad[1])
-        return gp, gt, None, None, None
+                                  ctx.needs_input_grad[1], prologue)
+        return gp, gt, None, None, None, None
 
 
 @LOSSES.register_module()
@@ -234,6 +235,9 @@ class GDLoss(nn.Module):
         return self._params_cache[1]
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        # `_prologue` is internal (head_loss.py): a bbox-coder decode fused into the kernel; `pred` (and `target`
+        # for the anchor coder) are then the ENCODED rows and the returned gradient is wrt them.
+        prologue = kwargs.pop('_prologue', None)
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
@@ -270,9 +274,9 @@ class GDLoss(nn.Module):
             raise ValueError('avg_factor can not be used with reduction="sum"')
 
         if reduction == 'none':
-            out = _GDPerPair.apply(p, t, w, params, float(scale))
+            out = _GDPerPair.apply(p, t, w, params, float(scale), prologue)
         else:
-            out = _GDReduced.apply(p, t, w, params, float(scale))
+            out = _GDReduced.apply(p, t, w, params, float(scale), prologue)
             if post_div is not None:
                 out = out / post_div
             if n == 0 and reduction == 'mean' and avg_factor is None:

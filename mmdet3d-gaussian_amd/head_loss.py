@@ -1,0 +1,77 @@
+"""Head-level slices of the two dense heads that call GDLoss, with the bbox-coder decode fused into the kernel
+(SURVEY.md §8f-1/f-2).  Each function restates the reference lines it replaces and keeps their argument meaning.
+
+* ``anchor_head_decoded_loss``  — GDAnchor3DHead.loss_single, the decoded-box branch
+  (/root/reference/mmdet3d_gaussian/models/dense_heads/gd_anchor3d_head.py:95-141).
+* ``center_head_gd_loss``       — CenterGDHead.loss, the `loss_gd` branch per task
+  (/root/reference/mmdet3d_gaussian/models/dense_heads/gd_centerpoint_head.py:413-434).
+Gather of the positives stays in torch (index kernels); decode x2 + loss + all their backward nodes are one launch.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _prologue(kind, aux, norm_bbox=False, out_size_factor=1.0, voxel_size=(1.0, 1.0), pc_range=(0.0, 0.0)):
+    p = _lib.Prologue()
+    p.kind = kind
+    p.norm_bbox = int(bool(norm_bbox))
+    p.aux = aux.data_ptr()
+    p.out_size_factor = float(out_size_factor)
+    p.voxel_size = (ctypes.c_float * 2)(float(voxel_size[0]), float(voxel_size[1]))
+    p.pc_range = (ctypes.c_float * 2)(float(pc_range[0]), float(pc_range[1]))
+    p._keepalive = aux  # the struct only holds a raw pointer
+    return p
+
+
+def anchor_decoded_gd_loss(loss_module, anchors, pos_bbox_pred, pos_bbox_targets, weight=None, avg_factor=None):
+    """loss_module(coder.decode(anchors, pos_bbox_pred), coder.decode(anchors, pos_bbox_targets), weight,
+    avg_factor=avg_factor) with mmdet3d's DeltaXYZWLHRBBoxCoder, in one launch (gd_anchor3d_head.py:133-141)."""
+    anchors = anchors.reshape(-1, 7).to(torch.float32).contiguous()
+    pro = _prologue(1, anchors)
+    return loss_module(pos_bbox_pred, pos_bbox_targets, weight, avg_factor=avg_factor, _prologue=pro)
+
+
+def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list, num_classes,
+                             num_total_samples, decode_weight=None, box_code_size=7):
+    """The decoded-box part of GDAnchor3DHead.loss_single (gd_anchor3d_head.py:95-141).
+
+    bbox_pred: (B, A*code, H, W) head output; bbox_targets / bbox_weights: (B, H*W*A, code); labels: (B, H*W*A);
+    anchor_list: (H*W*A, code) anchors of one sample (repeated over the batch as the reference does, :110-112).
+    decode_weight: train_cfg['decode_weight'] (list of `code` floats) or None.
+    Returns loss_bbox of the decoded branch (`pos_bbox_pred.sum()` when there are no positives, :160-161)."""
+    mini_batch = bbox_pred.shape[0]
+    bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, box_code_size)
+    bbox_targets = bbox_targets.reshape(-1, box_code_size)
+    bbox_weights = bbox_weights.reshape(-1, box_code_size)
+    labels = labels.reshape(-1)
+    pos_inds = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1)
+    pos_bbox_pred = bbox_pred[pos_inds]
+    if len(pos_inds) == 0:
+        return pos_bbox_pred.sum()
+    pos_bbox_targets = bbox_targets[pos_inds]
+    anchors = anchor_list.reshape(-1, box_code_size).repeat(mini_batch, 1)[pos_inds]
+    weight = None
+    if decode_weight:
+        weight = bbox_weights[pos_inds] * bbox_weights.new_tensor(decode_weight)
+    return anchor_decoded_gd_loss(loss_module, anchors, pos_bbox_pred, pos_bbox_targets, weight,
+                                  avg_factor=num_total_samples)
+
+
+def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
+    """loss_gd of one CenterGDHead task (gd_centerpoint_head.py:413-434):
+        target_gd = coder.encode(anno_boxes)[..., :7]
+        pred_gd   = coder.decode(pos_ind[..., 1:], pred, correct_yaw=False)[..., :7]
+        loss_gd   = loss_module(pred_gd, target_gd, avg_factor=max(num_pos, 1))
+    pos_ind: (B, K, 3) long [b, x, y]; pred: (B, K, C>=7) gathered raw head outputs [reg(2), height, dim(3), yaw, ...];
+    anno_boxes: (B, K, >=7).  The decode runs inside the kernel; the gradient reaches pred[..., :7]."""
+    target_gd = anno_boxes[..., :7].reshape(-1, 7)        # encode() leaves the first 7 entries as they are (:11-16)
+    locs = pos_ind[..., 1:].reshape(-1, 2).to(torch.float32).contiguous()
+    pro = _prologue(2, locs, norm_bbox=coder.norm_bbox, out_size_factor=coder.out_size_factor,
+                    voxel_size=coder.voxel_size, pc_range=coder.pc_range)
+    pred7 = pred[..., :7].reshape(-1, 7)
+    if pred7.numel() == 0:
+        return pred.new_zeros((1,))
+    return loss_module(pred7, target_gd, avg_factor=max(num_pos, 1), _prologue=pro)

@@ -55,6 +55,11 @@ def lib():
             fn = getattr(L, 'gd_oracle_loss' + sfx)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.POINTER(Params), vp, vp, vp, i64, real, vp, vp, vp, vp, ctypes.c_int]
+        for sfx, real in (('_f32', ctypes.c_float), ('_f64', ctypes.c_double)):
+            fn = getattr(L, 'gd_oracle_loss_decoded' + sfx)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int, vp, real, real, real, real, real,
+                           vp, vp, vp, i64, real, vp, vp, vp, vp]
         for name in ('rbox_oracle_nms_bev', 'rbox_oracle_nms_normal'):
             fn = getattr(L, name)
             fn.restype = i64
@@ -119,6 +124,32 @@ def gd_loss(pred, target, params, row_weight=None, scale=1.0, dtype=np.float64,
         ctypes.cast(ctypes.byref(total), ctypes.c_void_p), _ptr(gp), _ptr(gt), int(nthreads))
     if rc != 0:
         raise RuntimeError(f'gd_oracle_loss{sfx} -> {rc}')
+    return dict(loss=loss, loss_sum=total.value, grad_pred=gp, grad_target=gt)
+
+
+PRO_ANCHOR_DELTA, PRO_CENTER = 1, 2
+
+
+def gd_loss_decoded(pred_enc, target, params, kind, aux, row_weight=None, scale=1.0, dtype=np.float64,
+                    norm_bbox=True, out_size_factor=1.0, voxel_size=(1.0, 1.0), pc_range=(0.0, 0.0)):
+    """Head-level oracle: bbox-coder decode (kind = PRO_ANCHOR_DELTA on pred and target with aux = anchors (N,7);
+    kind = PRO_CENTER on pred only with aux = locs (N,2)) followed by the GD loss, gradients chained back to the
+    ENCODED rows.  Same contract as gd3d_loss_fused_decoded."""
+    dtype = np.dtype(dtype)
+    sfx = '_f32' if dtype == np.float32 else '_f64'
+    pred = np.ascontiguousarray(np.asarray(pred_enc, dtype=dtype).reshape(-1, 7))
+    target = np.ascontiguousarray(np.asarray(target, dtype=dtype).reshape(-1, 7))
+    n = pred.shape[0]
+    aux = np.ascontiguousarray(np.asarray(aux, dtype=dtype).reshape(n, 7 if kind == PRO_ANCHOR_DELTA else 2))
+    w = None if row_weight is None else np.ascontiguousarray(np.asarray(row_weight, dtype=dtype).reshape(n))
+    loss = np.empty(n, dtype); gp = np.empty((n, 7), dtype); gt = np.empty((n, 7), dtype)
+    total = ctypes.c_double(0.0)
+    rc = getattr(lib(), 'gd_oracle_loss_decoded' + sfx)(
+        ctypes.byref(params), int(kind), int(bool(norm_bbox)), _ptr(aux), float(out_size_factor), float(voxel_size[0]),
+        float(voxel_size[1]), float(pc_range[0]), float(pc_range[1]), _ptr(pred), _ptr(target), _ptr(w), n,
+        float(scale), _ptr(loss), ctypes.cast(ctypes.byref(total), ctypes.c_void_p), _ptr(gp), _ptr(gt))
+    if rc != 0:
+        raise RuntimeError(f'gd_oracle_loss_decoded{sfx} -> {rc}')
     return dict(loss=loss, loss_sum=total.value, grad_pred=gp, grad_target=gt)
 
 
