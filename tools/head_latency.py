@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Head-level train-step slice latency: decode(anchors, pred) + decode(anchors, target)
++ GDLoss(decode_weight (P,7), avg_factor) forward + backward.
+  fused   : amd.anchor_decoded_gd_loss (decode inside the kernel, 1 launch fwd)
+  unfused : torch coder mirror + amd.GDLoss (plain fused loss, decode as torch ops + autograd)
+  eager   : torch coder mirror + oracle/gd_torch.py (reference-style eager op chain)"""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mmdet3d_gaussian_amd as amd
+from oracle import gd_torch
+dev = torch.device('cuda:0')
+coder = amd.DeltaXYZWLHRBBoxCoder()
+def timeit(fn, iters):
+    for _ in range(10): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e6
+for lt in ('kld3d', 'gwd3d', 'bd3d'):
+    mod = amd.GDLoss(lt, fun='log1p', tau=0.0, loss_weight=5.0)
+    for P in (64, 512, 4096, 65536):
+        g = torch.Generator(device=dev).manual_seed(P)
+        an = torch.rand(P, 7, generator=g, device=dev) * torch.tensor([70, 80, 1, 1.5, 3, .5, 1.5], device=dev) + torch.tensor([0, -40, -2, .6, .9, 1.4, 0], device=dev)
+        te = torch.randn(P, 7, generator=g, device=dev) * 0.3
+        pe = (te + torch.randn(P, 7, generator=g, device=dev) * 0.1).requires_grad_(True)
+        w = torch.ones(P, 7, device=dev)
+        def fused():
+            pe.grad = None; amd.anchor_decoded_gd_loss(mod, an, pe, te, w, avg_factor=P).backward()
+        def unfused():
+            pe.grad = None; mod(coder.decode(an, pe), coder.decode(an, te), w, avg_factor=P).backward()
+        def eager():
+            pe.grad = None
+            gd_torch.gd_loss(coder.decode(an, pe), coder.decode(an, te), lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).backward()
+        a, b, c = timeit(fused, 200), timeit(unfused, 100), timeit(eager, 50)
+        print(json.dumps(dict(loss=lt, P=P, fused_us=round(a, 1), unfused_us=round(b, 1), eager_torch_us=round(c, 1),
+                              speedup_vs_eager=round(c / a, 1))), flush=True)
