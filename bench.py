@@ -137,7 +137,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: calls made by other threads (e.g. the RCCL watchdog) must not invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             graph_outs = compute(False)
 
     def step(record):
