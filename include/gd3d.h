@@ -178,6 +178,29 @@ int riou_eval_bev(const float* det, int64_t nd, const float* gt, int64_t ng, flo
 int riou_eval_3d(const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset,
                  float* iou, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dynamic point-to-voxel scatter-reduce.  Replaces
+ * dynamic_point_to_voxel_scatter_reduce / dynamic_point_to_voxel_backward
+ * (/root/reference/mmdet3d_gaussian/ops/voxel/src/voxelization.h:35-79,
+ *  src/scatter_points_cuda.cu:183-321) behind ops/voxel/scatter.py:29-72.
+ *   feats (n,c) fp32; map (n) int32 point->voxel (-1 = dropped point); count (v) int32 points per voxel;
+ *   order (n_valid...) int32: point ids grouped by voxel in ascending point id (stable argsort of map, with the
+ *   -1 entries skipped by seg[0]); seg (v+1) int32 segment bounds into `order`.
+ *   reduce: GD3D_REDUCE_* = the reference's reduce_t (voxelization.h:4).
+ * vox_scatter_reduce : out (v,c) = max | mean | sum over the voxel's points; argmax (v,c) int32 (max only,
+ *                      nullable) receives the smallest point id attaining the max.
+ * vox_scatter_backward: grad_feats (n,c): sum -> grad_vox[map[i]], mean -> / count, max -> routed to argmax,
+ *                      0 elsewhere (the kernel zero-fills).  Deterministic, no float atomics.
+ * ---------------------------------------------------------------------------------- */
+enum { GD3D_REDUCE_SUM = 0, GD3D_REDUCE_MEAN = 1, GD3D_REDUCE_MAX = 2 };
+
+int vox_scatter_reduce(const float* feats, const int32_t* order, const int32_t* seg, int64_t n,
+                       int32_t c, int64_t v, int reduce, float* out, int32_t* argmax, void* stream);
+
+int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_t* count,
+                         const int32_t* argmax, int64_t n, int32_t c, int64_t v, int reduce,
+                         float* grad_feats, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

@@ -20,6 +20,7 @@ ARCH = 'gfx950'
 SOURCES = {
     'gd3d_loss.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],
     'rbox.hip': ['-ffp-contract=off'],
+    'voxel_scatter.hip': [],
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,168 @@
+// voxel_scatter.hip — dynamic point-to-voxel scatter-reduce (max / mean / sum), forward and backward, for gfx950
+// (SURVEY.md §8f-4).  Replaces the reference's atomic kernels
+//   /root/reference/mmdet3d_gaussian/ops/voxel/src/scatter_points_cuda.cu:80-179 (feats_reduce_kernel,
+//   add_reduce_traceback_grad_kernel, max_reduce_traceback_scatter_idx_kernel, max_reduce_scatter_grad_kernel)
+// behind ops/voxel/scatter.py:29-72 (`scatter_reduce`).
+//
+// CDNA4 design: no float CAS / atomicAdd.  The host groups the points by voxel once per `Scatter`
+// (`order` = stable argsort of the point->voxel map, `seg` = segment starts), then
+//   forward : a sub-wave of CP = pow2 >= C lanes owns one voxel, lane = channel; it walks the voxel's points in
+//             ascending point index (4 independent row loads in flight) and keeps sum / max (+ the arg max point id)
+//             in registers; rows are read as contiguous C*4-byte runs.  Deterministic (fixed order), one store per
+//             output element.
+//   backward: sum/mean = pure gather of the voxel gradient row by the map (coalesced over channels);
+//             max      = zero fill + one store per (voxel, channel) at the arg max recorded by the forward — the same
+//             point the reference picks (atomicMin over equal-to-max points = smallest point index).
+// HBM-bound: reads N*C*4 + N*4, writes V*C*4 (+ V*C*4 arg max).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gd3d.h"
+
+namespace vox {
+
+template <int REDUCE>
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ feats, const int* __restrict__ order,
+                                                     const int* __restrict__ seg, int c, int cp, long long v,
+                                                     float* __restrict__ out, int* __restrict__ argmax) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int groups = 64 / cp;  // voxels per wave
+  const int sub = lane / cp, ch0 = lane - sub * cp;
+  const long long vox = wave * groups + sub;
+  if (vox >= v) return;
+  const int b = seg[vox], e = seg[vox + 1];
+  for (int ch = ch0; ch < c; ch += cp) {  // cp == 64 and c > 64: several channel passes
+    float acc = (REDUCE == GD3D_REDUCE_MAX) ? -__builtin_inff() : 0.0f;
+    int arg = -1;
+    int k = b;
+    for (; k + 4 <= e; k += 4) {
+      int pid[4];
+      float x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pid[u] = order[k + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = feats[(long long)pid[u] * c + ch];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (REDUCE == GD3D_REDUCE_MAX) {
+          if (x[u] > acc) {  // strict: the first (smallest) point index wins ties; NaN never wins (fmaxf semantics)
+            acc = x[u];
+            arg = pid[u];
+          }
+        } else {
+          acc += x[u];
+        }
+      }
+    }
+    for (; k < e; ++k) {
+      const int pid = order[k];
+      const float x = feats[(long long)pid * c + ch];
+      if (REDUCE == GD3D_REDUCE_MAX) {
+        if (x > acc) {
+          acc = x;
+          arg = pid;
+        }
+      } else {
+        acc += x;
+      }
+    }
+    if (REDUCE == GD3D_REDUCE_MEAN) acc = acc / (float)(e - b);
+    out[vox * c + ch] = acc;
+    if (REDUCE == GD3D_REDUCE_MAX && argmax != nullptr) argmax[vox * c + ch] = arg;
+  }
+}
+
+// grad_feats[i, :] = map[i] >= 0 ? grad_vox[map[i], :] (/ count) : 0
+template <bool MEAN>
+__global__ __launch_bounds__(256) void gather_grad_kernel(const float* __restrict__ gvox, const int* __restrict__ map,
+                                                          const int* __restrict__ count, long long n, int c,
+                                                          float* __restrict__ gfeats) {
+  const long long total = n * c;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const long long i = idx / c;
+    const int ch = (int)(idx - i * c);
+    const int m = map[i];
+    float g = 0.0f;
+    if (m >= 0) {
+      g = gvox[(long long)m * c + ch];
+      if (MEAN) g = g / (float)count[m];
+    }
+    gfeats[idx] = g;
+  }
+}
+
+__global__ __launch_bounds__(256) void max_grad_kernel(const float* __restrict__ gvox, const int* __restrict__ argmax,
+                                                       long long v, int c, float* __restrict__ gfeats) {
+  const long long total = v * c;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const int pid = argmax[idx];
+    if (pid >= 0) gfeats[(long long)pid * c + (idx % c)] = gvox[idx];
+  }
+}
+
+static int pow2_at_least(int c) {
+  int p = 1;
+  while (p < c && p < 64) p <<= 1;
+  return p;
+}
+
+}  // namespace vox
+
+using namespace vox;
+
+extern "C" {
+
+int vox_scatter_reduce(const float* feats, const int32_t* order, const int32_t* seg, int64_t n, int32_t c, int64_t v,
+                       int reduce, float* out, int32_t* argmax, void* stream) {
+  if (n < 0 || v < 0 || c <= 0) return GD3D_E_BADARG;
+  if (reduce != GD3D_REDUCE_SUM && reduce != GD3D_REDUCE_MEAN && reduce != GD3D_REDUCE_MAX) return GD3D_E_BADARG;
+  if (v == 0) return 0;
+  if (feats == nullptr || order == nullptr || seg == nullptr || out == nullptr) return GD3D_E_BADARG;
+  if (n > 0x7fffffffLL) return GD3D_E_TOOLARGE;  // point ids are int32, as in the reference
+  const int cp = pow2_at_least(c);
+  const long long waves = (v + (64 / cp) - 1) / (64 / cp);
+  const long long blocks = (waves + 3) / 4;
+  if (blocks > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  const dim3 grid((unsigned)blocks), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (reduce == GD3D_REDUCE_MAX)
+    hipLaunchKernelGGL((reduce_kernel<GD3D_REDUCE_MAX>), grid, blk, 0, s, feats, order, seg, (int)c, cp, (long long)v, out, argmax);
+  else if (reduce == GD3D_REDUCE_MEAN)
+    hipLaunchKernelGGL((reduce_kernel<GD3D_REDUCE_MEAN>), grid, blk, 0, s, feats, order, seg, (int)c, cp, (long long)v, out, argmax);
+  else
+    hipLaunchKernelGGL((reduce_kernel<GD3D_REDUCE_SUM>), grid, blk, 0, s, feats, order, seg, (int)c, cp, (long long)v, out, argmax);
+  return (int)hipGetLastError();
+}
+
+int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_t* count, const int32_t* argmax, int64_t n,
+                         int32_t c, int64_t v, int reduce, float* grad_feats, void* stream) {
+  if (n < 0 || v < 0 || c <= 0) return GD3D_E_BADARG;
+  if (reduce != GD3D_REDUCE_SUM && reduce != GD3D_REDUCE_MEAN && reduce != GD3D_REDUCE_MAX) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (grad_feats == nullptr) return GD3D_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (v == 0) return (int)hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
+  if (grad_vox == nullptr) return GD3D_E_BADARG;
+  if (reduce == GD3D_REDUCE_MAX) {
+    if (argmax == nullptr) return GD3D_E_BADARG;
+    hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (v * c + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(max_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grad_vox, argmax, (long long)v, (int)c, grad_feats);
+  } else {
+    if (map == nullptr || (reduce == GD3D_REDUCE_MEAN && count == nullptr)) return GD3D_E_BADARG;
+    long long blocks = (n * c + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (reduce == GD3D_REDUCE_MEAN)
+      hipLaunchKernelGGL((gather_grad_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, grad_vox, map, count, (long long)n, (int)c, grad_feats);
+    else
+      hipLaunchKernelGGL((gather_grad_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, grad_vox, map, count, (long long)n, (int)c, grad_feats);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

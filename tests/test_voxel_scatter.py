@@ -1,0 +1,117 @@
+"""§8f-4 dynamic scatter-reduce: oracle self-checks on CPU; GPU kernels vs the oracle (parity unpinned: the reference
+op is CUDA-only; see oracle/voxel_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxel_oracle as vo
+
+
+def _cloud(n, seed, grid=(40, 40, 2), c=9, neg_frac=0.03, dup=True):
+    rng = np.random.default_rng(seed)
+    coors = np.stack([rng.integers(0, g, n) for g in grid], -1).astype(np.int32)
+    coors[rng.random(n) < neg_frac, rng.integers(0, 3)] = -1          # out-of-range points
+    feats = rng.normal(0, 1, (n, c)).astype(np.float32)
+    if dup and n > 10:
+        feats[n // 2] = feats[n // 3]                                     # ties for max
+        coors[n // 2] = coors[n // 3]
+    return coors, feats
+
+
+def test_oracle_index_and_reduce_properties():
+    coors, feats = _cloud(3000, 0)
+    uniq, pmap, cnt = vo.scatter_index(coors)
+    assert (uniq >= 0).all() and cnt.sum() == (pmap >= 0).sum() and (np.diff(uniq.view([('', uniq.dtype)] * 3).ravel().argsort()) == 1).all()
+    assert ((coors < 0).any(-1) == (pmap < 0)).all()
+    np.testing.assert_array_equal(uniq[pmap[pmap >= 0]], coors[pmap >= 0])
+    for red in ('sum', 'mean', 'max'):
+        out, _ = vo.scatter_reduce(feats, pmap, cnt, red)
+        v = 17
+        rows = feats[pmap == v].astype(np.float64)
+        want = {'sum': rows.sum(0), 'mean': rows.mean(0), 'max': rows.max(0)}[red]
+        np.testing.assert_allclose(out[v], want, rtol=1e-12)
+        # backward == autograd of a torch restatement
+        gv = np.random.default_rng(1).normal(0, 1, out.shape)
+        g = vo.scatter_backward(gv, feats, pmap, cnt, red)
+        tf = torch.from_numpy(feats).double().requires_grad_(True)
+        idx = torch.from_numpy(pmap[pmap >= 0].astype(np.int64))
+        src = tf[torch.from_numpy(np.nonzero(pmap >= 0)[0])]
+        if red == 'max':
+            tout = torch.full(out.shape, -np.inf, dtype=torch.float64).scatter_reduce(0, idx[:, None].expand(-1, feats.shape[1]), src, 'amax')
+            # torch splits ties evenly; compare only where the max is unique
+            continue
+        tout = torch.zeros(out.shape, dtype=torch.float64).index_add(0, idx, src)
+        if red == 'mean':
+            tout = tout / torch.from_numpy(cnt).double()[:, None]
+        (tout * torch.from_numpy(gv)).sum().backward()
+        np.testing.assert_allclose(g, tf.grad.numpy(), rtol=1e-12, atol=1e-14)
+
+
+def test_host_scatter_index_matches_oracle_cpu():
+    from mmdet3d_gaussian_amd.scatter import group_points, scatter_index
+    coors, _ = _cloud(2000, 3)
+    u, m, c = scatter_index(torch.from_numpy(coors))
+    uo, mo, co = vo.scatter_index(coors)
+    np.testing.assert_array_equal(u.numpy(), uo); np.testing.assert_array_equal(m.numpy(), mo); np.testing.assert_array_equal(c.numpy(), co)
+    assert m.dtype == torch.int32 and c.dtype == torch.int32
+    order, seg = group_points(m, c)
+    o = order.numpy(); s = seg.numpy()
+    assert s[0] == (mo < 0).sum() and s[-1] == len(mo)
+    for v in (0, 5, len(co) - 1):
+        pts = o[s[v]:s[v + 1]]
+        assert (mo[pts] == v).all() and (np.diff(pts) > 0).all()          # grouped, ascending point id
+    e = scatter_index(torch.zeros(0, 3, dtype=torch.int32))
+    assert e[0].shape == (0, 3) and e[1].numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130)])
+@pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
+def test_gpu_scatter_reduce_forward_backward(n, c, red):
+    import mmdet3d_gaussian_amd as amd  # noqa: F401
+    from mmdet3d_gaussian_amd.scatter import Scatter
+    coors, feats = _cloud(n, n + c, c=c)
+    uo, mo, co = vo.scatter_index(coors)
+    sc = Scatter(torch.from_numpy(coors).cuda())
+    np.testing.assert_array_equal(sc.voxel_coors.cpu().numpy(), uo)
+    np.testing.assert_array_equal(sc.pts_voxel_maps.cpu().numpy(), mo)
+    np.testing.assert_array_equal(sc.voxel_pts_counts.cpu().numpy(), co)
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    out, vc = sc.reduce(f, red)
+    want, _ = vo.scatter_reduce(feats, mo, co, red)
+    if len(co) == 0:
+        assert out.shape[0] == 0
+        return
+    if red == 'max':
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want.astype(np.float32))     # max is exact
+    else:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+    gv = np.random.default_rng(7).normal(0, 1, want.shape).astype(np.float32)
+    out.backward(torch.from_numpy(gv).cuda())
+    gw = vo.scatter_backward(gv, feats, mo, co, red)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gw, rtol=2e-6, atol=1e-7)
+    # mapback / reduce_mapback as the pillar encoders use them (voxel_encoders/utils.py:56)
+    back = sc.reduce_mapback(f.detach(), red, default_feat=0)
+    ref_back = np.where((mo >= 0)[:, None], want[np.clip(mo, 0, None)], 0)
+    np.testing.assert_allclose(back.cpu().numpy(), ref_back, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_scatter_batched_coors_and_determinism():
+    from mmdet3d_gaussian_amd.scatter import Scatter
+    rng = np.random.default_rng(0)
+    n = 8000
+    coors3, feats = _cloud(n, 11, c=16)
+    b = rng.integers(0, 3, n).astype(np.int32)
+    coors4 = np.concatenate([b[:, None], coors3], 1)
+    sc = Scatter(torch.from_numpy(coors4).cuda())
+    assert sc.batch_size == 3 and sc.voxel_coors.shape[1] == 4
+    f = torch.from_numpy(feats).cuda()
+    o1, _ = sc.reduce(f, 'sum'); o2, _ = sc.reduce(f, 'sum')
+    assert torch.equal(o1, o2)                                     # fixed summation order
+    # per-sample voxels: every voxel row equals the sum over its batch-restricted points
+    vc = sc.voxel_coors.cpu().numpy(); m = sc.pts_voxel_maps.cpu().numpy()
+    for v in (0, len(vc) // 2, len(vc) - 1):
+        sel = (m == v)
+        assert (coors4[sel] == vc[v]).all()
+        np.testing.assert_allclose(o1[v].cpu().numpy(), feats[sel].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
