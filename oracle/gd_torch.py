@@ -17,6 +17,8 @@ _SQRT2_TERM = 4.656854249492381
 
 def _gauss(box, c):
     box = box.reshape(-1, 7)
+    if not isinstance(c, torch.Tensor):
+        c = torch.tensor(c).to(box)          # as the reference (:9-10): fp32-rounded, then cast to the box dtype
     x, y, z, w, h, l, r = box.unbind(-1)
     X, Y, Z = x + c[0] * w, y + c[1] * h, z + c[2] * l                      # :12 (unclamped dims)
     a = 0.5 * w.clamp(min=1e-7, max=1e7)                                    # :13,:19
