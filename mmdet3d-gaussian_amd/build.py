@@ -3,6 +3,7 @@
 Plain ``hipcc --offload-arch=gfx950``: no torch headers, no hipify, no cmake.  The library is built
 IN-TREE (mmdet3d-gaussian_amd/libgd3d.so) so that it travels to the GPU box with the snapshot.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -38,11 +39,25 @@ def _deps():
     return out
 
 
+HASH_PATH = LIB_PATH + '.srchash'
+
+
+def source_hash():
+    """Content hash of everything the library is built from (mtimes do not survive a snapshot to another box)."""
+    h = hashlib.sha256()
+    for d in sorted(os.path.normpath(x) for x in _deps()):
+        if os.path.exists(d):
+            h.update(os.path.basename(d).encode())
+            with open(d, 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.isfile(LIB_PATH):
+    if not os.path.isfile(LIB_PATH) or not os.path.isfile(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in _deps() if os.path.exists(d))
+    with open(HASH_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -52,7 +67,7 @@ def build(force=False, verbose=False):
     hipcc = hipcc_path()
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libgd3d.so')
-    objdir = os.path.join(PKG_DIR, 'build')
+    objdir = os.path.join(PKG_DIR, 'build', str(os.getpid()))  # per process: ranks may build concurrently
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src, flags in SOURCES.items():
@@ -67,11 +82,16 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
         objs.append(obj)
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB_PATH + '.tmp'] + objs
+    tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
-    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    os.replace(tmp, LIB_PATH)  # atomic
+    with open(HASH_PATH + f'.{os.getpid()}', 'w') as f:
+        f.write(source_hash())
+    os.replace(HASH_PATH + f'.{os.getpid()}', HASH_PATH)
+    shutil.rmtree(objdir, ignore_errors=True)
     return LIB_PATH
 
 
