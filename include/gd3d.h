@@ -130,6 +130,20 @@ int gd3d_loss_fused_decoded(const gd3d_params* params, const gd3d_prologue* prol
                             float* loss_sum, float* grad_pred, float* grad_target,
                             void* workspace, void* stream);
 
+/* The same slice with the GATHER of the positives fused in as well (one thread per positive, gd_anchor3d_head.py:95-141):
+ *   bbox_pred (B, A*7, H, W) raw head output (NCHW, read in place: no permute copy, no index kernels);
+ *   bbox_targets / bbox_weights (M,7) with M = B*H*W*A and row m = ((b*H + h)*W + w)*A + a (bbox_weights nullable);
+ *   decode_weight: HOST array of 7 floats or NULL (train_cfg['decode_weight']); w_i = mean(bbox_weights[m,:] * decode_weight);
+ *   anchors (H*W*A, 7): anchors of ONE sample (the reference repeats them over the batch, :110-112);
+ *   pos_inds (P) int64 positive rows m; scale = loss_weight / avg_factor;
+ *   *loss_sum = scale * sum_i w_i L_i ;  grad_bbox_pred (B, A*7, H, W) must be ZERO-FILLED by the caller and receives
+ *   d loss / d bbox_pred at the positives' 7 channels (nullable).  workspace: gd3d_loss_workspace_bytes(P). */
+int gd3d_anchor_head_loss(const gd3d_params* params, const float* bbox_pred, int32_t B, int32_t A,
+                          int32_t H, int32_t W, const float* bbox_targets, const float* bbox_weights,
+                          const float* decode_weight, const float* anchors, const int64_t* pos_inds,
+                          int64_t P, float scale, float* loss_sum, float* grad_bbox_pred,
+                          void* workspace, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

@@ -273,6 +273,91 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Anchor-head slice with the gather fused in (gd_anchor3d_head.py:95-141): one thread per POSITIVE.
+// It reads its 7 encoded predictions straight out of the NCHW head output (B, A*7, H, W) — no permute/reshape copy,
+// no index kernels — its target / weight rows from the (M,7) arrays and its anchor from the per-sample anchor list,
+// decodes both boxes (DeltaXYZWLHR), evaluates the loss and scatters the chained gradient back into the NCHW
+// gradient (pre-zeroed by the caller).  P is O(1e2..1e4): latency-bound, so no LDS tiling.
+struct HeadArgs {
+  const float* bbox_pred;      // (B, A*7, H, W)
+  const float* bbox_targets;   // (M,7), M = B*H*W*A, row m = ((b*H + h)*W + w)*A + a
+  const float* bbox_weights;   // (M,7) nullable
+  const float* anchors;        // (H*W*A, 7) anchors of one sample
+  const long long* pos_inds;   // (P)
+  float* grad_bbox_pred;       // (B, A*7, H, W), zero-filled by the caller; nullable
+  float* partials;
+  long long P;
+  int A, H, W;
+  float dw[7];                 // train_cfg['decode_weight'] (all 1 when weights are given without it)
+  float scale, alpha, tau, c0, c1, c2;
+};
+
+template <int LOSS, int FUN, bool FLAG>
+__global__ __launch_bounds__(TILE) void head_anchor_kernel(const HeadArgs a) {
+  __shared__ float swave[TILE / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long i = (long long)blockIdx.x * TILE + tid;
+  const bool valid = i < a.P;
+  float fl = 0.0f;
+  if (valid) {
+    const long long m = a.pos_inds[i];
+    const long long hwa = (long long)a.H * a.W * a.A;
+    const long long b = m / hwa, r = m - b * hwa;
+    const int an_i = (int)(r % a.A);
+    const long long hw = r / a.A;                                  // h*W + w
+    const long long plane = (long long)a.H * a.W;
+    const float* pbase = a.bbox_pred + ((b * a.A + an_i) * 7) * plane + hw;   // + k*plane per channel
+    float pe[7], te[7], an[7], pv[7], tv[7];
+    float wi = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      pe[k] = pbase[k * plane];
+      te[k] = a.bbox_targets[m * 7 + k];
+      an[k] = a.anchors[r * 7 + k];
+    }
+    if (a.bbox_weights != nullptr) {
+      float sum = a.bbox_weights[m * 7] * a.dw[0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) sum += a.bbox_weights[m * 7 + k] * a.dw[k];
+      wi = sum / 7.0f;
+    }
+    DecodeJac Jp, Jt;
+    decode_anchor(pe, an, pv, Jp);
+    decode_anchor(te, an, tv, Jt);
+    const float c[3] = {a.c0, a.c1, a.c2};
+    const float f = a.scale * wi;
+    float g1[7], g2[7];
+    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
+    fl = f * L;
+    if (a.grad_bbox_pred != nullptr) {
+      encode_grad(g1, Jp, true);
+      float* gbase = a.grad_bbox_pred + ((b * a.A + an_i) * 7) * plane + hw;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) gbase[k * plane] = g1[k];
+    }
+  }
+  if (a.partials != nullptr) {
+    const float ws = wave_sum(fl);
+    if (lane == 0) swave[wave] = ws;
+    __syncthreads();
+    if (tid == 0) a.partials[blockIdx.x] = (swave[0] + swave[1]) + (swave[2] + swave[3]);
+  }
+}
+
+template <int LOSS, int FUN>
+static void launch_head(bool flag, unsigned grid, hipStream_t s, const HeadArgs& a) {
+  if (flag) hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, true>), dim3(grid), dim3(TILE), 0, s, a);
+  else hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, false>), dim3(grid), dim3(TILE), 0, s, a);
+}
+
+template <int LOSS>
+static void launch_head_fun(int fun, bool flag, unsigned grid, hipStream_t s, const HeadArgs& a) {
+  if (fun == GD3D_FUN_LOG1P) launch_head<LOSS, GD3D_FUN_LOG1P>(flag, grid, s, a);
+  else launch_head<LOSS, GD3D_FUN_NONE>(flag, grid, s, a);
+}
+
 // second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; every thread
 // issues all of its 16-B loads before the first add (the kernel is pure latency: 39 K floats at 10 M pairs).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, long long nb,
@@ -471,6 +556,66 @@ int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* st
   const long long nparts = (n + TILE - 1) / TILE;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nparts, loss_sum);
   return (int)hipGetLastError();
+}
+
+int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
+                          const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
+                          const float* anchors, const int64_t* pos_inds, int64_t P, float scale, float* loss_sum,
+                          float* grad_bbox_pred, void* workspace, void* stream) {
+  if (p == nullptr || P < 0 || B <= 0 || A <= 0 || H <= 0 || W <= 0) return GD3D_E_BADARG;
+  if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
+  if (p->loss_type == GD3D_KFIOU3D) {
+    if (p->fun != GD3D_FUN_NONE && p->fun != GD3D_FUN_EXPM1 && p->fun != GD3D_FUN_NLOG) return GD3D_E_BADARG;
+  } else if (p->fun != GD3D_FUN_NONE && p->fun != GD3D_FUN_LOG1P) {
+    return GD3D_E_BADARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) {
+    if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+    return 0;
+  }
+  if (bbox_pred == nullptr || bbox_targets == nullptr || anchors == nullptr || pos_inds == nullptr) return GD3D_E_BADARG;
+  if (loss_sum != nullptr && workspace == nullptr) return GD3D_E_BADARG;
+  HeadArgs a;
+  a.bbox_pred = bbox_pred;
+  a.bbox_targets = bbox_targets;
+  a.bbox_weights = bbox_weights;
+  a.anchors = anchors;
+  a.pos_inds = (const long long*)pos_inds;
+  a.grad_bbox_pred = grad_bbox_pred;
+  a.partials = (float*)workspace;
+  a.P = P;
+  a.A = A;
+  a.H = H;
+  a.W = W;
+  for (int k = 0; k < 7; ++k) a.dw[k] = decode_weight != nullptr ? decode_weight[k] : 1.0f;  // HOST array of 7
+  a.scale = scale;
+  a.alpha = p->alpha;
+  a.tau = p->tau;
+  a.c0 = p->center_offset[0];
+  a.c1 = p->center_offset[1];
+  a.c2 = p->center_offset[2];
+  const long long nb = (P + TILE - 1) / TILE;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  const bool flag = p->flag != 0;
+  const unsigned grid = (unsigned)nb;
+  switch (p->loss_type) {
+    case GD3D_GWD3D: launch_head_fun<GD3D_GWD3D>(p->fun, flag, grid, s, a); break;
+    case GD3D_KLD3D: launch_head_fun<GD3D_KLD3D>(p->fun, flag, grid, s, a); break;
+    case GD3D_BD3D: launch_head_fun<GD3D_BD3D>(p->fun, flag, grid, s, a); break;
+    case GD3D_JD3D: launch_head_fun<GD3D_JD3D>(p->fun, flag, grid, s, a); break;
+    case GD3D_KLD3D_SYMMAX: launch_head_fun<GD3D_KLD3D_SYMMAX>(p->fun, flag, grid, s, a); break;
+    case GD3D_KLD3D_SYMMIN: launch_head_fun<GD3D_KLD3D_SYMMIN>(p->fun, flag, grid, s, a); break;
+    default:
+      if (p->fun == GD3D_FUN_EXPM1) launch_head<GD3D_KFIOU3D, GD3D_FUN_EXPM1>(false, grid, s, a);
+      else if (p->fun == GD3D_FUN_NLOG) launch_head<GD3D_KFIOU3D, GD3D_FUN_NLOG>(false, grid, s, a);
+      else launch_head<GD3D_KFIOU3D, GD3D_FUN_NONE>(false, grid, s, a);
+      break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (loss_sum != nullptr) return gd3d_loss_reduce(workspace, P, loss_sum, stream);
+  return 0;
 }
 
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream) {

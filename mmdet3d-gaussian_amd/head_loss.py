@@ -60,6 +60,66 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
                                   avg_factor=num_total_samples)
 
 
+class _AnchorHeadFused(torch.autograd.Function):
+    """gather of the positives + decode x2 + loss + gradient scatter into the NCHW head output: one launch."""
+
+    @staticmethod
+    def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_inds, params, dw, scale):
+        lib = _lib.load()
+        B, C, H, W = bbox_pred.shape
+        A = C // 7
+        P = pos_inds.numel()
+        dev = bbox_pred.device
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.zeros_like(bbox_pred) if need_grad else None
+        buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
+        dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
+        with torch.cuda.device(dev):
+            rc = lib.gd3d_anchor_head_loss(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(),
+                                           None if bbox_weights is None else bbox_weights.data_ptr(), dwp,
+                                           anchors.data_ptr(), pos_inds.data_ptr(), P, scale, buf[0].data_ptr(),
+                                           None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'gd3d_anchor_head_loss')
+        ctx.grad = grad
+        return buf[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        g = ctx.grad
+        go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
+        with torch.cuda.device(g.device):
+            _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
+                                           torch.cuda.current_stream().cuda_stream), 'gd3d_scale_rows')
+        return g, None, None, None, None, None, None, None
+
+
+def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list, num_classes,
+                                   num_total_samples, decode_weight=None):
+    """Same contract as anchor_head_decoded_loss, but the positives are gathered INSIDE the kernel straight from the
+    NCHW head output (no permute/reshape copy, no index kernels, no scatter in backward): nonzero() is the only torch
+    op left on the path.  Requires a reduced loss (mean/sum) without per-call kwargs."""
+    from .gd_loss import GDLoss
+    assert isinstance(loss_module, GDLoss) and loss_module.reduction != 'none'
+    B, C, H, W = bbox_pred.shape
+    labels = labels.reshape(-1)
+    pos_inds = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1)
+    if pos_inds.numel() == 0:
+        return bbox_pred.sum() * 0
+    bp = bbox_pred if bbox_pred.dtype == torch.float32 else bbox_pred.float()
+    weights = None
+    if decode_weight:
+        weights = bbox_weights.reshape(-1, 7).to(torch.float32).contiguous()
+    den = num_total_samples if loss_module.reduction == 'mean' else 1.0
+    scale = float(loss_module.loss_weight) / float(den)
+    out = _AnchorHeadFused.apply(bp.contiguous(), bbox_targets.reshape(-1, 7).to(torch.float32).contiguous(), weights,
+                                 anchor_list.reshape(-1, 7).to(torch.float32).contiguous(), pos_inds.contiguous(),
+                                 loss_module._params({}), decode_weight if decode_weight else None, scale)
+    return out
+
+
 def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
     """loss_gd of one CenterGDHead task (gd_centerpoint_head.py:413-434):
         target_gd = coder.encode(anno_boxes)[..., :7]

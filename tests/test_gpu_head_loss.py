@@ -97,3 +97,45 @@ def test_anchor_head_slice_end_to_end(amd):
     # no positives -> pos_bbox_pred.sum() == 0 with a graph (:160-161)
     z = amd.anchor_head_decoded_loss(mod, bbox_pred, bbox_targets, bbox_weights, torch.full_like(labels, C), anchors, C, 1.0, dw)
     assert z.item() == 0.0 and z.requires_grad
+
+
+@pytest.mark.parametrize('lt,red', [('kld3d', 'mean'), ('gwd3d', 'mean'), ('bd3d', 'sum')])
+def test_anchor_head_gather_fused_matches_unfused_and_oracle(amd, lt, red):
+    """Gather + decode + loss + gradient scatter in ONE launch straight from the NCHW head output, vs (a) the
+    torch-gather + fused-decode path and (b) the fp64 oracle on numpy-gathered rows."""
+    torch.manual_seed(1)
+    B, A, H, W, C = 3, 6, 10, 7, 3
+    n_per = H * W * A
+    anchors = torch.rand(n_per, 7).cuda() * torch.tensor([70, 80, 1, 1.5, 3, 0.5, 1.5]).cuda() + torch.tensor([0, -40, -2, .6, .9, 1.4, 0]).cuda()
+    bbox_pred = (torch.randn(B, A * 7, H, W) * 0.1).cuda().requires_grad_(True)
+    bbox_targets = (torch.randn(B, n_per, 7) * 0.2).cuda()
+    bbox_weights = torch.rand(B, n_per, 7).cuda()
+    labels = torch.randint(0, C + 2, (B, n_per)).cuda()
+    dw = [1.0, 1.0, 0.5, 1.0, 2.0, 1.0, 1.0]
+    mod = amd.GDLoss(lt, fun='log1p', tau=1.0, loss_weight=5.0, reduction=red)
+    avg = 77.0 if red == 'mean' else None
+    ref = amd.anchor_head_decoded_loss(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw)
+    ref.backward(); g_ref = bbox_pred.grad.clone(); bbox_pred.grad = None
+    out = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw)
+    (out * 3.0).backward()                     # upstream gradient != 1 exercises the scale kernel on the NCHW grad
+    assert abs(out.item() - ref.item()) <= 1e-5 * (1 + abs(ref.item()))
+    sc = g_ref.abs().max().item()
+    assert (bbox_pred.grad / 3.0 - g_ref).abs().max().item() <= 2e-5 * (1 + sc)
+    nz = (labels.reshape(-1) >= 0) & (labels.reshape(-1) < C)
+    gflat = bbox_pred.grad.permute(0, 2, 3, 1).reshape(-1, 7)
+    assert gflat[~nz].abs().max().item() == 0.0          # nothing written outside the positives
+    # oracle on numpy-gathered rows
+    pos = nz.nonzero().reshape(-1).cpu().numpy()
+    bp = bbox_pred.detach().permute(0, 2, 3, 1).reshape(-1, 7).cpu().numpy()[pos]
+    bt = bbox_targets.reshape(-1, 7).cpu().numpy()[pos]
+    an = anchors.cpu().numpy()[pos % n_per]
+    w = (bbox_weights.reshape(-1, 7).cpu().numpy()[pos].astype(np.float64) * np.array(dw)).mean(-1)
+    scale = 5.0 / (avg or 1.0)
+    r = oracle.gd_loss_decoded(bp, bt, oracle.make_params(lt, fun='log1p', tau=1.0), oracle.PRO_ANCHOR_DELTA, an,
+                               row_weight=w, scale=scale)
+    assert abs(out.item() - r['loss_sum']) <= 2e-5 * (1 + abs(r['loss_sum']))
+    got = (gflat[nz] / 3.0).cpu().numpy()
+    assert np.abs(got - r['grad_pred']).max() <= 5e-5 * (1 + np.abs(r['grad_pred']).max())
+    # no positives
+    z = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, torch.full_like(labels, C), anchors, C, 1.0, dw)
+    assert z.item() == 0.0

@@ -35,3 +35,26 @@ for lt in ('kld3d', 'gwd3d', 'bd3d'):
         a, b, c = timeit(fused, 200), timeit(unfused, 100), timeit(eager, 50)
         print(json.dumps(dict(loss=lt, P=P, fused_us=round(a, 1), unfused_us=round(b, 1), eager_torch_us=round(c, 1),
                               speedup_vs_eager=round(c / a, 1))), flush=True)
+
+# gather-fused variant from raw NCHW head output (KITTI geometry: 248 x 216 x 6 anchors), vs the torch-gather path
+B, A, H, W, C = 2, 6, 248, 216, 3
+n_per = H * W * A
+anchors = torch.rand(n_per, 7, device=dev) * torch.tensor([70, 80, 1, 1.5, 3, .5, 1.5], device=dev) + torch.tensor([0, -40, -2, .6, .9, 1.4, 0], device=dev)
+bbox_pred = (torch.randn(B, A * 7, H, W, device=dev) * 0.1).requires_grad_(True)
+bbox_targets = torch.randn(B, n_per, 7, device=dev) * 0.2
+bbox_weights = torch.ones(B, n_per, 7, device=dev)
+for npos in (200, 2000):
+    labels = torch.full((B, n_per), C, device=dev, dtype=torch.long)
+    idx = torch.randperm(B * n_per, device=dev)[:npos]
+    labels.view(-1)[idx] = 0
+    mod = amd.GDLoss('kld3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    dw = [1.0] * 7
+    def gather_torch():
+        bbox_pred.grad = None
+        amd.anchor_head_decoded_loss(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, float(npos), dw).backward()
+    def gather_fused():
+        bbox_pred.grad = None
+        amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, float(npos), dw).backward()
+    a, b = timeit(gather_fused, 100), timeit(gather_torch, 50)
+    print(json.dumps(dict(slice='loss_single decoded branch from NCHW', B=B, anchors_per_sample=n_per, positives=npos,
+                          gather_fused_us=round(a, 1), torch_gather_us=round(b, 1), speedup=round(b / a, 2))), flush=True)
