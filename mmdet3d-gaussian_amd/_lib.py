@@ -59,6 +59,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    override = os.environ.get('GD3D_LIB')  # A/B runs of experimental builds (tools/build_variants.py)
+    if override:
+        L = ctypes.CDLL(override)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+        return _lib
     if _build.is_stale():
         try:
             _build.build()

@@ -45,11 +45,15 @@ GD_DEV void sincos_f(float x, float& s, float& c) {
   c = ((n + 1) & 2) ? -cv : cv;
 }
 
-// log1p with the (1+d) rounding error folded back in
-GD_DEV float log1p_f(float d) {
+GD_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (base 2), 1 ulp
+constexpr float LN2 = 0.6931471805599453f;
+
+// log1p with the (1+d) rounding error folded back in; *inv_u returns 1/(1+d) (= d log1p / dd) from the same v_rcp
+GD_DEV float log1p_f(float d, float& inv_u) {
   const float u = 1.0f + d;
-  const float corr = (d - (u - 1.0f)) * frcp(u);
-  return __logf(u) + corr;  // __logf -> v_log_f32 * ln2 (1 ulp of the result)
+  inv_u = frcp(u);
+  const float corr = (d - (u - 1.0f)) * inv_u;
+  return fmaf(flog2(u), LN2, corr);
 }
 
 // ------------------------------------------------------------------ box -> Gaussian
@@ -128,8 +132,7 @@ template <int FUN>
 GD_DEV float post(float d, float tau, float& deriv) {
   float f, df;
   if (FUN == GD3D_FUN_LOG1P) {
-    f = log1p_f(d);
-    df = frcp(1.0f + d);
+    f = log1p_f(d, df);
   } else if (FUN == GD3D_FUN_EXPM1) {
     f = expm1f(d);
     df = f + 1.0f;
@@ -152,10 +155,11 @@ GD_DEV float post(float d, float tau, float& deriv) {
 
 // clamp(0).sqrt(): value and d sqrt/du under autograd rules (slope 0 for u < 0, +inf at u == 0).
 // u * 0 keeps a NaN a NaN where clamp(0) would (torch.clamp propagates NaN) and is 0 otherwise.
+// One v_rsq_f32 serves both: sqrt(u) = u * rsq(u), 1/(2 sqrt(u)) = rsq(u)/2 (rsq(0) = +inf as required).
 GD_DEV float sqrt0(float u, float& dsu) {
-  const bool pos = u > 0.0f;
-  const float s = pos ? fsqrt(u) : u * 0.0f;
-  dsu = (u >= 0.0f) ? 0.5f * frcp(s) : 0.0f;
+  const float r = __builtin_amdgcn_rsqf(u);
+  const float s = (u > 0.0f) ? u * r : u * 0.0f;
+  dsu = (u >= 0.0f) ? 0.5f * r : 0.0f;
   return s;
 }
 
@@ -178,8 +182,9 @@ GD_DEV float gwd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Ad
   float dn = dist, iscale = 1.0f;
   if (NORMALIZE) {
     // scale = 2 exp((ln D + ln ep + ln et)/6) = 2 (D ep et)^(1/6)
-    const float L = __logf(D) + __logf(p.e * t.e);
-    iscale = 0.5f * __expf(L * (-1.0f / 6.0f));
+    // 2 exp((ln D + ln ep + ln et)/6) = 2 * 2^((log2 D + log2(ep et))/6)
+    const float L2 = flog2(D) + flog2(p.e * t.e);
+    iscale = 0.5f * __builtin_amdgcn_exp2f(L2 * (-1.0f / 6.0f));
     dn = dist * iscale;
   }
   float dpost;
@@ -237,9 +242,9 @@ GD_DEV float kld_fwd(const Box& p, const Box& t, float ia2, KldI& k) {
   float whlr = 0.5f * fmaf(k.iE, t.e * t.e, tr);
   // (ln ap + ln bp + ln ep) - (ln at + ln bt + ln et) as one log of a ratio would overflow for
   // clamped dims; keep two logs of products (each product is within fp32 range: >= 1.25e-22)
-  const float lp = __logf(p.a * p.b * p.e);
-  const float lt = __logf(t.a * t.b * t.e);
-  whlr = whlr + (lp - lt) - 1.5f;
+  const float lp = flog2(p.a * p.b * p.e);
+  const float lt = flog2(t.a * t.b * t.e);
+  whlr = fmaf(lp - lt, LN2, whlr) - 1.5f;
   return fmaf(xyz, ia2, whlr);
 }
 
@@ -356,9 +361,9 @@ GD_DEV float bd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj
   const float S11 = 0.5f * (p.S11 + t.S11), S12 = 0.5f * (p.S12 + t.S12), S22 = 0.5f * (p.S22 + t.S22);
   const float Ep = p.e * p.e, Et = t.e * t.e, Sl = 0.5f * (Ep + Et);
   const float det_raw = fmaf(S11, S22, -S12 * S12);
+  // clamp(min=1e-7): a NaN det_raw can only come from NaN inputs, which already poison dX/dY/dZ -> v_max is enough
   const float mdet = det_raw >= 1e-7f ? 1.0f : 0.0f;
-  float det = det_raw >= 1e-7f ? det_raw : 1e-7f;
-  det = (det_raw != det_raw) ? det_raw : det;
+  const float det = __builtin_fmaxf(det_raw, 1e-7f);
   const float idet = frcp(det);
   const float I11 = S22 * idet, I12 = -S12 * idet, I22 = S11 * idet;
   const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
@@ -367,8 +372,7 @@ GD_DEV float bd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj
   const float xyz = 0.125f * fmaf(dZ * dZ, iSl, quad);
   // 0.5(ln det + ln Sl) - 0.25(ln Ap + ln Bp + ln Ep) - 0.25(ln At + ln Bt + ln Et)
   //   = 0.5 (ln det + ln Sl) - 0.5 (ln(ap bp ep) + ln(at bt et))
-  float whlr = 0.5f * (__logf(det) + __logf(Sl));
-  whlr = whlr - 0.5f * (__logf(p.a * p.b * p.e) + __logf(t.a * t.b * t.e));
+  const float whlr = (0.5f * LN2) * ((flog2(det) + flog2(Sl)) - (flog2(p.a * p.b * p.e) + flog2(t.a * t.b * t.e)));
   float d = fmaf(xyz, ia2, whlr), ds = 1.0f;
   if (SQRT) d = sqrt0(d, ds);
   float dpost;

@@ -24,9 +24,17 @@
 
 namespace gd3d {
 
-constexpr int TILE = 256;            // pairs per workgroup
+#ifndef GD_TILE
+#define GD_TILE 256                  // pairs (= threads) per workgroup; multiples of 256 give whole 1-KiB DMA pieces.
+#endif                               // r01 A/B inside bench.py under rocprofv3 (tools/ab_rocprof.sh): 512 halves the
+                                     // partials (reduce stage 7.1 -> 5.1 us) but the VALU-heaviest kernel (bd3d) loses
+                                     // ~2 us to 8-wave barriers (135.7-139.0 -> 139.5-140.4 us); 1024 is 4 % slower.
+constexpr int TILE = GD_TILE;        // pairs per workgroup
 constexpr int TILE_F = TILE * 7;     // floats per tensor tile (1792)
 constexpr int TILE_V4 = TILE_F / 4;  // 16-byte vectors per tensor tile (448)
+constexpr int NPIECE = TILE_F / 256; // 1-KiB LDS-DMA pieces per tensor tile (7)
+constexpr int NWAVE = TILE / 64;     // waves per workgroup (4)
+constexpr int HEAD_T = 256;          // threads per workgroup of the head-level gather kernel
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void gbl_cptr_t;
@@ -57,16 +65,16 @@ GD_DEV void store_v4(float* dst, const float* src_lds, int idx) {
 GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, float* st, int wave, int lane,
                            const float* gw7, float* sw7) {
 #pragma unroll
-  for (int j0 = 0; j0 < 24; j0 += 4) {
+  for (int j0 = 0; j0 < 3 * NPIECE; j0 += NWAVE) {
     const int j = j0 + wave;  // wave-uniform
-    if (j < 7) {
+    if (j < NPIECE) {
       __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gpred + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, DMA_AUX);
-    } else if (j < 14) {
-      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - 7) * 256 + lane * 4), (lds_ptr_t*)(st + (j - 7) * 256), 16, 0,
-                                       DMA_AUX);
-    } else if (j < 21 && gw7 != nullptr) {
-      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gw7 + (j - 14) * 256 + lane * 4), (lds_ptr_t*)(sw7 + (j - 14) * 256), 16, 0,
-                                       DMA_AUX);
+    } else if (j < 2 * NPIECE) {
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - NPIECE) * 256 + lane * 4),
+                                       (lds_ptr_t*)(st + (j - NPIECE) * 256), 16, 0, DMA_AUX);
+    } else if (j < 3 * NPIECE && gw7 != nullptr) {
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gw7 + (j - 2 * NPIECE) * 256 + lane * 4),
+                                       (lds_ptr_t*)(sw7 + (j - 2 * NPIECE) * 256), 16, 0, DMA_AUX);
     }
   }
 }
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   float* const sp = smem;
   float* const st = smem + TILE_F;
   float* const swave = smem + 2 * TILE_F;
-  float* const sw7 = smem + 2 * TILE_F + 4;
+  float* const sw7 = smem + 2 * TILE_F + 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -251,14 +259,15 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   }
   __syncthreads();
   if (a.partials != nullptr && tid == 0) {
-    bsum = (swave[0] + swave[1]) + (swave[2] + swave[3]);
+#pragma unroll
+    for (int w4 = 0; w4 < NWAVE; w4 += 4) bsum += (swave[w4] + swave[w4 + 1]) + (swave[w4 + 2] + swave[w4 + 3]);
     a.partials[blockIdx.x] = bsum;
   }
 
   if (fast) {
     if (a.gp != nullptr) {
       store_v4(a.gp + base * 7, sp, tid);
-      if (tid < TILE_V4 - TILE) store_v4(a.gp + base * 7, sp, tid + TILE);
+      if (tid < TILE_V4 - TILE) store_v4(a.gp + base * 7, sp, tid + TILE);  // 7/4 vectors per thread
     }
     if (GT) {
       store_v4(a.gt + base * 7, st, tid);
@@ -294,11 +303,11 @@ struct HeadArgs {
 };
 
 template <int LOSS, int FUN, bool FLAG>
-__global__ __launch_bounds__(TILE) void head_anchor_kernel(const HeadArgs a) {
-  __shared__ float swave[TILE / 64];
+__global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
+  __shared__ float swave[HEAD_T / 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long i = (long long)blockIdx.x * TILE + tid;
+  const long long i = (long long)blockIdx.x * HEAD_T + tid;
   const bool valid = i < a.P;
   float fl = 0.0f;
   if (valid) {
@@ -348,8 +357,8 @@ __global__ __launch_bounds__(TILE) void head_anchor_kernel(const HeadArgs a) {
 
 template <int LOSS, int FUN>
 static void launch_head(bool flag, unsigned grid, hipStream_t s, const HeadArgs& a) {
-  if (flag) hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, true>), dim3(grid), dim3(TILE), 0, s, a);
-  else hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, false>), dim3(grid), dim3(TILE), 0, s, a);
+  if (flag) hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, true>), dim3(grid), dim3(HEAD_T), 0, s, a);
+  else hipLaunchKernelGGL((head_anchor_kernel<LOSS, FUN, false>), dim3(grid), dim3(HEAD_T), 0, s, a);
 }
 
 template <int LOSS>
@@ -415,7 +424,7 @@ struct Geometry {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
-  const size_t lds = (size_t)(2 * TILE_F + 4 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+  const size_t lds = (size_t)(2 * TILE_F + 16 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
   hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), lds, s, a);
 }
 
@@ -452,9 +461,9 @@ using namespace gd3d;
 extern "C" {
 
 size_t gd3d_loss_workspace_bytes(int64_t n) {
-  // one fp32 partial per workgroup; sized for the one-tile-per-workgroup geometry (the largest one)
+  // one fp32 partial per workgroup; sized for 256-row workgroups (the finest geometry any kernel here uses)
   if (n <= 0) return 16;
-  const int64_t nb = (n + TILE - 1) / TILE;
+  const int64_t nb = (n + 255) / 256;
   return (size_t)(((nb + 1) * 4 + 15) / 16 * 16);
 }
 
@@ -595,7 +604,7 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];
   a.c2 = p->center_offset[2];
-  const long long nb = (P + TILE - 1) / TILE;
+  const long long nb = (P + HEAD_T - 1) / HEAD_T;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const bool flag = p->flag != 0;
   const unsigned grid = (unsigned)nb;
@@ -614,7 +623,10 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  if (loss_sum != nullptr) return gd3d_loss_reduce(workspace, P, loss_sum, stream);
+  if (loss_sum != nullptr) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nb, loss_sum);
+    return (int)hipGetLastError();
+  }
   return 0;
 }
 

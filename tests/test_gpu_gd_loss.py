@@ -104,9 +104,9 @@ def _synthetic(n, seed):
 
 
 @pytest.mark.parametrize('lt', ['gwd3d', 'kld3d', 'bd3d', 'jd3d', 'kld3d_symmax', 'kld3d_symmin', 'kfiou3d'])
-@pytest.mark.parametrize('n', [1, 255, 256, 257, 100_003])
+@pytest.mark.parametrize('n', [1, 255, 256, 257, 511, 512, 513, 100_003])
 def test_against_fp64_oracle_ragged_sizes(amd, lt, n):
-    """Seeded synthetic pairs vs the fp64 oracle, incl. tile-boundary sizes (tile = 256 pairs).
+    """Seeded synthetic pairs vs the fp64 oracle, incl. tile-boundary sizes (tile = 512 pairs, DMA pieces per 256).
     Shipped KITTI setting: fun=log1p, tau=1, loss_weight=5; reduction 'sum' keeps grads O(1)."""
     pred, tgt = _synthetic(n, seed=n)
     fun = 'expm1' if lt == 'kfiou3d' else 'log1p'

@@ -27,22 +27,30 @@ def main():
     gp = torch.empty_like(pred); total = torch.zeros((), device=dev)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for path in libs:
-        L = load(path)
-        ws = torch.empty(L.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    rounds = int(os.environ.get('ROUNDS', 5))
+    libs_loaded = [(os.path.basename(p), load(p)) for p in libs]
+    res = {name: {lt: [] for lt in ('gwd3d', 'kld3d', 'bd3d')} for name, _ in libs_loaded}
+    loss_val = {}
+    for r in range(rounds):                      # interleaved rounds in ONE process (cdna guide §5.4 rule 24)
+        for name, L in libs_loaded:
+            ws = torch.empty(L.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            for lt in ('gwd3d', 'kld3d', 'bd3d'):
+                prm = amd.make_params(lt, 'log1p', 1.0, 1.0, (0, 0, 0.5), {})
+                call = lambda: L.gd3d_loss_fused(ctypes.byref(prm), vp(pred), vp(tgt), None, n, 5.0 / n, None, vp(total), vp(gp), None, vp(ws), s)
+                for _ in range(3): assert call() == 0
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters): call()
+                e1.record(); torch.cuda.synchronize()
+                res[name][lt].append(e0.elapsed_time(e1) / iters * 1e3)
+                loss_val[(name, lt)] = total.item()
+    for name, _ in libs_loaded:
         out = []
         for lt in ('gwd3d', 'kld3d', 'bd3d'):
-            prm = amd.make_params(lt, 'log1p', 1.0, 1.0, (0, 0, 0.5), {})
-            call = lambda: L.gd3d_loss_fused(ctypes.byref(prm), vp(pred), vp(tgt), None, n, 5.0 / n, None, vp(total), vp(gp), None, vp(ws), s)
-            for _ in range(5): assert call() == 0
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters): call()
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / iters * 1e3
-            out.append(f'{lt} {us:7.1f} us {88 * n / us / 1e3:7.1f} GB/s loss={total.item():.6f}')
-        print(f'{os.path.basename(path):28s} ' + ' | '.join(out), flush=True)
+            v = sorted(res[name][lt]); med = v[len(v) // 2]
+            out.append(f'{lt} min {v[0]:6.1f} med {med:6.1f} us ({88 * n / med / 1e3:6.0f} GB/s) loss={loss_val[(name, lt)]:.6f}')
+        print(f'{name:24s} ' + ' | '.join(out), flush=True)
 
 if __name__ == '__main__':
     main()
