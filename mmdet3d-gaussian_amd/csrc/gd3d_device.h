@@ -413,13 +413,13 @@ GD_DEV float bd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj
 
 // ------------------------------------------------------------------ kfiou3d (ref :227-248)
 template <int FUN, bool GT>
-GD_DEV float kfiou(const Box& p, const Box& t, Adj& gp, Adj& gt) {
+GD_DEV float kfiou(const Box& p, const Box& t, float nanp, Adj& gp, Adj& gt) {
   const float S11 = p.S11 + t.S11, S12 = p.S12 + t.S12, S22 = p.S22 + t.S22;
   const float det2 = fmaf(S11, S22, -S12 * S12);
   const float detl = fmaf(p.e, p.e, t.e * t.e);
   const float det = det2 * detl;
-  // kfiou3d never touches the centre, so a NaN dim must be re-injected here (see half_clamp); X,Y,Z carry it
-  const float nanp = (p.X + p.Y + p.Z) * 0.0f + (t.X + t.Y + t.Z) * 0.0f;  // 0, or NaN if any input is NaN/inf
+  // kfiou3d never touches the centre, so a NaN DIM (which half_clamp swallows) is re-injected here: nanp is 0, or NaN
+  // when one of the six raw dims is NaN (torch.clamp propagates NaN); positions and yaw are legitimately ignored
   const float vp = p.a * p.b * p.e + nanp, vt = t.a * t.b * t.e;
   const float m = det >= 1e-7f ? 1.0f : 0.0f;
   float detc = det >= 1e-7f ? det : 1e-7f;
@@ -478,7 +478,11 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
   else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, alpha, tau, gp, gt);
-  else out = kfiou<FUN, GT>(p, t, gp, gt);
+  else {
+    const bool dim_nan = (pv[3] != pv[3]) || (pv[4] != pv[4]) || (pv[5] != pv[5]) || (tv[3] != tv[3]) ||
+                         (tv[4] != tv[4]) || (tv[5] != tv[5]);
+    out = kfiou<FUN, GT>(p, t, dim_nan ? __builtin_nanf("") : 0.0f, gp, gt);
+  }
   box_grad(p, gp, c, f, gpred);
   if (GT) box_grad(t, gt, c, f, gtgt);
   return out;
