@@ -94,6 +94,8 @@ GD_DEV void rotdiag_bwd(float dA, float dB, float co, float si, float m12, float
   g_r = fmaf(g22 - g11, 2.0f * m12, g12 * (dA - dB) * (cc - ss));
 }
 
+// SIGMA = false skips sin/cos and the covariance entries (gwd3d only needs the yaw DIFFERENCE, see gwd<>)
+template <bool SIGMA>
 GD_DEV void box_make(const float (&v)[7], const float (&c)[3], Box& o) {
   o.X = fmaf(c[0], v[3], v[0]);
   o.Y = fmaf(c[1], v[4], v[1]);
@@ -101,10 +103,12 @@ GD_DEV void box_make(const float (&v)[7], const float (&c)[3], Box& o) {
   o.a = half_clamp(v[3], o.mw);
   o.b = half_clamp(v[4], o.mh);
   o.e = half_clamp(v[5], o.ml);
-  sincos_f(v[6], o.si, o.co);
   o.A = o.a * o.a;
   o.B = o.b * o.b;
-  rotdiag(o.A, o.B, o.co, o.si, o.S11, o.S12, o.S22);
+  if (SIGMA) {
+    sincos_f(v[6], o.si, o.co);
+    rotdiag(o.A, o.B, o.co, o.si, o.S11, o.S12, o.S22);
+  }
 }
 
 GD_DEV void sigma_bwd(const Box& bx, float g11, float g12, float g22, Adj& g) {
@@ -164,26 +168,43 @@ GD_DEV float sqrt0(float u, float& dsu) {
 }
 
 // ------------------------------------------------------------------ gwd3d (ref :42-106)
+// The reference forms whlr = tr(Sp) + tr(St) - 2 sqrt(tr(Sp St) + 2 sqrt(det Sp det St)) + (ep-et)^2 from the covariance
+// entries (:81-97), which cancels catastrophically when the boxes are close (its own fp32 result is off by ~2e-4 there,
+// SURVEY.md §4).  The same quantity in a cancellation-free closed form, with d = r_p - r_t, r0 = ap at + bp bt and
+// K = (ap^2-bp^2)(at^2-bt^2):
+//     tr(Sp St) + 2 ap bp at bt = r0^2 - K sin^2 d =: q
+//     tr(Sp) + tr(St) - 2 sqrt(q) = (ap-at)^2 + (bp-bt)^2 + 2 K sin^2 d / (r0 + sqrt q)
+// (identity noted in SURVEY.md §8a; every term is a product of small differences, none is a difference of large
+// numbers).  One sin/cos of the yaw difference replaces two sin/cos + two R S^2 R^T.  Gradients by direct
+// differentiation of the same form:
+//     d/d ap = 2 [(ap-at) + at m + ap (At-Bt) sin^2 d / sqrt q],  m = 1 - r0/sqrt q = -K sin^2 d / ((r0 + sqrt q) sqrt q)
+//     d/d bp = 2 [(bp-bt) + bt m - bp (At-Bt) sin^2 d / sqrt q],  d/d r_p = 2 K sin d cos d / sqrt q = - d/d r_t
 template <int FUN, bool NORMALIZE, bool GT>
-GD_DEV float gwd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float gwd(const Box& p, const Box& t, float dr, float alpha, float tau, Adj& gp, Adj& gt) {
   const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
   const float dxyz = fmaf(dX, dX, fmaf(dY, dY, dZ * dZ));
-  const float T = fmaf(p.S11, t.S11, fmaf(2.0f * p.S12, t.S12, p.S22 * t.S22));
-  const float Dp = p.a * p.b, Dt = t.a * t.b, D = Dp * Dt;
-  const float q = fmaf(2.0f, D, T);
-  float dsq;
-  const float sq = sqrt0(q, dsq);
-  const float de = p.e - t.e;
-  const float whlr = fmaf(de, de, fmaf(-2.0f, sq, (p.A + p.B) + (t.A + t.B)));
+  float sd, cd;
+  sincos_f(dr, sd, cd);
+  const float s2 = sd * sd;
+  const float r0 = fmaf(p.a, t.a, p.b * t.b);
+  const float dAp = (p.a - p.b) * (p.a + p.b), dAt = (t.a - t.b) * (t.a + t.b);
+  const float K = dAp * dAt;
+  const float Ks2 = K * s2;
+  const float q = fmaf(r0, r0, -Ks2);  // >= (ap bt + bp at)^2 > 0 for clamped dims; NaN inputs stay NaN
+  const float rq = __builtin_amdgcn_rsqf(q);
+  const float sq = q * rq;
+  const float irs = frcp(r0 + sq);
+  const float da = p.a - t.a, db = p.b - t.b, de = p.e - t.e;
+  const float whlr = fmaf(de, de, fmaf(da, da, fmaf(db, db, 2.0f * Ks2 * irs)));
   const float a2 = alpha * alpha;
   const float u = fmaf(a2, whlr, dxyz);
   float ddist;
   const float dist = sqrt0(u, ddist);
   float dn = dist, iscale = 1.0f;
+  const float Dp = p.a * p.b, Dt = t.a * t.b;
   if (NORMALIZE) {
-    // scale = 2 exp((ln D + ln ep + ln et)/6) = 2 (D ep et)^(1/6)
     // 2 exp((ln D + ln ep + ln et)/6) = 2 * 2^((log2 D + log2(ep et))/6)
-    const float L2 = flog2(D) + flog2(p.e * t.e);
+    const float L2 = flog2(Dp * Dt) + flog2(p.e * t.e);
     iscale = 0.5f * __builtin_amdgcn_exp2f(L2 * (-1.0f / 6.0f));
     dn = dist * iscale;
   }
@@ -193,29 +214,24 @@ GD_DEV float gwd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Ad
   const float g_dist = dpost * iscale;
   const float g_L = NORMALIZE ? -dpost * dn * (1.0f / 6.0f) : 0.0f;
   const float g_u = g_dist * ddist;
-  const float g_w = g_u * a2;
-  const float g_q = -2.0f * g_w * dsq;
-  const float iap = frcp(p.a), ibp = frcp(p.b), iep = frcp(p.e);
-  // d ln D / d a_p = 1/a_p : keep the log route separate from the 2*g_q*D route
-  const float g_D = 2.0f * g_q;
+  const float g_w2 = 2.0f * g_u * a2;          // 2 x adjoint of whlr
+  const float m = -Ks2 * irs * rq;             // 1 - r0 / sqrt(q)
+  const float e_t = dAt * s2 * rq, e_p = dAp * s2 * rq;
   gp.gX = 2.0f * g_u * dX;
   gp.gY = 2.0f * g_u * dY;
   gp.gZ = 2.0f * g_u * dZ;
-  gp.ga = fmaf(g_w, 2.0f * p.a, fmaf(g_D, p.b * Dt, g_L * iap));
-  gp.gb = fmaf(g_w, 2.0f * p.b, fmaf(g_D, p.a * Dt, g_L * ibp));
-  gp.ge = fmaf(g_w, 2.0f * de, g_L * iep);
-  gp.gr = 0.0f;
-  sigma_bwd(p, g_q * t.S11, 2.0f * g_q * t.S12, g_q * t.S22, gp);
+  gp.ga = fmaf(g_w2, fmaf(p.a, e_t, fmaf(t.a, m, da)), g_L * frcp(p.a));
+  gp.gb = fmaf(g_w2, fmaf(-p.b, e_t, fmaf(t.b, m, db)), g_L * frcp(p.b));
+  gp.ge = fmaf(g_w2, de, g_L * frcp(p.e));
+  gp.gr = g_w2 * K * sd * cd * rq;
   if (GT) {
-    const float iat = frcp(t.a), ibt = frcp(t.b), iet = frcp(t.e);
     gt.gX = -gp.gX;
     gt.gY = -gp.gY;
     gt.gZ = -gp.gZ;
-    gt.ga = fmaf(g_w, 2.0f * t.a, fmaf(g_D, Dp * t.b, g_L * iat));
-    gt.gb = fmaf(g_w, 2.0f * t.b, fmaf(g_D, Dp * t.a, g_L * ibt));
-    gt.ge = fmaf(-g_w, 2.0f * de, g_L * iet);
-    gt.gr = 0.0f;
-    sigma_bwd(t, g_q * p.S11, 2.0f * g_q * p.S12, g_q * p.S22, gt);
+    gt.ga = fmaf(g_w2, fmaf(t.a, e_p, fmaf(p.a, m, -da)), g_L * frcp(t.a));
+    gt.gb = fmaf(g_w2, fmaf(-t.b, e_p, fmaf(p.b, m, -db)), g_L * frcp(t.b));
+    gt.ge = fmaf(-g_w2, de, g_L * frcp(t.e));
+    gt.gr = -gp.gr;
   }
   return out;
 }
@@ -469,10 +485,10 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
                        float tau, float f, float (&gpred)[7], float (&gtgt)[7]) {
   Box p, t;
   Adj gp, gt;
-  box_make(pv, c, p);
-  box_make(tv, c, t);
+  box_make<LOSS != GD3D_GWD3D>(pv, c, p);
+  box_make<LOSS != GD3D_GWD3D>(tv, c, t);
   float out;
-  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
+  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6] - tv[6], alpha, tau, gp, gt);
   else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
