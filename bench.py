@@ -222,7 +222,7 @@ def main():
                                                  for k, v in kern_ms.items()}},
             'loss_values': {k: round(v, 6) for k, v in losses.items()},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
         print(json.dumps(line), flush=True)
     if use_dist:

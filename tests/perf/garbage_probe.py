@@ -1,7 +1,7 @@
 """Probe: garbage inputs (NaN, inf, zeros, negative / huge dims, huge yaw) — finite/NaN pattern of the HIP kernel vs the
 fp64 oracle.  Not a parity requirement (the reference yields NaN/inf soup here too); documents the behaviour."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import mmdet3d_gaussian_amd as amd, oracle
 rng = np.random.default_rng(0)

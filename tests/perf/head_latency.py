@@ -5,7 +5,7 @@
   unfused : torch coder mirror + amd.GDLoss (plain fused loss, decode as torch ops + autograd)
   eager   : torch coder mirror + oracle/gd_torch.py (reference-style eager op chain)"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mmdet3d_gaussian_amd as amd

@@ -2,7 +2,7 @@
 """Rotated BEV NMS timing: GPU (C ABI kernels only, and nms_gpu end to end incl. sort + count sync) vs the CPU oracle.
 SURVEY.md §8d config 5 stand-in: Waymo-like boxes, thr 0.25; nuScenes: n=1000 thr 0.2."""
 import ctypes, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import mmdet3d_gaussian_amd as amd, oracle

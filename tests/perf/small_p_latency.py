@@ -4,7 +4,7 @@ loss_weight=5): P positives, weight (P,7)=1, avg_factor=P; forward + backward pe
 Compares the fused HIP path (GDLoss) with the reference-style eager PyTorch op chain on the same MI355X
 (oracle/gd_torch.py — written in entry form, fewer kernels than the reference's own bmm chain, so conservative)."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import math, torch
 import mmdet3d_gaussian_amd as amd

@@ -21,10 +21,12 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SAL
 python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 # context measurements (not bench lines): HBM ceilings, NMS, small-P / head-level train-step slices
 [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
-python3 tools/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
-python3 tools/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
-python3 tools/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tools/nms_time.py > /dev/null 2>&1
+python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
+python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
+python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
 cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
+python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
+python3 tools/accuracy_report.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_accuracy_report.txt
 python3 tools/profile_summary.py $OUT $R
 ls -la $OUT
