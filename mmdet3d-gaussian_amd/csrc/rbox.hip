@@ -3,11 +3,10 @@
 //
 // NMS (replaces mmdet3d iou3d_cuda.nms_gpu, whose mask goes D->H and is scanned on the host):
 //   1. obox_prep_kernel: one thread per box: sin/cos + rotated corners once -> 64-byte OBox records.
-//   2. nms_mask_kernel:  one 256-thread workgroup per (row block, col block >= row block) pair of
-//      64-box blocks.  Lane r of wave s tests row box r against 16 column boxes (s*16 .. s*16+15)
-//      that sit in LDS (wave-wide broadcast reads); per-thread polygon vertices live in LDS
-//      [slot][thread]; the four 16-bit partial words are OR-ed through LDS into the 64-bit mask word.
-//      This is compute/latency-bound integer+fp32 work (no HBM roofline: N=4096 reads 256 KB, writes 1 MB).
+//   2. nms_mask_kernel:  one wave per (row box, 64-box column block at or right of its own block): lane l tests the
+//      row box against column box l, the ballot is the mask word; per-thread polygon vertices live in LDS
+//      [slot][thread] (12 KiB per wave).  Compute/latency-bound integer+fp32 work (no HBM roofline: N=4096 reads
+//      256 KB, writes 1 MB).
 //   3. nms_scan_kernel:  the greedy scan as ONE wave that never leaves the device: the 64-box
 //      diagonal word of each block is resolved with scalar readlane steps, then the mask rows of the
 //      boxes just kept are OR-ed into the removed-set (LDS) with independent, pipelined row loads.
@@ -32,140 +31,140 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict_
   out[i] = o;
 }
 
+// One WAVE per (row box i, 64-box column block c >= block of i): lane l tests box i against box 64c + l and the
+// wave-wide ballot IS the 64-bit mask word — no partial words, no barrier.  One wave per workgroup keeps the per-thread
+// polygon scratch at 12 KiB of LDS (13 workgroups per CU); far-apart pairs leave through the exact bounding-circle
+// early-out, so most waves retire after ~20 instructions.  blockIdx.x = (upper-triangle block pair) * 64 + row-in-block.
 template <bool NORMAL>
-__global__ __launch_bounds__(NMS_T) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
-                                                         int n, int cb, float thresh,
-                                                         unsigned long long* __restrict__ mask) {
-  // upper-triangular block pairs only: linear block id -> (row, col >= row)
-  __shared__ OBox scol[64];
-  __shared__ float sraw[64 * 5];
-  __shared__ unsigned int spart[4][64];
-  __shared__ VertexScratch<NORMAL ? 1 : NMS_T> vs;
-
-  int row = 0, rem = blockIdx.x;
-  // rows have cb, cb-1, ... blocks; walk (cb is small: <= 1024)
-  while (rem >= cb - row) {
-    rem -= cb - row;
-    ++row;
-  }
-  const int col = row + rem;
-  const int tid = threadIdx.x, r = tid & 63, seg = tid >> 6;
-  const int ncol = min(64, n - col * 64);
-  const int i = row * 64 + r;
-
-  if (NORMAL) {
-    for (int k = tid; k < ncol * 5; k += NMS_T) sraw[k] = boxes[(size_t)col * 64 * 5 + k];
-  } else {
-    // 64 records x 16 dwords, cooperative copy
-    const float* src = reinterpret_cast<const float*>(ob + (size_t)col * 64);
-    float* dst = reinterpret_cast<float*>(scol);
-    for (int k = tid; k < ncol * 16; k += NMS_T) dst[k] = src[k];
-  }
-  __syncthreads();
-
-  unsigned int bits = 0;
-  if (i < n) {
-    OBox A;
-    float araw[5];
-    if (NORMAL) {
+__global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
+                                                      int n, int cb, float thresh,
+                                                      unsigned long long* __restrict__ mask) {
+  __shared__ VertexScratch<NORMAL ? 1 : 64> vs;
+  const int lane = threadIdx.x;
+  const unsigned pair = blockIdx.x >> 6;
+  const int r_in = blockIdx.x & 63;
+  // pair -> (rb, c): pairs before row block rb: rb*cb - rb(rb-1)/2
+  int rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
+  rb = max(0, min(rb, cb - 1));
+  while (rb > 0 && (unsigned)(rb * cb - rb * (rb - 1) / 2) > pair) --rb;
+  while ((unsigned)((rb + 1) * cb - (rb + 1) * rb / 2) <= pair) ++rb;
+  const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
+  const int i = rb * 64 + r_in;
+  if (i >= n) return;
+  const int j = c * 64 + lane;
+  const bool act = j < n && !(rb == c && j <= i);
+  bool hit = false;
+  if constexpr (NORMAL) {
+    if (act) {
+      float a[5], b[5];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) araw[k] = boxes[(size_t)i * 5 + k];
-    } else {
-      A = ob[i];
+      for (int k = 0; k < 5; ++k) {
+        a[k] = boxes[(size_t)i * 5 + k];
+        b[k] = boxes[(size_t)j * 5 + k];
+      }
+      hit = iou_normal(a, b) > thresh;
     }
-    const int j0 = seg * 16;
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = j0 + jj;
-      if (j >= ncol) break;
-      if (row == col && j <= r) continue;
-      float iou;
-      if constexpr (NORMAL) iou = iou_normal(araw, &sraw[j * 5]);
-      else iou = iou_bev<NMS_T>(A, scol[j], vs, tid);
-      if (iou > thresh) bits |= 1u << jj;
+  } else {
+    if (act) {
+      const OBox A = ob[i];  // wave-uniform address: served as a broadcast
+      const OBox B = ob[j];
+      hit = iou_bev<64>(A, B, vs, lane) > thresh;
     }
   }
-  spart[seg][r] = bits;
-  __syncthreads();
-  if (tid < 64 && i < n) {
-    const unsigned long long w = (unsigned long long)spart[0][r] | ((unsigned long long)spart[1][r] << 16) |
-                                 ((unsigned long long)spart[2][r] << 32) | ((unsigned long long)spart[3][r] << 48);
-    mask[(size_t)i * cb + col] = w;
-  }
+  const unsigned long long word = __ballot(hit);
+  if (lane == 0) mask[(size_t)i * cb + c] = word;
 }
 
 constexpr int SCAN_T = 256;
 __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int cb,
                                                           long long* __restrict__ keep, long long* __restrict__ num_keep) {
-  // One workgroup of 4 waves walks the 64-box blocks in order.
-  //   resolve  (wave 0): the block's diagonal mask word per lane; a scalar loop visits only the boxes that are still
-  //            alive (s_ff1 over the complement of the removed word), v_readlane fetches the kept box's word.
-  //   propagate (all waves): the mask rows of the boxes just kept are OR-ed into the LDS-resident removed-set;
-  //            wave v takes every 4th kept row, 8 independent 8-byte loads in flight per lane, ds_or_b64 to merge.
+  // One workgroup of 4 waves walks the 64-box blocks in order, ONE barrier per block.
+  //   wave 0 (resolve): lane l holds the diagonal word mask[64c+l][c] and the "urgent" word mask[64c+l][c+1] of
+  //     block c, both prefetched during the previous block (neither depends on the removed-set).  A scalar loop visits
+  //     only the boxes still alive (s_ff1 over the complement of the removed word, v_readlane of the kept box's word);
+  //     the kept lanes then OR their urgent word into remv[c+1] (ds_or_b64), which is all block c+1 needs from block c.
+  //   waves 1-3 (propagate, one block behind): OR the mask rows of the boxes kept in block c-1 into remv[c+1..]
+  //     (every 3rd kept row per wave, 8 independent 8-byte loads in flight per lane).  Word c+1 receives block c-1's
+  //     rows here, one full barrier interval before block c+1 is resolved.
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cb words
-  __shared__ unsigned long long skept;
+  __shared__ unsigned long long skept[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int w = tid; w < cb; w += SCAN_T) remv[w] = 0ull;
+  if (tid < 2) skept[tid] = 0ull;
   __syncthreads();
   int count = 0;
-  for (int c = 0; c < cb; ++c) {
+  unsigned long long diag_next = 0ull, urg_next = 0ull;
+  if (wave == 0 && lane < n) {
+    diag_next = mask[(size_t)lane * cb];
+    if (cb > 1) urg_next = mask[(size_t)lane * cb + 1];
+  }
+  for (int c = 0; c <= cb; ++c) {  // iteration cb only drains the last propagate
     if (wave == 0) {
-      const int i = c * 64 + lane;
-      const unsigned long long diag = (i < n) ? mask[(size_t)i * cb + c] : 0ull;
-      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-      unsigned long long cur = remv[c];
-      // (the builtin returns a signed int: go through unsigned before widening)
-      cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
-      const int nvalid = min(64, n - c * 64);
-      if (nvalid < 64) cur |= ~0ull << nvalid;
-      unsigned long long kept = 0ull;
-      unsigned long long cand = ~cur;
-      while (cand) {  // scalar, wave-uniform: one iteration per KEPT box
-        const int l = __builtin_ctzll(cand);
-        const unsigned long long dl =
-            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
-        kept |= 1ull << l;
-        cur |= dl;                        // dl only has bits above l
-        cand = (cand & (cand - 1)) & ~cur;
-      }
-      if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
-      if (lane == 0) skept = kept;
-    }
-    __syncthreads();
-    unsigned long long kb = skept;
-    kb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kb >> 32)) << 32) |
-         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)kb);
-    count += __builtin_popcountll(kb);
-    if (c + 1 < cb && kb) {
-      // drop the kept rows this wave does not own: keep bit #k of kb iff k % 4 == wave
-      unsigned long long mine = 0ull, t = kb;
-      int k = 0;
-      while (t) {
-        const unsigned long long low = t & (~t + 1ull);
-        if ((k & 3) == wave) mine |= low;
-        t ^= low;
-        ++k;
-      }
-      for (int w0 = c + 1; w0 < cb; w0 += 64) {
-        const int w = w0 + lane;
-        const bool act = w < cb;
-        unsigned long long acc = 0ull;
-        unsigned long long mb = mine;
-        while (mb) {
-          int l[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            l[u] = mb ? __builtin_ctzll(mb) : -1;
-            mb = mb ? (mb & (mb - 1)) : 0ull;
-          }
-          unsigned long long v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(c * 64 + l[u]) * cb + w] : 0ull;
-          acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+      if (c < cb) {
+        const int i = c * 64 + lane;
+        const unsigned long long diag = diag_next, urg = urg_next;
+        const int i_next = i + 64;
+        diag_next = (c + 1 < cb && i_next < n) ? mask[(size_t)i_next * cb + (c + 1)] : 0ull;
+        urg_next = (c + 2 < cb && i_next < n) ? mask[(size_t)i_next * cb + (c + 2)] : 0ull;
+        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+        unsigned long long cur = remv[c];
+        // (the builtin returns a signed int: go through unsigned before widening)
+        cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
+              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
+        const int nvalid = min(64, n - c * 64);
+        if (nvalid < 64) cur |= ~0ull << nvalid;
+        unsigned long long kept = 0ull;
+        unsigned long long cand = ~cur;
+        while (cand) {  // scalar, wave-uniform: one iteration per KEPT box
+          const int l = __builtin_ctzll(cand);
+          const unsigned long long dl =
+              ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
+              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
+          kept |= 1ull << l;
+          cur |= dl;                        // dl only has bits above l
+          cand = (cand & (cand - 1)) & ~cur;
         }
-        if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: four waves merge into the same words
+        const bool mine = (kept >> lane) & 1ull;
+        if (mine) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
+        if (mine && c + 1 < cb && urg) atomicOr(&remv[c + 1], urg);
+        count += __builtin_popcountll(kept);
+        if (lane == 0) skept[c & 1] = kept;
+      }
+    } else if (c >= 1) {
+      const int k = c - 1;  // block whose kept rows are propagated now
+      unsigned long long kb = skept[k & 1];
+      kb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kb >> 32)) << 32) |
+           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)kb);
+      if (k + 2 < cb && kb) {
+        // keep bit #q of kb iff q % 3 == wave - 1
+        unsigned long long mine = 0ull, t = kb;
+        int q = 0;
+        while (t) {
+          const unsigned long long low = t & (~t + 1ull);
+          if (q == wave - 1) mine |= low;
+          t ^= low;
+          q = (q == 2) ? 0 : q + 1;
+        }
+        for (int w0 = k + 2; w0 < cb; w0 += 64) {
+          const int w = w0 + lane;
+          const bool act = w < cb;
+          unsigned long long acc = 0ull;
+          unsigned long long mb = mine;
+          while (mb) {
+            int l[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              l[u] = mb ? __builtin_ctzll(mb) : -1;
+              mb = mb ? (mb & (mb - 1)) : 0ull;
+            }
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cb + w] : 0ull;
+            acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+          }
+          if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
+        }
       }
     }
     __syncthreads();
@@ -267,13 +266,11 @@ static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, i
   if (!normal) {
     hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, ni, ob);
   }
-  const unsigned nblk = (unsigned)((long long)cb * (cb + 1) / 2);
+  const unsigned nblk = (unsigned)((long long)cb * (cb + 1) / 2 * 64);  // <= 1024*1025/2*64 < 2^26
   if (normal)
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(NMS_T), 0, s, (const OBox*)ob, boxes, ni, cb, thresh,
-                       mask);
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, thresh, mask);
   else
-    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(NMS_T), 0, s, (const OBox*)ob, boxes, ni, cb, thresh,
-                       mask);
+    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, thresh, mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_T), (size_t)cb * sizeof(unsigned long long), s,
                      (const unsigned long long*)mask, ni, cb, (long long*)keep, (long long*)num_keep);
   return (int)hipGetLastError();
