@@ -34,45 +34,58 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict_
 // One WAVE per (row box i, 64-box column block c >= block of i): lane l tests box i against box 64c + l and the
 // wave-wide ballot IS the 64-bit mask word — no partial words, no barrier.  One wave per workgroup keeps the per-thread
 // polygon scratch at 12 KiB of LDS (13 workgroups per CU); far-apart pairs leave through the exact bounding-circle
-// early-out, so most waves retire after ~20 instructions.  blockIdx.x = (upper-triangle block pair) * 64 + row-in-block.
+// early-out, so most rows cost ~20 instructions.  A wave walks `rows` consecutive row boxes against the same 64
+// column boxes (loaded once); blockIdx.x = (upper-triangle block pair) * (64 / rows) + row group.
+// `rows` (1, 2, 4 or 8; host-chosen) = row boxes a wave walks through against the same 64 column boxes: 1 keeps small
+// problems latency-short (n = 1000: 49 us vs 80 us at 8), 8 keeps large ones from being workgroup-dispatch bound
+// (n = 9000: 640 K one-wave workgroups -> 80 K; 965 -> 834 us).
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
-                                                      int n, int cb, float thresh,
+                                                      int n, int cb, int rows, float thresh,
                                                       unsigned long long* __restrict__ mask) {
   __shared__ VertexScratch<NORMAL ? 1 : 64> vs;
   const int lane = threadIdx.x;
-  const unsigned pair = blockIdx.x >> 6;
-  const int r_in = blockIdx.x & 63;
+  const int groups = 64 / rows;
+  const unsigned pair = blockIdx.x / groups;
+  const int r0 = (int)(blockIdx.x % groups) * rows;
   // pair -> (rb, c): pairs before row block rb: rb*cb - rb(rb-1)/2
   int rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
   rb = max(0, min(rb, cb - 1));
   while (rb > 0 && (unsigned)(rb * cb - rb * (rb - 1) / 2) > pair) --rb;
   while ((unsigned)((rb + 1) * cb - (rb + 1) * rb / 2) <= pair) ++rb;
   const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
-  const int i = rb * 64 + r_in;
-  if (i >= n) return;
   const int j = c * 64 + lane;
-  const bool act = j < n && !(rb == c && j <= i);
-  bool hit = false;
-  if constexpr (NORMAL) {
-    if (act) {
-      float a[5], b[5];
+  OBox B;
+  float braw[5];
+  if (j < n) {
+    if constexpr (NORMAL) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        a[k] = boxes[(size_t)i * 5 + k];
-        b[k] = boxes[(size_t)j * 5 + k];
-      }
-      hit = iou_normal(a, b) > thresh;
-    }
-  } else {
-    if (act) {
-      const OBox A = ob[i];  // wave-uniform address: served as a broadcast
-      const OBox B = ob[j];
-      hit = iou_bev<64>(A, B, vs, lane) > thresh;
+      for (int k = 0; k < 5; ++k) braw[k] = boxes[(size_t)j * 5 + k];
+    } else {
+      B = ob[j];
     }
   }
-  const unsigned long long word = __ballot(hit);
-  if (lane == 0) mask[(size_t)i * cb + c] = word;
+  for (int r = 0; r < rows; ++r) {
+    const int i = rb * 64 + r0 + r;  // wave-uniform
+    if (i >= n) break;
+    const bool act = j < n && !(rb == c && j <= i);
+    bool hit = false;
+    if constexpr (NORMAL) {
+      if (act) {
+        float a[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] = boxes[(size_t)i * 5 + k];
+        hit = iou_normal(a, braw) > thresh;
+      }
+    } else {
+      if (act) {
+        const OBox A = ob[i];  // wave-uniform address: served as a broadcast
+        hit = iou_bev<64>(A, B, vs, lane) > thresh;
+      }
+    }
+    const unsigned long long word = __ballot(hit);
+    if (lane == 0) mask[(size_t)i * cb + c] = word;
+  }
 }
 
 constexpr int SCAN_T = 256;
@@ -266,11 +279,14 @@ static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, i
   if (!normal) {
     hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, ni, ob);
   }
-  const unsigned nblk = (unsigned)((long long)cb * (cb + 1) / 2 * 64);  // <= 1024*1025/2*64 < 2^26
+  const long long pairs = (long long)cb * (cb + 1) / 2;
+  int rows = 1;
+  while (rows < 8 && pairs * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
+  const unsigned nblk = (unsigned)(pairs * (64 / rows));
   if (normal)
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, thresh, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, rows, thresh, mask);
   else
-    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, thresh, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, rows, thresh, mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_T), (size_t)cb * sizeof(unsigned long long), s,
                      (const unsigned long long*)mask, ni, cb, (long long*)keep, (long long*)num_keep);
   return (int)hipGetLastError();
