@@ -107,3 +107,25 @@ def test_eval_iou_large_matches_oracle(amd):
     got = amd.iou_3d(torch.from_numpy(d).cuda(), torch.from_numpy(g).cuda()).cpu().numpy()
     np.testing.assert_allclose(got, oracle.eval_iou_3d(d, g), atol=1e-5, rtol=0)
     assert amd.iou_bev(torch.zeros(0, 7).cuda(), torch.from_numpy(g).cuda()).shape == (0, 500)
+
+
+def test_nms_degenerate_geometry_bit_exact(amd):
+    """Zero-area, identical, shared-edge, nested, axis-aligned, huge and NaN boxes: no hang, no fault, and the same keep
+    list as the oracle (the fp32 operation sequence is the same on both sides, also for garbage)."""
+    rng = np.random.default_rng(3)
+    n = 640
+    boxes, scores = nms_boxes(n, seed=12)
+    boxes[0:40, 2] = boxes[0:40, 0]                       # zero width
+    boxes[40:80] = boxes[40]                              # identical copies
+    boxes[80:120, 4] = 0.0                                # axis aligned
+    boxes[120:160] = boxes[80:120]; boxes[120:160, 0] += (boxes[80:120, 2] - boxes[80:120, 0]); boxes[120:160, 2] += (boxes[80:120, 2] - boxes[80:120, 0])  # shared edge
+    c = (boxes[160:200, :2] + boxes[160:200, 2:4]) / 2
+    boxes[200:240, :2] = c - 0.1; boxes[200:240, 2:4] = c + 0.1; boxes[200:240, 4] = boxes[160:200, 4]            # nested
+    boxes[240:250, :4] *= 1e4                             # far away / huge
+    boxes[250:255, 1] = np.nan                            # NaN coordinate
+    boxes[255:260, 4] = np.inf                            # inf angle
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    for thr in (0.0, 0.25, 0.9):
+        want = oracle.nms_gpu_oracle(boxes, scores, thr)
+        got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
