@@ -27,8 +27,9 @@ namespace gd3d {
 #ifndef GD_TILE
 #define GD_TILE 256                  // pairs (= threads) per workgroup; multiples of 256 give whole 1-KiB DMA pieces.
 #endif                               // r01 A/B inside bench.py under rocprofv3 (tools/ab_rocprof.sh): 512 halves the
-                                     // partials (reduce stage 7.1 -> 5.1 us) but the VALU-heaviest kernel (bd3d) loses
-                                     // ~2 us to 8-wave barriers (135.7-139.0 -> 139.5-140.4 us); 1024 is 4 % slower.
+                                     // partials (reduce stage 6.9 -> 4.9 us) and is neutral for the fused kernel once
+                                     // it is below ~300 VALU/pair, but gave only +0.5 % step throughput with ~1 us
+                                     // longer event-bracketed kernels (noise level); 1024 is 4 % slower.  256 ships.
 constexpr int TILE = GD_TILE;        // pairs per workgroup
 constexpr int TILE_F = TILE * 7;     // floats per tensor tile (1792)
 constexpr int TILE_V4 = TILE_F / 4;  // 16-byte vectors per tensor tile (448)
@@ -49,7 +50,6 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
 #endif
 constexpr int DMA_AUX = GD_NT_LOAD ? 2 : 0;
-constexpr int NUM_CU = 256;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
