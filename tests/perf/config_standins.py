@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Loss/NMS-level stand-ins for BASELINE.json configs 2, 4 and 5 on ONE MI355X (SURVEY.md §8d maps each config to the
+nearest shipped reference config).  Per-GPU work of one training / inference step of the hot path only (the network body
+is out of scope); every value is checked against the oracle once before timing.
+  config 2: PointPillars KITTI 3-class, KLD (tau=0, log1p): anchor head decoded-box branch from raw NCHW output,
+            B=6 samples x 321 408 anchors, ~60 positives per sample (gd_anchor3d_head.py:95-141).
+  config 4: nuScenes CenterPoint (nearest shipped; BASELINE says PointPillars), BCD: 6 tasks x samples_per_gpu=8 x <=500
+            objects: center_head_gd_loss per task (gd_centerpoint_head.py:413-434).
+  config 5: Waymo PointPillars, GWD + rotated NMS: loss at 4096 positives + nms_gpu(4096 boxes, thr 0.25, max 500) x 3
+            classes, keep indices checked bit-exact."""
+import json, math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+import mmdet3d_gaussian_amd as amd, oracle
+from rbox_inputs import nms_boxes
+dev = torch.device('cuda:0')
+def timeit(fn, it):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
+
+# ---- config 2
+B, A, H, W, C = 6, 6, 248, 216, 3
+n_per = H * W * A
+g = torch.Generator(device=dev).manual_seed(0)
+anchors = torch.rand(n_per, 7, generator=g, device=dev) * torch.tensor([70, 80, 1, 1.5, 3, .5, 1.5], device=dev) + torch.tensor([0, -40, -2, .6, .9, 1.4, 0], device=dev)
+bbox_pred = (torch.randn(B, A * 7, H, W, generator=g, device=dev) * 0.1).requires_grad_(True)
+bbox_targets = torch.randn(B, n_per, 7, generator=g, device=dev) * 0.2
+bbox_weights = torch.ones(B, n_per, 7, device=dev)
+labels = torch.full((B, n_per), C, device=dev, dtype=torch.long)
+labels.view(-1)[torch.randperm(B * n_per, generator=g, device=dev)[:60 * B]] = 0
+mod = amd.GDLoss('kld3d', fun='log1p', tau=0.0, loss_weight=5.0)
+def step2():
+    bbox_pred.grad = None
+    amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, 360.0, [1.0] * 7).backward()
+us = timeit(step2, 100)
+print(json.dumps(dict(config=2, what='anchor-head decoded-box loss slice fwd+bwd from NCHW, KITTI geometry', batch=B,
+                      anchors=B * n_per, positives=60 * B, us_per_step=round(us, 1))), flush=True)
+
+# ---- config 4
+coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+Bs, K, tasks = 8, 500, 6
+modb = amd.GDLoss('bd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+data = []
+for _ in range(tasks):
+    P = Bs * K
+    pos = torch.stack([torch.randint(0, Bs, (P,), generator=g, device=dev), torch.randint(0, 128, (P,), generator=g, device=dev),
+                       torch.randint(0, 128, (P,), generator=g, device=dev)], -1)
+    xy = (pos[:, 1:].float() + torch.rand(P, 2, generator=g, device=dev)) * 0.8 - 51.2
+    anno = torch.cat([xy, torch.rand(P, 1, generator=g, device=dev) * 4 - 3, torch.rand(P, 3, generator=g, device=dev) * 2 + 0.5,
+                      torch.rand(P, 1, generator=g, device=dev) * 6 - 3, torch.randn(P, 2, generator=g, device=dev)], -1)
+    pred = torch.cat([torch.rand(P, 2, generator=g, device=dev), anno[:, 2:3], anno[:, 3:6].log(), anno[:, 6:7],
+                      anno[:, 6:7].sin(), anno[:, 6:7].cos(), anno[:, 7:9]], -1)
+    pred = (pred + torch.randn(P, 11, generator=g, device=dev) * 0.1).requires_grad_(True)
+    data.append((pos, pred, anno))
+def step4():
+    for pos, pred, anno in data:
+        pred.grad = None
+        amd.center_head_gd_loss(modb, coder, pos, pred, anno, num_pos=float(Bs * K)).backward()
+us = timeit(step4, 50)
+print(json.dumps(dict(config=4, what='6 CenterPoint tasks x center_head_gd_loss (bd3d) fwd+bwd, samples_per_gpu=8',
+                      positives_per_task=Bs * K, us_per_step=round(us, 1), us_per_task=round(us / tasks, 1))), flush=True)
+
+# ---- config 5
+P = 4096
+t = torch.rand(P, 7, generator=g, device=dev) * torch.tensor([150, 150, 4, 2, 4, 1.5, 6.28], device=dev) + torch.tensor([-75, -75, -3, .5, .5, .5, -3.14], device=dev)
+p = (t + torch.randn(P, 7, generator=g, device=dev) * 0.1).requires_grad_(True)
+modg = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+def loss5():
+    p.grad = None; modg(p, t, avg_factor=float(P)).backward()
+us_loss = timeit(loss5, 100)
+cls = []
+ok = True
+for c in range(3):
+    b, s = nms_boxes(4096, seed=100 + c)
+    cls.append((torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev)))
+    want = oracle.nms_gpu_oracle(b, s, 0.25, post_max_size=500)
+    got = amd.nms_gpu(cls[-1][0], cls[-1][1], 0.25, post_max_size=500).cpu().numpy()
+    ok &= bool(np.array_equal(got, want))
+def nms5():
+    for b, s in cls: amd.nms_gpu(b, s, 0.25, post_max_size=500)
+us_nms = timeit(nms5, 20)
+print(json.dumps(dict(config=5, what='GWD loss fwd+bwd at 4096 positives + nms_gpu(4096, thr .25, max 500) x 3 classes',
+                      loss_us=round(us_loss, 1), nms_us_3_classes=round(us_nms, 1), keep_bit_exact=ok)), flush=True)

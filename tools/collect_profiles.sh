@@ -26,6 +26,7 @@ python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_smal
 python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
 cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
+python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config_standins.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
 python3 tools/accuracy_report.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_accuracy_report.txt
 python3 tools/profile_summary.py $OUT $R
