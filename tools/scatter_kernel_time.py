@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of vox_scatter_reduce / vox_scatter_backward through the C ABI (no autograd)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import mmdet3d_gaussian_amd as amd
+from mmdet3d_gaussian_amd.scatter import Scatter, group_points
+lib = amd.load_library()
+dev = torch.device('cuda:0')
+def t(fn, it=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it * 1e3
+for n, c, grid in ((2_000_000, 64, (432, 496, 1)), (2_000_000, 16, (432, 496, 1)), (2_000_000, 10, (432, 496, 1)), (120_000, 64, (432, 496, 1))):
+    g = torch.Generator(device=dev).manual_seed(0)
+    coors = torch.stack([torch.randint(0, s, (n,), generator=g, device=dev) for s in grid], -1).int()
+    feats = torch.randn(n, c, generator=g, device=dev)
+    sc = Scatter(coors); v = sc.voxel_coors.shape[0]
+    order, seg = group_points(sc.pts_voxel_maps, sc.voxel_pts_counts)
+    out = torch.empty(v, c, device=dev); arg = torch.empty(v, c, dtype=torch.int32, device=dev)
+    gv = torch.randn(v, c, device=dev); gf = torch.empty(n, c, device=dev)
+    for red, name in ((2, 'max'), (1, 'mean'), (0, 'sum')):
+        f = t(lambda: lib.vox_scatter_reduce(feats.data_ptr(), order.data_ptr(), seg.data_ptr(), n, c, v, red, out.data_ptr(), arg.data_ptr() if red == 2 else None, None))
+        b = t(lambda: lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), arg.data_ptr() if red == 2 else None, n, c, v, red, gf.data_ptr(), None))
+        fb = n * c * 4 + n * 4 + v * c * 4 * (2 if red == 2 else 1)
+        bb = (n * c * 4 + v * c * 4 * (2 if red == 2 else 1)) if red == 2 else (n * c * 4 + n * 4 + v * c * 4)
+        print(f'n={n} c={c} v={v} {name:4s}: fwd {f:7.1f} us ({fb / f / 1e3:6.0f} GB/s)  bwd {b:7.1f} us ({bb / b / 1e3:6.0f} GB/s)', flush=True)
