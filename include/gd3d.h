@@ -176,6 +176,16 @@ int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
 int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
                     int64_t* num_keep, void* workspace, void* stream);
 
+/* Same, taking the UNSORTED boxes plus the score order (what `scores.sort(descending=True)` returns, already cut to
+ * pre_max_size): box i of the NMS is boxes[order[i]], and `keep` receives indices into the caller's original box
+ * numbering (= order[kept]) — the gather before and the index mapping after the call disappear.
+ *   boxes (any number of rows >= max(order)+1, 5) fp32;  order (n) int64;  keep (n) int64;  num_keep (1) int64. */
+int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep,
+                     int64_t* num_keep, void* workspace, void* stream);
+
+int rnms_normal_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh,
+                            int64_t* keep, int64_t* num_keep, void* workspace, void* stream);
+
 /* Pairwise rotated BEV IoU in the NMS box format (mmdet3d `boxes_iou_bev`):
  *   a (na,5), b (nb,5) [x1,y1,x2,y2,ry] -> iou (na,nb) fp32 row-major. */
 int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou,

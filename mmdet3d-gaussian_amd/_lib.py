@@ -41,6 +41,8 @@ SYMBOLS = {
     'rnms_workspace_bytes': (_sz, [_i64]),
     'rnms_bev': (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     'rnms_normal_bev': (_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+    'rnms_bev_ordered': (_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+    'rnms_normal_bev_ordered': (_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_bev': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_3d': (_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp]),

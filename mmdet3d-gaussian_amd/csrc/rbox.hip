@@ -20,12 +20,15 @@ namespace rbox {
 
 constexpr int NMS_T = 256;
 
-__global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict__ boxes, int n, OBox* __restrict__ out) {
+// `order` (nullable): score order computed by the caller; box i of the NMS is boxes[order[i]] (saves the gather pass)
+__global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict__ boxes, const long long* __restrict__ order,
+                                                        int n, OBox* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const size_t src = order != nullptr ? (size_t)order[i] : (size_t)i;
   float b[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) b[k] = boxes[(size_t)i * 5 + k];
+  for (int k = 0; k < 5; ++k) b[k] = boxes[src * 5 + k];
   OBox o;
   obox_make(b, o);
   out[i] = o;
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict_
 // (n = 9000: 640 K one-wave workgroups -> 80 K; 965 -> 834 us).
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
-                                                      int n, int cb, int rows, float thresh,
-                                                      unsigned long long* __restrict__ mask) {
+                                                      const long long* __restrict__ order, int n, int cb, int rows,
+                                                      float thresh, unsigned long long* __restrict__ mask) {
   __shared__ VertexScratch<NORMAL ? 1 : 64> vs;
   const int lane = threadIdx.x;
   const int groups = 64 / rows;
@@ -59,8 +62,9 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
   float braw[5];
   if (j < n) {
     if constexpr (NORMAL) {
+      const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) braw[k] = boxes[(size_t)j * 5 + k];
+      for (int k = 0; k < 5; ++k) braw[k] = boxes[sj * 5 + k];
     } else {
       B = ob[j];
     }
@@ -72,9 +76,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
     bool hit = false;
     if constexpr (NORMAL) {
       if (act) {
+        const size_t si = order != nullptr ? (size_t)order[i] : (size_t)i;
         float a[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) a[k] = boxes[(size_t)i * 5 + k];
+        for (int k = 0; k < 5; ++k) a[k] = boxes[si * 5 + k];
         hit = iou_normal(a, braw) > thresh;
       }
     } else {
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
 }
 
 constexpr int SCAN_T = 256;
-__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int cb,
+__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                          const long long* __restrict__ order, int n, int cb,
                                                           long long* __restrict__ keep, long long* __restrict__ num_keep) {
   // One workgroup of 4 waves walks the 64-box blocks in order, ONE barrier per block.
   //   wave 0 (resolve): lane l holds the diagonal word mask[64c+l][c] and the "urgent" word mask[64c+l][c+1] of
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
           cand = (cand & (cand - 1)) & ~cur;
         }
         const bool mine = (kept >> lane) & 1ull;
-        if (mine) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = i;
+        if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
+          keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = order != nullptr ? order[i] : (long long)i;
         if (mine && c + 1 < cb && urg) atomicOr(&remv[c + 1], urg);
         count += __builtin_popcountll(kept);
         if (lane == 0) skept[c & 1] = kept;
@@ -266,8 +273,9 @@ size_t rnms_workspace_bytes(int64_t n) {
   return align_up((size_t)n * sizeof(OBox), 256) + (size_t)n * cb * sizeof(unsigned long long);
 }
 
-static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
-                     void* workspace, void* stream) {
+static int rnms_impl(bool normal, const float* boxes, const int64_t* order_, int64_t n, float thresh, int64_t* keep,
+                     int64_t* num_keep, void* workspace, void* stream) {
+  const long long* order = (const long long*)order_;
   if (n < 0 || num_keep == nullptr) return GD3D_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), s);
@@ -277,29 +285,43 @@ static int rnms_impl(bool normal, const float* boxes, int64_t n, float thresh, i
   OBox* ob = (OBox*)workspace;
   unsigned long long* mask = (unsigned long long*)((char*)workspace + align_up((size_t)n * sizeof(OBox), 256));
   if (!normal) {
-    hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, ni, ob);
+    hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, order, ni, ob);
   }
   const long long pairs = (long long)cb * (cb + 1) / 2;
   int rows = 1;
   while (rows < 8 && pairs * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
   const unsigned nblk = (unsigned)(pairs * (64 / rows));
   if (normal)
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, rows, thresh, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, order, ni, cb, rows, thresh,
+                       mask);
   else
-    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, ni, cb, rows, thresh, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, order, ni, cb, rows, thresh,
+                       mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_T), (size_t)cb * sizeof(unsigned long long), s,
-                     (const unsigned long long*)mask, ni, cb, (long long*)keep, (long long*)num_keep);
+                     (const unsigned long long*)mask, order, ni, cb, (long long*)keep, (long long*)num_keep);
   return (int)hipGetLastError();
 }
 
 int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep, void* workspace,
              void* stream) {
-  return rnms_impl(false, boxes_sorted, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(false, boxes_sorted, nullptr, n, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
+                     void* workspace, void* stream) {
+  if (n > 0 && order == nullptr) return GD3D_E_BADARG;
+  return rnms_impl(false, boxes, order, n, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_normal_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep,
+                            int64_t* num_keep, void* workspace, void* stream) {
+  if (n > 0 && order == nullptr) return GD3D_E_BADARG;
+  return rnms_impl(true, boxes, order, n, thresh, keep, num_keep, workspace, stream);
 }
 
 int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
                     void* workspace, void* stream) {
-  return rnms_impl(true, boxes_sorted, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(true, boxes_sorted, nullptr, n, thresh, keep, num_keep, workspace, stream);
 }
 
 int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou, void* stream) {

@@ -44,19 +44,21 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
     order = scores.sort(0, descending=True)[1]
     if pre_max_size is not None:
         order = order[:pre_max_size]
-    sorted_boxes = boxes[order].contiguous()
-    n = sorted_boxes.shape[0]
+    order = order.contiguous()
+    n = order.shape[0]
     dev = boxes.device
     if n == 0:
         return order.new_zeros((0,))
     with torch.cuda.device(dev):
         keep = torch.empty(n, dtype=torch.int64, device=dev)
-        num = torch.zeros(1, dtype=torch.int64, device=dev)
+        num = torch.empty(1, dtype=torch.int64, device=dev)
         ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        fn = lib.rnms_normal_bev if normal else lib.rnms_bev
-        _lib.check(fn(_ptr(sorted_boxes), n, float(thresh), _ptr(keep), _ptr(num), _ptr(ws), _stream(dev)), name)
+        # the kernels read boxes[order[i]] themselves and emit kept indices in the caller's numbering
+        fn = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
+        _lib.check(fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
+                      ws.data_ptr(), torch.cuda.current_stream().cuda_stream), name)
     k = int(num.item())  # the one unavoidable sync: the result length is data dependent
-    keep = order[keep[:k]].contiguous()
+    keep = keep[:k]
     if post_max_size is not None:
         keep = keep[:post_max_size]
     return keep
