@@ -30,6 +30,12 @@ def anchor_decoded_gd_loss(loss_module, anchors, pos_bbox_pred, pos_bbox_targets
     """loss_module(coder.decode(anchors, pos_bbox_pred), coder.decode(anchors, pos_bbox_targets), weight,
     avg_factor=avg_factor) with mmdet3d's DeltaXYZWLHRBBoxCoder, in one launch (gd_anchor3d_head.py:133-141)."""
     anchors = anchors.reshape(-1, 7).to(torch.float32).contiguous()
+    n = pos_bbox_pred.reshape(-1, 7).shape[0]
+    if anchors.shape[0] != n or pos_bbox_targets.reshape(-1, 7).shape[0] != n:
+        raise RuntimeError(f'anchors {tuple(anchors.shape)}, pred {tuple(pos_bbox_pred.shape)} and targets '
+                           f'{tuple(pos_bbox_targets.shape)} must have the same number of rows')
+    if anchors.device != pos_bbox_pred.device:
+        raise RuntimeError('anchors and predictions live on different devices')
     pro = _prologue(1, anchors)
     return loss_module(pos_bbox_pred, pos_bbox_targets, weight, avg_factor=avg_factor, _prologue=pro)
 
@@ -104,7 +110,18 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
     from .gd_loss import GDLoss
     assert isinstance(loss_module, GDLoss) and loss_module.reduction != 'none'
     B, C, H, W = bbox_pred.shape
+    if C % 7 != 0:
+        raise RuntimeError(f'bbox_pred has {C} channels, expected a multiple of the box code size 7')
+    M = B * H * W * (C // 7)
     labels = labels.reshape(-1)
+    # the kernel indexes by position: every operand must cover exactly the B*H*W*A anchors (no OOB reads on the GPU)
+    if labels.numel() != M or bbox_targets.numel() != M * 7 or anchor_list.numel() != (M // B) * 7 or \
+            (decode_weight and bbox_weights.numel() != M * 7):
+        raise RuntimeError(f'shape mismatch: bbox_pred {tuple(bbox_pred.shape)} implies {M} anchors; labels '
+                           f'{labels.numel()}, bbox_targets {bbox_targets.numel() // 7}, anchors per sample '
+                           f'{anchor_list.numel() // 7}')
+    if decode_weight and len(decode_weight) != 7:
+        raise RuntimeError('decode_weight must have 7 entries')
     pos_inds = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1)
     if pos_inds.numel() == 0:
         return bbox_pred.sum() * 0
@@ -129,6 +146,9 @@ def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
     anno_boxes: (B, K, >=7).  The decode runs inside the kernel; the gradient reaches pred[..., :7]."""
     target_gd = anno_boxes[..., :7].reshape(-1, 7)        # encode() leaves the first 7 entries as they are (:11-16)
     locs = pos_ind[..., 1:].reshape(-1, 2).to(torch.float32).contiguous()
+    if locs.shape[0] != pred[..., :7].reshape(-1, 7).shape[0] or locs.shape[0] != target_gd.shape[0]:
+        raise RuntimeError(f'pos_ind {tuple(pos_ind.shape)}, pred {tuple(pred.shape)} and anno_boxes '
+                           f'{tuple(anno_boxes.shape)} must describe the same number of objects')
     pro = _prologue(2, locs, norm_bbox=coder.norm_bbox, out_size_factor=coder.out_size_factor,
                     voxel_size=coder.voxel_size, pc_range=coder.pc_range)
     pred7 = pred[..., :7].reshape(-1, 7)

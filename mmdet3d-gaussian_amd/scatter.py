@@ -75,6 +75,10 @@ class _ScatterReduce(Function):
             return feats.clone().detach()
         feats32 = feats.contiguous() if feats.dtype == torch.float32 else feats.float().contiguous()
         n, c = feats32.shape
+        if point2voxel_map.numel() != n or point2voxel_map.dtype != torch.int32 or \
+                voxel_points_count.dtype != torch.int32:
+            raise RuntimeError('scatter_reduce: point2voxel_map must be an int32 tensor with one entry per point and '
+                               'voxel_points_count int32 (as scatter_index returns them)')
         v = voxel_points_count.numel()
         order, seg = grouping if grouping is not None else group_points(point2voxel_map, voxel_points_count)
         out = torch.empty((v, c), dtype=torch.float32, device=feats.device)

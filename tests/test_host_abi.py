@@ -120,3 +120,24 @@ def test_product_never_imports_oracle():
 def test_xywhr2xyxyr():
     b = torch.tensor([[1.0, 2.0, 4.0, 2.0, 0.3]])
     assert torch.allclose(amd.xywhr2xyxyr(b), torch.tensor([[-1.0, 1.0, 3.0, 3.0, 0.3]]))
+
+
+def test_head_slices_validate_shapes_before_touching_the_gpu():
+    """Position-indexed kernels must never be launched with operands that do not cover the index range."""
+    m = amd.GDLoss('kld3d')
+    B, A, H, W = 1, 2, 3, 4
+    bbox_pred = torch.zeros(B, A * 7, H, W)
+    M = B * H * W * A
+    good = dict(bbox_targets=torch.zeros(B, M, 7), bbox_weights=torch.ones(B, M, 7), labels=torch.zeros(B, M, dtype=torch.long),
+                anchor_list=torch.zeros(M, 7))
+    with pytest.raises(RuntimeError, match='shape mismatch'):
+        amd.anchor_head_decoded_loss_fused(m, bbox_pred, good['bbox_targets'][:, :-1], good['bbox_weights'], good['labels'],
+                                           good['anchor_list'], 3, 1.0, [1.0] * 7)
+    with pytest.raises(RuntimeError, match='shape mismatch'):
+        amd.anchor_head_decoded_loss_fused(m, bbox_pred, good['bbox_targets'], good['bbox_weights'], good['labels'],
+                                           good['anchor_list'][:-1], 3, 1.0, [1.0] * 7)
+    with pytest.raises(RuntimeError, match='multiple of the box code size'):
+        amd.anchor_head_decoded_loss_fused(m, torch.zeros(1, 13, 3, 4), good['bbox_targets'], good['bbox_weights'],
+                                           good['labels'], good['anchor_list'], 3, 1.0, None)
+    with pytest.raises(RuntimeError, match='same number of rows'):
+        amd.anchor_decoded_gd_loss(m, torch.zeros(5, 7), torch.zeros(4, 7), torch.zeros(4, 7))
