@@ -144,6 +144,15 @@ int gd3d_anchor_head_loss(const gd3d_params* params, const float* bbox_pred, int
                           int64_t P, float scale, float* loss_sum, float* grad_bbox_pred,
                           void* workspace, void* stream);
 
+/* Dense form of the same slice: no positive list at all.  One thread per ANCHOR m tests labels[m] (int64 (M), positive iff
+ * 0 <= label < num_classes, gd_anchor3d_head.py:101-105) and leaves unless positive — torch.nonzero() (a host sync), the
+ * compaction and every index kernel disappear from the training step.  workspace: gd3d_loss_workspace_bytes(M). */
+int gd3d_anchor_head_loss_dense(const gd3d_params* params, const float* bbox_pred, int32_t B, int32_t A,
+                                int32_t H, int32_t W, const float* bbox_targets, const float* bbox_weights,
+                                const float* decode_weight, const float* anchors, const int64_t* labels,
+                                int32_t num_classes, float scale, float* loss_sum, float* grad_bbox_pred,
+                                void* workspace, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

@@ -36,6 +36,9 @@ SYMBOLS = {
     'gd3d_anchor_head_loss': (_int, [ctypes.POINTER(Params), _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.c_int32, _vp, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _i64, _f32, _vp,
                                      _vp, _vp, _vp]),
+    'gd3d_anchor_head_loss_dense': (_int, [ctypes.POINTER(Params), _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, _vp, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp,
+                                           ctypes.c_int32, _f32, _vp, _vp, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),

@@ -293,7 +293,9 @@ struct HeadArgs {
   const float* bbox_targets;   // (M,7), M = B*H*W*A, row m = ((b*H + h)*W + w)*A + a
   const float* bbox_weights;   // (M,7) nullable
   const float* anchors;        // (H*W*A, 7) anchors of one sample
-  const long long* pos_inds;   // (P)
+  const long long* pos_inds;   // (P) positive rows, or NULL: dense mode, thread m tests labels[m] itself
+  const long long* labels;     // dense mode: (M) class labels; positive iff 0 <= label < num_classes
+  int num_classes;
   float* grad_bbox_pred;       // (B, A*7, H, W), zero-filled by the caller; nullable
   float* partials;
   long long P;
@@ -308,10 +310,18 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long i = (long long)blockIdx.x * HEAD_T + tid;
-  const bool valid = i < a.P;
+  bool valid = i < a.P;
+  long long m = i;
+  if (valid) {
+    if (a.pos_inds != nullptr) {
+      m = a.pos_inds[i];
+    } else {  // dense mode: no nonzero()/compaction/host sync upstream; non-positives leave here
+      const long long lab = a.labels[i];
+      valid = lab >= 0 && lab < a.num_classes;
+    }
+  }
   float fl = 0.0f;
   if (valid) {
-    const long long m = a.pos_inds[i];
     const long long hwa = (long long)a.H * a.W * a.A;
     const long long b = m / hwa, r = m - b * hwa;
     const int an_i = (int)(r % a.A);
@@ -567,10 +577,11 @@ int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* st
   return (int)hipGetLastError();
 }
 
-int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
-                          const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
-                          const float* anchors, const int64_t* pos_inds, int64_t P, float scale, float* loss_sum,
-                          float* grad_bbox_pred, void* workspace, void* stream) {
+static int anchor_head_impl(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
+                            const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
+                            const float* anchors, const int64_t* pos_inds, const int64_t* labels, int32_t num_classes,
+                            int64_t P, float scale, float* loss_sum, float* grad_bbox_pred, void* workspace,
+                            void* stream) {
   if (p == nullptr || P < 0 || B <= 0 || A <= 0 || H <= 0 || W <= 0) return GD3D_E_BADARG;
   if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
   if (p->loss_type == GD3D_KFIOU3D) {
@@ -583,7 +594,8 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
     if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
     return 0;
   }
-  if (bbox_pred == nullptr || bbox_targets == nullptr || anchors == nullptr || pos_inds == nullptr) return GD3D_E_BADARG;
+  if (bbox_pred == nullptr || bbox_targets == nullptr || anchors == nullptr) return GD3D_E_BADARG;
+  if (pos_inds == nullptr && labels == nullptr) return GD3D_E_BADARG;
   if (loss_sum != nullptr && workspace == nullptr) return GD3D_E_BADARG;
   HeadArgs a;
   a.bbox_pred = bbox_pred;
@@ -591,6 +603,8 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
   a.bbox_weights = bbox_weights;
   a.anchors = anchors;
   a.pos_inds = (const long long*)pos_inds;
+  a.labels = (const long long*)labels;
+  a.num_classes = num_classes;
   a.grad_bbox_pred = grad_bbox_pred;
   a.partials = (float*)workspace;
   a.P = P;
@@ -628,6 +642,25 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
     return (int)hipGetLastError();
   }
   return 0;
+}
+
+int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
+                          const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
+                          const float* anchors, const int64_t* pos_inds, int64_t P, float scale, float* loss_sum,
+                          float* grad_bbox_pred, void* workspace, void* stream) {
+  if (P > 0 && pos_inds == nullptr) return GD3D_E_BADARG;
+  return anchor_head_impl(p, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, pos_inds, nullptr, 0,
+                          P, scale, loss_sum, grad_bbox_pred, workspace, stream);
+}
+
+int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
+                                const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
+                                const float* anchors, const int64_t* labels, int32_t num_classes, float scale,
+                                float* loss_sum, float* grad_bbox_pred, void* workspace, void* stream) {
+  if (B <= 0 || A <= 0 || H <= 0 || W <= 0 || labels == nullptr) return GD3D_E_BADARG;
+  const int64_t M = (int64_t)B * A * H * W;
+  return anchor_head_impl(p, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, nullptr, labels,
+                          num_classes, M, scale, loss_sum, grad_bbox_pred, workspace, stream);
 }
 
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream) {

@@ -67,25 +67,33 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
 
 
 class _AnchorHeadFused(torch.autograd.Function):
-    """gather of the positives + decode x2 + loss + gradient scatter into the NCHW head output: one launch."""
+    """selection/gather of the positives + decode x2 + loss + gradient scatter into the NCHW head output: one launch.
+    `pos_or_labels` is either the (P,) int64 positive list (dense=False) or the (M,) int64 label map (dense=True)."""
 
     @staticmethod
-    def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_inds, params, dw, scale):
+    def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
+                num_classes=0):
         lib = _lib.load()
         B, C, H, W = bbox_pred.shape
         A = C // 7
-        P = pos_inds.numel()
+        P = pos_or_labels.numel()
         dev = bbox_pred.device
         need_grad = ctx.needs_input_grad[0]
         grad = torch.zeros_like(bbox_pred) if need_grad else None
         buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
         dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
+        wp = None if bbox_weights is None else bbox_weights.data_ptr()
+        gp = None if grad is None else grad.data_ptr()
         with torch.cuda.device(dev):
-            rc = lib.gd3d_anchor_head_loss(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(),
-                                           None if bbox_weights is None else bbox_weights.data_ptr(), dwp,
-                                           anchors.data_ptr(), pos_inds.data_ptr(), P, scale, buf[0].data_ptr(),
-                                           None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream)
+            stream = torch.cuda.current_stream().cuda_stream
+            if dense:
+                rc = lib.gd3d_anchor_head_loss_dense(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
+                                                     dwp, anchors.data_ptr(), pos_or_labels.data_ptr(), int(num_classes),
+                                                     scale, buf[0].data_ptr(), gp, buf[4:].data_ptr(), stream)
+            else:
+                rc = lib.gd3d_anchor_head_loss(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp, dwp,
+                                               anchors.data_ptr(), pos_or_labels.data_ptr(), P, scale, buf[0].data_ptr(),
+                                               gp, buf[4:].data_ptr(), stream)
         _lib.check(rc, 'gd3d_anchor_head_loss')
         ctx.grad = grad
         return buf[0]
@@ -99,14 +107,17 @@ class _AnchorHeadFused(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
                                            torch.cuda.current_stream().cuda_stream), 'gd3d_scale_rows')
-        return g, None, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None, None, None
 
 
 def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list, num_classes,
-                                   num_total_samples, decode_weight=None):
-    """Same contract as anchor_head_decoded_loss, but the positives are gathered INSIDE the kernel straight from the
-    NCHW head output (no permute/reshape copy, no index kernels, no scatter in backward): nonzero() is the only torch
-    op left on the path.  Requires a reduced loss (mean/sum) without per-call kwargs."""
+                                   num_total_samples, decode_weight=None, dense=True):
+    """Same contract as anchor_head_decoded_loss, but everything between the raw NCHW head output and the loss runs
+    INSIDE one kernel (no permute/reshape copy, no index kernels, no scatter in backward).
+      dense=True : one thread per ANCHOR tests its label itself; torch.nonzero() — a host sync — and the compaction go
+                   away too, the call is fully asynchronous (no-positive batches simply yield 0 and a zero gradient);
+      dense=False: one thread per positive of a torch.nonzero() list (less device work, one sync).
+    Requires a reduced loss (mean/sum) without per-call kwargs."""
     from .gd_loss import GDLoss
     assert isinstance(loss_module, GDLoss) and loss_module.reduction != 'none'
     B, C, H, W = bbox_pred.shape
@@ -122,9 +133,12 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
                            f'{anchor_list.numel() // 7}')
     if decode_weight and len(decode_weight) != 7:
         raise RuntimeError('decode_weight must have 7 entries')
-    pos_inds = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1)
-    if pos_inds.numel() == 0:
-        return bbox_pred.sum() * 0
+    if dense:
+        sel = labels.to(torch.int64).contiguous()
+    else:
+        sel = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1).contiguous()
+        if sel.numel() == 0:
+            return bbox_pred.sum() * 0
     bp = bbox_pred if bbox_pred.dtype == torch.float32 else bbox_pred.float()
     weights = None
     if decode_weight:
@@ -132,8 +146,9 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
     den = num_total_samples if loss_module.reduction == 'mean' else 1.0
     scale = float(loss_module.loss_weight) / float(den)
     out = _AnchorHeadFused.apply(bp.contiguous(), bbox_targets.reshape(-1, 7).to(torch.float32).contiguous(), weights,
-                                 anchor_list.reshape(-1, 7).to(torch.float32).contiguous(), pos_inds.contiguous(),
-                                 loss_module._params({}), decode_weight if decode_weight else None, scale)
+                                 anchor_list.reshape(-1, 7).to(torch.float32).contiguous(), sel,
+                                 loss_module._params({}), decode_weight if decode_weight else None, scale, bool(dense),
+                                 int(num_classes))
     return out
 
 

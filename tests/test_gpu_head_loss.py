@@ -116,6 +116,12 @@ def test_anchor_head_gather_fused_matches_unfused_and_oracle(amd, lt, red):
     avg = 77.0 if red == 'mean' else None
     ref = amd.anchor_head_decoded_loss(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw)
     ref.backward(); g_ref = bbox_pred.grad.clone(); bbox_pred.grad = None
+    # dense (label test in the kernel, no nonzero) and list (nonzero) forms must agree bit for bit in the gradient
+    od = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw, dense=True)
+    od.backward(); g_dense = bbox_pred.grad.clone(); bbox_pred.grad = None
+    ol = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw, dense=False)
+    ol.backward(); g_list = bbox_pred.grad.clone(); bbox_pred.grad = None
+    assert torch.equal(g_dense, g_list) and abs(od.item() - ol.item()) <= 1e-6 * (1 + abs(ol.item()))
     out = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, avg, dw)
     (out * 3.0).backward()                     # upstream gradient != 1 exercises the scale kernel on the NCHW grad
     assert abs(out.item() - ref.item()) <= 1e-5 * (1 + abs(ref.item()))
