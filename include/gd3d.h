@@ -153,6 +153,37 @@ int gd3d_anchor_head_loss_dense(const gd3d_params* params, const float* bbox_pre
                                 int32_t num_classes, float scale, float* loss_sum, float* grad_bbox_pred,
                                 void* workspace, void* stream);
 
+/* The whole regression loss of GDAnchor3DHead.loss_single (gd_anchor3d_head.py:95-159) in one launch:
+ *   loss_bbox = loss_decoded_bbox(decode(anchors, pred), decode(anchors, target), decode_weight, avg_factor)   (:133-141)
+ *             + loss_bbox(pred', target', code_weight, avg_factor)                                             (:152-159)
+ * where the second term is mmdet's SmoothL1Loss (third party) on the ENCODED rows, after mmdet3d's
+ * add_sin_difference when diff_rad_by_sin (pred'[6] = sin p6 cos t6, target'[6] = cos p6 sin t6).
+ *   smooth_l1 == NULL         : only the Gaussian-distance term (same as the two functions above);
+ *   smooth_l1->beta           : SmoothL1Loss.beta; 0 selects L1Loss;
+ *   smooth_l1->scale          : loss_weight / avg_factor of that term;
+ *   smooth_l1->has_code_weight: element weight = bbox_weights[m,k] * code_weight[k] (bbox_weights required), else 1
+ *                               (the reference passes weight=None when train_cfg['code_weight'] is falsy, :124-127).
+ * The positives are named by EXACTLY ONE of pos_inds (P rows) or labels (dense form, P ignored).
+ * With smooth_l1 != NULL the Gaussian term is weighted by mean_k(bbox_weights*decode_weight) only when decode_weight
+ * != NULL (:128-131); *loss_sum receives the SUM of both terms, grad_bbox_pred (zero-filled by the caller) their
+ * combined gradient.  workspace: gd3d_loss_workspace_bytes(P or M). */
+typedef struct gd3d_smooth_l1 {
+  float beta;
+  float scale;
+  int32_t diff_rad_by_sin;
+  int32_t has_code_weight;
+  float code_weight[7];
+  float reserved;
+} gd3d_smooth_l1;
+
+int gd3d_anchor_head_bbox_loss(const gd3d_params* params, const gd3d_smooth_l1* smooth_l1,
+                               const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
+                               const float* bbox_targets, const float* bbox_weights,
+                               const float* decode_weight, const float* anchors,
+                               const int64_t* pos_inds, int64_t P, const int64_t* labels,
+                               int32_t num_classes, float scale, float* loss_sum,
+                               float* grad_bbox_pred, void* workspace, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

@@ -19,8 +19,8 @@ from .registry import LOSSES, Registry, build_loss
 from . import sharded
 from .coders import CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
 from .scatter import Scatter, scatter_index, scatter_reduce
-from .head_loss import (anchor_decoded_gd_loss, anchor_head_decoded_loss, anchor_head_decoded_loss_fused,
-                        center_head_gd_loss)
+from .head_loss import (anchor_decoded_gd_loss, anchor_head_bbox_loss, anchor_head_decoded_loss,
+                        anchor_head_decoded_loss_fused, center_head_gd_loss)
 
 
 def build(force=False, verbose=False):
@@ -31,4 +31,4 @@ def build(force=False, verbose=False):
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
-           'anchor_head_decoded_loss_fused', 'center_head_gd_loss', 'Scatter', 'scatter_index', 'scatter_reduce']
+           'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'Scatter', 'scatter_index', 'scatter_reduce']

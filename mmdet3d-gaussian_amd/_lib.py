@@ -25,6 +25,12 @@ class Prologue(ctypes.Structure):
                 ('pc_range', ctypes.c_float * 2), ('reserved', ctypes.c_float)]
 
 
+class SmoothL1(ctypes.Structure):
+    """gd3d_smooth_l1 (include/gd3d.h)."""
+    _fields_ = [('beta', ctypes.c_float), ('scale', ctypes.c_float), ('diff_rad_by_sin', ctypes.c_int32),
+                ('has_code_weight', ctypes.c_int32), ('code_weight', ctypes.c_float * 7), ('reserved', ctypes.c_float)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -39,6 +45,10 @@ SYMBOLS = {
     'gd3d_anchor_head_loss_dense': (_int, [ctypes.POINTER(Params), _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int32, _vp, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp,
                                            ctypes.c_int32, _f32, _vp, _vp, _vp, _vp]),
+    'gd3d_anchor_head_bbox_loss': (_int, [ctypes.POINTER(Params), ctypes.POINTER(SmoothL1), _vp, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp,
+                                          ctypes.POINTER(ctypes.c_float), _vp, _vp, _i64, _vp, ctypes.c_int32, _f32, _vp,
+                                          _vp, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),

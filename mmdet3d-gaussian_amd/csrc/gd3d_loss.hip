@@ -302,6 +302,13 @@ struct HeadArgs {
   int A, H, W;
   float dw[7];                 // train_cfg['decode_weight'] (all 1 when weights are given without it)
   float scale, alpha, tau, c0, c1, c2;
+  // encoded-box SmoothL1 term of loss_single (gd_anchor3d_head.py:152-159), added to the same sum / gradient
+  int dw_on;                   // GD term weighted by mean_k(bbox_weights * dw); else unweighted
+  int sl1;                     // 0: off
+  int sl1_cw;                  // element weight = bbox_weights * cw (train_cfg['code_weight']); else 1
+  int sin_diff;                // diff_rad_by_sin: add_sin_difference on the yaw column
+  float beta, sl1_scale;       // SmoothL1Loss.beta (0 = L1Loss), loss_weight / avg_factor
+  float cw[7];
 };
 
 template <int LOSS, int FUN, bool FLAG>
@@ -328,18 +335,19 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
     const long long hw = r / a.A;                                  // h*W + w
     const long long plane = (long long)a.H * a.W;
     const float* pbase = a.bbox_pred + ((b * a.A + an_i) * 7) * plane + hw;   // + k*plane per channel
-    float pe[7], te[7], an[7], pv[7], tv[7];
+    float pe[7], te[7], an[7], pv[7], tv[7], wrow[7];
     float wi = 1.0f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       pe[k] = pbase[k * plane];
       te[k] = a.bbox_targets[m * 7 + k];
       an[k] = a.anchors[r * 7 + k];
+      wrow[k] = a.bbox_weights != nullptr ? a.bbox_weights[m * 7 + k] : 1.0f;
     }
-    if (a.bbox_weights != nullptr) {
-      float sum = a.bbox_weights[m * 7] * a.dw[0];
+    if (a.dw_on) {
+      float sum = wrow[0] * a.dw[0];
 #pragma unroll
-      for (int k = 1; k < 7; ++k) sum += a.bbox_weights[m * 7 + k] * a.dw[k];
+      for (int k = 1; k < 7; ++k) sum += wrow[k] * a.dw[k];
       wi = sum / 7.0f;
     }
     DecodeJac Jp, Jt;
@@ -350,8 +358,38 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
     float g1[7], g2[7];
     const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
     fl = f * L;
+    float gs[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.sl1) {  // uniform.  mmdet smooth_l1_loss on the ENCODED rows, weight (P,7), sum / avg_factor
+      float d[7], j6 = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = pe[k] - te[k];
+      if (a.sin_diff) {  // add_sin_difference: sin(p)cos(t) vs cos(p)sin(t); both sides depend on the prediction
+        float sp6, cp6, st6, ct6;
+        sincos_f(pe[6], sp6, cp6);
+        sincos_f(te[6], st6, ct6);
+        d[6] = sp6 * ct6 - cp6 * st6;
+        j6 = cp6 * ct6 + sp6 * st6;
+      } else {
+        d[6] = pe[6] - te[6];
+      }
+      float ls = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float ad = fabsf(d[k]);
+        const bool quad = ad < a.beta;
+        const float l = quad ? 0.5f * ad * ad / a.beta : ad - 0.5f * a.beta;
+        const float sg = d[k] > 0.0f ? 1.0f : (d[k] < 0.0f ? -1.0f : 0.0f);   // torch abs'(0) = 0
+        const float g = quad ? d[k] / a.beta : sg;
+        const float w = a.sl1_cw ? wrow[k] * a.cw[k] : 1.0f;
+        ls += l * w;
+        gs[k] = g * w * a.sl1_scale * (k == 6 ? j6 : 1.0f);
+      }
+      fl += a.sl1_scale * ls;
+    }
     if (a.grad_bbox_pred != nullptr) {
       encode_grad(g1, Jp, true);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) g1[k] += gs[k];
       float* gbase = a.grad_bbox_pred + ((b * a.A + an_i) * 7) * plane + hw;
 #pragma unroll
       for (int k = 0; k < 7; ++k) gbase[k * plane] = g1[k];
@@ -577,8 +615,9 @@ int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* st
   return (int)hipGetLastError();
 }
 
-static int anchor_head_impl(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
-                            const float* bbox_targets, const float* bbox_weights, const float* decode_weight,
+static int anchor_head_impl(const gd3d_params* p, const gd3d_smooth_l1* sl1, const float* bbox_pred, int32_t B, int32_t A,
+                            int32_t H, int32_t W, const float* bbox_targets, const float* bbox_weights,
+                            const float* decode_weight,
                             const float* anchors, const int64_t* pos_inds, const int64_t* labels, int32_t num_classes,
                             int64_t P, float scale, float* loss_sum, float* grad_bbox_pred, void* workspace,
                             void* stream) {
@@ -612,6 +651,21 @@ static int anchor_head_impl(const gd3d_params* p, const float* bbox_pred, int32_
   a.H = H;
   a.W = W;
   for (int k = 0; k < 7; ++k) a.dw[k] = decode_weight != nullptr ? decode_weight[k] : 1.0f;  // HOST array of 7
+  a.dw_on = bbox_weights != nullptr && (decode_weight != nullptr || sl1 == nullptr);
+  a.sl1 = 0;
+  a.sl1_cw = a.sin_diff = 0;
+  a.beta = a.sl1_scale = 0.0f;
+  for (int k = 0; k < 7; ++k) a.cw[k] = 1.0f;
+  if (sl1 != nullptr) {
+    if (!(sl1->beta >= 0.0f)) return GD3D_E_BADARG;
+    if (sl1->has_code_weight && bbox_weights == nullptr) return GD3D_E_BADARG;
+    a.sl1 = 1;
+    a.sl1_cw = sl1->has_code_weight != 0;
+    a.sin_diff = sl1->diff_rad_by_sin != 0;
+    a.beta = sl1->beta;
+    a.sl1_scale = sl1->scale;
+    for (int k = 0; k < 7; ++k) a.cw[k] = sl1->code_weight[k];
+  }
   a.scale = scale;
   a.alpha = p->alpha;
   a.tau = p->tau;
@@ -649,8 +703,20 @@ int gd3d_anchor_head_loss(const gd3d_params* p, const float* bbox_pred, int32_t 
                           const float* anchors, const int64_t* pos_inds, int64_t P, float scale, float* loss_sum,
                           float* grad_bbox_pred, void* workspace, void* stream) {
   if (P > 0 && pos_inds == nullptr) return GD3D_E_BADARG;
-  return anchor_head_impl(p, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, pos_inds, nullptr, 0,
-                          P, scale, loss_sum, grad_bbox_pred, workspace, stream);
+  return anchor_head_impl(p, nullptr, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, pos_inds,
+                          nullptr, 0, P, scale, loss_sum, grad_bbox_pred, workspace, stream);
+}
+
+int gd3d_anchor_head_bbox_loss(const gd3d_params* p, const gd3d_smooth_l1* sl1, const float* bbox_pred, int32_t B,
+                               int32_t A, int32_t H, int32_t W, const float* bbox_targets, const float* bbox_weights,
+                               const float* decode_weight, const float* anchors, const int64_t* pos_inds, int64_t P,
+                               const int64_t* labels, int32_t num_classes, float scale, float* loss_sum,
+                               float* grad_bbox_pred, void* workspace, void* stream) {
+  if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return GD3D_E_BADARG;
+  if ((pos_inds != nullptr) == (labels != nullptr)) return GD3D_E_BADARG;  // exactly one way to name the positives
+  if (labels != nullptr) P = (int64_t)B * A * H * W;
+  return anchor_head_impl(p, sl1, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, pos_inds,
+                          labels, num_classes, P, scale, loss_sum, grad_bbox_pred, workspace, stream);
 }
 
 int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,
@@ -659,8 +725,8 @@ int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, in
                                 float* loss_sum, float* grad_bbox_pred, void* workspace, void* stream) {
   if (B <= 0 || A <= 0 || H <= 0 || W <= 0 || labels == nullptr) return GD3D_E_BADARG;
   const int64_t M = (int64_t)B * A * H * W;
-  return anchor_head_impl(p, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, nullptr, labels,
-                          num_classes, M, scale, loss_sum, grad_bbox_pred, workspace, stream);
+  return anchor_head_impl(p, nullptr, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, nullptr,
+                          labels, num_classes, M, scale, loss_sum, grad_bbox_pred, workspace, stream);
 }
 
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream) {

@@ -67,12 +67,12 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
 
 
 class _AnchorHeadFused(torch.autograd.Function):
-    """selection/gather of the positives + decode x2 + loss + gradient scatter into the NCHW head output: one launch.
+    """selection/gather of the positives + decode x2 + loss(es) + gradient scatter into the NCHW head output: one launch.
     `pos_or_labels` is either the (P,) int64 positive list (dense=False) or the (M,) int64 label map (dense=True)."""
 
     @staticmethod
     def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
-                num_classes=0):
+                num_classes=0, sl1=None):
         lib = _lib.load()
         B, C, H, W = bbox_pred.shape
         A = C // 7
@@ -83,18 +83,14 @@ class _AnchorHeadFused(torch.autograd.Function):
         buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
         dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
         wp = None if bbox_weights is None else bbox_weights.data_ptr()
-        gp = None if grad is None else grad.data_ptr()
+        sel = pos_or_labels.data_ptr()
         with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
-            if dense:
-                rc = lib.gd3d_anchor_head_loss_dense(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
-                                                     dwp, anchors.data_ptr(), pos_or_labels.data_ptr(), int(num_classes),
-                                                     scale, buf[0].data_ptr(), gp, buf[4:].data_ptr(), stream)
-            else:
-                rc = lib.gd3d_anchor_head_loss(params, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp, dwp,
-                                               anchors.data_ptr(), pos_or_labels.data_ptr(), P, scale, buf[0].data_ptr(),
-                                               gp, buf[4:].data_ptr(), stream)
-        _lib.check(rc, 'gd3d_anchor_head_loss')
+            rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
+                                                dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
+                                                int(num_classes), scale, buf[0].data_ptr(),
+                                                None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'gd3d_anchor_head_bbox_loss')
         ctx.grad = grad
         return buf[0]
 
@@ -107,7 +103,49 @@ class _AnchorHeadFused(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
                                            torch.cuda.current_stream().cuda_stream), 'gd3d_scale_rows')
-        return g, None, None, None, None, None, None, None, None, None
+        return (g,) + (None,) * 10
+
+
+def _seven(w, name):
+    """train_cfg['code_weight'] / ['decode_weight']: a list of 7 or a scalar (the shipped configs say `decode_weight=1`,
+    which `bbox_weights.new_tensor(1)` broadcasts, gd_anchor3d_head.py:128-131).  Falsy -> None, as `if w:` does."""
+    if isinstance(w, torch.Tensor):
+        w = w.tolist()
+    if not w:
+        return None
+    if isinstance(w, (int, float)):
+        return [float(w)] * 7
+    if len(w) != 7:
+        raise RuntimeError(f'{name} must be a scalar or have 7 entries')
+    return [float(x) for x in w]
+
+
+def _head_operands(bbox_pred, bbox_targets, bbox_weights, labels, anchor_list, need_weights):
+    B, C, H, W = bbox_pred.shape
+    if C % 7 != 0:
+        raise RuntimeError(f'bbox_pred has {C} channels, expected a multiple of the box code size 7')
+    M = B * H * W * (C // 7)
+    labels = labels.reshape(-1)
+    # the kernel indexes by position: every operand must cover exactly the B*H*W*A anchors (no OOB reads on the GPU)
+    if labels.numel() != M or bbox_targets.numel() != M * 7 or anchor_list.numel() != (M // B) * 7 or \
+            (need_weights and (bbox_weights is None or bbox_weights.numel() != M * 7)):
+        raise RuntimeError(f'shape mismatch: bbox_pred {tuple(bbox_pred.shape)} implies {M} anchors; labels '
+                           f'{labels.numel()}, bbox_targets {bbox_targets.numel() // 7}, anchors per sample '
+                           f'{anchor_list.numel() // 7}, bbox_weights '
+                           f'{None if bbox_weights is None else bbox_weights.numel() // 7}')
+    for t in (bbox_targets, labels, anchor_list) + ((bbox_weights,) if need_weights else ()):
+        if t.device != bbox_pred.device:
+            raise RuntimeError('head-loss operands live on different devices')
+    bp = (bbox_pred if bbox_pred.dtype == torch.float32 else bbox_pred.float()).contiguous()
+    weights = bbox_weights.reshape(-1, 7).to(torch.float32).contiguous() if need_weights else None
+    return (bp, bbox_targets.reshape(-1, 7).to(torch.float32).contiguous(), weights,
+            anchor_list.reshape(-1, 7).to(torch.float32).contiguous(), labels)
+
+
+def _select(labels, num_classes, dense):
+    if dense:
+        return labels.to(torch.int64).contiguous()
+    return ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1).contiguous()
 
 
 def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list, num_classes,
@@ -120,36 +158,66 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
     Requires a reduced loss (mean/sum) without per-call kwargs."""
     from .gd_loss import GDLoss
     assert isinstance(loss_module, GDLoss) and loss_module.reduction != 'none'
-    B, C, H, W = bbox_pred.shape
-    if C % 7 != 0:
-        raise RuntimeError(f'bbox_pred has {C} channels, expected a multiple of the box code size 7')
-    M = B * H * W * (C // 7)
-    labels = labels.reshape(-1)
-    # the kernel indexes by position: every operand must cover exactly the B*H*W*A anchors (no OOB reads on the GPU)
-    if labels.numel() != M or bbox_targets.numel() != M * 7 or anchor_list.numel() != (M // B) * 7 or \
-            (decode_weight and bbox_weights.numel() != M * 7):
-        raise RuntimeError(f'shape mismatch: bbox_pred {tuple(bbox_pred.shape)} implies {M} anchors; labels '
-                           f'{labels.numel()}, bbox_targets {bbox_targets.numel() // 7}, anchors per sample '
-                           f'{anchor_list.numel() // 7}')
-    if decode_weight and len(decode_weight) != 7:
-        raise RuntimeError('decode_weight must have 7 entries')
-    if dense:
-        sel = labels.to(torch.int64).contiguous()
-    else:
-        sel = ((labels >= 0) & (labels < num_classes)).nonzero(as_tuple=False).reshape(-1).contiguous()
-        if sel.numel() == 0:
-            return bbox_pred.sum() * 0
-    bp = bbox_pred if bbox_pred.dtype == torch.float32 else bbox_pred.float()
-    weights = None
-    if decode_weight:
-        weights = bbox_weights.reshape(-1, 7).to(torch.float32).contiguous()
+    dw = _seven(decode_weight, 'decode_weight')
+    bp, bt, weights, anchors, labels = _head_operands(bbox_pred, bbox_targets, bbox_weights, labels, anchor_list,
+                                                      dw is not None)
+    sel = _select(labels, num_classes, dense)
+    if not dense and sel.numel() == 0:
+        return bbox_pred.sum() * 0
     den = num_total_samples if loss_module.reduction == 'mean' else 1.0
     scale = float(loss_module.loss_weight) / float(den)
-    out = _AnchorHeadFused.apply(bp.contiguous(), bbox_targets.reshape(-1, 7).to(torch.float32).contiguous(), weights,
-                                 anchor_list.reshape(-1, 7).to(torch.float32).contiguous(), sel,
-                                 loss_module._params({}), decode_weight if decode_weight else None, scale, bool(dense),
-                                 int(num_classes))
-    return out
+    return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_module._params({}), dw, scale, bool(dense),
+                                  int(num_classes), None)
+
+
+def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list,
+                          num_classes, num_total_samples, code_weight=None, decode_weight=None, diff_rad_by_sin=True,
+                          dense=True):
+    """`loss_bbox` as GDAnchor3DHead.loss_single returns it (gd_anchor3d_head.py:95-161), in ONE launch:
+
+        loss_decoded_bbox(decode(anchors, pos_pred), decode(anchors, pos_targets), decode_weight, avg_factor)  (:133-141)
+      + loss_bbox(pos_pred', pos_targets', code_weight, avg_factor)                                            (:150-159)
+
+    loss_decoded_bbox: this package's GDLoss (reduction 'mean').  loss_bbox: the encoded-box regression loss — mmdet's
+    SmoothL1Loss / L1Loss module itself or anything with `.beta` (absent/0 = L1), `.loss_weight`, `.reduction`, or a
+    config dict (`dict(type='SmoothL1Loss', beta=1/9, loss_weight=2.0)`).  code_weight / decode_weight:
+    train_cfg entries (list of 7, scalar, or falsy = weight None, :124-131).  diff_rad_by_sin: add_sin_difference
+    (:150-152).  No positives: 0 with a zero gradient (:160-161)."""
+    from .gd_loss import GDLoss
+    assert isinstance(loss_decoded_bbox, GDLoss)
+    if loss_decoded_bbox.reduction != 'mean':
+        raise ValueError('avg_factor can not be used with reduction="sum"' if loss_decoded_bbox.reduction == 'sum'
+                         else 'anchor_head_bbox_loss needs a reduced loss')
+    if isinstance(loss_bbox, dict):
+        kind = loss_bbox.get('type', 'SmoothL1Loss')
+        beta = float(loss_bbox.get('beta', 1.0)) if kind == 'SmoothL1Loss' else 0.0
+        lw, red = float(loss_bbox.get('loss_weight', 1.0)), loss_bbox.get('reduction', 'mean')
+    else:
+        beta = float(getattr(loss_bbox, 'beta', 0.0))
+        lw, red = float(loss_bbox.loss_weight), getattr(loss_bbox, 'reduction', 'mean')
+        kind = type(loss_bbox).__name__
+    if kind not in ('SmoothL1Loss', 'L1Loss'):
+        raise RuntimeError(f'encoded-box loss {kind!r} is not fused; supported: SmoothL1Loss, L1Loss')
+    if kind == 'SmoothL1Loss' and not beta > 0:
+        raise AssertionError('SmoothL1Loss needs beta > 0')          # mmdet smooth_l1_loss: assert beta > 0
+    if red != 'mean':
+        raise ValueError('avg_factor can not be used with reduction="sum"' if red == 'sum'
+                         else 'anchor_head_bbox_loss needs a reduced loss')
+    cw, dw = _seven(code_weight, 'code_weight'), _seven(decode_weight, 'decode_weight')
+    bp, bt, weights, anchors, labels = _head_operands(bbox_pred, bbox_targets, bbox_weights, labels, anchor_list,
+                                                      cw is not None or dw is not None)
+    sel = _select(labels, num_classes, dense)
+    if not dense and sel.numel() == 0:
+        return bbox_pred.sum() * 0
+    sl1 = _lib.SmoothL1()
+    sl1.beta = beta
+    sl1.scale = lw / float(num_total_samples)
+    sl1.diff_rad_by_sin = int(bool(diff_rad_by_sin))
+    sl1.has_code_weight = int(cw is not None)
+    sl1.code_weight = (ctypes.c_float * 7)(*(cw or [1.0] * 7))
+    scale = float(loss_decoded_bbox.loss_weight) / float(num_total_samples)
+    return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_decoded_bbox._params({}), dw, scale, bool(dense),
+                                  int(num_classes), sl1)
 
 
 def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):

@@ -13,10 +13,14 @@ from oracle import gd_torch
 dev = torch.device('cuda:0')
 coder = amd.DeltaXYZWLHRBBoxCoder()
 def timeit(fn, iters):
+    """best of 3 timed loops (first-use code-object loads and allocator growth stay out of the number)"""
     for _ in range(10): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(iters): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e6
+    best = float('inf')
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters): fn()
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / iters * 1e6)
+    return best
 for lt in ('kld3d', 'gwd3d', 'bd3d'):
     mod = amd.GDLoss(lt, fun='log1p', tau=0.0, loss_weight=5.0)
     for P in (64, 512, 4096, 65536):
@@ -58,3 +62,25 @@ for npos in (200, 2000):
     a, b = timeit(gather_fused, 100), timeit(gather_torch, 50)
     print(json.dumps(dict(slice='loss_single decoded branch from NCHW', B=B, anchors_per_sample=n_per, positives=npos,
                           gather_fused_us=round(a, 1), torch_gather_us=round(b, 1), speedup=round(b / a, 2))), flush=True)
+
+# the WHOLE regression loss of loss_single (:95-161): GD on decoded boxes + SmoothL1 on encoded boxes (code_weight,
+# add_sin_difference) in one launch, vs the eager torch restatement of the same lines (oracle/head_torch.py)
+from oracle import head_torch  # noqa: E402
+sl1 = dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0)
+cw = [1., 1., 1., 0., 0., 0., 0.]
+for npos in (200, 2000):
+    labels = torch.full((B, n_per), C, device=dev, dtype=torch.long)
+    labels.view(-1)[torch.randperm(B * n_per, device=dev)[:npos]] = 0
+    mod = amd.GDLoss('kfiou3d', fun='nlog', loss_weight=5.0)     # kitti kfiou5 config: the one with live code weights
+    def full_fused():
+        bbox_pred.grad = None
+        amd.anchor_head_bbox_loss(mod, sl1, bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, float(npos),
+                                  code_weight=cw, decode_weight=1).backward()
+    def full_eager():
+        bbox_pred.grad = None
+        head_torch.loss_single_bbox(bbox_pred, bbox_targets, bbox_weights, labels, anchors, C, float(npos),
+                                    gd=dict(loss_type='kfiou3d', fun='nlog', loss_weight=5.0),
+                                    sl1=dict(beta=1.0 / 9.0, loss_weight=2.0), code_weight=cw, decode_weight=1).backward()
+    a, b = timeit(full_fused, 100), timeit(full_eager, 30)
+    print(json.dumps(dict(slice='loss_single regression loss (GD + SmoothL1) from NCHW', B=B, anchors_per_sample=n_per,
+                          positives=npos, fused_us=round(a, 1), eager_torch_us=round(b, 1), speedup=round(b / a, 1))), flush=True)

@@ -145,3 +145,86 @@ def test_anchor_head_gather_fused_matches_unfused_and_oracle(amd, lt, red):
     # no positives
     z = amd.anchor_head_decoded_loss_fused(mod, bbox_pred, bbox_targets, bbox_weights, torch.full_like(labels, C), anchors, C, 1.0, dw)
     assert z.item() == 0.0
+
+
+def _head_inputs(seed, B=3, A=6, H=10, W=7, C=3, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    n_per = H * W * A
+    anchors = torch.rand(n_per, 7, generator=g) * torch.tensor([70, 80, 1, 1.5, 3, 0.5, 1.5]) + torch.tensor([0, -40, -2, .6, .9, 1.4, 0])
+    bbox_pred = torch.randn(B, A * 7, H, W, generator=g) * 0.15
+    bbox_targets = torch.randn(B, n_per, 7, generator=g) * 0.2
+    bbox_weights = torch.rand(B, n_per, 7, generator=g)
+    labels = torch.randint(-1, C + 2, (B, n_per), generator=g)
+    # make a few |diff| land exactly on 0 and across beta so both SmoothL1 branches and the abs'(0)=0 rule are hit
+    bt = bbox_targets.reshape(-1, 7); bp = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 7)
+    bt[::5, :3] = bp[::5, :3]
+    bbox_targets = bt.reshape(B, n_per, 7)
+    return anchors, bbox_pred, bbox_targets, bbox_weights, labels, C
+
+
+SL1_CASES = [
+    # (GD loss type, gd kwargs, sl1 cfg, code_weight, decode_weight, diff_rad_by_sin)
+    ('kfiou3d', dict(fun='nlog'), dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), [1., 1., 1., 0., 0., 0., 0.], 1, True),
+    ('kld3d', dict(fun='log1p', tau=1.0), dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), [0.] * 7, 1, True),
+    ('gwd3d', dict(fun='log1p', tau=0.0), dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0), [1.0] * 7, [1, 1, .5, 1, 2, 1, 1], True),
+    ('bd3d', dict(fun='log1p', tau=1.0), dict(type='SmoothL1Loss', beta=0.5, loss_weight=2.0), None, None, False),
+    ('jd3d', dict(fun='log1p', tau=1.0), dict(type='L1Loss', loss_weight=0.25), [1, 2, 3, 4, 5, 6, 7], None, True),
+]
+
+
+@pytest.mark.parametrize('dense', [True, False])
+@pytest.mark.parametrize('case', range(len(SL1_CASES)))
+def test_anchor_head_bbox_loss_full_regression_term(amd, case, dense):
+    """loss_bbox of loss_single (:95-161) = GD on decoded boxes + SmoothL1/L1 on encoded boxes (add_sin_difference,
+    code_weight), one launch, vs the fp64 torch restatement with autograd (oracle/head_torch.py)."""
+    from oracle import head_torch
+    lt, kw, sl1, cw, dw, sin = SL1_CASES[case]
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(case)
+    avg = 53.0
+    mod = amd.GDLoss(lt, loss_weight=5.0, **kw)
+    bp = bbox_pred.cuda().requires_grad_(True)
+    out = amd.anchor_head_bbox_loss(mod, sl1, bp, bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(), anchors.cuda(), C,
+                                    avg, code_weight=cw, decode_weight=dw, diff_rad_by_sin=sin, dense=dense)
+    out.backward()
+
+    def ref(dtype):
+        p = bbox_pred.to(dtype).requires_grad_(True)
+        beta = sl1.get('beta', 1.0) if sl1['type'] == 'SmoothL1Loss' else 0.0
+        r = head_torch.loss_single_bbox(p, bbox_targets.to(dtype), bbox_weights.to(dtype), labels, anchors.to(dtype), C, avg,
+                                        gd=dict(loss_type=lt, loss_weight=5.0, **kw), sl1=dict(beta=beta, loss_weight=sl1['loss_weight']),
+                                        code_weight=cw, decode_weight=dw, diff_rad_by_sin=sin)
+        r.backward()
+        return r.item(), p.grad.numpy()
+    l64, g64 = ref(torch.float64)
+    l32, g32 = ref(torch.float32)
+    tol_l = 1e-5 + 3 * abs(l32 - l64) / (1 + abs(l64))
+    assert abs(out.item() - l64) <= tol_l * (1 + abs(l64)), (out.item(), l64, l32)
+    got = bp.grad.cpu().numpy().astype(np.float64)
+    sc = np.abs(g64).max()
+    tol_g = 1e-5 + 3 * np.abs(g32 - g64).max() / (1 + sc)
+    assert np.abs(got - g64).max() <= tol_g * (1 + sc), (np.abs(got - g64).max(), np.abs(g32 - g64).max())
+    nz = ((labels.reshape(-1) >= 0) & (labels.reshape(-1) < C))
+    gflat = bp.grad.permute(0, 2, 3, 1).reshape(-1, 7)
+    assert gflat[~nz.cuda()].abs().max().item() == 0.0
+
+
+def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd):
+    """No positive anchor -> 0 with a zero gradient (:160); the encoded-box loss may be an mmdet-style module object."""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(11)
+
+    class SmoothL1Loss:          # attribute surface of mmdet's module
+        beta, loss_weight, reduction = 1.0 / 9.0, 2.0, 'mean'
+    mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    bp = bbox_pred.cuda().requires_grad_(True)
+    z = amd.anchor_head_bbox_loss(mod, SmoothL1Loss(), bp, bbox_targets.cuda(), bbox_weights.cuda(),
+                                  torch.full_like(labels, C).cuda(), anchors.cuda(), C, 1.0, code_weight=[1.0] * 7, decode_weight=1)
+    z.backward()
+    assert z.item() == 0.0 and bp.grad.abs().max().item() == 0.0
+    a = amd.anchor_head_bbox_loss(mod, SmoothL1Loss(), bp, bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(), anchors.cuda(),
+                                  C, 9.0, code_weight=[1.0] * 7, decode_weight=1)
+    b = amd.anchor_head_bbox_loss(mod, dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), bp, bbox_targets.cuda(),
+                                  bbox_weights.cuda(), labels.cuda(), anchors.cuda(), C, 9.0, code_weight=[1.0] * 7, decode_weight=[1.0] * 7)
+    assert a.item() == b.item()
+    with pytest.raises(RuntimeError):
+        amd.anchor_head_bbox_loss(mod, dict(type='FocalLoss'), bp, bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(),
+                                  anchors.cuda(), C, 9.0)

@@ -24,3 +24,33 @@ def test_torch_restatement_matches_reference_f64(case):
             scale = np.abs(np.where(np.isfinite(ref), ref, 0)).max(-1, keepdims=True)
             err = np.abs(ours.numpy() - ref)
             assert (err[np.isfinite(ref)] <= (1e-6 * (1 + scale) * np.ones_like(ref))[np.isfinite(ref)]).all()
+
+
+def test_head_torch_restatements_against_independent_formulas():
+    """oracle/head_torch.py restates three third-party pieces (mmdet smooth_l1 / l1, mmdet3d add_sin_difference and
+    delta decode).  Independent checks: torch's own F.smooth_l1_loss (same published formula), the identity
+    sin(a)cos(b) - cos(a)sin(b) = sin(a - b), and decode(encode(x)) == x with the product-side coder mirror."""
+    import importlib.util
+    import os
+    import torch.nn.functional as F
+    from oracle import head_torch
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(200, 7, generator=g, dtype=torch.float64)
+    t = p + torch.randn(200, 7, generator=g, dtype=torch.float64) * 0.2
+    w = torch.rand(200, 7, generator=g, dtype=torch.float64)
+    for beta in (1.0 / 9.0, 0.5, 1.0):
+        ours = head_torch.smooth_l1(p, t, w, 13.0, beta, 2.0)
+        ref = 2.0 * (F.smooth_l1_loss(p, t, beta=beta, reduction='none') * w).sum() / 13.0
+        assert abs(ours.item() - ref.item()) <= 1e-12 * (1 + abs(ref.item()))
+    l1 = head_torch.smooth_l1(p, t, None, 7.0, 0.0, 0.25)
+    assert abs(l1.item() - 0.25 * (p - t).abs().sum().item() / 7.0) <= 1e-12
+    a, b = head_torch.add_sin_difference(p, t)
+    assert torch.allclose(a[:, 6] - b[:, 6], torch.sin(p[:, 6] - t[:, 6]), atol=1e-14)
+    assert torch.equal(a[:, :6], p[:, :6]) and torch.equal(b[:, :6], t[:, :6])
+    spec = importlib.util.spec_from_file_location(
+        'coders_mirror', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mmdet3d-gaussian_amd', 'coders.py'))
+    cm = importlib.util.module_from_spec(spec); spec.loader.exec_module(cm)
+    anchors = torch.rand(200, 7, generator=g, dtype=torch.float64) + 0.5
+    boxes = torch.rand(200, 7, generator=g, dtype=torch.float64) + 0.5
+    enc = cm.DeltaXYZWLHRBBoxCoder.encode(anchors, boxes)
+    assert torch.allclose(head_torch.delta_decode(anchors, enc), boxes, atol=1e-12)
