@@ -226,6 +226,30 @@ int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float 
 int rnms_normal_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh,
                             int64_t* keep, int64_t* num_keep, void* workspace, void* stream);
 
+/* G independent NMS problems in ONE set of launches (classes of a multi-class NMS, pvrcnn_bbox_head.py:452-477; the
+ * samples / tasks a head loops over, gd_centerpoint_head.py:322-345): all groups index the same box array.
+ *   mode     : 0 rotated BEV IoU (nms_gpu), 1 axis-aligned IoU (nms_normal_gpu), 2 circle (below; boxes is (N,2));
+ *   order    : (groups, cap) int64, row g = box indices of group g by descending score; only its first counts[g] used;
+ *   counts   : (groups) int32 ON THE DEVICE — group sizes are data dependent (score thresholds), reading them in the
+ *              kernels removes the per-group host sync the reference loop pays; values are clamped to [0, cap];
+ *   thresh   : (groups) fp32 on the device (per-class thresholds);
+ *   keep     : (groups, cap) int64, row g receives the kept box indices (caller's numbering) in score order;
+ *   num_keep : (groups) int64.   workspace: rnms_batched_workspace_bytes(groups, cap).
+ * Each group's result equals the single call on that group (same kernels, blockIdx.y = group). */
+size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap);
+
+int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const int32_t* counts,
+                 int32_t groups, int64_t cap, const float* thresh, int64_t* keep, int64_t* num_keep,
+                 void* workspace, void* stream);
+
+/* Circle NMS (mmdet3d `circle_nms(dets, thresh, post_max_size)`, numba, CPU; the reference copies the detections
+ * D->H for it, gd_centerpoint_head.py:256-272): centres xy (rows, 2) fp32, order (n) by descending score; box j is
+ * suppressed by a kept i before it iff (x_i-x_j)^2 + (y_i-y_j)^2 <= thresh (fp32 distance, float64 compare; note
+ * the published code compares the SQUARED distance with the radius as given).  keep/num_keep as rnms_bev_ordered;
+ * workspace: rnms_workspace_bytes(n). */
+int rnms_circle_ordered(const float* xy, const int64_t* order, int64_t n, double thresh,
+                        int64_t* keep, int64_t* num_keep, void* workspace, void* stream);
+
 /* Pairwise rotated BEV IoU in the NMS box format (mmdet3d `boxes_iou_bev`):
  *   a (na,5), b (nb,5) [x1,y1,x2,y2,ry] -> iou (na,nb) fp32 row-major. */
 int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou,

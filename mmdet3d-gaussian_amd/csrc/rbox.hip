@@ -19,38 +19,68 @@
 namespace rbox {
 
 constexpr int NMS_T = 256;
+enum { MODE_ROT = 0, MODE_NORMAL = 1, MODE_CIRCLE = 2 };
+
+// One launch serves G independent NMS problems ("groups": classes, samples, tasks) over a shared box array:
+// group g owns order[g*cap .. g*cap + n_g), n_g = counts[g] read ON THE DEVICE (no host sync to size the launch;
+// grids are sized for `cap` and surplus workgroups leave after one scalar load).  G = 1 with counts == NULL is the plain call.
+struct NmsArgs {
+  const float* boxes;          // (N,5) [x1,y1,x2,y2,r]; MODE_CIRCLE: (N,2) centres
+  const long long* order;      // (G, cap) score order per group (indices into boxes); NULL (G = 1 only): identity
+  const int* counts;           // (G) device, nullable
+  const float* thresh_dev;     // (G) device, nullable -> thresh / thresh_d
+  int n, cap, cbs, rows;       // cbs = ceil(cap / 64): mask row stride in words
+  float thresh;
+  double thresh_d;             // MODE_CIRCLE: numba compares the float32 distance with a float64 threshold
+};
+
+__device__ __forceinline__ int group_n(const NmsArgs& a, int g) {
+  if (a.counts == nullptr) return a.n;
+  const int c = a.counts[g];
+  return c < 0 ? 0 : (c > a.cap ? a.cap : c);
+}
 
 // `order` (nullable): score order computed by the caller; box i of the NMS is boxes[order[i]] (saves the gather pass)
-__global__ __launch_bounds__(256) void obox_prep_kernel(const float* __restrict__ boxes, const long long* __restrict__ order,
-                                                        int n, OBox* __restrict__ out) {
+__global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* __restrict__ out) {
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const size_t src = order != nullptr ? (size_t)order[i] : (size_t)i;
+  const size_t src = a.order != nullptr ? (size_t)a.order[(size_t)g * a.cap + i] : (size_t)i;
   float b[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) b[k] = boxes[src * 5 + k];
+  for (int k = 0; k < 5; ++k) b[k] = a.boxes[src * 5 + k];
   OBox o;
   obox_make(b, o);
-  out[i] = o;
+  out[(size_t)g * a.cap + i] = o;
 }
 
 // One WAVE per (row box i, 64-box column block c >= block of i): lane l tests box i against box 64c + l and the
 // wave-wide ballot IS the 64-bit mask word — no partial words, no barrier.  One wave per workgroup keeps the per-thread
 // polygon scratch at 12 KiB of LDS (13 workgroups per CU); far-apart pairs leave through the exact bounding-circle
 // early-out, so most rows cost ~20 instructions.  A wave walks `rows` consecutive row boxes against the same 64
-// column boxes (loaded once); blockIdx.x = (upper-triangle block pair) * (64 / rows) + row group.
+// column boxes (loaded once); blockIdx.x = (upper-triangle block pair) * (64 / rows) + row group; blockIdx.y = group.
 // `rows` (1, 2, 4 or 8; host-chosen) = row boxes a wave walks through against the same 64 column boxes: 1 keeps small
 // problems latency-short (n = 1000: 49 us vs 80 us at 8), 8 keeps large ones from being workgroup-dispatch bound
 // (n = 9000: 640 K one-wave workgroups -> 80 K; 965 -> 834 us).
-template <bool NORMAL>
-__global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ ob, const float* __restrict__ boxes,
-                                                      const long long* __restrict__ order, int n, int cb, int rows,
-                                                      float thresh, unsigned long long* __restrict__ mask) {
-  __shared__ VertexScratch<NORMAL ? 1 : 64> vs;
+template <int MODE>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
+                                                      unsigned long long* __restrict__ mask_) {
+  __shared__ VertexScratch<MODE == MODE_ROT ? 64 : 1> vs;
   const int lane = threadIdx.x;
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const int rows = a.rows;
   const int groups = 64 / rows;
   const unsigned pair = blockIdx.x / groups;
+  if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
   const int r0 = (int)(blockIdx.x % groups) * rows;
+  const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
+  const OBox* ob = ob_ + (size_t)g * a.cap;
+  unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
+  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
+  const double thresh_d = a.thresh_dev != nullptr ? (double)a.thresh_dev[g] : a.thresh_d;
   // pair -> (rb, c): pairs before row block rb: rb*cb - rb(rb-1)/2
   int rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
   rb = max(0, min(rb, cb - 1));
@@ -61,10 +91,14 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
   OBox B;
   float braw[5];
   if (j < n) {
-    if constexpr (NORMAL) {
+    if constexpr (MODE == MODE_NORMAL) {
       const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) braw[k] = boxes[sj * 5 + k];
+      for (int k = 0; k < 5; ++k) braw[k] = a.boxes[sj * 5 + k];
+    } else if constexpr (MODE == MODE_CIRCLE) {
+      const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
+      braw[0] = a.boxes[sj * 2];
+      braw[1] = a.boxes[sj * 2 + 1];
     } else {
       B = ob[j];
     }
@@ -74,13 +108,20 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
     if (i >= n) break;
     const bool act = j < n && !(rb == c && j <= i);
     bool hit = false;
-    if constexpr (NORMAL) {
+    if constexpr (MODE == MODE_NORMAL) {
       if (act) {
         const size_t si = order != nullptr ? (size_t)order[i] : (size_t)i;
-        float a[5];
+        float ar[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) a[k] = boxes[si * 5 + k];
-        hit = iou_normal(a, braw) > thresh;
+        for (int k = 0; k < 5; ++k) ar[k] = a.boxes[si * 5 + k];
+        hit = iou_normal(ar, braw) > thresh;
+      }
+    } else if constexpr (MODE == MODE_CIRCLE) {
+      if (act) {  // mmdet3d circle_nms: dist = (x_i - x_j)^2 + (y_i - y_j)^2 ; suppressed iff dist <= thresh
+        const size_t si = order != nullptr ? (size_t)order[i] : (size_t)i;
+        const float dx = a.boxes[si * 2] - braw[0], dy = a.boxes[si * 2 + 1] - braw[1];
+        const float dist = dx * dx + dy * dy;
+        hit = (double)dist <= thresh_d;
       }
     } else {
       if (act) {
@@ -89,14 +130,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const OBox* __restrict__ o
       }
     }
     const unsigned long long word = __ballot(hit);
-    if (lane == 0) mask[(size_t)i * cb + c] = word;
+    if (lane == 0) mask[(size_t)i * a.cbs + c] = word;
   }
 }
 
 constexpr int SCAN_T = 256;
-__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                          const long long* __restrict__ order, int n, int cb,
-                                                          long long* __restrict__ keep, long long* __restrict__ num_keep) {
+__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
+                                                          long long* __restrict__ keep_, long long* __restrict__ num_keep) {
   // One workgroup of 4 waves walks the 64-box blocks in order, ONE barrier per block.
   //   wave 0 (resolve): lane l holds the diagonal word mask[64c+l][c] and the "urgent" word mask[64c+l][c+1] of
   //     block c, both prefetched during the previous block (neither depends on the removed-set).  A scalar loop visits
@@ -105,8 +145,15 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
   //   waves 1-3 (propagate, one block behind): OR the mask rows of the boxes kept in block c-1 into remv[c+1..]
   //     (every 3rd kept row per wave, 8 independent 8-byte loads in flight per lane).  Word c+1 receives block c-1's
   //     rows here, one full barrier interval before block c+1 is resolved.
-  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cb words
+  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
   __shared__ unsigned long long skept[2];
+  const int g = blockIdx.x;  // one workgroup per group
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const size_t cbs = (size_t)a.cbs;
+  const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
+  const unsigned long long* mask = mask_ + (size_t)g * a.cap * cbs;
+  long long* keep = keep_ + (size_t)g * a.cap;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int w = tid; w < cb; w += SCAN_T) remv[w] = 0ull;
@@ -115,8 +162,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
   int count = 0;
   unsigned long long diag_next = 0ull, urg_next = 0ull;
   if (wave == 0 && lane < n) {
-    diag_next = mask[(size_t)lane * cb];
-    if (cb > 1) urg_next = mask[(size_t)lane * cb + 1];
+    diag_next = mask[(size_t)lane * cbs];
+    if (cb > 1) urg_next = mask[(size_t)lane * cbs + 1];
   }
   for (int c = 0; c <= cb; ++c) {  // iteration cb only drains the last propagate
     if (wave == 0) {
@@ -124,8 +171,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
         const int i = c * 64 + lane;
         const unsigned long long diag = diag_next, urg = urg_next;
         const int i_next = i + 64;
-        diag_next = (c + 1 < cb && i_next < n) ? mask[(size_t)i_next * cb + (c + 1)] : 0ull;
-        urg_next = (c + 2 < cb && i_next < n) ? mask[(size_t)i_next * cb + (c + 2)] : 0ull;
+        diag_next = (c + 1 < cb && i_next < n) ? mask[(size_t)i_next * cbs + (c + 1)] : 0ull;
+        urg_next = (c + 2 < cb && i_next < n) ? mask[(size_t)i_next * cbs + (c + 2)] : 0ull;
         const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
         unsigned long long cur = remv[c];
         // (the builtin returns a signed int: go through unsigned before widening)
@@ -180,7 +227,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
             }
             unsigned long long v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cb + w] : 0ull;
+            for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cbs + w] : 0ull;
             acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
           }
           if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
@@ -189,7 +236,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const unsigned long lo
     }
     __syncthreads();
   }
-  if (tid == 0) *num_keep = count;
+  if (tid == 0) num_keep[g] = count;
 }
 
 // pairwise IoU matrices ------------------------------------------------------------------
@@ -273,55 +320,96 @@ size_t rnms_workspace_bytes(int64_t n) {
   return align_up((size_t)n * sizeof(OBox), 256) + (size_t)n * cb * sizeof(unsigned long long);
 }
 
-static int rnms_impl(bool normal, const float* boxes, const int64_t* order_, int64_t n, float thresh, int64_t* keep,
-                     int64_t* num_keep, void* workspace, void* stream) {
-  const long long* order = (const long long*)order_;
-  if (n < 0 || num_keep == nullptr) return GD3D_E_BADARG;
+size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
+  if (groups <= 0 || cap <= 0) return 16;
+  const size_t cb = (size_t)((cap + 63) / 64);
+  return align_up((size_t)groups * cap * sizeof(OBox), 256) + (size_t)groups * cap * cb * sizeof(unsigned long long);
+}
+
+// shared by the single and the batched entry points: G groups of up to `cap` boxes
+static int rnms_launch(int mode, const float* boxes, const int64_t* order, const int32_t* counts, int32_t G, int64_t cap,
+                       float thresh, double thresh_d, const float* thresh_dev, int64_t* keep, int64_t* num_keep,
+                       void* workspace, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), s);
-  if (boxes == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
-  if (n > RNMS_MAX_N) return GD3D_E_TOOLARGE;
-  const int ni = (int)n, cb = (ni + 63) / 64;
+  if (cap > RNMS_MAX_N) return GD3D_E_TOOLARGE;
+  if (G > 65535) return GD3D_E_TOOLARGE;
+  NmsArgs a;
+  a.boxes = boxes;
+  a.order = (const long long*)order;
+  a.counts = (const int*)counts;
+  a.thresh_dev = thresh_dev;
+  a.n = counts == nullptr ? (int)cap : 0;
+  a.cap = (int)cap;
+  a.cbs = ((int)cap + 63) / 64;
+  a.thresh = thresh;
+  a.thresh_d = thresh_d;
   OBox* ob = (OBox*)workspace;
-  unsigned long long* mask = (unsigned long long*)((char*)workspace + align_up((size_t)n * sizeof(OBox), 256));
-  if (!normal) {
-    hipLaunchKernelGGL(obox_prep_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, boxes, order, ni, ob);
-  }
-  const long long pairs = (long long)cb * (cb + 1) / 2;
+  unsigned long long* mask =
+      (unsigned long long*)((char*)workspace + align_up((size_t)G * cap * sizeof(OBox), 256));
+  const long long pairs = (long long)a.cbs * (a.cbs + 1) / 2;
   int rows = 1;
-  while (rows < 8 && pairs * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
-  const unsigned nblk = (unsigned)(pairs * (64 / rows));
-  if (normal)
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, order, ni, cb, rows, thresh,
-                       mask);
-  else
-    hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(nblk), dim3(64), 0, s, (const OBox*)ob, boxes, order, ni, cb, rows, thresh,
-                       mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(SCAN_T), (size_t)cb * sizeof(unsigned long long), s,
-                     (const unsigned long long*)mask, order, ni, cb, (long long*)keep, (long long*)num_keep);
+  while (rows < 8 && pairs * G * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
+  a.rows = rows;
+  if (pairs * (64 / rows) > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  const dim3 mgrid((unsigned)(pairs * (64 / rows)), (unsigned)G);
+  if (mode == MODE_ROT) {
+    hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_ROT>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+  } else if (mode == MODE_NORMAL) {
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+  } else {
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+  }
+  hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)G), dim3(SCAN_T), (size_t)a.cbs * sizeof(unsigned long long), s, a,
+                     (const unsigned long long*)mask, (long long*)keep, (long long*)num_keep);
   return (int)hipGetLastError();
+}
+
+static int rnms_impl(int mode, const float* boxes, const int64_t* order, int64_t n, float thresh, double thresh_d,
+                     int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  if (n < 0 || num_keep == nullptr) return GD3D_E_BADARG;
+  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), (hipStream_t)stream);
+  if (boxes == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  return rnms_launch(mode, boxes, order, nullptr, 1, n, thresh, thresh_d, nullptr, keep, num_keep, workspace, stream);
+}
+
+int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const int32_t* counts, int32_t groups, int64_t cap,
+                 const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  if (mode < MODE_ROT || mode > MODE_CIRCLE || groups < 0 || cap < 0) return GD3D_E_BADARG;
+  if (groups == 0) return 0;
+  if (num_keep == nullptr) return GD3D_E_BADARG;
+  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, (hipStream_t)stream);
+  if (boxes == nullptr || order == nullptr || counts == nullptr || thresh == nullptr || keep == nullptr ||
+      workspace == nullptr)
+    return GD3D_E_BADARG;
+  return rnms_launch(mode, boxes, order, counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_circle_ordered(const float* xy, const int64_t* order, int64_t n, double thresh, int64_t* keep, int64_t* num_keep,
+                        void* workspace, void* stream) {
+  return rnms_impl(MODE_CIRCLE, xy, order, n, (float)thresh, thresh, keep, num_keep, workspace, stream);
 }
 
 int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep, void* workspace,
              void* stream) {
-  return rnms_impl(false, boxes_sorted, nullptr, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(MODE_ROT, boxes_sorted, nullptr, n, thresh, 0.0, keep, num_keep, workspace, stream);
 }
 
 int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
                      void* workspace, void* stream) {
   if (n > 0 && order == nullptr) return GD3D_E_BADARG;
-  return rnms_impl(false, boxes, order, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(MODE_ROT, boxes, order, n, thresh, 0.0, keep, num_keep, workspace, stream);
 }
 
 int rnms_normal_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep,
                             int64_t* num_keep, void* workspace, void* stream) {
   if (n > 0 && order == nullptr) return GD3D_E_BADARG;
-  return rnms_impl(true, boxes, order, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(MODE_NORMAL, boxes, order, n, thresh, 0.0, keep, num_keep, workspace, stream);
 }
 
 int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,
                     void* workspace, void* stream) {
-  return rnms_impl(true, boxes_sorted, nullptr, n, thresh, keep, num_keep, workspace, stream);
+  return rnms_impl(MODE_NORMAL, boxes_sorted, nullptr, n, thresh, 0.0, keep, num_keep, workspace, stream);
 }
 
 int riou_bev_xyxyr(const float* a, int64_t na, const float* b, int64_t nb, float* iou, void* stream) {

@@ -41,7 +41,7 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
     if scores.shape[0] != boxes.shape[0]:
         raise RuntimeError(f'{name}: {boxes.shape[0]} boxes but {scores.shape[0]} scores')
     lib = _lib.load()
-    order = scores.sort(0, descending=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]   # ties: lower index first (mmdet3d leaves them unspecified)
     if pre_max_size is not None:
         order = order[:pre_max_size]
     order = order.contiguous()
@@ -75,6 +75,116 @@ def nms_gpu(boxes, scores, thresh, pre_max_size=None, post_max_size=None, pre_ma
 def nms_normal_gpu(boxes, scores, thresh):
     """Axis-aligned BEV NMS (angle ignored), mmdet3d `nms_normal_gpu`."""
     return _nms(boxes, scores, thresh, None, None, normal=True)
+
+
+_THRESH_CACHE = {}
+
+
+def _thresh_tensor(thresh, groups, dev):
+    vals = tuple(float(t) for t in thresh) if isinstance(thresh, (list, tuple)) else (float(thresh),) * groups
+    if len(vals) != groups:
+        raise RuntimeError(f'{len(vals)} thresholds for {groups} groups')
+    key = (vals, dev)
+    t = _THRESH_CACHE.get(key)
+    if t is None:
+        if len(_THRESH_CACHE) > 64:
+            _THRESH_CACHE.clear()
+        t = _THRESH_CACHE[key] = torch.tensor(vals, dtype=torch.float32, device=dev)
+    return t
+
+
+def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_max_size=None, normal=False,
+                    circle=False):
+    """G independent NMS problems over ONE box array in one set of launches and one host sync.
+
+    boxes (N,5) [x1,y1,x2,y2,ry] (circle=True: (N,2) centres); scores (G,N); valid (G,N) bool or None — which boxes take
+    part in group g (e.g. `box_probs[:, k] >= score_thr[k]`, pvrcnn_bbox_head.py:454); thresh: float or G floats.
+    Returns a list of G LongTensors: kept indices into `boxes`, by descending score — each equal to
+    `nms_gpu(boxes[valid[g]], scores[g][valid[g]], thresh[g], pre_max_size, post_max_size)` mapped back through
+    `valid[g].nonzero()`.  Group sizes stay on the device (the kernels read them), so the loop-over-classes of the
+    reference, with two host syncs per class, becomes three launches and one sync."""
+    name = 'nms_gpu_batched'
+    boxes = _check_boxes(boxes, 2 if circle else 5, name)
+    if scores.dim() != 2 or scores.shape[1] != boxes.shape[0]:
+        raise RuntimeError(f'{name}: scores must be (G,{boxes.shape[0]}), got {tuple(scores.shape)}')
+    if valid is not None and valid.shape != scores.shape:
+        raise RuntimeError(f'{name}: valid {tuple(valid.shape)} vs scores {tuple(scores.shape)}')
+    if scores.device != boxes.device or (valid is not None and valid.device != boxes.device):
+        raise RuntimeError(f'{name}: operands live on different devices')
+    G, N = scores.shape
+    dev = boxes.device
+    if G == 0:
+        return []
+    if N == 0:
+        return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if valid is None:
+            key = scores
+            counts = torch.full((G,), N, dtype=torch.int32, device=dev)
+        else:
+            valid = valid.to(torch.bool)
+            key = scores.masked_fill(~valid, float('-inf'))
+            counts = valid.sum(1, dtype=torch.int32)
+        order = key.sort(dim=1, descending=True, stable=True)[1]
+        cap = N
+        if pre_max_size is not None:
+            cap = max(min(N, int(pre_max_size)), 0)
+            order = order[:, :cap]
+            counts = counts.clamp(max=cap)
+        if cap == 0:
+            return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
+        order = order.contiguous()
+        th = _thresh_tensor(thresh, G, dev)
+        keep = torch.empty((G, cap), dtype=torch.int64, device=dev)
+        num = torch.empty(G, dtype=torch.int64, device=dev)
+        ws = torch.empty(lib.rnms_batched_workspace_bytes(G, cap), dtype=torch.uint8, device=dev)
+        mode = 2 if circle else (1 if normal else 0)
+        _lib.check(lib.rnms_batched(mode, boxes.data_ptr(), order.data_ptr(), counts.data_ptr(), G, cap, th.data_ptr(),
+                                    keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), name)
+    nums = num.tolist()  # the one sync: G data-dependent result lengths
+    out = []
+    for g in range(G):
+        k = keep[g, :nums[g]]
+        out.append(k if post_max_size is None else k[:post_max_size])
+    return out
+
+
+def multi_class_nms(box_probs, boxes_for_nms, score_thr, nms_thr, use_rotate_nms=True):
+    """PVRCNNBboxHead.multi_class_nms (pvrcnn_bbox_head.py:438-480) with the class loop inside one batched NMS.
+    box_probs (N,C); boxes_for_nms (N,5) [x1,y1,x2,y2,ry]; score_thr / nms_thr: float or list of C.
+    Returns `selected` as the reference does: the kept indices of class 0, then class 1, ... (`[]` when none)."""
+    N, C = box_probs.shape
+    st = score_thr if isinstance(score_thr, (list, tuple)) else [score_thr] * C
+    sc = box_probs.t().contiguous().to(torch.float32)
+    valid = sc >= _thresh_tensor(st, C, sc.device).unsqueeze(1)
+    per_class = nms_gpu_batched(boxes_for_nms, sc, nms_thr, valid, normal=not use_rotate_nms)
+    sel = [k for k in per_class if k.shape[0] > 0]
+    return torch.cat(sel, dim=0) if sel else []
+
+
+def circle_nms(dets, thresh, post_max_size=83):
+    """mmdet3d `circle_nms` on the device (the reference copies the detections to the host for the numba version,
+    gd_centerpoint_head.py:256-272).  dets (N,3) [x, y, score]; a detection is suppressed by a kept, higher-scored one
+    iff (dx^2 + dy^2) <= thresh.  Returns kept indices (LongTensor on dets.device), at most post_max_size."""
+    dets = _check_boxes(dets, 3, 'circle_nms')
+    n = dets.shape[0]
+    dev = dets.device
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        order = dets[:, 2].sort(dim=0, descending=True, stable=True)[1].contiguous()
+        xy = dets[:, :2].contiguous()
+        keep = torch.empty(n, dtype=torch.int64, device=dev)
+        num = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.rnms_circle_ordered(xy.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(),
+                                           num.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   'circle_nms')
+    keep = keep[:int(num.item())]
+    return keep if post_max_size is None else keep[:post_max_size]
 
 
 def boxes_iou_bev(boxes_a, boxes_b):

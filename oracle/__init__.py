@@ -200,6 +200,30 @@ def nms_gpu_oracle(boxes, scores, thresh, pre_max_size=None, post_max_size=None,
     return keep.astype(np.int64)
 
 
+def circle_nms(dets, thresh, post_max_size=83):
+    """Restatement of mmdet3d's numba `circle_nms(dets, thresh, post_max_size)` (third party, absent, unpinned —
+    PARITY UNPINNED), mmdet3d/core/utils/gaussian.py: order by descending score; a detection is suppressed by an
+    earlier kept one iff (dx^2 + dy^2) <= thresh (float32 distance compared with the Python-float threshold).
+    Ties in the score keep the lower index first (numpy's reversed argsort leaves them unspecified)."""
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    x, y = dets[:, 0], dets[:, 1]
+    order = np.argsort(-dets[:, 2], kind='stable')
+    n = dets.shape[0]
+    suppressed = np.zeros(n, bool)
+    keep = []
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[_i + 1:]
+        dx, dy = x[i] - x[rest], y[i] - y[rest]
+        dist = (dx * dx + dy * dy).astype(np.float32)          # fp32 products and sum, no fused multiply-add
+        suppressed[rest[dist.astype(np.float64) <= float(thresh)]] = True
+    keep = np.asarray(keep, dtype=np.int64)
+    return keep if post_max_size is None else keep[:post_max_size]
+
+
 def iou_bev_xyxyr(a, b):
     a, b = _boxes(a, 5), _boxes(b, 5)
     out = np.empty((a.shape[0], b.shape[0]), np.float32)

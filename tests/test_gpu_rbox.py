@@ -129,3 +129,73 @@ def test_nms_degenerate_geometry_bit_exact(amd):
         want = oracle.nms_gpu_oracle(boxes, scores, thr)
         got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
         np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('normal', [False, True])
+def test_batched_nms_equals_per_group_calls_and_oracle(amd, normal):
+    """G groups (classes) over one box array, group sizes read on the device: each group's keep list must equal both the
+    single-call nms_gpu on the compacted group and the CPU oracle, bit for bit — incl. an empty group, a full group,
+    a 1-box group and per-group thresholds."""
+    n, G = 1500, 5
+    boxes, _ = nms_boxes(n, seed=21)
+    rng = np.random.default_rng(5)
+    scores = rng.uniform(0, 1, (G, n)).astype(np.float32)
+    valid = scores >= np.array([0.3, 2.0, 0.0, 0.9, 0.5], np.float32)[:, None]      # group 1 empty, group 2 full
+    valid[3] = False; valid[3, 77] = True                                          # group 3: a single box
+    thr = [0.25, 0.5, 0.1, 0.7, 0.01]
+    b = torch.from_numpy(boxes).cuda(); s = torch.from_numpy(scores).cuda(); v = torch.from_numpy(valid).cuda()
+    got = amd.nms_gpu_batched(b, s, thr, v, normal=normal)
+    assert len(got) == G
+    single = amd.nms_normal_gpu if normal else amd.nms_gpu
+    for g in range(G):
+        idx = np.nonzero(valid[g])[0]
+        want = idx[oracle.nms_gpu_oracle(boxes[idx], scores[g, idx], thr[g], normal=normal)] if len(idx) else np.zeros(0, np.int64)
+        assert np.array_equal(got[g].cpu().numpy(), want), g
+        if len(idx):
+            one = single(b[v[g]], s[g][v[g]], thr[g])
+            assert torch.equal(got[g], v[g].nonzero().reshape(-1)[one])
+    # pre / post cuts apply per group; no mask = every box takes part
+    cut = amd.nms_gpu_batched(b, s, 0.25, None, pre_max_size=700, post_max_size=50, normal=normal)
+    for g in range(G):
+        want = oracle.nms_gpu_oracle(boxes, scores[g], 0.25, 700, 50, normal=normal)
+        assert np.array_equal(cut[g].cpu().numpy(), want)
+
+
+def test_multi_class_nms_matches_reference_loop(amd):
+    """pvrcnn_bbox_head.py:438-480 restated as the loop it is (score mask -> nonzero -> nms -> original_idxs[selected]
+    -> cat) on the oracle vs the one-shot batched call."""
+    n, C = 2000, 3
+    boxes, _ = nms_boxes(n, seed=8)
+    rng = np.random.default_rng(9)
+    probs = rng.uniform(0, 1, (n, C)).astype(np.float32)
+    score_thr, nms_thr = [0.6, 0.1, 0.99], [0.1, 0.3, 0.5]
+    want = []
+    for k in range(C):
+        m = probs[:, k] >= np.float32(score_thr[k])
+        if m.sum() > 0:
+            idx = np.nonzero(m)[0]
+            sel = oracle.nms_gpu_oracle(boxes[idx], probs[idx, k], nms_thr[k])
+            if len(sel):
+                want.append(idx[sel])
+    want = np.concatenate(want)
+    got = amd.multi_class_nms(torch.from_numpy(probs).cuda(), torch.from_numpy(boxes).cuda(), score_thr, nms_thr)
+    assert np.array_equal(got.cpu().numpy(), want)
+    none = amd.multi_class_nms(torch.from_numpy(probs).cuda(), torch.from_numpy(boxes).cuda(), 2.0, 0.1)
+    assert isinstance(none, list) and none == []
+
+
+@pytest.mark.parametrize('n,thr', [(1, 1.0), (500, 4.0), (3000, 0.85), (3000, 0.175), (5000, 12.0)])
+def test_circle_nms_bit_exact(amd, n, thr):
+    """mmdet3d circle_nms restated (oracle) vs the device version: same kept indices, same order, post_max_size cut."""
+    rng = np.random.default_rng(n)
+    nc = max(1, n // 6)
+    c = rng.uniform(-50, 50, (nc, 2))
+    xy = c[rng.integers(0, nc, n)] + rng.normal(0, 0.6, (n, 2))
+    dets = np.concatenate([xy, rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    dets[::7, :2] = dets[0, :2]                       # exact duplicates: distance 0 <= thresh
+    want = oracle.circle_nms(dets, thr, post_max_size=83)
+    got = amd.circle_nms(torch.from_numpy(dets).cuda(), thr, post_max_size=83)
+    assert np.array_equal(got.cpu().numpy(), want)
+    full = amd.circle_nms(torch.from_numpy(dets).cuda(), thr, post_max_size=None)
+    assert np.array_equal(full.cpu().numpy(), oracle.circle_nms(dets, thr, post_max_size=None))
+    assert amd.circle_nms(torch.zeros(0, 3).cuda(), thr).numel() == 0
