@@ -266,6 +266,21 @@ int riou_eval_bev(const float* det, int64_t nd, const float* gt, int64_t ng, flo
 int riou_eval_3d(const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset,
                  float* iou, void* stream);
 
+/* BEV centre distance (affinity.cpp:83-105, `LidarCenterTransBEV`): det (nd, det_cols), gt (ng, gt_cols) row-major,
+ * columns 0 and 1 are the centre -> dist (nd, ng) fp32 = sqrt(dx^2 + dy^2). */
+int riou_eval_trans_bev(const float* det, int64_t nd, int32_t det_cols, const float* gt, int64_t ng,
+                        int32_t gt_cols, float* dist, void* stream);
+
+/* COCO-style greedy matcher (matcher.cpp:8-74, `MatcherCoCo`), all on the device:
+ *   cost (nd, ng) fp32 row-major (e.g. the negated IoU matrix the kernels above wrote), cost_thrs (nt) fp32,
+ *   is_ignore / is_crowd (ng) bytes (0/1)  ->  matched (nt, nd) int32: gt index or -1.
+ * For every threshold the detections are visited in row order; a detection takes the cheapest gt with cost <= thr
+ * that is still free (or a crowd gt), a non-ignore gt beating any ignore gt, ties going to the later gt.  Bit-exact
+ * with the reference (integer output).  ng <= 1048576. */
+int eval_match_coco(const float* cost, const float* cost_thrs, const uint8_t* is_ignore,
+                    const uint8_t* is_crowd, int64_t nd, int64_t ng, int64_t nt, int32_t* matched,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Dynamic point-to-voxel scatter-reduce.  Replaces
  * dynamic_point_to_voxel_scatter_reduce / dynamic_point_to_voxel_backward

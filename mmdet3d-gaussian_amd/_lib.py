@@ -62,6 +62,8 @@ SYMBOLS = {
     'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_bev': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_3d': (_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp]),
+    'riou_eval_trans_bev': (_int, [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _vp]),
+    'eval_match_coco': (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     'vox_scatter_reduce': (_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp, _vp]),
     'vox_scatter_backward': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),

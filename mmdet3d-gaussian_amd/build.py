@@ -22,6 +22,7 @@ SOURCES = {
     'gd3d_loss.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],
     'rbox.hip': ['-ffp-contract=off'],
     'voxel_scatter.hip': [],
+    'eval_match.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,123 @@
+"""Device-side mirror of the reference's evaluation helpers:
+
+* ``trans_bev`` / ``iou_3d`` / ``iou_bev``  — /root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:8-105 as bound in
+  ops/eval/eval_utils.cpp:26-36; the affinity callables ``LidarCenterTransBEV`` / ``LidarIOU3D`` / ``LidarIOUBEV``
+  restate core/evaluation/affinity.py:5-32 (same names, ``LARGER_CLOSER``, argument meaning, crowd assertion).
+* ``match_coco`` and ``MatcherCoCo`` — ops/eval/matcher.cpp:8-74 behind core/evaluation/matcher.py:6-37 (negated
+  affinities and thresholds when ``affinity_cost_negate``).
+
+The reference computes all of this on the CPU from numpy arrays.  Here the affinity matrix is produced and consumed in
+HBM; numpy inputs are accepted and moved to the current device, results are returned as tensors on that device.
+There is no CPU implementation behind these functions.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .iou3d import iou_3d, iou_bev
+
+
+def _dev_tensor(x, dtype, name):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError(f'{name}: the MI355X implementation has no CPU path and no GPU is visible')
+        x = x.cuda()
+    return x.to(dtype).contiguous()
+
+
+def trans_bev(det_bboxes, gt_bboxes):
+    """(D,C>=2),(G,C'>=2) -> (D,G) distance between BEV centres (columns 0,1), affinity.cpp:83-105."""
+    d = _dev_tensor(det_bboxes, torch.float32, 'trans_bev')
+    g = _dev_tensor(gt_bboxes, torch.float32, 'trans_bev').to(d.device)
+    if d.dim() != 2 or g.dim() != 2 or d.shape[1] < 2 or g.shape[1] < 2:
+        raise RuntimeError(f'trans_bev: expected (D,>=2) and (G,>=2), got {tuple(d.shape)} and {tuple(g.shape)}')
+    out = torch.empty((d.shape[0], g.shape[0]), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        _lib.check(_lib.load().riou_eval_trans_bev(d.data_ptr(), d.shape[0], d.shape[1], g.data_ptr(), g.shape[0],
+                                                   g.shape[1], out.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), 'riou_eval_trans_bev')
+    return out
+
+
+def match_coco(cost_mat, cost_thrs, is_ignore, is_crowd):
+    """(D,G) costs, (T) thresholds, (G) bool flags -> (T,D) int32 tensor: matched gt index or -1 (matcher.cpp:8-74)."""
+    cost = _dev_tensor(cost_mat, torch.float32, 'match_coco')
+    if cost.dim() != 2:
+        raise RuntimeError(f'match_coco: cost matrix must be 2-D, got {tuple(cost.shape)}')
+    dev = cost.device
+    thrs = _dev_tensor(cost_thrs, torch.float32, 'match_coco').to(dev).reshape(-1)
+    ign = _dev_tensor(is_ignore, torch.uint8, 'match_coco').to(dev).reshape(-1)
+    crowd = _dev_tensor(is_crowd, torch.uint8, 'match_coco').to(dev).reshape(-1)
+    D, G = cost.shape
+    if ign.numel() != G or crowd.numel() != G:
+        raise RuntimeError(f'match_coco: {G} gts but {ign.numel()} ignore / {crowd.numel()} crowd flags')
+    T = thrs.numel()
+    out = torch.empty((T, D), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().eval_match_coco(cost.data_ptr(), thrs.data_ptr(), ign.data_ptr(), crowd.data_ptr(), D, G, T,
+                                               out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   'eval_match_coco')
+    return out
+
+
+class LidarCenterTransBEV:
+    LARGER_CLOSER = False
+
+    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
+        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
+        return trans_bev(det_bboxes, gt_bboxes)
+
+
+class LidarIOU3D:
+    LARGER_CLOSER = True
+
+    def __init__(self, z_offset=0.5):
+        self.z_offset = z_offset
+
+    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
+        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
+        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOU3D')
+        return iou_3d(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOU3D').to(d.device), self.z_offset)
+
+
+class LidarIOUBEV:
+    LARGER_CLOSER = True
+
+    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
+        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
+        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOUBEV')
+        return iou_bev(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOUBEV').to(d.device))
+
+
+class BaseMatcher:
+    def __init__(self, match_thrs, affinity_cost_negate=True):
+        self._match_thrs = match_thrs
+        self.negate = affinity_cost_negate
+
+    @property
+    def match_thrs(self):
+        return self._match_thrs
+
+    def __call__(self, affinity, gt_isignore=None, gt_iscrowd=None):
+        affinity = _dev_tensor(affinity, torch.float32, 'matcher')
+        G = affinity.shape[1]
+        if gt_iscrowd is None:
+            gt_iscrowd = torch.zeros(G, dtype=torch.bool, device=affinity.device)
+        if gt_isignore is None:
+            gt_isignore = torch.zeros(G, dtype=torch.bool, device=affinity.device)
+        thrs = np.array(self.match_thrs, np.float32)
+        if self.negate:
+            return self.match(-affinity, -thrs, gt_isignore, gt_iscrowd)
+        return self.match(affinity, thrs, gt_isignore, gt_iscrowd)
+
+    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
+        raise NotImplementedError
+
+
+class MatcherCoCo(BaseMatcher):
+    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
+        return match_coco(affinity, match_thrs, gt_isignore, gt_iscrowd)

@@ -72,6 +72,10 @@ def lib():
         L.rbox_oracle_eval_iou_bev.argtypes = [vp, i64, vp, i64, vp]
         L.rbox_oracle_eval_iou_3d.restype = None
         L.rbox_oracle_eval_iou_3d.argtypes = [vp, i64, vp, i64, f32, vp]
+        L.rbox_oracle_trans_bev.restype = None
+        L.rbox_oracle_trans_bev.argtypes = [vp, i64, i64, vp, i64, i64, vp]
+        L.rbox_oracle_match_coco.restype = None
+        L.rbox_oracle_match_coco.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
         _lib = L
     return _lib
 
@@ -242,6 +246,25 @@ def eval_iou_3d(det, gt, z_offset=0.5):
     det, gt = _boxes(det, 7), _boxes(gt, 7)
     out = np.empty((det.shape[0], gt.shape[0]), np.float32)
     lib().rbox_oracle_eval_iou_3d(_ptr(det), det.shape[0], _ptr(gt), gt.shape[0], float(z_offset), _ptr(out))
+    return out
+
+
+def eval_trans_bev(det, gt):
+    """affinity.cpp:83-105: (D,cols>=2),(G,cols>=2) -> (D,G) BEV centre distance."""
+    det = np.ascontiguousarray(det, np.float32); gt = np.ascontiguousarray(gt, np.float32)
+    out = np.empty((det.shape[0], gt.shape[0]), np.float32)
+    lib().rbox_oracle_trans_bev(_ptr(det), det.shape[0], det.shape[1], _ptr(gt), gt.shape[0], gt.shape[1], _ptr(out))
+    return out
+
+
+def match_coco(cost_mat, cost_thrs, is_ignore, is_crowd):
+    """matcher.cpp:8-74: (D,G) costs, (T) thresholds, (G) bools -> (T,D) int32 matched gt index or -1."""
+    cost = np.ascontiguousarray(cost_mat, np.float32)
+    thrs = np.ascontiguousarray(cost_thrs, np.float32)
+    ign = np.ascontiguousarray(is_ignore, np.uint8); crowd = np.ascontiguousarray(is_crowd, np.uint8)
+    nd, ng = cost.shape
+    out = np.empty((thrs.shape[0], nd), np.int32)
+    lib().rbox_oracle_match_coco(_ptr(cost), _ptr(thrs), _ptr(ign), _ptr(crowd), nd, ng, thrs.shape[0], _ptr(out))
     return out
 
 

@@ -391,3 +391,44 @@ void rbox_oracle_eval_iou_3d(const float *det, int64_t nd, const float *gt, int6
       out[di * ng + gi] = iv / uv;
     }
 }
+
+/* affinity.cpp:83-105 — BEV centre distance (LidarCenterTransBEV).  `cols` = row length of det / gt (the reference
+ * reads columns 0 and 1 of whatever 2-D arrays it is given).  Whether the reference's unqualified `sqrt` binds to the
+ * float or the double overload does not matter: a double sqrt of a float argument rounded back to float equals the
+ * correctly rounded float sqrt (53 >= 2*24 + 2).  Pinned against oracle/_ref bit for bit. */
+void rbox_oracle_trans_bev(const float *det, int64_t nd, int64_t dcols, const float *gt, int64_t ng, int64_t gcols,
+                           float *out) {
+  for (int64_t di = 0; di < nd; ++di)
+    for (int64_t gi = 0; gi < ng; ++gi) {
+      const float dx = det[di * dcols] - gt[gi * gcols], dy = det[di * dcols + 1] - gt[gi * gcols + 1];
+      out[di * ng + gi] = sqrtf(dx * dx + dy * dy);
+    }
+}
+
+/* matcher.cpp:8-74 — COCO-style greedy matching of detections (rows, in the given order) to ground truths for every
+ * cost threshold: a detection takes the cheapest still-free (or crowd) gt with cost <= thr, non-ignore gts beating
+ * ignore ones; ties go to the LATER gt (`<=`).  matched (n_thr, n_det) int32, -1 = unmatched. */
+void rbox_oracle_match_coco(const float *cost, const float *thrs, const uint8_t *is_ignore, const uint8_t *is_crowd,
+                            int64_t nd, int64_t ng, int64_t nt, int32_t *matched) {
+  uint8_t *taken = (uint8_t *)calloc((size_t)(nt * ng > 0 ? nt * ng : 1), 1);
+  for (int64_t t = 0; t < nt; ++t)
+    for (int64_t d = 0; d < nd; ++d) {
+      const float thr = thrs[t];
+      float best = thr;
+      int64_t m = -1;
+      for (int64_t g = 0; g < ng; ++g) {
+        if (taken[t * ng + g] && !is_crowd[g]) continue;
+        const float v = cost[d * ng + g];
+        if (m == -1) {
+          if (v <= best) { best = v; m = g; }
+        } else if (is_ignore[m]) {
+          if (!is_ignore[g]) {
+            if (v <= thr) { best = v; m = g; }
+          } else if (v <= best) { best = v; m = g; }
+        } else if (!is_ignore[g] && v <= best) { best = v; m = g; }
+      }
+      if (m != -1) taken[t * ng + m] = 1;
+      matched[t * nd + d] = (int32_t)m;
+    }
+  free(taken);
+}

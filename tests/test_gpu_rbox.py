@@ -199,3 +199,42 @@ def test_circle_nms_bit_exact(amd, n, thr):
     full = amd.circle_nms(torch.from_numpy(dets).cuda(), thr, post_max_size=None)
     assert np.array_equal(full.cpu().numpy(), oracle.circle_nms(dets, thr, post_max_size=None))
     assert amd.circle_nms(torch.zeros(0, 3).cuda(), thr).numel() == 0
+
+
+def test_match_coco_and_trans_bev_vs_reference_golden(amd):
+    """Device matcher / centre-distance vs vectors produced by the reference's own compiled matcher.cpp / affinity.cpp."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'match_coco.npz'))
+    for name in g['cases']:
+        got = amd.match_coco(g[f'{name}.cost'], g[f'{name}.thrs'], g[f'{name}.ignore'], g[f'{name}.crowd'])
+        assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), g[f'{name}.matched']), name
+    assert np.array_equal(amd.trans_bev(g['trans.det'], g['trans.gt']).cpu().numpy(), g['trans.dist'])
+    # column stride other than 7
+    assert np.array_equal(amd.trans_bev(g['trans.det'][:, :2], g['trans.gt'][:, :3]).cpu().numpy(), g['trans.dist'])
+
+
+@pytest.mark.parametrize('D,G,T', [(3000, 50, 10), (200, 5000, 3), (1, 1, 1), (64, 64, 4), (500, 65, 2)])
+def test_match_coco_large_vs_oracle(amd, D, G, T):
+    rng = np.random.default_rng(D + G)
+    cost = np.round(-rng.uniform(0, 1, (D, G)), 2).astype(np.float32)        # rounded: plenty of exact ties
+    cost[rng.uniform(0, 1, (D, G)) < 0.01] = -0.0                             # signed zeros compare equal to +0
+    thrs = -np.linspace(0.0, 0.9, T).astype(np.float32)
+    ign = rng.uniform(0, 1, G) < 0.3; crowd = rng.uniform(0, 1, G) < 0.1
+    want = oracle.match_coco(cost, thrs, ign, crowd)
+    got = amd.match_coco(torch.from_numpy(cost).cuda(), thrs, torch.from_numpy(ign).cuda(), crowd)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_matcher_class_pipeline_iou_to_matches(amd):
+    """core/evaluation flow on the device: LidarIOU3D affinity -> MatcherCoCo (negated costs) vs the same flow on the
+    CPU oracle (iou_3d oracle is pinned to the compiled reference; the matcher too)."""
+    det = eval_boxes(300, seed=1, spread=25.0); gt = eval_boxes(40, seed=2, spread=25.0)
+    gt[:20, :] = det[:20, :] + np.float32(0.05)
+    aff = amd.LidarIOU3D(z_offset=0.5)(det, gt)
+    m = amd.MatcherCoCo([0.3, 0.5, 0.7])
+    ign = np.zeros(40, bool); ign[::4] = True
+    got = m(aff, gt_isignore=ign)
+    aff_o = oracle.eval_iou_3d(det, gt, 0.5)
+    assert np.array_equal(aff.cpu().numpy(), aff_o)
+    want = oracle.match_coco(-aff_o, -np.array([0.3, 0.5, 0.7], np.float32), ign, np.zeros(40, bool))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert amd.LidarCenterTransBEV.LARGER_CLOSER is False and amd.LidarIOUBEV.LARGER_CLOSER is True
