@@ -128,18 +128,30 @@ def main():
         return outs
 
     graph = None
+    graph_note = None
     if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                compute(False)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: calls made by other threads (e.g. the RCCL watchdog) must not invalidate the capture
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-            graph_outs = compute(False)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    compute(False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: calls made by other threads (e.g. the RCCL watchdog) must not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                graph_outs = compute(False)
+        except Exception as e:  # noqa: BLE001 — a failed capture must not cost the measurement: launch eagerly instead
+            graph = None
+            graph_note = f'hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches'
+            torch.cuda.synchronize(dev)
+        if use_dist:  # every rank must take the same path (the collective pattern is identical either way, but keep
+            ok = torch.tensor([1 if graph is not None else 0], device=dev)   # the launch mode reported by rank 0 true)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0 and graph is not None:
+                graph = None
+                graph_note = 'hipGraph capture failed on another rank; eager launches'
 
     def step(record):
         outs = compute(record) if graph is None else (graph.replay() or graph_outs)
@@ -211,7 +223,7 @@ def main():
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward '
                                    '(fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
-                       'launch': 'hipGraph replay' if graph is not None else 'eager',
+                       'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
