@@ -66,6 +66,7 @@ SYMBOLS = {
     'eval_match_coco': (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     'vox_scatter_reduce': (_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp, _vp]),
     'vox_scatter_backward': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
+    'vox_scatter_backward_grouped': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

@@ -65,7 +65,7 @@ def test_host_scatter_index_matches_oracle_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130)])
+@pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130), (9000, 16), (7000, 128), (4000, 12)])
 @pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
 def test_gpu_scatter_reduce_forward_backward(n, c, red):
     import mmdet3d_gaussian_amd as amd  # noqa: F401
@@ -115,3 +115,34 @@ def test_gpu_scatter_batched_coors_and_determinism():
         sel = (m == v)
         assert (coors4[sel] == vc[v]).all()
         np.testing.assert_allclose(o1[v].cpu().numpy(), feats[sel].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c', [4, 16, 64, 100])
+@pytest.mark.parametrize('red', [0, 1, 2])
+def test_gpu_backward_voxel_order_equals_map_order(c, red):
+    """vox_scatter_backward_grouped (each voxel row read once, streamed to its points) must produce the same bits as the
+    map-ordered gather, incl. zero rows for the points outside every voxel (3 % of the cloud) and untouched arg-max ties."""
+    import mmdet3d_gaussian_amd as amd
+    from mmdet3d_gaussian_amd.scatter import Scatter, group_points
+    lib = amd.load_library()
+    n = 30000
+    coors, feats = _cloud(n, 100 + c, c=c, neg_frac=0.03)
+    sc = Scatter(torch.from_numpy(coors).cuda())
+    order, seg = group_points(sc.pts_voxel_maps, sc.voxel_pts_counts)
+    assert int(seg[0]) > 0                                  # there ARE invalid points in this cloud
+    v = sc.voxel_coors.shape[0]
+    f = torch.from_numpy(feats).cuda()
+    out = torch.empty(v, c, device='cuda'); arg = torch.empty(v, c, dtype=torch.int32, device='cuda')
+    assert lib.vox_scatter_reduce(f.data_ptr(), order.data_ptr(), seg.data_ptr(), n, c, v, red, out.data_ptr(),
+                                  arg.data_ptr() if red == 2 else None, None) == 0
+    gv = torch.randn(v, c, device='cuda')
+    a = torch.full((n, c), float('nan'), device='cuda'); b = torch.full((n, c), float('nan'), device='cuda')
+    am = arg.data_ptr() if red == 2 else None
+    assert lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), am, n, c, v,
+                                    red, a.data_ptr(), None) == 0
+    assert lib.vox_scatter_backward_grouped(gv.data_ptr(), order.data_ptr(), seg.data_ptr(), am, n, c, v, red, b.data_ptr(),
+                                            None) == 0
+    torch.cuda.synchronize()
+    assert not torch.isnan(b).any() and torch.equal(a, b)
+    assert (b[sc.pts_voxel_maps < 0] == 0).all()

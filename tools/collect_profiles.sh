@@ -29,6 +29,7 @@ cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
 python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config_standins.jsonl
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
+python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
 python3 tools/accuracy_report.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_accuracy_report.txt
 python3 tools/profile_summary.py $OUT $R
 ls -la $OUT

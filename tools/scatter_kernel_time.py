@@ -27,6 +27,12 @@ for n, c, grid in ((2_000_000, 64, (432, 496, 1)), (2_000_000, 16, (432, 496, 1)
     for red, name in ((2, 'max'), (1, 'mean'), (0, 'sum')):
         f = t(lambda: lib.vox_scatter_reduce(feats.data_ptr(), order.data_ptr(), seg.data_ptr(), n, c, v, red, out.data_ptr(), arg.data_ptr() if red == 2 else None, None))
         b = t(lambda: lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), arg.data_ptr() if red == 2 else None, n, c, v, red, gf.data_ptr(), None))
+        b2 = t(lambda: lib.vox_scatter_backward_grouped(gv.data_ptr(), order.data_ptr(), seg.data_ptr(), arg.data_ptr() if red == 2 else None, n, c, v, red, gf.data_ptr(), None)) if c % 4 == 0 else float('nan')
         fb = n * c * 4 + n * 4 + v * c * 4 * (2 if red == 2 else 1)
         bb = (n * c * 4 + v * c * 4 * (2 if red == 2 else 1)) if red == 2 else (n * c * 4 + n * 4 + v * c * 4)
-        print(f'n={n} c={c} v={v} {name:4s}: fwd {f:7.1f} us ({fb / f / 1e3:6.0f} GB/s)  bwd {b:7.1f} us ({bb / b / 1e3:6.0f} GB/s)', flush=True)
+        print(f'n={n} c={c} v={v} {name:4s}: fwd {f:7.1f} us ({fb / f / 1e3:6.0f} GB/s)  bwd(map order) {b:7.1f} us ({bb / b / 1e3:6.0f} GB/s)  bwd(voxel order) {b2:7.1f} us', flush=True)
+    # ceiling probes on the same data: a plain random row gather (feats[order], read N*C*4 + write N*C*4) and a
+    # streaming copy of the same bytes — what the memory system gives a segmented reduce over randomly placed rows
+    gi = t(lambda: torch.index_select(feats, 0, order.long()))
+    cp = t(lambda: gf.copy_(feats))
+    print(f'n={n} c={c}: torch index_select(feats, order) {gi:7.1f} us ({2 * n * c * 4 / gi / 1e3:6.0f} GB/s r+w)   copy {cp:7.1f} us ({2 * n * c * 4 / cp / 1e3:6.0f} GB/s r+w)', flush=True)
