@@ -65,14 +65,20 @@ def cpu_baseline(sample_pairs, seed):
     p, t = pred.numpy(), tgt.numpy()
     loss = np.empty(sample_pairs, np.float32)
     gp = np.empty((sample_pairs, 7), np.float32)
-    t0 = time.perf_counter()
-    for lt in LOSSES:
-        prm = oracle.make_params(lt, fun='log1p', tau=1.0)
-        oracle.gd_loss_timed(p, t, prm, 5.0 / sample_pairs, loss, gp, cores)
-    dt = time.perf_counter() - t0
-    return {'value': round(3 * sample_pairs / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle (oracle/gd_oracle.c), '
-                      f'OpenMP {cores} threads, {dt:.2f} s'}
+    prms = [oracle.make_params(lt, fun='log1p', tau=1.0) for lt in LOSSES]
+    for prm in prms:  # untimed pass: page in the buffers, spin up the OpenMP team
+        oracle.gd_loss_timed(p[:100000], t[:100000], prm, 5.0 / sample_pairs, loss[:100000], gp[:100000], cores)
+    reps, t0 = 0, time.perf_counter()
+    while True:  # whole passes over the sample until ~10 s of wall time are spent (bounded: at most 64 passes)
+        for prm in prms:
+            oracle.gd_loss_timed(p, t, prm, 5.0 / sample_pairs, loss, gp, cores)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or reps >= 64:
+            break
+    return {'value': round(3 * sample_pairs * reps / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} pass(es) over {sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle '
+                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall'}
 
 
 def main():
