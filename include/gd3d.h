@@ -184,6 +184,40 @@ int gd3d_anchor_head_bbox_loss(const gd3d_params* params, const gd3d_smooth_l1* 
                                int32_t num_classes, float scale, float* loss_sum,
                                float* grad_bbox_pred, void* workspace, void* stream);
 
+/* CenterGDHead regression losses of up to 8 tasks in ONE launch (gd_centerpoint_head.py:402-441), reading the head
+ * outputs where they lie.  Per task (host struct, device pointers):
+ *   maps[6]   : reg (B,2,H,W) | height (B,1,H,W) | dim (B,3,H,W) | yaw (B,1,H,W) | dir (B,2,H,W) | vel (B,2,H,W), NCHW
+ *               fp32; reg may be NULL (0.5 is used, :377-378), vel NULL when n_l1 == 2, dir NULL when n_l1 == 0;
+ *   grads[6]  : gradient maps of the same shapes, ZERO-FILLED by the caller (any may be NULL); the kernel accumulates
+ *               with float atomics (two objects may share a cell);
+ *   pos_ind   : (n,3) int64 [batch, x, y] (:72-80);  anno : (n, anno_cols) fp32 boxes [x,y,z,w,l,h,yaw(,vx,vy)];
+ *   gd_scale  : loss_weight / avg_factor of loss_gd,  l1_scale: the same for loss_bbox (L1Loss).
+ * coder: kind GD3D_PRO_CENTER (norm_bbox, out_size_factor, voxel_size, pc_range; aux ignored).
+ * code_weights: HOST array of n_l1 (0, 2 or 4) floats = train_cfg['code_weights'] for [sin, cos(, vx, vy)].
+ * losses (num_tasks, 2) fp32 on the device: [loss_l1, loss_gd] per task.
+ * workspace: gd3d_center_head_workspace_bytes(num_tasks, max n).
+ * gd3d_center_head_scale: autograd backward for upstream gradients != 1: grads of task t are multiplied by
+ *   grad_losses[t*2+1] (reg/height/dim/yaw) or grad_losses[t*2] (dir/vel), device scalars, early exit when == 1. */
+typedef struct gd3d_center_task {
+  const float* maps[6];
+  float* grads[6];
+  const int64_t* pos_ind;
+  const float* anno;
+  int64_t n;
+  int32_t B, H, W, anno_cols;
+  float gd_scale, l1_scale;
+} gd3d_center_task;
+
+size_t gd3d_center_head_workspace_bytes(int32_t num_tasks, int64_t max_n);
+
+int gd3d_center_head_loss(const gd3d_params* params, const gd3d_prologue* coder,
+                          const gd3d_center_task* tasks, int32_t num_tasks,
+                          const float* code_weights, int32_t n_l1, float* losses, void* workspace,
+                          void* stream);
+
+int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks,
+                           const float* grad_losses, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

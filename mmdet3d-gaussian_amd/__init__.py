@@ -22,7 +22,7 @@ from .coders import CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
 from .evaluation import (LidarCenterTransBEV, LidarIOU3D, LidarIOUBEV, MatcherCoCo, match_coco, trans_bev)
 from .scatter import Scatter, scatter_index, scatter_reduce
 from .head_loss import (anchor_decoded_gd_loss, anchor_head_bbox_loss, anchor_head_decoded_loss,
-                        anchor_head_decoded_loss_fused, center_head_gd_loss)
+                        anchor_head_decoded_loss_fused, center_head_gd_loss, center_head_losses)
 
 
 def build(force=False, verbose=False):
@@ -33,5 +33,5 @@ def build(force=False, verbose=False):
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'multi_class_nms', 'circle_nms',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
-           'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'Scatter', 'scatter_index', 'scatter_reduce',
+           'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
            'trans_bev', 'match_coco', 'MatcherCoCo', 'LidarCenterTransBEV', 'LidarIOU3D', 'LidarIOUBEV']

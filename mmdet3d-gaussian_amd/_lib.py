@@ -31,6 +31,14 @@ class SmoothL1(ctypes.Structure):
                 ('has_code_weight', ctypes.c_int32), ('code_weight', ctypes.c_float * 7), ('reserved', ctypes.c_float)]
 
 
+class CenterTask(ctypes.Structure):
+    """gd3d_center_task (include/gd3d.h)."""
+    _fields_ = [('maps', ctypes.c_void_p * 6), ('grads', ctypes.c_void_p * 6), ('pos_ind', ctypes.c_void_p),
+                ('anno', ctypes.c_void_p), ('n', ctypes.c_int64), ('B', ctypes.c_int32), ('H', ctypes.c_int32),
+                ('W', ctypes.c_int32), ('anno_cols', ctypes.c_int32), ('gd_scale', ctypes.c_float),
+                ('l1_scale', ctypes.c_float)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -49,6 +57,10 @@ SYMBOLS = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp,
                                           ctypes.POINTER(ctypes.c_float), _vp, _vp, _i64, _vp, ctypes.c_int32, _f32, _vp,
                                           _vp, _vp, _vp]),
+    'gd3d_center_head_workspace_bytes': (_sz, [ctypes.c_int32, _i64]),
+    'gd3d_center_head_loss': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
+                                     ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp]),
+    'gd3d_center_head_scale': (_int, [ctypes.POINTER(CenterTask), ctypes.c_int32, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),

@@ -415,6 +415,167 @@ static void launch_head_fun(int fun, bool flag, unsigned grid, hipStream_t s, co
   else launch_head<LOSS, GD3D_FUN_NONE>(flag, grid, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// CenterGDHead regression losses of ALL tasks in one launch (gd_centerpoint_head.py:402-441):
+//   per task: pred = cat(reg, height, dim, yaw, dir[, vel])[b, :, y, x] gathered at the positives (:416-420, the cat and
+//   the gather never materialise: a thread reads its 9/11 values straight from the NCHW head maps), pred_gd =
+//   coder.decode(locs, pred)[:7] (:422-423), target = coder.encode(anno) (:409-411: [anno[:7], sin yaw, cos yaw, vel]),
+//   loss_gd = GDLoss(pred_gd, target[:7], avg_factor) (:433-434), loss_l1 = L1Loss(pred[7:], target[7:], code_weights,
+//   avg_factor) (:426-432).  Gradients are accumulated into the (zero-filled) per-head gradient maps with float atomics
+//   (two objects of a task may share a cell; the reference's index backward accumulates as well).
+// blockIdx.y = task; partials[(task * 2 + term) * pstride + block], term 0 = l1, 1 = gd.
+constexpr int CENTER_MAX_TASKS = 8;
+struct CenterTask {
+  const float* maps[6];  // reg(2) height(1) dim(3) yaw(1) dir(2) vel(2); reg / vel nullable
+  float* grads[6];       // nullable
+  const long long* pos_ind;
+  const float* anno;
+  long long n;
+  int B, H, W, anno_cols;
+  float gd_scale, l1_scale;
+};
+struct CenterArgs {
+  CenterTask t[CENTER_MAX_TASKS];
+  int num_tasks, n_l1, norm_bbox;
+  float osf, vs0, vs1, pc0, pc1;
+  float alpha, tau, c0, c1, c2;
+  float cw[4];
+  float* partials;
+  long long pstride;
+};
+
+template <int LOSS, int FUN, bool FLAG>
+__global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a) {
+  __shared__ float swave[2][HEAD_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = blockIdx.y;
+  const CenterTask& T = a.t[ti];
+  const long long i = (long long)blockIdx.x * HEAD_T + tid;
+  if ((long long)blockIdx.x * HEAD_T >= T.n) return;  // uniform: this task has fewer positives than the largest one
+  float fgd = 0.0f, fl1 = 0.0f;
+  bool live = i < T.n;
+  long long b = 0, x = 0, y = 0;
+  if (live) {
+    b = T.pos_ind[i * 3];
+    x = T.pos_ind[i * 3 + 1];
+    y = T.pos_ind[i * 3 + 2];
+    if (b < 0 || b >= T.B || x < 0 || x >= T.W || y < 0 || y >= T.H) {
+      // an index outside the head map (the reference would fault in its gather): no memory is touched for it and both
+      // losses of the task come out NaN, so the error is loud without a host-side range check (= a sync per task)
+      live = false;
+      fgd = fl1 = __builtin_nanf("");
+    }
+  }
+  if (live) {
+    const long long plane = (long long)T.H * T.W;
+    const long long off = y * T.W + x;
+    // channel k of head h at this cell: maps[h][(b * ch_h + k) * plane + off]
+    float enc[7];
+    enc[0] = T.maps[0] != nullptr ? T.maps[0][(b * 2 + 0) * plane + off] : 0.5f;  // no 'reg' head: 0.5 (:377-378)
+    enc[1] = T.maps[0] != nullptr ? T.maps[0][(b * 2 + 1) * plane + off] : 0.5f;
+    enc[2] = T.maps[1][b * plane + off];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) enc[3 + k] = T.maps[2][(b * 3 + k) * plane + off];
+    enc[6] = T.maps[3][b * plane + off];
+    float tv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tv[k] = T.anno[i * T.anno_cols + k];
+    // decode (centerpoint_bbox_yaw_coders.py:18-31, correct_yaw=False)
+    float pv[7], jac[7];
+    pv[0] = (enc[0] + (float)x) * a.osf * a.vs0 + a.pc0;
+    pv[1] = (enc[1] + (float)y) * a.osf * a.vs1 + a.pc1;
+    pv[2] = enc[2];
+#pragma unroll
+    for (int k = 3; k < 6; ++k) {
+      pv[k] = a.norm_bbox ? expf(enc[k]) : enc[k];
+      jac[k] = a.norm_bbox ? pv[k] : 1.0f;
+    }
+    pv[6] = enc[6];
+    jac[0] = a.osf * a.vs0; jac[1] = a.osf * a.vs1; jac[2] = 1.0f; jac[6] = 1.0f;
+    const float c[3] = {a.c0, a.c1, a.c2};
+    float g1[7], g2[7];
+    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.tau, T.gd_scale, g1, g2);
+    fgd = T.gd_scale * L;
+    // L1 on the remaining channels: dir (sin, cos) and velocity
+    float sy, cy;
+    sincos_f(tv[6], sy, cy);
+    float gl1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < a.n_l1) {
+        const float p = k < 2 ? T.maps[4][(b * 2 + k) * plane + off] : T.maps[5][(b * 2 + (k - 2)) * plane + off];
+        const float t = k == 0 ? sy : (k == 1 ? cy : T.anno[i * T.anno_cols + 7 + (k - 2)]);
+        const float d = p - t;
+        fl1 += fabsf(d) * a.cw[k];
+        gl1[k] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * a.cw[k] * T.l1_scale;  // torch abs'(0) = 0
+      }
+    }
+    fl1 *= T.l1_scale;
+    // scatter: GD gradient -> reg / height / dim / yaw maps, L1 gradient -> dir / vel maps
+    if (T.grads[0] != nullptr) {
+      atomicAdd(&T.grads[0][(b * 2 + 0) * plane + off], g1[0] * jac[0]);
+      atomicAdd(&T.grads[0][(b * 2 + 1) * plane + off], g1[1] * jac[1]);
+    }
+    if (T.grads[1] != nullptr) atomicAdd(&T.grads[1][b * plane + off], g1[2]);
+    if (T.grads[2] != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) atomicAdd(&T.grads[2][(b * 3 + k) * plane + off], g1[3 + k] * jac[3 + k]);
+    }
+    if (T.grads[3] != nullptr) atomicAdd(&T.grads[3][b * plane + off], g1[6]);
+    if (T.grads[4] != nullptr) {
+      atomicAdd(&T.grads[4][(b * 2 + 0) * plane + off], gl1[0]);
+      atomicAdd(&T.grads[4][(b * 2 + 1) * plane + off], gl1[1]);
+    }
+    if (T.grads[5] != nullptr && a.n_l1 > 2) {
+      atomicAdd(&T.grads[5][(b * 2 + 0) * plane + off], gl1[2]);
+      atomicAdd(&T.grads[5][(b * 2 + 1) * plane + off], gl1[3]);
+    }
+  }
+  const float w0 = wave_sum(fl1), w1 = wave_sum(fgd);
+  if (lane == 0) {
+    swave[0][wave] = w0;
+    swave[1][wave] = w1;
+  }
+  __syncthreads();
+  if (tid < 2)
+    a.partials[((long long)ti * 2 + tid) * a.pstride + blockIdx.x] =
+        (swave[tid][0] + swave[tid][1]) + (swave[tid][2] + swave[tid][3]);
+}
+
+// one workgroup per (task, term): fixed-order fp64 sum of that slice of partials -> losses[task * 2 + term]
+__global__ __launch_bounds__(256) void center_reduce_kernel(const CenterArgs a, float* __restrict__ losses) {
+  __shared__ double sd[256];
+  const int ti = blockIdx.x >> 1, term = blockIdx.x & 1, tid = threadIdx.x;
+  const long long nb = (a.t[ti].n + HEAD_T - 1) / HEAD_T;
+  const float* p = a.partials + ((long long)ti * 2 + term) * a.pstride;
+  double acc = 0.0;
+  for (long long k = tid; k < nb; k += 256) acc += (double)p[k];
+  sd[tid] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (tid < s2) sd[tid] += sd[tid + s2];
+    __syncthreads();
+  }
+  if (tid == 0) losses[ti * 2 + term] = (float)sd[0];
+}
+
+// backward of the same call when the upstream gradient is not all ones: grads of task t are scaled by
+// gout[t*2 + 1] (reg / height / dim / yaw: the GD term) or gout[t*2] (dir / vel: the L1 term); a (task, map) slice whose
+// factor is exactly 1 exits after one scalar load.  blockIdx.y = task * 6 + map.
+__global__ __launch_bounds__(256) void center_scale_kernel(const CenterArgs a, const float* __restrict__ gout) {
+  const int ti = blockIdx.y / 6, m = blockIdx.y - ti * 6;
+  const CenterTask& T = a.t[ti];
+  float* gmap = T.grads[m];
+  if (gmap == nullptr) return;
+  const float gs = gout[ti * 2 + (m < 4 ? 1 : 0)];
+  if (gs == 1.0f) return;
+  const int ch = (m == 0 || m >= 4) ? 2 : (m == 2 ? 3 : 1);
+  const long long nflt = (long long)T.B * ch * T.H * T.W;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < nflt; k += (long long)gridDim.x * 256) gmap[k] *= gs;
+}
+
 // second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; every thread
 // issues all of its 16-B loads before the first add (the kernel is pure latency: 39 K floats at 10 M pairs).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, long long nb,
@@ -727,6 +888,134 @@ int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, in
   const int64_t M = (int64_t)B * A * H * W;
   return anchor_head_impl(p, nullptr, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, nullptr,
                           labels, num_classes, M, scale, loss_sum, grad_bbox_pred, workspace, stream);
+}
+
+static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                       const float* code_weights, int32_t n_l1, void* workspace, CenterArgs& a, long long& max_n) {
+  if (p == nullptr || coder == nullptr || tasks == nullptr || num_tasks <= 0 || num_tasks > CENTER_MAX_TASKS)
+    return GD3D_E_BADARG;
+  if (n_l1 != 0 && n_l1 != 2 && n_l1 != 4) return GD3D_E_BADARG;
+  if (n_l1 > 0 && code_weights == nullptr) return GD3D_E_BADARG;
+  a.num_tasks = num_tasks;
+  a.n_l1 = n_l1;
+  a.norm_bbox = coder->norm_bbox;
+  a.osf = coder->out_size_factor;
+  a.vs0 = coder->voxel_size[0];
+  a.vs1 = coder->voxel_size[1];
+  a.pc0 = coder->pc_range[0];
+  a.pc1 = coder->pc_range[1];
+  a.alpha = p->alpha;
+  a.tau = p->tau;
+  a.c0 = p->center_offset[0];
+  a.c1 = p->center_offset[1];
+  a.c2 = p->center_offset[2];
+  for (int k = 0; k < 4; ++k) a.cw[k] = k < n_l1 ? code_weights[k] : 0.0f;
+  max_n = 0;
+  for (int t = 0; t < num_tasks; ++t) {
+    const gd3d_center_task& s = tasks[t];
+    if (s.n < 0 || s.B <= 0 || s.H <= 0 || s.W <= 0) return GD3D_E_BADARG;
+    if (s.n > 0) {
+      if (s.pos_ind == nullptr || s.anno == nullptr || s.anno_cols < 7 + (n_l1 > 2 ? 2 : 0)) return GD3D_E_BADARG;
+      for (int m = 1; m <= 3; ++m)
+        if (s.maps[m] == nullptr) return GD3D_E_BADARG;
+      if (n_l1 >= 2 && s.maps[4] == nullptr) return GD3D_E_BADARG;
+      if (n_l1 == 4 && s.maps[5] == nullptr) return GD3D_E_BADARG;
+    }
+    CenterTask& d = a.t[t];
+    for (int m = 0; m < 6; ++m) {
+      d.maps[m] = s.maps[m];
+      d.grads[m] = s.grads[m];
+    }
+    d.pos_ind = (const long long*)s.pos_ind;
+    d.anno = s.anno;
+    d.n = s.n;
+    d.B = s.B;
+    d.H = s.H;
+    d.W = s.W;
+    d.anno_cols = s.anno_cols;
+    d.gd_scale = s.gd_scale;
+    d.l1_scale = s.l1_scale;
+    if (s.n > max_n) max_n = s.n;
+  }
+  a.partials = (float*)workspace;
+  a.pstride = (max_n + HEAD_T - 1) / HEAD_T;
+  return 0;
+}
+
+size_t gd3d_center_head_workspace_bytes(int32_t num_tasks, int64_t max_n) {
+  if (num_tasks <= 0 || max_n <= 0) return 16;
+  const int64_t nb = (max_n + HEAD_T - 1) / HEAD_T;
+  return (size_t)((2 * (int64_t)num_tasks * nb * 4 + 15) / 16 * 16);
+}
+
+int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                          const float* code_weights, int32_t n_l1, float* losses, void* workspace, void* stream) {
+  CenterArgs a;
+  long long max_n = 0;
+  const int rc = center_fill(p, coder, tasks, num_tasks, code_weights, n_l1, workspace, a, max_n);
+  if (rc != 0) return rc;
+  if (losses == nullptr) return GD3D_E_BADARG;
+  if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
+  if (p->loss_type == GD3D_KFIOU3D) {
+    if (p->fun != GD3D_FUN_NONE && p->fun != GD3D_FUN_EXPM1 && p->fun != GD3D_FUN_NLOG) return GD3D_E_BADARG;
+  } else if (p->fun != GD3D_FUN_NONE && p->fun != GD3D_FUN_LOG1P) {
+    return GD3D_E_BADARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (max_n == 0) return (int)hipMemsetAsync(losses, 0, sizeof(float) * 2 * (size_t)num_tasks, s);
+  if (workspace == nullptr) return GD3D_E_BADARG;
+  if (a.pstride > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  const dim3 grid((unsigned)a.pstride, (unsigned)num_tasks);
+  const bool flag = p->flag != 0;
+#define GD3D_CENTER_LAUNCH(LT, FN, FL) hipLaunchKernelGGL((head_center_kernel<LT, FN, FL>), grid, dim3(HEAD_T), 0, s, a)
+#define GD3D_CENTER_FUN(LT)                                                   \
+  if (p->fun == GD3D_FUN_LOG1P) {                                             \
+    if (flag) GD3D_CENTER_LAUNCH(LT, GD3D_FUN_LOG1P, true);                   \
+    else GD3D_CENTER_LAUNCH(LT, GD3D_FUN_LOG1P, false);                       \
+  } else {                                                                    \
+    if (flag) GD3D_CENTER_LAUNCH(LT, GD3D_FUN_NONE, true);                    \
+    else GD3D_CENTER_LAUNCH(LT, GD3D_FUN_NONE, false);                        \
+  }
+  switch (p->loss_type) {
+    case GD3D_GWD3D: GD3D_CENTER_FUN(GD3D_GWD3D) break;
+    case GD3D_KLD3D: GD3D_CENTER_FUN(GD3D_KLD3D) break;
+    case GD3D_BD3D: GD3D_CENTER_FUN(GD3D_BD3D) break;
+    case GD3D_JD3D: GD3D_CENTER_FUN(GD3D_JD3D) break;
+    case GD3D_KLD3D_SYMMAX: GD3D_CENTER_FUN(GD3D_KLD3D_SYMMAX) break;
+    case GD3D_KLD3D_SYMMIN: GD3D_CENTER_FUN(GD3D_KLD3D_SYMMIN) break;
+    default:
+      if (p->fun == GD3D_FUN_EXPM1) GD3D_CENTER_LAUNCH(GD3D_KFIOU3D, GD3D_FUN_EXPM1, false);
+      else if (p->fun == GD3D_FUN_NLOG) GD3D_CENTER_LAUNCH(GD3D_KFIOU3D, GD3D_FUN_NLOG, false);
+      else GD3D_CENTER_LAUNCH(GD3D_KFIOU3D, GD3D_FUN_NONE, false);
+      break;
+  }
+#undef GD3D_CENTER_FUN
+#undef GD3D_CENTER_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  // tasks without positives: their partial slices are never written; the reduce reads nb = 0 entries -> 0
+  hipLaunchKernelGGL(center_reduce_kernel, dim3(2 * (unsigned)num_tasks), dim3(256), 0, s, a, losses);
+  return (int)hipGetLastError();
+}
+
+int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks, const float* grad_losses, void* stream) {
+  if (tasks == nullptr || num_tasks <= 0 || num_tasks > CENTER_MAX_TASKS || grad_losses == nullptr) return GD3D_E_BADARG;
+  CenterArgs a;
+  a.num_tasks = num_tasks;
+  for (int t = 0; t < num_tasks; ++t) {
+    for (int m = 0; m < 6; ++m) {
+      a.t[t].maps[m] = nullptr;
+      a.t[t].grads[m] = tasks[t].grads[m];
+    }
+    if (tasks[t].B <= 0 || tasks[t].H <= 0 || tasks[t].W <= 0) return GD3D_E_BADARG;
+    a.t[t].B = tasks[t].B;
+    a.t[t].H = tasks[t].H;
+    a.t[t].W = tasks[t].W;
+    a.t[t].n = 0;
+  }
+  hipLaunchKernelGGL(center_scale_kernel, dim3(64, 6 * (unsigned)num_tasks), dim3(256), 0, (hipStream_t)stream, a,
+                     grad_losses);
+  return (int)hipGetLastError();
 }
 
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream) {

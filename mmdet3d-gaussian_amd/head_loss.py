@@ -238,3 +238,129 @@ def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
     if pred7.numel() == 0:
         return pred.new_zeros((1,))
     return loss_module(pred7, target_gd, avg_factor=max(num_pos, 1), _prologue=pro)
+
+
+_CENTER_HEADS = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
+_CENTER_CH = (2, 1, 3, 1, 2, 2)
+
+
+class _CenterHeadFused(torch.autograd.Function):
+    """All tasks' loss_l1 / loss_gd straight from the NCHW head maps: one launch forward (+ one reduce), one launch
+    backward.  `layout[t][h]` = index into `maps` of head h of task t, or -1."""
+
+    @staticmethod
+    def forward(ctx, meta, *maps):
+        lib = _lib.load()
+        params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta
+        T = len(layout)
+        dev = maps[0].device
+        tasks = (_lib.CenterTask * T)()
+        # one zero fill for every gradient map of every task (36 maps at 6 tasks): views into a single flat buffer
+        need = [bool(ctx.needs_input_grad[1 + k]) for k in range(len(maps))]
+        sizes = [m.numel() if nd else 0 for m, nd in zip(maps, need)]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev) if any(need) else None
+        grads, off = [], 0
+        for m, nd, sz in zip(maps, need, sizes):
+            grads.append(flat[off:off + sz].view_as(m) if nd else None)
+            off += sz
+        max_n = 0
+        for t in range(T):
+            tk = tasks[t]
+            for h in range(6):
+                k = layout[t][h]
+                tk.maps[h] = maps[k].data_ptr() if k >= 0 else None
+                tk.grads[h] = grads[k].data_ptr() if (k >= 0 and grads[k] is not None) else None
+            ref = maps[layout[t][1]]
+            tk.B, tk.H, tk.W = ref.shape[0], ref.shape[2], ref.shape[3]
+            tk.n = pos_inds[t].shape[0]
+            tk.pos_ind = pos_inds[t].data_ptr()
+            tk.anno = annos[t].data_ptr()
+            tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
+            tk.gd_scale, tk.l1_scale = scales[t]
+            max_n = max(max_n, tk.n)
+        losses = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
+        cwp = (ctypes.c_float * max(n_l1, 1))(*[float(x) for x in cw[:n_l1]])
+        with torch.cuda.device(dev):
+            rc = lib.gd3d_center_head_loss(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'gd3d_center_head_loss')
+        ctx.tasks, ctx.grads, ctx.keep = tasks, grads, (pos_inds, annos, maps)
+        return losses
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_losses):
+        lib = _lib.load()
+        go = grad_losses.contiguous().float()
+        dev = go.device
+        with torch.cuda.device(dev):
+            rc = lib.gd3d_center_head_scale(ctx.tasks, len(ctx.tasks), go.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'gd3d_center_head_scale')
+        return (None,) + tuple(ctx.grads)
+
+
+def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_boxes, num_pos, code_weights):
+    """`loss_l1` and `loss_gd` of EVERY CenterGDHead task (gd_centerpoint_head.py:402-441) in one launch, reading the
+    head outputs where they lie: no `_reconstruct_bbox` cat (:372-387), no `_gather_feat` (:59-63), no coder calls, no
+    per-task loss modules and none of their autograd nodes.
+
+    loss_gd: this package's GDLoss (reduction 'mean');  loss_bbox: mmdet's L1Loss module, anything with `.loss_weight`
+    (and `.reduction` == 'mean'), or a config dict;  coder: CenterPointBBoxYawCoder;
+    preds_dicts: per task a dict with the raw head outputs 'height', 'dim', 'yaw', 'dir' and optionally 'reg', 'vel'
+    (B, c, H, W) — `preds_dict[0]` of the reference;  pos_inds: per task (n,3) long [batch, x, y] (:72-80);
+    anno_boxes: per task (n, 7 | 9);  num_pos: per task the positive count (avg_factor = max(num_pos, 1), :405-408);
+    code_weights: train_cfg['code_weights'] for [sin, cos(, vx, vy)].
+    Returns a list of (loss_l1, loss_gd) pairs, one per task (0-dim tensors; the graph reaches the head maps)."""
+    from .gd_loss import GDLoss
+    assert isinstance(loss_gd, GDLoss)
+    if loss_gd.reduction != 'mean':
+        raise ValueError('center_head_losses needs reduction="mean" (avg_factor is given)')
+    if isinstance(loss_bbox, dict):
+        kind, lw, red = loss_bbox.get('type', 'L1Loss'), float(loss_bbox.get('loss_weight', 1.0)), loss_bbox.get('reduction', 'mean')
+    else:
+        kind, lw, red = type(loss_bbox).__name__, float(loss_bbox.loss_weight), getattr(loss_bbox, 'reduction', 'mean')
+    if kind != 'L1Loss' or red != 'mean':
+        raise RuntimeError(f'encoded-box loss {kind!r} (reduction {red!r}) is not fused; supported: L1Loss, mean')
+    T = len(preds_dicts)
+    if not (len(pos_inds) == len(anno_boxes) == len(num_pos) == T) or T == 0 or T > 8:
+        raise RuntimeError('center_head_losses: 1..8 tasks, one entry per task in every list')
+    has_vel = all('vel' in d for d in preds_dicts)
+    n_l1 = 4 if has_vel else 2
+    cw = [float(x) for x in code_weights]
+    if len(cw) != n_l1:
+        raise RuntimeError(f'{len(cw)} code_weights for {n_l1} L1 channels (dir{", vel" if has_vel else ""})')
+    maps, layout, pis, ans, scales = [], [], [], [], []
+    dev = preds_dicts[0]['height'].device
+    for t, d in enumerate(preds_dicts):
+        row = []
+        B, _, H, W = d['height'].shape
+        for h, name in enumerate(_CENTER_HEADS):
+            if name in d and not (name == 'vel' and not has_vel):
+                m = d[name]
+                if tuple(m.shape) != (B, _CENTER_CH[h], H, W) or m.device != dev:
+                    raise RuntimeError(f"task {t}: head '{name}' has shape {tuple(m.shape)}, expected {(B, _CENTER_CH[h], H, W)}")
+                row.append(len(maps))
+                maps.append((m if m.dtype == torch.float32 else m.float()).contiguous())
+            elif name in ('height', 'dim', 'yaw', 'dir'):
+                raise RuntimeError(f"task {t}: head '{name}' is missing")
+            else:
+                row.append(-1)
+        layout.append(row)
+        pi = pos_inds[t].reshape(-1, 3).to(device=dev, dtype=torch.int64).contiguous()
+        an = anno_boxes[t]
+        an = an.reshape(pi.shape[0], an.shape[-1] if an.dim() >= 1 and an.numel() else 7 + (2 if has_vel else 0))
+        an = an.to(device=dev, dtype=torch.float32).contiguous()
+        if an.shape[0] and an.shape[1] < 7 + (2 if has_vel else 0):
+            raise RuntimeError(f'task {t}: anno_boxes has {an.shape[1]} columns')
+        # (index VALUES are range-checked inside the kernel: an out-of-map cell touches no memory and turns the task's
+        #  losses into NaN — no host-side min/max, i.e. no sync)
+        pis.append(pi)
+        ans.append(an)
+        avg = max(float(num_pos[t]), 1.0)
+        scales.append((float(loss_gd.loss_weight) / avg, lw / avg))
+    pro = _prologue(2, maps[0], norm_bbox=coder.norm_bbox, out_size_factor=coder.out_size_factor,
+                    voxel_size=coder.voxel_size, pc_range=coder.pc_range)
+    losses = _CenterHeadFused.apply((loss_gd._params({}), pro, layout, pis, ans, scales, cw, n_l1), *maps)
+    flat = losses.reshape(-1).unbind(0)          # one autograd node for all 2T scalars
+    return [(flat[2 * t], flat[2 * t + 1]) for t in range(T)]

@@ -73,3 +73,41 @@ def loss_single_bbox(bbox_pred, bbox_targets, bbox_weights, labels, anchor_list,
             pp, pt = add_sin_difference(pp, pt)
         loss = loss + smooth_l1(pp, pt, cw, num_total_samples, sl1['beta'], sl1['loss_weight'])
     return loss
+
+
+def center_head_task_losses(preds, pos_ind, anno, num_pos, coder_cfg, gd, l1_loss_weight, code_weights):
+    """One task of CenterGDHead.loss (gd_centerpoint_head.py:409-434) op for op, autograd for the backward.
+    preds: dict of (B,c,H,W) maps ('reg' optional, 'vel' optional); pos_ind (n,3) long [b,x,y]; anno (n, 7|9);
+    coder_cfg: dict(pc_range, out_size_factor, voxel_size, norm_bbox) — CenterPointBBoxYawCoder.encode/decode restated
+    (centerpoint_bbox_yaw_coders.py:11-31, correct_yaw=False); gd: dict(loss_type, loss_weight, **kw).
+    Returns (loss_l1, loss_gd)."""
+    parts = []
+    if 'reg' in preds:
+        parts.append(preds['reg'])
+    else:
+        b, _, h, w = preds['height'].shape
+        parts.append(preds['height'].new_full((b, 2, h, w), 0.5))                       # :377-378
+    parts += [preds['height'], preds['dim'], preds['yaw'], preds['dir']]
+    if 'vel' in preds:
+        parts.append(preds['vel'])
+    pred = torch.cat(parts, dim=1)                                                     # _reconstruct_bbox :372-387
+    pred = pred[pos_ind[:, 0], :, pos_ind[:, 2], pos_ind[:, 1]]                        # _gather_feat :59-63
+    yaw = anno[..., 6]
+    target_box = torch.cat((anno[..., :7], torch.stack((yaw.sin(), yaw.cos()), -1), anno[..., 7:]), -1)   # encode
+    target_l1, target_gd = target_box[..., 7:], target_box[..., :7]
+    locs = pos_ind[:, 1:].to(pred.dtype)
+    osf, vs, pc = coder_cfg['out_size_factor'], coder_cfg['voxel_size'], coder_cfg['pc_range']
+    x = (pred[..., 0] + locs[..., 0]) * osf * vs[0] + pc[0]
+    y = (pred[..., 1] + locs[..., 1]) * osf * vs[1] + pc[1]
+    dim = pred[..., 3:6].exp() if coder_cfg['norm_bbox'] else pred[..., 3:6]
+    pred_gd = torch.cat((x[:, None], y[:, None], pred[..., 2:3], dim, pred[..., 6:7]), -1)
+    pred_l1 = pred[..., 7:]
+    w = target_l1.new_tensor(code_weights).unsqueeze(0).expand_as(target_l1)
+    avg = max(num_pos, 1)
+    if target_box.numel() == 0:
+        z = pred.new_zeros((1,))
+        return z, z
+    loss_l1 = l1_loss_weight * ((pred_l1 - target_l1).abs() * w).sum() / avg           # mmdet L1Loss, mean + avg_factor
+    gd = dict(gd)
+    loss_gd = gd_torch.gd_loss(pred_gd, target_gd, gd.pop('loss_type'), avg_factor=avg, **gd)
+    return loss_l1, loss_gd

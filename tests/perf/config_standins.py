@@ -63,6 +63,34 @@ us = timeit(step4, 50)
 print(json.dumps(dict(config=4, what='6 CenterPoint tasks x center_head_gd_loss (bd3d) fwd+bwd, samples_per_gpu=8',
                       positives_per_task=Bs * K, us_per_step=round(us, 1), us_per_task=round(us / tasks, 1))), flush=True)
 
+# the same step from the RAW head maps: all regression losses (loss_l1 + loss_gd) of the 6 tasks in one launch, vs the
+# op-for-op eager restatement of gd_centerpoint_head.py:409-434 per task (oracle/head_torch.py)
+from oracle import head_torch  # noqa: E402
+cfg4 = dict(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+maps4 = []
+for _ in range(tasks):
+    maps4.append({k: (torch.randn(Bs, c, 128, 128, generator=g, device=dev) * 0.3).requires_grad_(True)
+                  for k, c in (('reg', 2), ('height', 1), ('dim', 3), ('yaw', 1), ('dir', 2), ('vel', 2))})
+l1cfg = dict(type='L1Loss', reduction='mean', loss_weight=0.25)
+cw4 = [1.0, 1.0, 0.2, 0.2]
+def step4_maps():
+    for d in maps4:
+        for v in d.values(): v.grad = None
+    out = amd.center_head_losses(modb, l1cfg, coder, maps4, [p for p, _, _ in data], [a for _, _, a in data], [Bs * K] * tasks, cw4)
+    sum(a + b for a, b in out).backward()
+def step4_eager():
+    for d in maps4:
+        for v in d.values(): v.grad = None
+    tot = 0
+    for d, (pos, _, anno) in zip(maps4, data):
+        l1, gd = head_torch.center_head_task_losses(d, pos, anno, Bs * K, cfg4, dict(loss_type='bd3d', fun='log1p', tau=0.0, loss_weight=5.0), 0.25, cw4)
+        tot = tot + l1 + gd
+    tot.backward()
+us_m, us_e = timeit(step4_maps, 50), timeit(step4_eager, 10)
+print(json.dumps(dict(config=4, what='all regression losses (loss_l1 + loss_gd) of 6 CenterPoint tasks from the raw head maps (8 x 128 x 128), fwd+bwd',
+                      positives_per_task=Bs * K, one_launch_us=round(us_m, 1), eager_torch_us=round(us_e, 1),
+                      speedup=round(us_e / us_m, 1))), flush=True)
+
 # ---- config 5
 P = 4096
 t = torch.rand(P, 7, generator=g, device=dev) * torch.tensor([150, 150, 4, 2, 4, 1.5, 6.28], device=dev) + torch.tensor([-75, -75, -3, .5, .5, .5, -3.14], device=dev)

@@ -228,3 +228,75 @@ def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd):
     with pytest.raises(RuntimeError):
         amd.anchor_head_bbox_loss(mod, dict(type='FocalLoss'), bp, bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(),
                                   anchors.cuda(), C, 9.0)
+
+
+@pytest.mark.parametrize('lt,kw,vel,reg', [('gwd3d', dict(fun='log1p', tau=0.0), True, True),
+                                           ('bd3d', dict(fun='log1p', tau=1.0), True, False),
+                                           ('kld3d', dict(fun='none', tau=0.0), False, True),
+                                           ('kfiou3d', dict(fun='nlog'), True, True)])
+def test_center_head_losses_all_tasks_one_launch(amd, lt, kw, vel, reg):
+    """CenterGDHead.loss regression terms (:402-441) for several tasks straight from the NCHW head maps, vs the op-for-op
+    torch restatement in fp64/fp32 with autograd (oracle/head_torch.py; coder formulas pinned by coder_center.npz, GD
+    loss by the gd golden files).  Covers a task without positives, duplicate cells (gradient accumulation), no 'reg'
+    head, no 'vel' head, and per-task upstream gradients != 1."""
+    from oracle import head_torch
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 16, 12
+    cfg = dict(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+    coder = amd.CenterPointBBoxYawCoder(pc_range=cfg['pc_range'], out_size_factor=4, voxel_size=cfg['voxel_size'], norm_bbox=True)
+    ns = [37, 0, 300]
+    tasks = []
+    for n in ns:
+        d = {'height': torch.randn(B, 1, H, W, generator=g) * 0.5, 'dim': torch.randn(B, 3, H, W, generator=g) * 0.3,
+             'yaw': torch.randn(B, 1, H, W, generator=g), 'dir': torch.randn(B, 2, H, W, generator=g)}
+        if reg:
+            d['reg'] = torch.rand(B, 2, H, W, generator=g)
+        if vel:
+            d['vel'] = torch.randn(B, 2, H, W, generator=g)
+        pi = torch.stack([torch.randint(0, B, (n,), generator=g), torch.randint(0, W, (n,), generator=g),
+                          torch.randint(0, H, (n,), generator=g)], -1)
+        if n > 10:
+            pi[5] = pi[2]; pi[7] = pi[2]                               # three objects in one cell
+        cx = (pi[:, 1].float() + 0.5) * 0.8 - 51.2; cy = (pi[:, 2].float() + 0.5) * 0.8 - 51.2
+        an = torch.stack([cx + torch.randn(n, generator=g) * 0.2, cy + torch.randn(n, generator=g) * 0.2,
+                          torch.randn(n, generator=g), torch.rand(n, generator=g) * 2 + 0.5, torch.rand(n, generator=g) * 4 + 0.5,
+                          torch.rand(n, generator=g) + 0.8, (torch.rand(n, generator=g) - 0.5) * 6.28] +
+                         ([torch.randn(n, generator=g), torch.randn(n, generator=g)] if vel else []), -1)
+        tasks.append((d, pi, an))
+    cw = [1.0, 1.0, 0.2, 0.2] if vel else [1.0, 0.5]
+    up = [(1.0, 1.0), (1.0, 1.0), (0.5, 3.0)]                          # upstream gradient of (l1, gd) per task
+    mod = amd.GDLoss(lt, loss_weight=5.0, **kw)
+    dev_tasks = [{k: v.cuda().requires_grad_(True) for k, v in d.items()} for d, _, _ in tasks]
+    out = amd.center_head_losses(mod, dict(type='L1Loss', reduction='mean', loss_weight=0.25), coder, dev_tasks,
+                                 [pi.cuda() for _, pi, _ in tasks], [an.cuda() for _, _, an in tasks], ns, cw)
+    total = sum(u[0] * o[0] + u[1] * o[1] for u, o in zip(up, out))
+    total.backward()
+
+    def ref(dtype):
+        res, grads = [], []
+        for (d, pi, an), n, u in zip(tasks, ns, up):
+            dd = {k: v.to(dtype).requires_grad_(True) for k, v in d.items()}
+            l1, gd = head_torch.center_head_task_losses(dd, pi, an.to(dtype), n, cfg, dict(loss_type=lt, loss_weight=5.0, **kw), 0.25, cw)
+            tot = u[0] * l1.sum() + u[1] * gd.sum()
+            if tot.requires_grad:                      # the reference returns plain zeros for a task without objects
+                tot.backward()
+            res.append((float(l1.sum().detach()), float(gd.sum().detach())))
+            grads.append({k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in dd.items()})
+        return res, grads
+    r64, g64 = ref(torch.float64)
+    r32, g32 = ref(torch.float32)
+    for t in range(len(ns)):
+        for j in range(2):
+            tol = 1e-5 + 3 * abs(r32[t][j] - r64[t][j]) / (1 + abs(r64[t][j]))
+            assert abs(out[t][j].item() - r64[t][j]) <= tol * (1 + abs(r64[t][j])), (t, j, out[t][j].item(), r64[t][j])
+        for k, v in dev_tasks[t].items():
+            got = v.grad.cpu().numpy().astype(np.float64) if v.grad is not None else np.zeros(v.shape)
+            sc = np.abs(g64[t][k]).max()
+            tol = 1e-5 + 3 * np.abs(g32[t][k] - g64[t][k]).max() / (1 + sc)
+            assert np.abs(got - g64[t][k]).max() <= tol * (1 + sc), (t, k)
+    assert out[1][0].item() == 0.0 and out[1][1].item() == 0.0          # the task without positives
+    # an index outside the head map poisons that task's losses instead of touching memory
+    bad = [pi.clone().cuda() for _, pi, _ in tasks]
+    bad[0][3, 1] = W
+    o2 = amd.center_head_losses(mod, dict(type='L1Loss', loss_weight=0.25), coder, dev_tasks, bad, [an.cuda() for _, _, an in tasks], ns, cw)
+    assert torch.isnan(o2[0][0]) and torch.isnan(o2[0][1]) and torch.isfinite(o2[2][1])
