@@ -63,9 +63,14 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
 // `rows` (1, 2, 4 or 8; host-chosen) = row boxes a wave walks through against the same 64 column boxes: 1 keeps small
 // problems latency-short (n = 1000: 49 us vs 80 us at 8), 8 keeps large ones from being workgroup-dispatch bound
 // (n = 9000: 640 K one-wave workgroups -> 80 K; 965 -> 834 us).
+// On a DIAGONAL block the lanes left of the row box are not idle: lane j < i evaluates the same predicate with the
+// operands in greedy order (box j first, box i second — bit for bit what row j's wave computes for its lane i), so the
+// ballot also yields "which earlier boxes of my block suppress box i".  That word goes to colm[i]; the scan resolves a
+// 64-box block from these column words in a few wave-parallel steps instead of one scalar step per kept box.
 template <int MODE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
-                                                      unsigned long long* __restrict__ mask_) {
+                                                      unsigned long long* __restrict__ mask_,
+                                                      unsigned long long* __restrict__ colm_) {
   __shared__ VertexScratch<MODE == MODE_ROT ? 64 : 1> vs;
   const int lane = threadIdx.x;
   const int g = blockIdx.y;
@@ -106,7 +111,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
   for (int r = 0; r < rows; ++r) {
     const int i = rb * 64 + r0 + r;  // wave-uniform
     if (i >= n) break;
-    const bool act = j < n && !(rb == c && j <= i);
+    const bool act = j < n && j != i;   // (off-diagonal blocks: j > i always)
+    const bool low = j < i;             // diagonal block only: lane box precedes the row box -> it goes first
     bool hit = false;
     if constexpr (MODE == MODE_NORMAL) {
       if (act) {
@@ -114,37 +120,78 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
         float ar[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) ar[k] = a.boxes[si * 5 + k];
-        hit = iou_normal(ar, braw) > thresh;
+        hit = (low ? iou_normal(braw, ar) : iou_normal(ar, braw)) > thresh;
       }
     } else if constexpr (MODE == MODE_CIRCLE) {
       if (act) {  // mmdet3d circle_nms: dist = (x_i - x_j)^2 + (y_i - y_j)^2 ; suppressed iff dist <= thresh
         const size_t si = order != nullptr ? (size_t)order[i] : (size_t)i;
-        const float dx = a.boxes[si * 2] - braw[0], dy = a.boxes[si * 2 + 1] - braw[1];
+        const float xi = a.boxes[si * 2], yi = a.boxes[si * 2 + 1];
+        const float dx = low ? braw[0] - xi : xi - braw[0], dy = low ? braw[1] - yi : yi - braw[1];
         const float dist = dx * dx + dy * dy;
         hit = (double)dist <= thresh_d;
       }
     } else {
       if (act) {
         const OBox A = ob[i];  // wave-uniform address: served as a broadcast
-        hit = iou_bev<64>(A, B, vs, lane) > thresh;
+        const OBox F = low ? B : A, S = low ? A : B;  // one call site: mixed lanes do not run the geometry twice
+        hit = iou_bev<64>(F, S, vs, lane) > thresh;
       }
     }
     const unsigned long long word = __ballot(hit);
-    if (lane == 0) mask[(size_t)i * a.cbs + c] = word;
+    if (lane == 0) {
+      if (rb == c) {
+        const int il = i & 63;
+        const unsigned long long below = (1ull << il) - 1ull;
+        mask[(size_t)i * a.cbs + c] = word & ~(below | (1ull << il));
+        colm_[(size_t)g * a.cap + i] = word & below;
+      } else {
+        mask[(size_t)i * a.cbs + c] = word;
+      }
+    }
   }
 }
 
+#ifdef SCAN_PROFILE
+#define SCAN_STAMP(k) do { if (lane == 0) dbg[(size_t)c * 16 + (k)] = clock64(); } while (0)
+#else
+#define SCAN_STAMP(k) do { } while (0)
+#endif
+
+// wave-wide OR on the DPP network (row_shr 1/2/4/8 inside each row of 16, row_bcast 15 / 31 across rows; lane 63 holds
+// the result): replaces up to 64 same-address ds_or_b64, which the LDS serialises.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_or(unsigned int v) {
+  return v | (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
+  v = dpp_or<0x111, 0xf>(v);
+  v = dpp_or<0x112, 0xf>(v);
+  v = dpp_or<0x114, 0xf>(v);
+  v = dpp_or<0x118, 0xf>(v);
+  v = dpp_or<0x142, 0xa>(v);
+  v = dpp_or<0x143, 0xc>(v);
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
+}
+
 constexpr int SCAN_T = 256;
+constexpr int SCAN_U = 16;  // mask rows in flight per propagate lane
 __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
-                                                          long long* __restrict__ keep_, long long* __restrict__ num_keep) {
+                                                          const unsigned long long* __restrict__ colm_,
+                                                          long long* __restrict__ keep_, long long* __restrict__ num_keep,
+                                                          long long* __restrict__ dbg) {
   // One workgroup of 4 waves walks the 64-box blocks in order, ONE barrier per block.
-  //   wave 0 (resolve): lane l holds the diagonal word mask[64c+l][c] and the "urgent" word mask[64c+l][c+1] of
-  //     block c, both prefetched during the previous block (neither depends on the removed-set).  A scalar loop visits
-  //     only the boxes still alive (s_ff1 over the complement of the removed word, v_readlane of the kept box's word);
-  //     the kept lanes then OR their urgent word into remv[c+1] (ds_or_b64), which is all block c+1 needs from block c.
+  //   wave 0 (resolve): lane l holds colm[64c+l] = the earlier boxes of block c that suppress box 64c+l (written by the
+  //     mask kernel) and its "urgent" word mask[64c+l][c+1], both prefetched during the previous block together with
+  //     the box id.  The block is resolved wave-parallel: kept = alive; repeat kept' = alive & ~ballot(col & kept) until
+  //     it stops changing — the unique solution of the triangular system the greedy order defines, reached in (longest
+  //     suppression chain + 1) steps of ~10 instructions, instead of one ~100-cycle scalar readlane step per kept box.
+  //     The kept lanes' urgent words are OR-reduced on the DPP network into remv[c+1]: all block c+1 needs from block c.
   //   waves 1-3 (propagate, one block behind): OR the mask rows of the boxes kept in block c-1 into remv[c+1..]
-  //     (every 3rd kept row per wave, 8 independent 8-byte loads in flight per lane).  Word c+1 receives block c-1's
-  //     rows here, one full barrier interval before block c+1 is resolved.
+  //     (every 3rd kept row per wave, SCAN_U independent 8-byte loads in flight per lane).  Word c+1 receives block
+  //     c-1's rows here, one full barrier interval before block c+1 is resolved.
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
   __shared__ unsigned long long skept[2];
   const int g = blockIdx.x;  // one workgroup per group
@@ -153,6 +200,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   const size_t cbs = (size_t)a.cbs;
   const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
   const unsigned long long* mask = mask_ + (size_t)g * a.cap * cbs;
+  const unsigned long long* colm = colm_ + (size_t)g * a.cap;
   long long* keep = keep_ + (size_t)g * a.cap;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,45 +208,55 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   if (tid < 2) skept[tid] = 0ull;
   __syncthreads();
   int count = 0;
-  unsigned long long diag_next = 0ull, urg_next = 0ull;
+  unsigned long long col_next = 0ull, urg_next = 0ull;
+  long long id_next = lane;
   if (wave == 0 && lane < n) {
-    diag_next = mask[(size_t)lane * cbs];
+    col_next = colm[lane];
     if (cb > 1) urg_next = mask[(size_t)lane * cbs + 1];
+    if (order != nullptr) id_next = order[lane];
   }
   for (int c = 0; c <= cb; ++c) {  // iteration cb only drains the last propagate
     if (wave == 0) {
       if (c < cb) {
+        SCAN_STAMP(0);
         const int i = c * 64 + lane;
-        const unsigned long long diag = diag_next, urg = urg_next;
+        const unsigned long long col = col_next, urg = urg_next;
+        const long long id = id_next;
         const int i_next = i + 64;
-        diag_next = (c + 1 < cb && i_next < n) ? mask[(size_t)i_next * cbs + (c + 1)] : 0ull;
-        urg_next = (c + 2 < cb && i_next < n) ? mask[(size_t)i_next * cbs + (c + 2)] : 0ull;
-        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+        const bool more = c + 1 < cb && i_next < n;
+        col_next = more ? colm[i_next] : 0ull;
+        urg_next = (more && c + 2 < cb) ? mask[(size_t)i_next * cbs + (c + 2)] : 0ull;
+        id_next = (more && order != nullptr) ? order[i_next] : (long long)i_next;
+        const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
         unsigned long long cur = remv[c];
         // (the builtin returns a signed int: go through unsigned before widening)
         cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
         const int nvalid = min(64, n - c * 64);
         if (nvalid < 64) cur |= ~0ull << nvalid;
-        unsigned long long kept = 0ull;
-        unsigned long long cand = ~cur;
-        while (cand) {  // scalar, wave-uniform: one iteration per KEPT box
-          const int l = __builtin_ctzll(cand);
-          const unsigned long long dl =
-              ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
-              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, l);
-          kept |= 1ull << l;
-          cur |= dl;                        // dl only has bits above l
-          cand = (cand & (cand - 1)) & ~cur;
+        const unsigned long long alive = ~cur;
+        unsigned long long kept = alive;
+        SCAN_STAMP(1);
+        for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
+          const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
+          const unsigned long long nk = alive & ~__ballot(sup);
+          if (nk == kept) break;
+          kept = nk;
         }
+        SCAN_STAMP(2);
         const bool mine = (kept >> lane) & 1ull;
         if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
-          keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = order != nullptr ? order[i] : (long long)i;
-        if (mine && c + 1 < cb && urg) atomicOr(&remv[c + 1], urg);
+          keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+        if (c + 1 < cb) {
+          const unsigned long long o1 = wave_or_u64(mine ? urg : 0ull);  // uniform
+          if (lane == 0 && o1) atomicOr(&remv[c + 1], o1);
+        }
         count += __builtin_popcountll(kept);
         if (lane == 0) skept[c & 1] = kept;
+        SCAN_STAMP(3);
       }
     } else if (c >= 1) {
+      if (wave == 1) SCAN_STAMP(8);
       const int k = c - 1;  // block whose kept rows are propagated now
       unsigned long long kb = skept[k & 1];
       kb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kb >> 32)) << 32) |
@@ -219,22 +277,26 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
           unsigned long long acc = 0ull;
           unsigned long long mb = mine;
           while (mb) {
-            int l[8];
+            int l[SCAN_U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < SCAN_U; ++u) {
               l[u] = mb ? __builtin_ctzll(mb) : -1;
               mb = mb ? (mb & (mb - 1)) : 0ull;
             }
-            unsigned long long v[8];
+            unsigned long long v[SCAN_U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cbs + w] : 0ull;
-            acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+            for (int u = 0; u < SCAN_U; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cbs + w] : 0ull;
+#pragma unroll
+            for (int u = 0; u < SCAN_U; ++u) acc |= v[u];
           }
           if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
         }
       }
     }
+    if (wave == 1 && c >= 1) SCAN_STAMP(9);
+    if (wave == 0 && c < cb) SCAN_STAMP(4);
     __syncthreads();
+    if (wave == 0 && c < cb) SCAN_STAMP(5);
   }
   if (tid == 0) num_keep[g] = count;
 }
@@ -317,13 +379,16 @@ extern "C" {
 size_t rnms_workspace_bytes(int64_t n) {
   if (n <= 0) return 16;
   const size_t cb = (size_t)((n + 63) / 64);
-  return align_up((size_t)n * sizeof(OBox), 256) + (size_t)n * cb * sizeof(unsigned long long);
+  return align_up((size_t)n * sizeof(OBox), 256) + align_up((size_t)n * cb * sizeof(unsigned long long), 256) +
+         (size_t)n * sizeof(unsigned long long);
 }
 
 size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
   if (groups <= 0 || cap <= 0) return 16;
   const size_t cb = (size_t)((cap + 63) / 64);
-  return align_up((size_t)groups * cap * sizeof(OBox), 256) + (size_t)groups * cap * cb * sizeof(unsigned long long);
+  return align_up((size_t)groups * cap * sizeof(OBox), 256) +
+         align_up((size_t)groups * cap * cb * sizeof(unsigned long long), 256) +
+         (size_t)groups * cap * sizeof(unsigned long long);
 }
 
 // shared by the single and the batched entry points: G groups of up to `cap` boxes
@@ -346,6 +411,8 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   OBox* ob = (OBox*)workspace;
   unsigned long long* mask =
       (unsigned long long*)((char*)workspace + align_up((size_t)G * cap * sizeof(OBox), 256));
+  unsigned long long* colm =  // per box: the earlier boxes of its own 64-block that suppress it
+      (unsigned long long*)((char*)mask + align_up((size_t)G * cap * a.cbs * sizeof(unsigned long long), 256));
   const long long pairs = (long long)a.cbs * (a.cbs + 1) / 2;
   int rows = 1;
   while (rows < 8 && pairs * G * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
@@ -354,14 +421,15 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   const dim3 mgrid((unsigned)(pairs * (64 / rows)), (unsigned)G);
   if (mode == MODE_ROT) {
     hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_ROT>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_ROT>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else if (mode == MODE_NORMAL) {
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else {
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   }
   hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)G), dim3(SCAN_T), (size_t)a.cbs * sizeof(unsigned long long), s, a,
-                     (const unsigned long long*)mask, (long long*)keep, (long long*)num_keep);
+                     (const unsigned long long*)mask, (const unsigned long long*)colm, (long long*)keep,
+                     (long long*)num_keep, (long long*)ob);
   return (int)hipGetLastError();
 }
 
