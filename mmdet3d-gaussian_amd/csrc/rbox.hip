@@ -176,24 +176,51 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
 }
 
-constexpr int SCAN_T = 256;
-constexpr int SCAN_U = 16;  // mask rows in flight per propagate lane
+// ---- greedy scan: one workgroup, phase-shifted waves, one LDS-only barrier per 64-box block ("interval") -------------
+// Measured with the cycle-stamp build (tools/scan_profile.py): a global-memory round trip from this CU is ~2700 cycles,
+// a resolved block ~1200.  So no wave may load and use a value inside one interval:
+//   wave 0 (resolver) reads everything it needs for block t — colm[64t+l], the three "urgent" words
+//     mask[64t+l][t+1..t+3] and the box id — from an LDS ring that other waves filled one interval earlier.  It solves
+//     the block wave-parallel (kept = alive; kept' = alive & ~ballot(col & kept) until stable: the unique solution of the
+//     triangular system the greedy order defines), OR-reduces the kept lanes' urgent words on the DPP network into
+//     remv[t+1..t+3], stores the kept ids and publishes the kept word.
+//   waves 1.. (3 groups x SCAN_GW, group j phase-shifted by j intervals) run super-iterations of three intervals:
+//     interval t0      ISSUE  : loads of the mask rows kept in block t0-1 (words >= t0+3; the group's waves split the
+//                               rows) and, rank 0 only, of the resolver's inputs for block t0+3;
+//     interval t0+1    nothing (the loads are in flight across two barriers; straight-line code inside ONE loop
+//                               iteration, so the compiler waits for them only at their first use);
+//     interval t0+2    CONSUME: OR the rows into remv (ds_or_b64), write the resolver's inputs into the ring.
+//   Block b's rows therefore reach remv[w >= b+4] during interval b+3, one barrier before block b+4 is resolved; words
+//   b+1..b+3 are covered by the urgent words.  Every wave executes exactly cb barriers.
+// History: one scalar readlane step per kept box + load->use inside the interval: 1.2-3.8 us per block.
+constexpr int SCAN_GW = 3;                      // waves per propagate group
+constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW);  // 640 threads
+constexpr int SCAN_NU = 3;                      // urgent words per box
+constexpr int SCAN_RING = 4;
+
+__device__ __forceinline__ void lds_barrier() {  // orders LDS only: global loads stay in flight across it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  // (the builtin returns a signed int: go through unsigned before widening)
+  return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+}
+
+// U rows x CH 64-word chunks in flight per propagate lane (registers: 2*U*CH VGPRs); rows / chunks beyond that are OR-ed
+// in synchronously during the issue interval (correct, slower; only very dense keeps or n > 64*(64*CH+4)).
+template <int U, int CH>
 __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
                                                           const unsigned long long* __restrict__ colm_,
                                                           long long* __restrict__ keep_, long long* __restrict__ num_keep,
                                                           long long* __restrict__ dbg) {
-  // One workgroup of 4 waves walks the 64-box blocks in order, ONE barrier per block.
-  //   wave 0 (resolve): lane l holds colm[64c+l] = the earlier boxes of block c that suppress box 64c+l (written by the
-  //     mask kernel) and its "urgent" word mask[64c+l][c+1], both prefetched during the previous block together with
-  //     the box id.  The block is resolved wave-parallel: kept = alive; repeat kept' = alive & ~ballot(col & kept) until
-  //     it stops changing — the unique solution of the triangular system the greedy order defines, reached in (longest
-  //     suppression chain + 1) steps of ~10 instructions, instead of one ~100-cycle scalar readlane step per kept box.
-  //     The kept lanes' urgent words are OR-reduced on the DPP network into remv[c+1]: all block c+1 needs from block c.
-  //   waves 1-3 (propagate, one block behind): OR the mask rows of the boxes kept in block c-1 into remv[c+1..]
-  //     (every 3rd kept row per wave, SCAN_U independent 8-byte loads in flight per lane).  Word c+1 receives block
-  //     c-1's rows here, one full barrier interval before block c+1 is resolved.
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
-  __shared__ unsigned long long skept[2];
+  __shared__ unsigned long long skept[4];
+  __shared__ int klist[4][64];  // lane indices of the boxes kept in a block, compacted (k-th kept box -> lane)
+  __shared__ unsigned long long rin[SCAN_RING][2 + SCAN_NU][64];  // [slot][col, urgent 1..3, id][lane]
   const int g = blockIdx.x;  // one workgroup per group
   const int n = group_n(a, g);
   const int cb = (n + 63) >> 6;
@@ -205,100 +232,151 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int w = tid; w < cb; w += SCAN_T) remv[w] = 0ull;
-  if (tid < 2) skept[tid] = 0ull;
-  __syncthreads();
-  int count = 0;
-  unsigned long long col_next = 0ull, urg_next = 0ull;
-  long long id_next = lane;
-  if (wave == 0 && lane < n) {
-    col_next = colm[lane];
-    if (cb > 1) urg_next = mask[(size_t)lane * cbs + 1];
-    if (order != nullptr) id_next = order[lane];
-  }
-  for (int c = 0; c <= cb; ++c) {  // iteration cb only drains the last propagate
-    if (wave == 0) {
-      if (c < cb) {
-        SCAN_STAMP(0);
-        const int i = c * 64 + lane;
-        const unsigned long long col = col_next, urg = urg_next;
-        const long long id = id_next;
-        const int i_next = i + 64;
-        const bool more = c + 1 < cb && i_next < n;
-        col_next = more ? colm[i_next] : 0ull;
-        urg_next = (more && c + 2 < cb) ? mask[(size_t)i_next * cbs + (c + 2)] : 0ull;
-        id_next = (more && order != nullptr) ? order[i_next] : (long long)i_next;
-        const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
-        unsigned long long cur = remv[c];
-        // (the builtin returns a signed int: go through unsigned before widening)
-        cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(cur >> 32)) << 32) |
-              (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)cur);
-        const int nvalid = min(64, n - c * 64);
-        if (nvalid < 64) cur |= ~0ull << nvalid;
-        const unsigned long long alive = ~cur;
-        unsigned long long kept = alive;
-        SCAN_STAMP(1);
-        for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
-          const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
-          const unsigned long long nk = alive & ~__ballot(sup);
-          if (nk == kept) break;
-          kept = nk;
-        }
-        SCAN_STAMP(2);
-        const bool mine = (kept >> lane) & 1ull;
-        if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
-          keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
-        if (c + 1 < cb) {
-          const unsigned long long o1 = wave_or_u64(mine ? urg : 0ull);  // uniform
-          if (lane == 0 && o1) atomicOr(&remv[c + 1], o1);
-        }
-        count += __builtin_popcountll(kept);
-        if (lane == 0) skept[c & 1] = kept;
-        SCAN_STAMP(3);
-      }
-    } else if (c >= 1) {
-      if (wave == 1) SCAN_STAMP(8);
-      const int k = c - 1;  // block whose kept rows are propagated now
-      unsigned long long kb = skept[k & 1];
-      kb = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kb >> 32)) << 32) |
-           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)kb);
-      if (k + 2 < cb && kb) {
-        // keep bit #q of kb iff q % 3 == wave - 1
-        unsigned long long mine = 0ull, t = kb;
-        int q = 0;
-        while (t) {
-          const unsigned long long low = t & (~t + 1ull);
-          if (q == wave - 1) mine |= low;
-          t ^= low;
-          q = (q == 2) ? 0 : q + 1;
-        }
-        for (int w0 = k + 2; w0 < cb; w0 += 64) {
-          const int w = w0 + lane;
-          const bool act = w < cb;
-          unsigned long long acc = 0ull;
-          unsigned long long mb = mine;
-          while (mb) {
-            int l[SCAN_U];
+  if (tid < 4) skept[tid] = 0ull;
+  lds_barrier();
+  const int NB = cb;  // intervals = barriers every wave executes in the main phase
+
+  // resolver inputs of block B for this lane (0 where the box or the word does not exist)
+  // field f of block B for this lane: 0 = column word, 1..3 = urgent words mask[i][B+f], 4 = box id.  (Contiguous
+  // copies of the urgent words were tried: +7 us in the mask kernel at n = 4096, nothing gained here.)
+  auto load_field = [&](int B, int f) -> unsigned long long {
+    const int i = B * 64 + lane;
+    const bool ok = B < cb && i < n;
+    if (f == 0) return ok ? colm[i] : 0ull;
+    if (f <= SCAN_NU) return (ok && B + f < cb) ? mask[(size_t)i * cbs + B + f] : 0ull;
+    return (unsigned long long)((ok && order != nullptr) ? order[i] : (long long)i);
+  };
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------- resolver
+    for (int B = 0; B < 3; ++B) {  // blocks 0..2: nobody runs ahead of them
 #pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) {
-              l[u] = mb ? __builtin_ctzll(mb) : -1;
-              mb = mb ? (mb & (mb - 1)) : 0ull;
-            }
-            unsigned long long v[SCAN_U];
-#pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) v[u] = (act && l[u] >= 0) ? mask[(size_t)(k * 64 + l[u]) * cbs + w] : 0ull;
-#pragma unroll
-            for (int u = 0; u < SCAN_U; ++u) acc |= v[u];
-          }
-          if (act && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
-        }
-      }
+      for (int f = 0; f < 2 + SCAN_NU; ++f) rin[B][f][lane] = load_field(B, f);
     }
-    if (wave == 1 && c >= 1) SCAN_STAMP(9);
-    if (wave == 0 && c < cb) SCAN_STAMP(4);
-    __syncthreads();
-    if (wave == 0 && c < cb) SCAN_STAMP(5);
+    int count = 0;
+    for (int c = 0; c < NB; ++c) {
+      SCAN_STAMP(0);
+      const int slot = c & (SCAN_RING - 1);
+      const unsigned long long col = rin[slot][0][lane];
+      unsigned long long urg[SCAN_NU];
+#pragma unroll
+      for (int k = 0; k < SCAN_NU; ++k) urg[k] = rin[slot][1 + k][lane];
+      const long long id = (long long)rin[slot][1 + SCAN_NU][lane];
+      const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
+      unsigned long long cur = uniform_u64(remv[c]);
+      const int nvalid = min(64, n - c * 64);
+      if (nvalid < 64) cur |= ~0ull << nvalid;
+      const unsigned long long alive = ~cur;
+      unsigned long long kept = alive;
+      SCAN_STAMP(1);
+      for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
+        const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
+        const unsigned long long nk = alive & ~__ballot(sup);
+        if (nk == kept) break;
+        kept = nk;
+      }
+      SCAN_STAMP(2);
+      const bool mine = (kept >> lane) & 1ull;
+      if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
+        keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+#pragma unroll
+      for (int k = 0; k < SCAN_NU; ++k) {
+        const unsigned long long o = wave_or_u64(mine ? urg[k] : 0ull);  // uniform; 0 past the last block
+        if (lane == 0 && o) atomicOr(&remv[c + 1 + k], o);
+      }
+      if (mine) klist[c & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = lane;
+      count += __builtin_popcountll(kept);
+      if (lane == 0) skept[c & 3] = kept;
+      SCAN_STAMP(3);
+      lds_barrier();
+      SCAN_STAMP(5);
+    }
+    if (lane == 0) num_keep[g] = count;
+  } else {
+    // ---------------------------------------------------------------- propagate / loader groups
+    const int grp = (wave - 1) / SCAN_GW, rank = (wave - 1) - grp * SCAN_GW;
+    const int lead = min(grp, NB);
+    const int S = (NB - lead) / 3;
+    const int trail = NB - lead - 3 * S;
+    for (int q = 0; q < lead; ++q) lds_barrier();
+    for (int s2 = 0; s2 < S; ++s2) {
+      const int t0 = grp + 3 * s2;
+      const int c = t0;  // (SCAN_STAMP index)
+      if (wave == 1) SCAN_STAMP(8);
+      // ---- interval t0: issue
+      const int bk = t0 - 1;             // block whose kept rows this group spreads
+      const int first = t0 + SCAN_NU;    // = bk + 1 + SCAN_NU: first word not covered by the urgent words
+      unsigned long long kb = 0ull;
+      if (bk >= 0 && first < cb) kb = uniform_u64(skept[bk & 3]);
+      // this wave's share: every SCAN_GW-th kept box, read from the compacted list the resolver left in LDS: lane u
+      // fetches the row of slot u, the slots then cost a v_readlane + multiply + load each (a lone wave pays ~5 cycles
+      // per instruction: walking the kept bits with ffbl / and / compare cost more than the memory round trip)
+      const int cnt = __builtin_popcountll(kb);
+      const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
+      const int myl = (lane < m) ? klist[bk & 3][rank + SCAN_GW * lane] : 0;
+      const unsigned long long* blk = mask + (size_t)(max(bk, 0) * 64) * cbs;
+      unsigned long long v[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) v[u][ch] = 0ull;
+        if (u < m) {  // uniform
+          const unsigned int off = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;  // < 64 * 1024
+#pragma unroll
+          for (int ch = 0; ch < CH; ++ch) {
+            const int w = first + ch * 64 + lane;
+            if (w < cb) v[u][ch] = blk[off + (unsigned int)w];
+          }
+        }
+      }
+      // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
+      const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
+      unsigned long long in[2];
+      in[0] = load_field(t0 + 3, fa);
+      in[1] = fb >= 0 ? load_field(t0 + 3, fb) : 0ull;
+      if (m > U || (m > 0 && first + 64 * CH < cb)) {  // overflow: finish it now, synchronously (rare)
+        for (int w0 = first; w0 < cb; w0 += 64) {
+          const int w = w0 + lane;
+          unsigned long long acc = 0ull;
+          for (int u = (w0 - first) < 64 * CH ? U : 0; u < m; ++u) {
+            const unsigned int off = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;
+            if (w < cb) acc |= blk[off + (unsigned int)w];
+          }
+          if (acc) atomicOr(&remv[w], acc);
+        }
+      }
+      if (wave == 1) SCAN_STAMP(10);
+      lds_barrier();
+      // ---- interval t0+1: the loads fly
+      lds_barrier();
+      if (wave == 1) SCAN_STAMP(11);
+      // ---- interval t0+2: consume.  The empty asm pins the first USE of every loaded register here: without it the
+      // scheduler hoists the (pure VALU) OR tree above the two barriers and has to wait for the loads before them.
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) asm volatile("" : "+v"(v[u][ch]));
+      asm volatile("" : "+v"(in[0]));
+      asm volatile("" : "+v"(in[1]));
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc |= v[u][ch];
+        const int w = first + ch * 64 + lane;
+        if (acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words (acc == 0 where w >= cb)
+      }
+      if (t0 + 3 < cb) {
+        const int slot = (t0 + 3) & (SCAN_RING - 1);
+        rin[slot][fa][lane] = in[0];
+        if (fb >= 0) rin[slot][fb][lane] = in[1];
+      }
+      if (wave == 1) SCAN_STAMP(9);
+      lds_barrier();
+      if (wave == 1) SCAN_STAMP(12);
+    }
+    for (int q = 0; q < trail; ++q) lds_barrier();
   }
-  if (tid == 0) num_keep[g] = count;
 }
 
 // pairwise IoU matrices ------------------------------------------------------------------
@@ -427,9 +505,17 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   } else {
     hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   }
-  hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)G), dim3(SCAN_T), (size_t)a.cbs * sizeof(unsigned long long), s, a,
-                     (const unsigned long long*)mask, (const unsigned long long*)colm, (long long*)keep,
-                     (long long*)num_keep, (long long*)ob);
+  const dim3 sgrid((unsigned)G), sblk(SCAN_T);
+  const size_t slds = (size_t)a.cbs * sizeof(unsigned long long);
+  if (a.cbs <= 64 + 1 + SCAN_NU)  // one 64-word chunk right of any block (n <= 4352): 22 rows x 1 chunk in flight
+    hipLaunchKernelGGL((nms_scan_kernel<22, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
+  else if (a.cbs <= 128 + 1 + SCAN_NU)  // n <= 8448
+    hipLaunchKernelGGL((nms_scan_kernel<22, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
+  else
+    hipLaunchKernelGGL((nms_scan_kernel<16, 3>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
   return (int)hipGetLastError();
 }
 

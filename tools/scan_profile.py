@@ -18,8 +18,9 @@ for n, thr, clutter in ((1000, 0.2, True), (4096, 0.25, True), (4096, 0.25, Fals
     torch.cuda.synchronize()
     cb = (n + 63) // 64
     st = ws[:cb * 16 * 8 + 16 * 8].view(torch.int64).cpu().numpy().reshape(-1, 16)[:cb].astype(np.float64)
-    iv = np.diff(st[:, 0])                       # interval start -> next interval start
-    d = lambda a, b: np.median(st[1:-1, b] - st[1:-1, a])
-    print(f'n={n} clutter={clutter} kept={int(num)} blocks={cb}: interval {np.median(iv):.0f} cyc | lds-read {d(0,1):.0f} resolve {d(1,2):.0f} '
-          f'store+or {d(2,3):.0f} to-barrier {d(3,4):.0f} barrier-wait {d(4,5):.0f} | propagate wave: work {d(8,9):.0f} ; '
-          f'prop start after w0 start {np.median(st[1:-1,8]-st[1:-1,0]):.0f}', flush=True)
+    iv = np.diff(st[:, 0])                       # resolver: interval start -> next interval start
+    d = lambda a, b, rows=slice(1, -1): np.median(st[rows, b] - st[rows, a])
+    grp = slice(3, cb - 6, 3)                    # wave 1 (group 0, rank 0) stamps live at rows t0 = 0, 3, 6, ...
+    print(f'n={n} clutter={clutter} kept={int(num)} blocks={cb}: interval {np.median(iv):.0f} cyc | resolver: lds-read {d(0,1):.0f} '
+          f'solve {d(1,2):.0f} store+or {d(2,3):.0f} barrier {d(3,5):.0f} | group wave: issue {d(8,10,grp):.0f} 2 barriers {d(10,11,grp):.0f} '
+          f'wait+consume {d(11,9,grp):.0f} barrier {d(9,12,grp):.0f}', flush=True)
