@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--pairs', type=int, default=10_000_000, help='pairs per GPU (default: BASELINE config 3)')
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--prewarm', type=float, default=1.0,
+                    help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
     args = ap.parse_args()
@@ -172,9 +174,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # a fresh box starts at its idle clocks and a 30 ms benchmark can be over before they have ramped: run untimed
+    # steps for a fixed wall time first (same step function; the W warmup steps still follow, then exactly K timed ones)
+    # The pre-warm steps are launched exactly like the timed ones (event pairs recorded when the timed region records
+    # them, then dropped): the first event pairs created after a few thousand event-free launches cost the host ~100 us
+    # each on this ROCm (tools/step_drift.py), which would make the timed region host-bound.
+    if args.prewarm > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm:
+            for _ in range(20):
+                step(graph is None)
+            torch.cuda.synchronize(dev)
+            for lt in LOSSES:
+                events[lt].clear()
     for _ in range(args.warmup):
-        step(False)
+        step(graph is None)
     sync_all()
+    for lt in LOSSES:
+        events[lt].clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(graph is None)

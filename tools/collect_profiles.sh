@@ -10,6 +10,8 @@ OUT=gpurun_out/$R
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-sample 0"
 SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0"
+# the plain bench line first, on the fresh box (the driver's round-end bench also runs on a fresh one)
+python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_kernel_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SHORT > $OUT/pmc_$c.log 2>&1
@@ -18,7 +20,6 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
   --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
-python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 # context measurements (not bench lines): HBM ceilings, NMS, small-P / head-level train-step slices
 [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
