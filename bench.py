@@ -7,18 +7,22 @@ Metric (BASELINE.json): M box-pairs/s, forward+backward, for GWD / KLD / BCD at 
 Workload (BASELINE.json configs[2]): 10 M synthetic anchor x gt pairs per GPU (SURVEY.md §8d recipe,
 seed 0), GDLoss(loss_type, fun='log1p', tau=1.0, alpha=1.0, reduction='mean', loss_weight=5.0).
 One "step" = gwd3d, kld3d and bd3d, each forward + backward over the whole batch, through the
-reference's module surface (GDLoss.forward -> autograd backward).  Inputs are resident in HBM before
+reference's module surface (GDLoss.forward x 3 -> one autograd backward of the summed losses, as a
+training step does with its loss dict).  Inputs are resident in HBM before
 the timed region.  value = (3 losses x pairs x steps x ranks) / max-over-ranks wall time.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), pairs sharded by rank with no
 data-path collective; once per step the three per-shard loss values are all-gathered (3 fp32 per rank),
 asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs.
 
-Launch mode.  N = 1 launches eagerly (the GPU, not the host, is the limit: 440 us of host work per 451 us step) so
-that every fused launch inside the timed region is bracketed by HIP events.  N > 1 replays a hipGraph of the step
-(torch.cuda.CUDAGraph; host cost 16 us/step) so that the per-step collective call does not make the host the
-limit; HIP events cannot be recorded inside a captured graph on ROCm, so there the kernel durations come from an
-eager pass run right after the timed region (`roofline.timing` says which).  `--graph` / `--no-graph` override.
+Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the timed region is bracketed by HIP events:
+with one backward() per step the host needs 190-300 us per step against 440-460 us of GPU time (one backward per loss
+cost ~60 us of autograd-engine thread hand-off each and made the step host-bound on boxes with busy host cores).
+N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~20 us/step) so that the per-step collective call
+cannot make the host the limit; HIP events cannot be recorded inside a captured graph on ROCm, so there every REPLAY is
+bracketed by an event pair in the timed region (`config.gpu_ms_per_step_events`) and the per-kernel durations come from
+an eager pass run right after it, same stream, same process (`roofline.timing` says which).  `--graph` / `--no-graph`
+override; on one MI355X both modes give the same step time within 1 %.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
@@ -91,7 +95,7 @@ def main():
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly, HIP events around every fused launch in-region (default for N = 1)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -116,24 +120,29 @@ def main():
     amd.load_library()
 
     n = args.pairs
-    pred, tgt = synthetic_pairs(n, seed=rank, device=dev)
-    pred.requires_grad_(True)
+    pred0, tgt = synthetic_pairs(n, seed=rank, device=dev)
+    # one leaf per loss (same values): the step calls backward() ONCE on the sum of the three losses, as a training
+    # step does with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations
+    # that are not part of the metric.  (One backward per loss costs ~60 us of autograd-engine thread hand-off each:
+    # 3 x that made the eager step host-bound on boxes with a slow host, see tools/host_profile.py.)
+    preds = {lt: pred0.clone().requires_grad_(True) for lt in LOSSES}
+    del pred0
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
                                     reduction='mean', loss_weight=5.0)) for lt in LOSSES}
     events = {lt: [] for lt in LOSSES}
     last = {}
 
     def compute(record):
-        """gwd3d, kld3d, bd3d: GDLoss forward + autograd backward each.  Returns the 3 detached loss scalars."""
-        outs = []
+        """gwd3d, kld3d, bd3d: GDLoss forward each, then autograd backward of their sum (every loss's fused kernel has
+        already produced its gradient; backward runs the three scale launches).  Returns the 3 detached loss scalars."""
+        losses_ = []
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if record else None
-            pred.grad = None
-            loss = mods[lt](pred, tgt)
-            loss.backward()
-            outs.append(loss.detach())
+            preds[lt].grad = None
+            losses_.append(mods[lt](preds[lt], tgt))
         gdl.PROFILE_EVENTS = None
-        return outs
+        (losses_[0] + losses_[1] + losses_[2]).backward()
+        return [l.detach() for l in losses_]
 
     graph = None
     graph_note = None
@@ -161,8 +170,21 @@ def main():
                 graph = None
                 graph_note = 'hipGraph capture failed on another rank; eager launches'
 
+    step_events = []
+
     def step(record):
-        outs = compute(record) if graph is None else (graph.replay() or graph_outs)
+        if graph is None:
+            outs = compute(record)
+        else:
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                graph.replay()
+                e1.record()
+                step_events.append((e0, e1))
+            else:
+                graph.replay()
+            outs = graph_outs
         if use_dist:  # one tiny collective per step: (3,) shard losses -> (world, 3)
             last['pending'] = amd.sharded.gather_shard_losses(torch.stack(outs), async_op=True)
         else:
@@ -183,18 +205,20 @@ def main():
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm:
             for _ in range(20):
-                step(graph is None)
+                step(True)
             torch.cuda.synchronize(dev)
             for lt in LOSSES:
                 events[lt].clear()
+            step_events.clear()
     for _ in range(args.warmup):
-        step(graph is None)
+        step(True)
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
+    step_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(graph is None)
+        step(True)
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU-bound iff this < elapsed)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -243,12 +267,15 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{n} synthetic anchor x gt 7-dof box pairs per GPU (BASELINE configs[2]); '
-                                   'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward '
-                                   '(fun=log1p, tau=1, reduction=mean, loss_weight=5)',
+                                   'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward over the whole batch '
+                                   '(one autograd backward() of the summed losses; fun=log1p, tau=1, reduction=mean, '
+                                   'loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
-                       'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4)},
+                       'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
+                       'gpu_ms_per_step_events': (round(sum(a.elapsed_time(b) for a, b in step_events) /
+                                                        max(len(step_events), 1), 4) if step_events else None)},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR, 'timing': timing,
