@@ -576,39 +576,44 @@ __global__ __launch_bounds__(256) void center_scale_kernel(const CenterArgs a, c
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < nflt; k += (long long)gridDim.x * 256) gmap[k] *= gs;
 }
 
-// second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; every thread
-// issues all of its 16-B loads before the first add (the kernel is pure latency: 39 K floats at 10 M pairs).
+// second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; the kernel is pure latency
+// (39 K floats at 10 M pairs): every thread issues ALL its 16-byte loads of a 48 K-partial round before the first add
+// (one memory round trip at 10 M pairs), then one barrier: thread t of wave 0 adds 16 consecutive per-thread sums from
+// LDS and the wave finishes with 6 shuffle steps.  Deterministic (fixed order), independent of the launch geometry.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, long long nb,
                                                                float* __restrict__ out) {
   __shared__ double sd[1024];
+  constexpr int RU = 12;
   const int tid = threadIdx.x;
   const long long nv = nb >> 2;  // whole float4s (the workspace is 16-byte aligned)
   const float4* p4 = reinterpret_cast<const float4*>(partials);
   double acc = 0.0;
-  for (long long i0 = 0; i0 < nv; i0 += 1024 * 8) {
-    float4 v[8];
+  for (long long i0 = 0; i0 < nv; i0 += 1024 * RU) {
+    float4 v[RU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < RU; ++u) {
       const long long i = i0 + (long long)u * 1024 + tid;
       v[u] = i < nv ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+    for (int u = 0; u < RU; ++u) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
   }
   const long long tail = (nv << 2) + tid;
   if (tail < nb) acc += (double)partials[tail];
   sd[tid] = acc;
   __syncthreads();
+  if (tid < 64) {
+    double s2 = 0.0;
 #pragma unroll
-  for (int s = 512; s > 0; s >>= 1) {
-    if (tid < s) sd[tid] += sd[tid + s];
-    __syncthreads();
+    for (int k = 0; k < 16; ++k) s2 += sd[tid * 16 + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s2 += __shfl_down(s2, off, 64);
+    if (tid == 0) *out = (float)s2;
   }
-  if (tid == 0) *out = (float)sd[0];
 }
 
 // grad[i,:] *= g  (scalar g: the whole grid exits after one scalar load when g == 1)
-__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ grad, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void scale_rows_kernel(float* __restrict__ grad, const float* __restrict__ g,
                                                          int per_row, long long nflt) {
   float gs = 1.0f;
   if (!per_row) {
@@ -1022,9 +1027,11 @@ int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* s
   if (n < 0 || (n > 0 && (grad == nullptr || g == nullptr))) return GD3D_E_BADARG;
   if (n == 0) return 0;
   const long long nflt = (long long)n * 7;
-  long long blocks = (nflt + 255) / 256;
-  if (blocks > 1024) blocks = 1024;  // grid-stride; small so that the g == 1 early exit costs ~2 us
-  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, g, per_row,
+  // grid-stride with FEW, LARGE workgroups: the common case is the g == 1 early exit, whose cost is the dispatch of the
+  // workgroups (1024 x 256 threads: 4.5 us; 256 x 1024 threads: the same 262 144 lanes for a real scaling pass)
+  long long blocks = (nflt + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, grad, g, per_row,
                      nflt);
   return (int)hipGetLastError();
 }
