@@ -15,7 +15,8 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), pairs shard
 data-path collective; once per step the three per-shard loss values are all-gathered (3 fp32 per rank),
 asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs.
 
-Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the timed region is bracketed by HIP events:
+Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the timed region carries its own HIP event pair
+(gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no marker packets):
 with one backward() per step the host needs 190-300 us per step against 440-460 us of GPU time (one backward per loss
 cost ~60 us of autograd-engine thread hand-off each and made the step host-bound on boxes with busy host cores).
 N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~20 us/step) so that the per-step collective call
@@ -26,8 +27,8 @@ override; on one MI355X both modes give the same step time within 1 %.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
-                 (88 B/pair) / average launch duration measured with HIP events recorded
-                 around every fused launch INSIDE the timed region, on the stream it is launched on.
+                 (88 B/pair) / average launch duration measured with a HIP event pair bound to
+                 every fused dispatch INSIDE the timed region, on the stream it is launched on.
   cpu_baseline : the fp32 CPU oracle ("port") timed on this host's cores on a bounded sample.
 """
 import argparse
@@ -95,7 +96,7 @@ def main():
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly, HIP events around every fused launch in-region (default for N = 1)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly, a HIP event pair bound to every fused dispatch in-region (default for N = 1)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -228,17 +229,19 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = tt.item()
-    timing = 'HIP events around every fused launch inside the timed region'
-    if graph is not None:  # events cannot be recorded inside a captured graph on ROCm: eager pass right after
+    timing = ('HIP event pair bound to every fused dispatch inside the timed region (hipExtLaunchKernel start/stop events: '
+              'begin/end timestamps of the dispatch itself, no marker packets)')
+    if graph is not None:  # events cannot be bound inside a captured graph on ROCm: eager pass right after
         for _ in range(min(args.steps, 10)):
             compute(True)
         torch.cuda.synchronize(dev)
-        timing = 'HIP events around every fused launch, eager pass run right after the graph-replayed timed region'
+        timing = ('HIP event pair bound to every fused dispatch (hipExtLaunchKernel start/stop events), eager pass run '
+                  'right after the graph-replayed timed region')
 
     # dominant-kernel durations from the HIP events recorded inside the timed region
     kern_ms = {}
     for lt in LOSSES:
-        d = [a.elapsed_time(b) for a, b in events[lt]]
+        d = [tm.elapsed_ms() for tm in events[lt]]
         kern_ms[lt] = sum(d) / max(len(d), 1)
     if use_dist:
         total, per_rank = last['pending'].result()   # (3,), (world, 3)

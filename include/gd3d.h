@@ -130,6 +130,23 @@ int gd3d_loss_fused_decoded(const gd3d_params* params, const gd3d_prologue* prol
                             float* loss_sum, float* grad_pred, float* grad_target,
                             void* workspace, void* stream);
 
+/* Profiling form of the same call (bench.py): the two hipEvent_t (as void*, from gd3d_prof_event_create; either may be
+ * NULL) are bound to the begin / end timestamps of the fused kernel's OWN dispatch (hipExtLaunchKernel), so
+ * gd3d_prof_event_elapsed_ms(start, stop) is that kernel's execution time — what rocprofv3 --kernel-trace reports for
+ * it — and no marker packets are added to the stream (events recorded around a launch cost two barrier packets, ~3 us
+ * per bracket, and would be charged to the kernel).  The reduce stage, when loss_sum != NULL, follows as usual and is
+ * outside the bracket.  With both events NULL this IS gd3d_loss_fused_decoded.  The elapsed-time query has
+ * hipEventElapsedTime semantics: it returns hipErrorNotReady (600) while the dispatch is in flight — synchronise first.
+ * (No reference counterpart: the reference has no native entry point on this path) */
+int gd3d_loss_fused_timed(const gd3d_params* params, const gd3d_prologue* prologue,
+                          const float* pred, const float* target, const float* row_weight,
+                          const float* weight7, int64_t n, float scale, float* loss,
+                          float* loss_sum, float* grad_pred, float* grad_target,
+                          void* workspace, void* stream, void* start_event, void* stop_event);
+int gd3d_prof_event_create(void** event);
+int gd3d_prof_event_destroy(void* event);
+int gd3d_prof_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
+
 /* The same slice with the GATHER of the positives fused in as well (one thread per positive, gd_anchor3d_head.py:95-141):
  *   bbox_pred (B, A*7, H, W) raw head output (NCHW, read in place: no permute copy, no index kernels);
  *   bbox_targets / bbox_weights (M,7) with M = B*H*W*A and row m = ((b*H + h)*W + w)*A + a (bbox_weights nullable);

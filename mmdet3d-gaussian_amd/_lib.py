@@ -47,6 +47,11 @@ SYMBOLS = {
     'gd3d_loss_fused_w7': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_fused_decoded': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32,
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_loss_fused_timed': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_prof_event_create': (_int, [ctypes.POINTER(_vp)]),
+    'gd3d_prof_event_destroy': (_int, [_vp]),
+    'gd3d_prof_event_elapsed_ms': (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     'gd3d_anchor_head_loss': (_int, [ctypes.POINTER(Params), _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.c_int32, _vp, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _i64, _f32, _vp,
                                      _vp, _vp, _vp]),

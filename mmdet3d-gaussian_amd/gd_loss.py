@@ -21,9 +21,36 @@ from .registry import LOSSES, register_with_mmdet
 LOSS_TYPES = {'gwd3d': 0, 'kld3d': 1, 'bd3d': 2, 'jd3d': 3, 'kld3d_symmax': 4, 'kld3d_symmin': 5, 'kfiou3d': 6}
 FUNS = {'none': 0, 'log1p': 1, 'expm1': 2, 'nlog': 3}
 
-# bench.py sets this to a list; every fused launch then appends a (start, end) torch.cuda.Event pair
-# recorded on the launch stream (HIP events around the kernel, inside the timed region).
+# bench.py sets this to a list; every fused launch then appends a DispatchTimer: a pair of HIP events bound to the
+# begin / end timestamps of that kernel's own dispatch (gd3d_loss_fused_timed), inside the timed region.
 PROFILE_EVENTS = None
+
+
+class DispatchTimer:
+    """Two hipEvent_t owned by libgd3d.so's runtime, handed to gd3d_loss_fused_timed; `elapsed_ms()` after a
+    synchronize is the execution time of the one fused dispatch they were bound to."""
+    __slots__ = ('start', 'stop', '_abi')
+
+    def __init__(self):
+        self.start = self.stop = None
+        self._abi = _library()
+        for slot in ('start', 'stop'):
+            h = ctypes.c_void_p()
+            _lib.check(self._abi.gd3d_prof_event_create(ctypes.byref(h)), 'gd3d_prof_event_create')
+            setattr(self, slot, h.value)
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(self._abi.gd3d_prof_event_elapsed_ms(self.start, self.stop, ctypes.byref(ms)),
+                   'gd3d_prof_event_elapsed_ms')
+        return ms.value
+
+    def __del__(self):
+        for slot in ('start', 'stop'):
+            h = getattr(self, slot, None)
+            if h:
+                self._abi.gd3d_prof_event_destroy(h)
+                setattr(self, slot, None)
 
 
 def make_params(loss_type, fun, tau, alpha, center_offset, kwargs):
@@ -111,15 +138,12 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
         if ev is None:
             rc = lib.gd3d_loss_fused_decoded(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
                                              _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
-        else:  # profiling: HIP events around the fused kernel alone; the reduce stage is launched separately
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rc = lib.gd3d_loss_fused_decoded(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
-                                             _ptr(loss), None, _ptr(gp), _ptr(gt), _ptr(ws), stream)
-            e1.record()
-            ev.append((e0, e1))
-            if rc == 0 and want_sum:
-                rc = lib.gd3d_loss_reduce(_ptr(ws), n, _ptr(total), stream)
+        else:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
+            tm = DispatchTimer()
+            rc = lib.gd3d_loss_fused_timed(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
+                                           _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream,
+                                           tm.start, tm.stop)
+            ev.append(tm)
     finally:
         if switch:
             _set_device(prev)

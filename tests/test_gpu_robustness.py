@@ -139,3 +139,39 @@ def test_avg_factor_as_device_tensor_no_host_sync(amd):
     b.backward()
     assert abs(a.item() - b.item()) <= 1e-6 * (1 + abs(b.item()))
     assert torch.allclose(g1, pred.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_dispatch_bound_events_time_the_fused_kernel_and_change_nothing(amd):
+    """gd3d_loss_fused_timed (bench.py's in-region timing): identical bits to the plain call, and the event pair bound to
+    the dispatch yields a positive duration that is no longer than an outer event bracket around the same launches."""
+    import time
+    from mmdet3d_gaussian_amd import gd_loss as gdl
+    p, t = _pairs(1_000_003, 7)
+    pred = torch.from_numpy(p).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(t).cuda()
+    mod = amd.GDLoss('bd3d', loss_weight=5.0)
+    plain = mod(pred, tgt)
+    plain.backward()
+    g_plain = pred.grad.clone()
+    pred.grad = None
+    timers = []
+    gdl.PROFILE_EVENTS = timers
+    try:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        timed = mod(pred, tgt)
+        e1.record()
+    finally:
+        gdl.PROFILE_EVENTS = None
+    timed.backward()
+    torch.cuda.synchronize()
+    assert len(timers) == 1
+    assert timed.item() == plain.item()
+    assert torch.equal(pred.grad, g_plain)
+    ms = timers[0].elapsed_ms()
+    assert 0.0 < ms <= e0.elapsed_time(e1)
+    # 1 M pairs move >= 84 MB: at the chip's 8 TB/s peak that is 10.5 us — a shorter reading would be a broken timer
+    assert ms * 1e-3 >= 84.0 * 1_000_003 / 8e12
+    del timers[:]
+    time.sleep(0)  # timers destroyed here: hipEventDestroy through the ABI must not raise

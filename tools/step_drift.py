@@ -63,5 +63,5 @@ for rec in (True, True):
     gdl.PROFILE_EVENTS = None
     th = time.perf_counter() - t0
     torch.cuda.synchronize(); tt = time.perf_counter() - t0
-    d = [a.elapsed_time(b) for a, b in ev]
+    d = [tm.elapsed_ms() for tm in ev]
     print(f'after {k} recorded burst steps, record={rec}: {tt / 60 * 1e3:.3f} ms/step (host enqueue {th / 60 * 1e3:.3f}) kernel {sum(d) / len(d) * 1e3:.1f} us', flush=True)
