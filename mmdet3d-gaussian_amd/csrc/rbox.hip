@@ -3,10 +3,11 @@
 //
 // NMS (replaces mmdet3d iou3d_cuda.nms_gpu, whose mask goes D->H and is scanned on the host):
 //   1. obox_prep_kernel: one thread per box: sin/cos + rotated corners once -> 64-byte OBox records.
-//   2. nms_mask_kernel:  one wave per (row box, 64-box column block at or right of its own block): lane l tests the
-//      row box against column box l, the ballot is the mask word; per-thread polygon vertices live in LDS
-//      [slot][thread] (12 KiB per wave).  Compute/latency-bound integer+fp32 work (no HBM roofline: N=4096 reads
-//      256 KB, writes 1 MB).
+//   2. nms_mask_compact_kernel (rotated) / nms_mask_kernel (axis-aligned, circle): one wave per (8..64 row boxes,
+//      64-box column block at or right of their own block).  Rotated: the cheap bounding-circle test for every pair
+//      first, survivors queued in LDS, then the full polygon-clipping predicate with the live lanes packed densely;
+//      per-thread polygon vertices live in LDS [slot][thread] (12 KiB per wave).  Compute/latency-bound integer+fp32
+//      work (no HBM roofline: N=4096 reads 256 KB, writes 1 MB).
 //   3. nms_scan_kernel:  the greedy scan as ONE wave that never leaves the device: the 64-box
 //      diagonal word of each block is resolved with scalar readlane steps, then the mask rows of the
 //      boxes just kept are OR-ed into the removed-set (LDS) with independent, pipelined row loads.
@@ -18,7 +19,6 @@
 
 namespace rbox {
 
-constexpr int NMS_T = 256;
 enum { MODE_ROT = 0, MODE_NORMAL = 1, MODE_CIRCLE = 2 };
 
 // One launch serves G independent NMS problems ("groups": classes, samples, tasks) over a shared box array:
@@ -55,23 +55,22 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
   out[(size_t)g * a.cap + i] = o;
 }
 
-// One WAVE per (row box i, 64-box column block c >= block of i): lane l tests box i against box 64c + l and the
-// wave-wide ballot IS the 64-bit mask word — no partial words, no barrier.  One wave per workgroup keeps the per-thread
-// polygon scratch at 12 KiB of LDS (13 workgroups per CU); far-apart pairs leave through the exact bounding-circle
-// early-out, so most rows cost ~20 instructions.  A wave walks `rows` consecutive row boxes against the same 64
-// column boxes (loaded once); blockIdx.x = (upper-triangle block pair) * (64 / rows) + row group; blockIdx.y = group.
-// `rows` (1, 2, 4 or 8; host-chosen) = row boxes a wave walks through against the same 64 column boxes: 1 keeps small
-// problems latency-short (n = 1000: 49 us vs 80 us at 8), 8 keeps large ones from being workgroup-dispatch bound
-// (n = 9000: 640 K one-wave workgroups -> 80 K; 965 -> 834 us).
+// Axis-aligned and circle NMS (cheap predicates, no polygon scratch): one WAVE per (row box i, 64-box column block
+// c >= block of i): lane l tests box i against box 64c + l and the wave-wide ballot IS the 64-bit mask word — no partial
+// words, no barrier.  A wave walks `rows` (1, 2, 4 or 8; host-chosen) consecutive row boxes against the same 64 column
+// boxes (loaded once): 1 keeps small problems latency-short, 8 keeps large ones from being workgroup-dispatch bound;
+// blockIdx.x = (upper-triangle block pair) * (64 / rows) + row group; blockIdx.y = group.
 // On a DIAGONAL block the lanes left of the row box are not idle: lane j < i evaluates the same predicate with the
 // operands in greedy order (box j first, box i second — bit for bit what row j's wave computes for its lane i), so the
 // ballot also yields "which earlier boxes of my block suppress box i".  That word goes to colm[i]; the scan resolves a
 // 64-box block from these column words in a few wave-parallel steps instead of one scalar step per kept box.
+// (Rotated boxes went through this kernel too until the compacted form below replaced it: n = 4096 99 -> 42 us,
+// n = 9000 293 -> 117 us, n = 1000 25 -> 23.5 us, same mask bits.)
 template <int MODE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
                                                       unsigned long long* __restrict__ mask_,
                                                       unsigned long long* __restrict__ colm_) {
-  __shared__ VertexScratch<MODE == MODE_ROT ? 64 : 1> vs;
+  static_assert(MODE == MODE_NORMAL || MODE == MODE_CIRCLE, "rotated boxes: nms_mask_compact_kernel");
   const int lane = threadIdx.x;
   const int g = blockIdx.y;
   const int n = group_n(a, g);
@@ -82,7 +81,6 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
   if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
   const int r0 = (int)(blockIdx.x % groups) * rows;
   const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
-  const OBox* ob = ob_ + (size_t)g * a.cap;
   unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
   const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
   const double thresh_d = a.thresh_dev != nullptr ? (double)a.thresh_dev[g] : a.thresh_d;
@@ -93,19 +91,15 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
   while ((unsigned)((rb + 1) * cb - (rb + 1) * rb / 2) <= pair) ++rb;
   const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
   const int j = c * 64 + lane;
-  OBox B;
   float braw[5];
   if (j < n) {
+    const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
     if constexpr (MODE == MODE_NORMAL) {
-      const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
 #pragma unroll
       for (int k = 0; k < 5; ++k) braw[k] = a.boxes[sj * 5 + k];
-    } else if constexpr (MODE == MODE_CIRCLE) {
-      const size_t sj = order != nullptr ? (size_t)order[j] : (size_t)j;
+    } else {
       braw[0] = a.boxes[sj * 2];
       braw[1] = a.boxes[sj * 2 + 1];
-    } else {
-      B = ob[j];
     }
   }
   for (int r = 0; r < rows; ++r) {
@@ -122,19 +116,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
         for (int k = 0; k < 5; ++k) ar[k] = a.boxes[si * 5 + k];
         hit = (low ? iou_normal(braw, ar) : iou_normal(ar, braw)) > thresh;
       }
-    } else if constexpr (MODE == MODE_CIRCLE) {
+    } else {
       if (act) {  // mmdet3d circle_nms: dist = (x_i - x_j)^2 + (y_i - y_j)^2 ; suppressed iff dist <= thresh
         const size_t si = order != nullptr ? (size_t)order[i] : (size_t)i;
         const float xi = a.boxes[si * 2], yi = a.boxes[si * 2 + 1];
         const float dx = low ? braw[0] - xi : xi - braw[0], dy = low ? braw[1] - yi : yi - braw[1];
         const float dist = dx * dx + dy * dy;
         hit = (double)dist <= thresh_d;
-      }
-    } else {
-      if (act) {
-        const OBox A = ob[i];  // wave-uniform address: served as a broadcast
-        const OBox F = low ? B : A, S = low ? A : B;  // one call site: mixed lanes do not run the geometry twice
-        hit = iou_bev<64>(F, S, vs, lane) > thresh;
       }
     }
     const unsigned long long word = __ballot(hit);
@@ -147,6 +135,124 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
       } else {
         mask[(size_t)i * a.cbs + c] = word;
       }
+    }
+  }
+}
+
+// Rotated mode, compacted: the same mask words, with the expensive lanes packed densely.
+// In nms_mask_kernel a wave pays a whole polygon-clipping pass whenever ANY of its 64 lanes survives the bounding-circle
+// test; on score-sorted detector output ~1 % of the pairs do, i.e. about every second (row, 64 columns) wave runs a pass
+// with one or two live lanes.  Here a wave owns `rows` (8..64) consecutive row boxes x one 64-box column block and works
+// in two phases per 16-row chunk:
+//   1. the circle test alone for every (row, lane) pair (~12 VALU per row; the row box's centre / extent are
+//      wave-uniform scalar loads), survivors appended to an LDS queue as (row << 6 | column) via ballot + mbcnt;
+//   2. whenever >= 64 candidates are queued (and once more at the end) lane l takes candidate l: loads both 64-byte
+//      records, runs the FULL predicate (iou_bev, which repeats the circle test — one code path, bit-identical
+//      decisions) and ORs its bit into the row's word in LDS.  Every clipping pass but the last has 64 live lanes.
+// The circle test is symmetric in its operands (squared differences, commutative sums), so on a DIAGONAL block it also
+// selects the (earlier box, row box) pairs that are evaluated in greedy operand order for colm[] — as in the plain kernel.
+// A pair that fails the circle test has overlap exactly 0 and IoU +0, which is "> thresh" only for thresh < 0: for such a
+// threshold (or a NaN one) every valid pair is queued, so the result stays that of the plain kernel.
+constexpr int CQ_ROWS = 16;                 // rows per chunk between drains
+constexpr int CQ_CAP = CQ_ROWS * 64 + 64;   // worst case of one chunk + the carried remainder (< 64)
+
+__global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
+                                                              unsigned long long* __restrict__ mask_,
+                                                              unsigned long long* __restrict__ colm_) {
+  __shared__ VertexScratch<64> vs;
+  __shared__ unsigned short queue[CQ_CAP];
+  __shared__ unsigned long long words[64];
+  const int lane = threadIdx.x;
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const int rows = a.rows;
+  const int groups = 64 / rows;
+  const unsigned pair = blockIdx.x / groups;
+  if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
+  const int r0 = (int)(blockIdx.x % groups) * rows;
+  const OBox* ob = ob_ + (size_t)g * a.cap;
+  unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
+  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
+  const bool all_pairs = !(thresh >= 0.0f);
+  int rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
+  rb = max(0, min(rb, cb - 1));
+  while (rb > 0 && (unsigned)(rb * cb - rb * (rb - 1) / 2) > pair) --rb;
+  while ((unsigned)((rb + 1) * cb - (rb + 1) * rb / 2) <= pair) ++rb;
+  const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
+  const int i0 = rb * 64 + r0;  // first row box of this wave
+  if (i0 >= n) return;
+  const int nrows = min(rows, n - i0);
+  const int j = c * 64 + lane;
+  const bool jv = j < n;
+  float bcx = 0.0f, bcy = 0.0f, bext = 0.0f;
+  if (jv) {
+    const OBox& B = ob[j];
+    bcx = B.cx;
+    bcy = B.cy;
+    bext = fabsf(B.x2 - B.x1) + fabsf(B.y2 - B.y1);
+  }
+  words[lane] = 0ull;
+  __syncthreads();
+  int qn = 0;  // queued candidates (wave-uniform)
+  for (int rbase = 0; rbase < nrows; rbase += CQ_ROWS) {
+    const int rend = min(rbase + CQ_ROWS, nrows);
+    for (int r = rbase; r < rend; ++r) {
+      const int i = i0 + r;  // wave-uniform -> scalar loads
+      const OBox& A = ob[i];
+      const float acx = A.cx, acy = A.cy;
+      const float aext = fabsf(A.x2 - A.x1) + fabsf(A.y2 - A.y1);
+      bool cand = false;
+      if (jv && j != i) {
+        // box_overlap's early-out, same operations (it is symmetric in the two boxes)
+        const float ddx = acx - bcx, ddy = acy - bcy;
+        const float reach = 0.5f * (aext + bext) + 1e-2f;
+        cand = all_pairs || !(ddx * ddx + ddy * ddy > reach * reach * 1.0001f);
+      }
+      const unsigned long long cw = __ballot(cand);
+      if (cand) {
+        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(cw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cw, 0u));
+        queue[qn + (int)before] = (unsigned short)((r << 6) | lane);
+      }
+      qn += __popcll(cw);
+    }
+    __syncthreads();
+    const bool last = rend >= nrows;
+    int done = 0;
+    while (qn - done >= 64 || (last && done < qn)) {
+      const int q = done + lane;
+      if (q < qn) {
+        const int e = queue[q];
+        const int r = e >> 6, jl = e & 63;
+        const int i = i0 + r, jj = c * 64 + jl;
+        const OBox A = ob[i];
+        const OBox B = ob[jj];
+        const bool low = jj < i;  // diagonal block only: the lane's box precedes the row box -> it goes first
+        const OBox F = low ? B : A, S = low ? A : B;
+        if (iou_bev<64>(F, S, vs, lane) > thresh) atomicOr(&words[r], 1ull << jl);
+      }
+      done += 64;
+    }
+    if (!last && done > 0) {  // carry the < 64 leftover candidates to the front of the queue
+      const int rem = qn - done;
+      unsigned short v = 0;
+      if (lane < rem) v = queue[done + lane];
+      __syncthreads();
+      if (lane < rem) queue[lane] = v;
+      qn = rem;
+    }
+    __syncthreads();
+  }
+  if (lane < nrows) {
+    const int i = i0 + lane;
+    const unsigned long long word = words[lane];
+    if (rb == c) {
+      const int il = i & 63;
+      const unsigned long long below = (1ull << il) - 1ull;
+      mask[(size_t)i * a.cbs + c] = word & ~(below | (1ull << il));
+      colm_[(size_t)g * a.cap + i] = word & below;
+    } else {
+      mask[(size_t)i * a.cbs + c] = word;
     }
   }
 }
@@ -301,7 +407,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
     for (int q = 0; q < lead; ++q) lds_barrier();
     for (int s2 = 0; s2 < S; ++s2) {
       const int t0 = grp + 3 * s2;
-      const int c = t0;  // (SCAN_STAMP index)
+      [[maybe_unused]] const int c = t0;  // (SCAN_STAMP index)
       if (wave == 1) SCAN_STAMP(8);
       // ---- interval t0: issue
       const int bk = t0 - 1;             // block whose kept rows this group spreads
@@ -492,14 +598,22 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   unsigned long long* colm =  // per box: the earlier boxes of its own 64-block that suppress it
       (unsigned long long*)((char*)mask + align_up((size_t)G * cap * a.cbs * sizeof(unsigned long long), 256));
   const long long pairs = (long long)a.cbs * (a.cbs + 1) / 2;
-  int rows = 1;
-  while (rows < 8 && pairs * G * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
+  int rows;
+  if (mode == MODE_ROT) {
+    // compacted kernel: 8..64 rows per wave, as many as keep >= ~1 K waves in the grid (measured, mask kernel alone:
+    // n = 1000: 23.5 us at 8 rows, 40 at 64; n = 4096: 49 at 16, 42.5 at 32 / 64; n = 9000: 234 at 8, 117 at 64)
+    rows = 64;
+    while (rows > 8 && pairs * G * (64 / rows) < 1024) rows /= 2;
+  } else {
+    rows = 1;
+    while (rows < 8 && pairs * G * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid
+  }
   a.rows = rows;
   if (pairs * (64 / rows) > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const dim3 mgrid((unsigned)(pairs * (64 / rows)), (unsigned)G);
   if (mode == MODE_ROT) {
     hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_ROT>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
+    hipLaunchKernelGGL(nms_mask_compact_kernel, mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else if (mode == MODE_NORMAL) {
     hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else {

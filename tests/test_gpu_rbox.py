@@ -77,6 +77,49 @@ def test_nms_mask_words_bit_exact(amd):
     np.testing.assert_array_equal(mask[upper], want[upper])
 
 
+def _mask_words(amd, bs, thr):
+    import ctypes
+    lib = amd.load_library()
+    n = bs.shape[0]
+    d = torch.from_numpy(bs).cuda()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda'); num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    ws = torch.zeros(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.rnms_bev(vp(d), n, thr, vp(keep), vp(num), vp(ws), None) == 0
+    torch.cuda.synchronize()
+    cb = (n + 63) // 64
+    off = (n * 64 + 255) // 256 * 256
+    mask = ws[off:off + n * cb * 8].cpu().numpy().view(np.uint64).reshape(n, cb)
+    upper = np.arange(cb)[None, :] >= np.arange(n)[:, None] // 64
+    return mask, upper, keep[:int(num.item())].cpu().numpy()
+
+
+@pytest.mark.parametrize('n,thr,kind', [
+    (2900, 0.25, 'clutter'),    # 64 rows per wave (>= 1024 block pairs), several 16-row chunks per wave
+    (1500, 0.3, 'pile'),        # hundreds of boxes on one spot: chunks overflow 64 candidates, remainders are carried
+    (200, 0.5, 'same'),         # every pair is a candidate and a hit: full queue in every chunk
+    (450, -0.5, 'clutter'),     # negative threshold: IoU 0 of far-apart pairs is a hit too (all-pairs mode)
+    (450, float('nan'), 'clutter'),  # NaN threshold: nothing is ever suppressed
+])
+def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
+    """The rotated mask kernel packs the pairs that survive the bounding-circle test densely before clipping them
+    (nms_mask_compact_kernel): queue overflow / carry, 8-64 rows per wave and the thresholds for which a far-apart pair
+    is NOT a non-hit must all give the oracle's words."""
+    boxes, scores = nms_boxes(n, seed=n, clutter=(kind != 'same'))
+    if kind == 'pile':
+        boxes[: n // 2] = boxes[0] + np.random.default_rng(5).normal(0, 0.05, (n // 2, 5)).astype(np.float32)
+    if kind == 'same':
+        boxes[:] = boxes[0]
+    order = np.argsort(-scores, kind='stable')
+    bs = np.ascontiguousarray(boxes[order])
+    want = oracle.nms_mask(bs, thr)
+    mask, upper, keep = _mask_words(amd, bs, thr)
+    np.testing.assert_array_equal(mask[upper], want[upper])
+    want_keep = oracle.nms_gpu_oracle(boxes, scores, thr)
+    got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
+    np.testing.assert_array_equal(got.cpu().numpy(), want_keep)
+
+
 def test_nms_normal(amd):
     boxes, scores = nms_boxes(2000, seed=4)
     want = oracle.nms_gpu_oracle(boxes, scores, 0.3, normal=True)
