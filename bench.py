@@ -13,7 +13,8 @@ the timed region.  value = (3 losses x pairs x steps x ranks) / max-over-ranks w
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), pairs sharded by rank with no
 data-path collective; once per step the three per-shard loss values are all-gathered (3 fp32 per rank),
-asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs.
+asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs
+(`--strong`: 10 M pairs in TOTAL, contiguous row ranges per rank — SURVEY.md §8e asks for both).
 
 Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the timed region carries its own HIP event pair
 (gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no marker packets):
@@ -92,6 +93,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--pairs', type=int, default=10_000_000, help='pairs per GPU (default: BASELINE config 3)')
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: --pairs is the TOTAL, split into contiguous row ranges over the ranks '
+                         '(SURVEY.md §8e; default is weak scaling, --pairs per GPU)')
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
@@ -120,7 +124,10 @@ def main():
     from mmdet3d_gaussian_amd import gd_loss as gdl
     amd.load_library()
 
-    n = args.pairs
+    if args.strong:   # contiguous row range [r N/G, (r+1) N/G) of the total
+        n = args.pairs * (rank + 1) // world - args.pairs * rank // world
+    else:
+        n = args.pairs
     pred0, tgt = synthetic_pairs(n, seed=rank, device=dev)
     # one leaf per loss (same values): the step calls backward() ONCE on the sum of the three losses, as a training
     # step does with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations
@@ -239,10 +246,12 @@ def main():
                   'right after the graph-replayed timed region')
 
     # dominant-kernel durations from the HIP events recorded inside the timed region
-    kern_ms = {}
+    kern_ms, kern_med, kern_min = {}, {}, {}
     for lt in LOSSES:
-        d = [tm.elapsed_ms() for tm in events[lt]]
+        d = sorted(tm.elapsed_ms() for tm in events[lt])
         kern_ms[lt] = sum(d) / max(len(d), 1)
+        kern_med[lt] = d[len(d) // 2] if d else 0.0
+        kern_min[lt] = d[0] if d else 0.0
     if use_dist:
         total, per_rank = last['pending'].result()   # (3,), (world, 3)
         vals = (total / world).tolist()               # mean over ranks of per-rank means (equal shard sizes)
@@ -251,7 +260,7 @@ def main():
     losses = dict(zip(LOSSES, vals))
 
     if rank == 0:
-        total_pairs = 3 * n * args.steps * world
+        total_pairs = 3 * (args.pairs if args.strong else n * world) * args.steps
         value = total_pairs / elapsed / 1e6
         dom = max(LOSSES, key=lambda k: kern_ms[k])          # slowest of the three fused kernels
         dom_s = kern_ms[dom] * 1e-3
@@ -268,8 +277,10 @@ def main():
             'metric': 'M box-pairs/sec (fwd+bwd) for GWD/KLD/BCD @10M pairs',
             'value': round(value, 2), 'unit': 'M box-pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{n} synthetic anchor x gt 7-dof box pairs per GPU (BASELINE configs[2]); '
+            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': (f'{args.pairs} synthetic anchor x gt 7-dof box pairs in total, row ranges of {n} per GPU '
+                                    if args.strong else
+                                    f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward over the whole batch '
                                    '(one autograd backward() of the summed losses; fun=log1p, tau=1, reduction=mean, '
                                    'loss_weight=5)',
@@ -283,6 +294,8 @@ def main():
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR, 'timing': timing,
                          'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
+                         'kernel_ms_median': {k: round(v, 4) for k, v in kern_med.items()},
+                         'kernel_ms_min': {k: round(v, 4) for k, v in kern_min.items()},
                          'mpairs_per_s_kernel': {k: round(n / (v * 1e-3) / 1e6, 1) if v > 0 else None
                                                  for k, v in kern_ms.items()}},
             'loss_values': {k: round(v, 6) for k, v in losses.items()},

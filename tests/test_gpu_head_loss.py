@@ -230,6 +230,41 @@ def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd):
                                   anchors.cuda(), C, 9.0)
 
 
+def test_anchor_head_bbox_loss_dense_replays_as_a_hipgraph(amd):
+    """The dense form (label test inside the kernel) has static shapes and no host sync, so loss_bbox fwd + bwd can be
+    captured once and replayed with new head outputs / labels in the same buffers: same bits as the eager call."""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(3)
+    lt, kw, sl1, cw, dw, sin = SL1_CASES[0]
+    mod = amd.GDLoss(lt, loss_weight=5.0, **kw)
+    bp = bbox_pred.cuda().requires_grad_(True)
+    bt, bw, lb, an = bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(), anchors.cuda()
+    avg = 37.0                                        # baked into the captured launch (kernel argument)
+
+    def step():
+        bp.grad = None
+        out = amd.anchor_head_bbox_loss(mod, sl1, bp, bt, bw, lb, an, C, avg, code_weight=cw, decode_weight=dw,
+                                        diff_rad_by_sin=sin, dense=True)
+        out.backward()
+        return out.detach(), bp.grad
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        l_g, g_g = step()
+    with torch.no_grad():                              # next "iteration": new predictions and labels, same buffers
+        bp.add_(0.05 * torch.randn_like(bp))
+        lb.copy_(lb.roll(7, dims=-1))
+    graph.replay(); torch.cuda.synchronize()
+    l_rep, g_rep = l_g.clone(), g_g.clone()
+    l_new, g_new = step()
+    torch.cuda.synchronize()
+    assert torch.equal(l_rep, l_new) and torch.equal(g_rep, g_new)
+    assert l_new.item() != 0.0 and g_new.abs().max().item() > 0.0
+
+
 @pytest.mark.parametrize('lt,kw,vel,reg', [('gwd3d', dict(fun='log1p', tau=0.0), True, True),
                                            ('bd3d', dict(fun='log1p', tau=1.0), True, False),
                                            ('kld3d', dict(fun='none', tau=0.0), False, True),
