@@ -21,9 +21,9 @@ Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the time
 with one backward() per step the host needs 190-300 us per step against 440-460 us of GPU time (one backward per loss
 cost ~60 us of autograd-engine thread hand-off each and made the step host-bound on boxes with busy host cores).
 N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~20 us/step) so that the per-step collective call
-cannot make the host the limit; HIP events cannot be recorded inside a captured graph on ROCm, so there every REPLAY is
-bracketed by an event pair in the timed region (`config.gpu_ms_per_step_events`) and the per-kernel durations come from
-an eager pass run right after it, same stream, same process (`roofline.timing` says which).  `--graph` / `--no-graph`
+cannot make the host the limit; HIP events cannot be bound inside a captured graph on ROCm, so there the per-kernel
+durations come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says
+which), followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph`
 override; on one MI355X both modes give the same step time within 1 %.
 
 The JSON line also carries
@@ -142,7 +142,8 @@ def main():
 
     def compute(record):
         """gwd3d, kld3d, bd3d: GDLoss forward each, then autograd backward of their sum (every loss's fused kernel has
-        already produced its gradient; backward runs the three scale launches).  Returns the 3 detached loss scalars."""
+        already produced its gradient; backward runs the three scale launches).  Returns the 3 detached loss scalars
+        (N > 1: stacked into the (3,) tensor the per-step collective sends — inside the captured graph)."""
         losses_ = []
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if record else None
@@ -150,7 +151,8 @@ def main():
             losses_.append(mods[lt](preds[lt], tgt))
         gdl.PROFILE_EVENTS = None
         (losses_[0] + losses_[1] + losses_[2]).backward()
-        return [l.detach() for l in losses_]
+        outs = [l.detach() for l in losses_]
+        return torch.stack(outs) if use_dist else outs
 
     graph = None
     graph_note = None
@@ -178,23 +180,14 @@ def main():
                 graph = None
                 graph_note = 'hipGraph capture failed on another rank; eager launches'
 
-    step_events = []
-
     def step(record):
         if graph is None:
             outs = compute(record)
         else:
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                graph.replay()
-                e1.record()
-                step_events.append((e0, e1))
-            else:
-                graph.replay()
+            graph.replay()   # nothing else enters the stream: no event brackets (marker packets) in the timed region
             outs = graph_outs
         if use_dist:  # one tiny collective per step: (3,) shard losses -> (world, 3)
-            last['pending'] = amd.sharded.gather_shard_losses(torch.stack(outs), async_op=True)
+            last['pending'] = amd.sharded.gather_shard_losses(outs, async_op=True)
         else:
             last['outs'] = outs
 
@@ -217,13 +210,11 @@ def main():
             torch.cuda.synchronize(dev)
             for lt in LOSSES:
                 events[lt].clear()
-            step_events.clear()
     for _ in range(args.warmup):
         step(True)
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
-    step_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -238,10 +229,18 @@ def main():
         elapsed = tt.item()
     timing = ('HIP event pair bound to every fused dispatch inside the timed region (hipExtLaunchKernel start/stop events: '
               'begin/end timestamps of the dispatch itself, no marker packets)')
+    replay_ms = None
     if graph is not None:  # events cannot be bound inside a captured graph on ROCm: eager pass right after
         for _ in range(min(args.steps, 10)):
             compute(True)
         torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(min(args.steps, 10)):   # GPU time of the bare replays (no collective), after the timed region
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        replay_ms = e0.elapsed_time(e1) / min(args.steps, 10)
         timing = ('HIP event pair bound to every fused dispatch (hipExtLaunchKernel start/stop events), eager pass run '
                   'right after the graph-replayed timed region')
 
@@ -288,8 +287,7 @@ def main():
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
-                       'gpu_ms_per_step_events': (round(sum(a.elapsed_time(b) for a, b in step_events) /
-                                                        max(len(step_events), 1), 4) if step_events else None)},
+                       'graph_replay_ms_per_step': round(replay_ms, 4) if replay_ms is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR, 'timing': timing,

@@ -46,18 +46,18 @@ class _GatherSum(torch.autograd.Function):
 class PendingGather:
     """Handle of an in-flight all_gather of shard losses; `.result()` joins it."""
 
-    def __init__(self, parts, work):
-        self._parts = parts
+    def __init__(self, gathered, work):
+        self._gathered = gathered   # (world, ...) — row r = rank r's shard loss(es)
         self._work = work
 
     def result(self):
         if self._work is not None:
             self._work.wait()  # stream-ordered on GPU backends: the host does not block
             self._work = None
-        shard_losses = torch.stack(self._parts)
-        total = self._parts[0].clone()
-        for p in self._parts[1:]:
-            total = total + p
+        shard_losses = self._gathered
+        total = shard_losses[0].clone()
+        for r in range(1, shard_losses.shape[0]):
+            total = total + shard_losses[r]  # fixed rank order: identical bits on every rank
         return total, shard_losses
 
 
@@ -65,12 +65,14 @@ def gather_shard_losses(local_loss, group=None, async_op=True):
     """Start the all_gather of this rank's (detached) shard loss — a scalar, or a small vector when several losses
     share one collective.  Returns a PendingGather whose result() is (sum over ranks, per-rank stack)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return PendingGather([local_loss.detach().clone()], None)
+        return PendingGather(local_loss.detach().clone().unsqueeze(0), None)
     world = dist.get_world_size(group)
     local = local_loss.detach().contiguous()
-    parts = [torch.empty_like(local) for _ in range(world)]
-    work = dist.all_gather(parts, local, group=group, async_op=async_op)
-    return PendingGather(parts, work if async_op else None)
+    # one output tensor, one collective kernel (the list form of all_gather adds `world` copy kernels per call)
+    flat = local.reshape(-1)    # 1-D in, (world * k) out: the layout every backend accepts (gloo rejects 0-dim inputs)
+    gathered = torch.empty(world * flat.numel(), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(gathered, flat, group=group, async_op=async_op)
+    return PendingGather(gathered.view((world,) + tuple(local.shape)), work if async_op else None)
 
 
 class ShardedGDLoss(torch.nn.Module):
