@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
 // operands in greedy order (box j first, box i second — bit for bit what row j's wave computes for its lane i), so the
 // ballot also yields "which earlier boxes of my block suppress box i".  That word goes to colm[i]; the scan resolves a
 // 64-box block from these column words in a few wave-parallel steps instead of one scalar step per kept box.
-// (Rotated boxes went through this kernel too until the compacted form below replaced it: n = 4096 99 -> 42 us,
-// n = 9000 293 -> 117 us, n = 1000 25 -> 23.5 us, same mask bits.)
+// (Rotated boxes went through this kernel too until the compacted form below replaced it: n = 4096 99 -> 29 us,
+// n = 9000 293 -> 97 us, n = 1000 25 -> 21 us, same mask bits.)
 template <int MODE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
                                                       unsigned long long* __restrict__ mask_,
@@ -192,16 +192,25 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
     bcy = B.cy;
     bext = fabsf(B.x2 - B.x1) + fabsf(B.y2 - B.y1);
   }
+  // lane r also holds row box i0 + r's centre / extent: the row loop reads them with v_readlane instead of one
+  // dependent scalar-load round trip per row (64 rows x ~500 cycles was most of phase 1)
+  float rcx = 0.0f, rcy = 0.0f, rext = 0.0f;
+  if (lane < nrows) {
+    const OBox& R = ob[i0 + lane];
+    rcx = R.cx;
+    rcy = R.cy;
+    rext = fabsf(R.x2 - R.x1) + fabsf(R.y2 - R.y1);
+  }
   words[lane] = 0ull;
   __syncthreads();
   int qn = 0;  // queued candidates (wave-uniform)
   for (int rbase = 0; rbase < nrows; rbase += CQ_ROWS) {
     const int rend = min(rbase + CQ_ROWS, nrows);
     for (int r = rbase; r < rend; ++r) {
-      const int i = i0 + r;  // wave-uniform -> scalar loads
-      const OBox& A = ob[i];
-      const float acx = A.cx, acy = A.cy;
-      const float aext = fabsf(A.x2 - A.x1) + fabsf(A.y2 - A.y1);
+      const int i = i0 + r;  // wave-uniform
+      const float acx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r));
+      const float acy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r));
+      const float aext = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r));
       bool cand = false;
       if (jv && j != i) {
         // box_overlap's early-out, same operations (it is symmetric in the two boxes)
@@ -600,10 +609,10 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   const long long pairs = (long long)a.cbs * (a.cbs + 1) / 2;
   int rows;
   if (mode == MODE_ROT) {
-    // compacted kernel: 8..64 rows per wave, as many as keep >= ~1 K waves in the grid (measured, mask kernel alone:
-    // n = 1000: 23.5 us at 8 rows, 40 at 64; n = 4096: 49 at 16, 42.5 at 32 / 64; n = 9000: 234 at 8, 117 at 64)
+    // compacted kernel: 8..64 rows per wave, as many as keep >= 256 waves in the grid (measured, mask kernel alone:
+    // n = 1000: 25 us at 8 rows, 21 at 32, 28 at 64; n = 4096: 47 at 16, 37 at 32, 29 at 64; n = 9000: 229 at 8, 97 at 64)
     rows = 64;
-    while (rows > 8 && pairs * G * (64 / rows) < 1024) rows /= 2;
+    while (rows > 8 && pairs * G * (64 / rows) < 256) rows /= 2;
   } else {
     rows = 1;
     while (rows < 8 && pairs * G * 64 / (rows * 2) >= 16384) rows *= 2;  // keep >= ~16 K waves in the grid

@@ -17,6 +17,10 @@
 namespace rbox {
 
 #define RB_DEV __device__ __forceinline__
+// phase stamps inside box_overlap for tools/clip_probe.hip (cycle accounting of one clipping pass); nothing in the product
+#ifndef RB_STAMP
+#define RB_STAMP(k) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ fixed-sequence fp32 math
 RB_DEV void fx_sincosf(float x, float& s, float& c) {
@@ -153,6 +157,7 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
     const float reach = 0.5f * (ra + rb) + 1e-2f;
     if (ddx * ddx + ddy * ddy > reach * reach * 1.0001f) return 0.0f;
   }
+  RB_STAMP(1);
   float pcx = 0.0f, pcy = 0.0f;
   int cnt = 0;
 #pragma unroll
@@ -169,6 +174,7 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
       }
     }
   }
+  RB_STAMP(2);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (in_box(A, B.c[k]) && cnt < 16) {
@@ -186,10 +192,12 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
       ++cnt;
     }
   }
+  RB_STAMP(3);
   if (cnt == 0) return 0.0f;
   pcx = pcx / (float)cnt;
   pcy = pcy / (float)cnt;
   for (int k = 0; k < cnt; ++k) vs.a[k][t] = fx_atan2f(vs.y[k][t] - pcy, vs.x[k][t] - pcx);
+  RB_STAMP(4);
   for (int j = 0; j < cnt - 1; ++j)
     for (int i = 0; i < cnt - j - 1; ++i) {
       const float a0 = vs.a[i][t], a1 = vs.a[i + 1][t];
@@ -203,6 +211,7 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
         vs.a[i + 1][t] = a0;
       }
     }
+  RB_STAMP(5);
   float area = 0.0f;
   const float x0 = vs.x[0][t], y0 = vs.y[0][t];
   for (int k = 0; k < cnt - 1; ++k) {
@@ -210,6 +219,7 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
     const float bx = vs.x[k + 1][t] - x0, by = vs.y[k + 1][t] - y0;
     area = area + (ax * by - ay * bx);
   }
+  RB_STAMP(6);
   return fabsf(area) / 2.0f;
 }
 
