@@ -41,18 +41,16 @@ RB_DEV void fx_sincosf(float x, float& s, float& c) {
   c = cv;
 }
 
+// atan2 as select chains instead of branches: every candidate value is computed with the operations of the branch it
+// belongs to (so the selected one is bit-identical to the branchy evaluation; divisions by zero on untaken candidates
+// produce inf / NaN that are discarded), and independent evaluations can overlap in the pipeline — a lone wave spent
+// ~680 dependent-issue cycles per call on the branchy form (tools/clip_probe.hip).
 RB_DEV float fx_atanf_pos(float t) {
-  float y0, x;
-  if (t > 2.414213562373095f) {
-    y0 = 1.5707963267948966f;
-    x = -(1.0f / t);
-  } else if (t > 0.4142135623730950f) {
-    y0 = 0.7853981633974483f;
-    x = (t - 1.0f) / (t + 1.0f);
-  } else {
-    y0 = 0.0f;
-    x = t;
-  }
+  const bool hi = t > 2.414213562373095f, mid = t > 0.4142135623730950f;
+  const float x_hi = -(1.0f / t);
+  const float x_mid = (t - 1.0f) / (t + 1.0f);
+  const float y0 = hi ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+  const float x = hi ? x_hi : (mid ? x_mid : t);
   const float z = x * x;
   const float p =
       (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
@@ -61,15 +59,13 @@ RB_DEV float fx_atanf_pos(float t) {
 
 RB_DEV float fx_atan2f(float y, float x) {
   const float PI_F = 3.14159265358979323846f;
-  if (x == 0.0f) {
-    if (y > 0.0f) return 1.5707963267948966f;
-    if (y < 0.0f) return -1.5707963267948966f;
-    return 0.0f;
-  }
   const float t = y / x;
-  float a = t < 0.0f ? -fx_atanf_pos(-t) : fx_atanf_pos(t);
-  if (x < 0.0f) a = (y < 0.0f) ? a - PI_F : a + PI_F;
-  return a;
+  const float ap = fx_atanf_pos(t < 0.0f ? -t : t);
+  float a = t < 0.0f ? -ap : ap;
+  const float shifted = (y < 0.0f) ? a - PI_F : a + PI_F;
+  a = (x < 0.0f) ? shifted : a;
+  const float axis = (y > 0.0f) ? 1.5707963267948966f : ((y < 0.0f) ? -1.5707963267948966f : 0.0f);
+  return (x == 0.0f) ? axis : a;
 }
 
 // ------------------------------------------------------------------ part 1: iou3d overlap
@@ -196,6 +192,62 @@ RB_DEV float box_overlap(const OBox& A, const OBox& B, VertexScratch<NT>& vs, in
   if (cnt == 0) return 0.0f;
   pcx = pcx / (float)cnt;
   pcy = pcy / (float)cnt;
+  // Fast path for <= 8 vertices (two convex quadrilaterals meet in at most 8 points; more only arise when a point is
+  // collected both as an intersection and as a corner): the reference sequence — angle of every vertex about the
+  // centroid, STABLE bubble sort by angle, fan area in sorted order — evaluated on registers.  The 8 angle evaluations
+  // are independent (a lone wave otherwise spends ~680 dependent-issue cycles per vertex, tools/clip_probe.hip), the sort
+  // is a 19-exchange network on the key (angle, collection index) — a strict total order, so the network yields exactly
+  // the permutation the stable bubble sort does, ties and +-0 included — and the area sum runs in that order with the
+  // reference's operations.  A NaN angle (NaN / inf input boxes) has no place in a total order: those pairs, and the
+  // ones with more than 8 vertices, take the literal sequence on the LDS arrays below.
+  if (cnt <= 8) {
+    float X[8], Y[8], K[8];
+    int I[8];
+    bool ordered = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      X[k] = vs.x[k][t];  // slots >= cnt hold stale values: keyed +inf below, never used by the area
+      Y[k] = vs.y[k][t];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float ang = fx_atan2f(Y[k] - pcy, X[k] - pcx);
+      const bool valid = k < cnt;
+      ordered = ordered && !(valid && ang != ang);
+      K[k] = valid ? ang : __builtin_inff();
+      I[k] = k;
+    }
+    if (ordered) {
+#define RB_CE(i, j)                                                          \
+  {                                                                          \
+    const bool sw = (K[i] > K[j]) || (K[i] == K[j] && I[i] > I[j]);          \
+    const float ka = K[i], xa = X[i], ya = Y[i];                             \
+    const int ia = I[i];                                                     \
+    K[i] = sw ? K[j] : ka;  X[i] = sw ? X[j] : xa;  Y[i] = sw ? Y[j] : ya;  I[i] = sw ? I[j] : ia; \
+    K[j] = sw ? ka : K[j];  X[j] = sw ? xa : X[j];  Y[j] = sw ? ya : Y[j];  I[j] = sw ? ia : I[j]; \
+  }
+      RB_CE(0, 2) RB_CE(1, 3) RB_CE(4, 6) RB_CE(5, 7)
+      RB_CE(0, 4) RB_CE(1, 5) RB_CE(2, 6) RB_CE(3, 7)
+      RB_CE(0, 1) RB_CE(2, 3) RB_CE(4, 5) RB_CE(6, 7)
+      RB_CE(2, 4) RB_CE(3, 5)
+      RB_CE(1, 4) RB_CE(3, 6)
+      RB_CE(1, 2) RB_CE(3, 4) RB_CE(5, 6)
+#undef RB_CE
+      RB_STAMP(4);
+      RB_STAMP(5);
+      float area = 0.0f;
+      const float x0 = X[0], y0 = Y[0];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float ax = X[k] - x0, ay = Y[k] - y0;
+        const float bx = X[k + 1] - x0, by = Y[k + 1] - y0;
+        const float next = area + (ax * by - ay * bx);
+        area = (k < cnt - 1) ? next : area;
+      }
+      RB_STAMP(6);
+      return fabsf(area) / 2.0f;
+    }
+  }
   for (int k = 0; k < cnt; ++k) vs.a[k][t] = fx_atan2f(vs.y[k][t] - pcy, vs.x[k][t] - pcx);
   RB_STAMP(4);
   for (int j = 0; j < cnt - 1; ++j)
