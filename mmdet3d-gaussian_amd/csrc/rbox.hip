@@ -153,7 +153,12 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
 // selects the (earlier box, row box) pairs that are evaluated in greedy operand order for colm[] — as in the plain kernel.
 // A pair that fails the circle test has overlap exactly 0 and IoU +0, which is "> thresh" only for thresh < 0: for such a
 // threshold (or a NaN one) every valid pair is queued, so the result stays that of the plain kernel.
-constexpr int CQ_ROWS = 16;                 // rows per chunk between drains
+#ifndef MASK_STAMP   // tools/mask_probe.hip: cycle stamps of one wave of the mask kernel; nothing in the product
+#define MASK_STAMP(k) do { } while (0)
+#define MASK_NOTE(v) do { } while (0)
+#define MASK_STAMP_SYNC(k) do { } while (0)
+#endif
+constexpr int CQ_ROWS = 16;                 // rows per chunk between drains (<= 32: one bit per row in a lane's mask)
 constexpr int CQ_CAP = CQ_ROWS * 64 + 64;   // worst case of one chunk + the carried remainder (< 64)
 
 __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
   const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
   const int i0 = rb * 64 + r0;  // first row box of this wave
   if (i0 >= n) return;
+  MASK_STAMP(0);
   const int nrows = min(rows, n - i0);
   const int j = c * 64 + lane;
   const bool jv = j < n;
@@ -203,43 +209,73 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
   }
   words[lane] = 0ull;
   __syncthreads();
+  MASK_STAMP(1);
   int qn = 0;  // queued candidates (wave-uniform)
   for (int rbase = 0; rbase < nrows; rbase += CQ_ROWS) {
     const int rend = min(rbase + CQ_ROWS, nrows);
-    for (int r = rbase; r < rend; ++r) {
-      const int i = i0 + r;  // wave-uniform
+    // circle tests of the chunk, straight-line: lane l (column box j) tests itself against the chunk's 16 row boxes
+    // (centre / extent broadcast by v_readlane) and keeps ITS OWN 16-bit candidate mask — no ballot, no branch, no LDS
+    // in the loop, rows independent of each other.  (A per-row ballot + divergent queue append ran at ~310 cycles per
+    // row for a lone wave — mixed SALU/VALU dependencies and three branches per row — half of a wave's life.)
+    unsigned colbits = 0u;
+    const int jdiag = j - i0 - rbase;  // lane's column box IS row box (rbase + k)  <=>  k == jdiag
+#pragma unroll
+    for (int k = 0; k < CQ_ROWS; ++k) {
+      const int r = rbase + k;  // < 64 always; rows >= nrows are masked off below
       const float acx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r));
       const float acy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r));
       const float aext = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r));
-      bool cand = false;
-      if (jv && j != i) {
-        // box_overlap's early-out, same operations (it is symmetric in the two boxes)
-        const float ddx = acx - bcx, ddy = acy - bcy;
-        const float reach = 0.5f * (aext + bext) + 1e-2f;
-        cand = all_pairs || !(ddx * ddx + ddy * ddy > reach * reach * 1.0001f);
-      }
-      const unsigned long long cw = __ballot(cand);
-      if (cand) {
-        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(cw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cw, 0u));
-        queue[qn + (int)before] = (unsigned short)((r << 6) | lane);
-      }
-      qn += __popcll(cw);
+      // box_overlap's early-out, same operations (it is symmetric in the two boxes)
+      const float ddx = acx - bcx, ddy = acy - bcy;
+      const float reach = 0.5f * (aext + bext) + 1e-2f;
+      const bool near = !(ddx * ddx + ddy * ddy > reach * reach * 1.0001f);
+      colbits |= (near && k != jdiag) ? (1u << k) : 0u;
     }
+    if (all_pairs) colbits = ~(jdiag >= 0 && jdiag < CQ_ROWS ? (1u << jdiag) : 0u);
+    colbits &= (rend - rbase >= 32) ? 0xffffffffu : ((1u << (rend - rbase)) - 1u);
+    if (!jv) colbits = 0u;
+    // queue append in bulk: inclusive scan of the 64 per-lane counts on the DPP network, then every lane walks the set
+    // bits of its own mask (a handful at detector densities)
+    const int cntl = __popc(colbits);
+    int incl = cntl;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1 (out-of-row reads 0)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    {
+      unsigned w = colbits;
+      int pos = qn + incl - cntl;
+      while (w != 0u) {
+        const int k = __builtin_ctz(w);
+        w &= w - 1u;
+        queue[pos++] = (unsigned short)(((rbase + k) << 6) | lane);
+      }
+    }
+    qn += __builtin_amdgcn_readlane(incl, 63);
+    MASK_NOTE(__builtin_amdgcn_readlane(incl, 63));
     __syncthreads();
+    MASK_STAMP(2 + 2 * (rbase / CQ_ROWS));
     const bool last = rend >= nrows;
     int done = 0;
     while (qn - done >= 64 || (last && done < qn)) {
       const int q = done + lane;
+      MASK_STAMP(10);
       if (q < qn) {
         const int e = queue[q];
         const int r = e >> 6, jl = e & 63;
         const int i = i0 + r, jj = c * 64 + jl;
         const OBox A = ob[i];
         const OBox B = ob[jj];
+        MASK_STAMP_SYNC(11);
         const bool low = jj < i;  // diagonal block only: the lane's box precedes the row box -> it goes first
         const OBox F = low ? B : A, S = low ? A : B;
-        if (iou_bev<64>(F, S, vs, lane) > thresh) atomicOr(&words[r], 1ull << jl);
+        const bool hit = iou_bev<64>(F, S, vs, lane) > thresh;
+        MASK_STAMP_SYNC(12);
+        if (hit) atomicOr(&words[r], 1ull << jl);
       }
+      MASK_STAMP_SYNC(13);
       done += 64;
     }
     if (!last && done > 0) {  // carry the < 64 leftover candidates to the front of the queue
@@ -251,6 +287,7 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
       qn = rem;
     }
     __syncthreads();
+    MASK_STAMP(3 + 2 * (rbase / CQ_ROWS));
   }
   if (lane < nrows) {
     const int i = i0 + lane;

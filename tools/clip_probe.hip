@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void probe(const float* __restrict__ a, const f
   out[p] = acc;
 }
 
-int main() {
+int run(int mode) {
   const int waves = 4096, n = waves * 64;
   std::vector<float> ha(n * 5), hb(n * 5);
   unsigned s = 12345u;
@@ -38,7 +38,10 @@ int main() {
   for (int i = 0; i < n; ++i) {  // car-sized boxes, the second one a jittered copy: 8 intersection vertices typically
     const float x = rnd() * 100.f, y = rnd() * 100.f, w = 4.5f + rnd() * 0.5f, h = 2.f + rnd() * 0.2f, r = rnd() * 6.28f - 3.14f;
     ha[i * 5 + 0] = x - w / 2; ha[i * 5 + 1] = y - h / 2; ha[i * 5 + 2] = x + w / 2; ha[i * 5 + 3] = y + h / 2; ha[i * 5 + 4] = r;
-    const float dx = rnd() * 0.6f - 0.3f, dy = rnd() * 0.6f - 0.3f, dr = rnd() * 0.3f - 0.15f;
+    // mode 0: jittered copies (coherent lanes, 8 vertices each); mode 1: what a queue of circle-test survivors looks
+    // like — shifts up to +-2.5 m, any relative yaw, a third of the pairs not overlapping at all
+    const float sh = mode ? 5.0f : 0.6f, ro = mode ? 3.0f : 0.3f;
+    const float dx = rnd() * sh - sh / 2, dy = rnd() * sh - sh / 2, dr = rnd() * ro - ro / 2;
     hb[i * 5 + 0] = x + dx - w / 2; hb[i * 5 + 1] = y + dy - h / 2; hb[i * 5 + 2] = x + dx + w / 2; hb[i * 5 + 3] = y + dy + h / 2;
     hb[i * 5 + 4] = r + dr;
   }
@@ -53,7 +56,7 @@ int main() {
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(rb_stamps), sizeof(st)));
   const char* names[8] = {"", "circle early-out", "16 segment intersections", "8 corner-in-box tests", "angles (atan2)", "bubble sort",
                           "fan area", "IoU division"};
-  printf("lone wave, 64 live lanes, s_memtime ticks per phase (total %lld):\n", st[7] - st[0]);
+  printf("%s pairs — lone wave, 64 live lanes, s_memtime ticks per phase (total %lld):\n", mode ? "diverse" : "jittered-copy", st[7] - st[0]);
   for (int k = 1; k < 8; ++k) printf("  %-26s %8lld\n", names[k], st[k] - st[k - 1]);
   // (2) wall time of one pass: a single wave vs enough waves to fill the chip
   hipEvent_t e0, e1;
@@ -70,5 +73,8 @@ int main() {
       printf("grid %5d waves x %d pass(es): %8.2f us per launch\n", g, reps, ms / 20 * 1e3);
     }
   }
+  CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
   return 0;
 }
+
+int main() { return run(0) || run(1); }
