@@ -24,7 +24,7 @@ def amd():
 
 @pytest.mark.parametrize('n,thr,clutter', [(1, 0.25, True), (2, 0.25, True), (63, 0.25, True), (64, 0.01, True),
                                            (65, 0.25, True), (129, 0.5, False), (1000, 0.2, True), (4096, 0.25, True),
-                                           (4096, 0.01, False), (9000, 0.7, True)])
+                                           (4096, 0.01, False), (9000, 0.7, True), (20000, 0.5, True)])
 def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
     boxes, scores = nms_boxes(n, seed=n + int(thr * 100), clutter=clutter)
     want = oracle.nms_gpu_oracle(boxes, scores, thr)
