@@ -21,7 +21,7 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
 # context measurements (not bench lines): HBM ceilings, NMS, small-P / head-level train-step slices
-[ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
+python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
 python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
