@@ -267,6 +267,20 @@ int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
 int rnms_normal_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep,
                     int64_t* num_keep, void* workspace, void* stream);
 
+/* The whole `nms_gpu` body in one call for up to rnms_scored_max_n() (= 16384) candidates — the heads cut to nms_pre
+ * before they call it.  The score order (descending, ties by ascending index, NaN first: what
+ * torch.sort(descending=True, stable=True) yields) is obtained by COUNTING, for every box, the boxes with a larger
+ * (score, -index) key — parallel over the whole chip, no sort — and the per-box prep is scattered straight to its rank;
+ * the `pre_max` cut (pre_max < 0: none) keeps ranks < pre_max.  Mask and scan follow as in rnms_bev_ordered.
+ *   boxes (n_all,5) fp32, scores (n_all) fp32; keep (min(n_all, pre_max)) int64 receives indices into `boxes` by
+ *   descending score; num_keep (1) int64; workspace: rnms_scored_workspace_bytes(n_all, min(n_all, pre_max)).
+ *   normal != 0: axis-aligned IoU (nms_normal_gpu).  n_all > rnms_scored_max_n(): GD3D_E_TOOLARGE (sort outside and
+ *   call rnms_bev_ordered). */
+int rnms_scored_max_n(void);
+size_t rnms_scored_workspace_bytes(int64_t n_all, int64_t n_keep);
+int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t n_all, int64_t pre_max, float thresh,
+                int64_t* keep, int64_t* num_keep, void* workspace, void* stream);
+
 /* Same, taking the UNSORTED boxes plus the score order (what `scores.sort(descending=True)` returns, already cut to
  * pre_max_size): box i of the NMS is boxes[order[i]], and `keep` receives indices into the caller's original box
  * numbering (= order[kept]) — the gather before and the index mapping after the call disappear.

@@ -55,6 +55,76 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
   out[(size_t)g * a.cap + i] = o;
 }
 
+// Score order + prep without torch.sort, for up to RANK_MAX candidates (the heads cut to nms_pre before they call nms_gpu).
+// Order = scores descending, ties by ascending index, NaN scores first: what torch.sort(descending=True, stable=True)
+// yields.  Every box gets one UNIQUE 64-bit key — (order-preserving map of the float) << 32 | ~index — so its position
+// in the order is simply the number of larger keys.  That count is embarrassingly parallel (a single-workgroup bitonic
+// sort of 4096 keys is LDS-bandwidth-bound at ~50 us; rocPRIM's radix sort behind torch.sort takes 16-24 us + launches):
+//   rank_count_kernel   grid (ceil(n/64), P): 64 boxes (lanes) x one 1/P slice of all keys, a quarter of the slice per
+//                       wave; partial counts go to prank[slice][box] — no atomics, deterministic;
+//   rank_scatter_kernel thread i sums its P partial counts = its rank r; if r < n_keep: order[r] = i and, for rotated
+//                       NMS, the OBox record of box i is written to slot r (this IS the prep kernel, scattered).
+constexpr int RANK_MAX = 16384;
+constexpr int RANK_SLICE = 256;   // keys per slice (64 per wave: one register chunk)
+
+__device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
+  unsigned u = __float_as_uint(s);
+  if (s != s) u = 0xffffffffu;              // any NaN: greatest
+  else {
+    if (u == 0x80000000u) u = 0u;           // -0.0 == +0.0 for the comparison torch.sort makes
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+
+__global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores, int n, int* __restrict__ prank) {
+  __shared__ int spart[4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int part = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = quarter of the slice
+  const int j0 = blockIdx.y * RANK_SLICE, j1 = min(j0 + RANK_SLICE, n);
+  const int i = blockIdx.x * 64 + lane;
+  const unsigned long long mine = i < n ? score_key(scores[i], (unsigned)i) : ~0ull;
+  const int len = j1 - j0, q = (len + 3) >> 2;
+  const int b = j0 + part * q, e = min(b + q, j1);
+  int cnt = 0;
+  // 64 keys at a time: lane l builds key b+l in registers, the 64 of them are broadcast by v_readlane (a loop over an LDS
+  // copy paid one dependent LDS round trip per key: 15 us per launch)
+  for (int jb = b; jb < e; jb += 64) {
+    const int j = jb + lane;
+    const unsigned long long kj = j < e ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
+    const unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      const unsigned long long kk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, t) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)klo, t);
+      cnt += kk > mine ? 1 : 0;
+    }
+  }
+  spart[part][lane] = cnt;
+  __syncthreads();
+  if (tid < 64 && i < n) prank[(size_t)blockIdx.y * n + i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
+}
+
+template <bool PREP>
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const int* __restrict__ prank,
+                                                          int n, int slices, int n_keep, long long* __restrict__ order,
+                                                          OBox* __restrict__ ob) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int r = 0;
+  for (int s2 = 0; s2 < slices; ++s2) r += prank[(size_t)s2 * n + i];
+  if (r >= n_keep) return;
+  order[r] = (long long)i;
+  if (PREP) {
+    float b[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)i * 5 + q];
+    OBox o;
+    obox_make(b, o);
+    ob[r] = o;
+  }
+}
+
 // Axis-aligned and circle NMS (cheap predicates, no polygon scratch): one WAVE per (row box i, 64-box column block
 // c >= block of i): lane l tests box i against box 64c + l and the wave-wide ballot IS the 64-bit mask word — no partial
 // words, no barrier.  A wave walks `rows` (1, 2, 4 or 8; host-chosen) consecutive row boxes against the same 64 column
@@ -624,7 +694,7 @@ size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
 // shared by the single and the batched entry points: G groups of up to `cap` boxes
 static int rnms_launch(int mode, const float* boxes, const int64_t* order, const int32_t* counts, int32_t G, int64_t cap,
                        float thresh, double thresh_d, const float* thresh_dev, int64_t* keep, int64_t* num_keep,
-                       void* workspace, void* stream) {
+                       void* workspace, void* stream, bool prepped = false) {
   hipStream_t s = (hipStream_t)stream;
   if (cap > RNMS_MAX_N) return GD3D_E_TOOLARGE;
   if (G > 65535) return GD3D_E_TOOLARGE;
@@ -658,7 +728,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   if (pairs * (64 / rows) > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const dim3 mgrid((unsigned)(pairs * (64 / rows)), (unsigned)G);
   if (mode == MODE_ROT) {
-    hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
+    if (!prepped) hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
     hipLaunchKernelGGL(nms_mask_compact_kernel, mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else if (mode == MODE_NORMAL) {
     hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
@@ -707,6 +777,43 @@ int rnms_circle_ordered(const float* xy, const int64_t* order, int64_t n, double
 int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep, void* workspace,
              void* stream) {
   return rnms_impl(MODE_ROT, boxes_sorted, nullptr, n, thresh, 0.0, keep, num_keep, workspace, stream);
+}
+
+int rnms_scored_max_n(void) { return RANK_MAX; }
+
+static int64_t rank_slices(int64_t n_all) { return (n_all + RANK_SLICE - 1) / RANK_SLICE; }
+
+size_t rnms_scored_workspace_bytes(int64_t n_all, int64_t n_keep) {
+  if (n_all < 1) n_all = 1;
+  if (n_keep < 1) n_keep = 1;
+  return align_up(rnms_workspace_bytes(n_keep), 256) + align_up((size_t)n_keep * sizeof(int64_t), 256) +
+         (size_t)rank_slices(n_all) * (size_t)n_all * sizeof(int);
+}
+
+int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t n_all, int64_t pre_max, float thresh,
+                int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  if (n_all < 0 || num_keep == nullptr) return GD3D_E_BADARG;
+  if (n_all > RANK_MAX) return GD3D_E_TOOLARGE;
+  const int64_t n = (pre_max >= 0 && pre_max < n_all) ? pre_max : n_all;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), s);
+  if (boxes == nullptr || scores == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
+  int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
+  const int slices = (int)rank_slices(n_all);
+  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores, (int)n_all,
+                     prank);
+  const dim3 sg((unsigned)((n_all + 255) / 256));
+  if (normal)
+    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const int*)prank, (int)n_all, slices, (int)n,
+                       order, (OBox*)workspace);
+  else
+    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const int*)prank, (int)n_all, slices, (int)n,
+                       order, (OBox*)workspace);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
+                     num_keep, workspace, stream, /*prepped=*/true);
 }
 
 int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,

@@ -41,27 +41,52 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
     if scores.shape[0] != boxes.shape[0]:
         raise RuntimeError(f'{name}: {boxes.shape[0]} boxes but {scores.shape[0]} scores')
     lib = _lib.load()
-    order = scores.sort(dim=0, descending=True, stable=True)[1]   # ties: lower index first (mmdet3d leaves them unspecified)
-    if pre_max_size is not None:
-        order = order[:pre_max_size]
-    order = order.contiguous()
-    n = order.shape[0]
     dev = boxes.device
+    n_all = boxes.shape[0]
+    if scores.device != dev:
+        raise RuntimeError(f'{name}: boxes and scores live on different devices')
+    if pre_max_size is not None and pre_max_size < 0:   # a negative slice bound, as `order[:pre_max_size]` would take it
+        pre_max_size = max(n_all + pre_max_size, 0)
+    n = n_all if pre_max_size is None else min(n_all, pre_max_size)
     if n == 0:
-        return order.new_zeros((0,))
+        return torch.zeros((0,), dtype=torch.int64, device=dev)
+    # up to 16384 candidates (the heads cut to nms_pre first) the library orders the scores itself (rank by counting, prep
+    # scattered to the rank: no torch.sort); float64 scores keep torch.sort (their order may differ after rounding to fp32)
+    fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
+                                                                                     torch.bfloat16)
     with torch.cuda.device(dev):
         keep = torch.empty(n, dtype=torch.int64, device=dev)
         num = torch.empty(1, dtype=torch.int64, device=dev)
-        ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        # the kernels read boxes[order[i]] themselves and emit kept indices in the caller's numbering
-        fn = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
-        _lib.check(fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
-                      ws.data_ptr(), torch.cuda.current_stream().cuda_stream), name)
+        stream = torch.cuda.current_stream().cuda_stream
+        if fused_sort:
+            sc = scores if scores.dtype == torch.float32 else scores.float()
+            sc = sc if sc.is_contiguous() else sc.contiguous()
+            ws = torch.empty(lib.rnms_scored_workspace_bytes(n_all, n), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rnms_scored(int(normal), boxes.data_ptr(), sc.data_ptr(), n_all, n, float(thresh), keep.data_ptr(),
+                                       num.data_ptr(), ws.data_ptr(), stream), name)
+        else:
+            order = scores.sort(dim=0, descending=True, stable=True)[1]   # ties: lower index first
+            order = order[:n].contiguous()
+            ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            # the kernels read boxes[order[i]] themselves and emit kept indices in the caller's numbering
+            fn = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
+            _lib.check(fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
+                          ws.data_ptr(), stream), name)
     k = int(num.item())  # the one unavoidable sync: the result length is data dependent
     keep = keep[:k]
     if post_max_size is not None:
         keep = keep[:post_max_size]
     return keep
+
+
+_SCORED_MAX = None
+
+
+def _scored_max(lib):
+    global _SCORED_MAX
+    if _SCORED_MAX is None:
+        _SCORED_MAX = int(lib.rnms_scored_max_n())
+    return _SCORED_MAX
 
 
 def nms_gpu(boxes, scores, thresh, pre_max_size=None, post_max_size=None, pre_maxsize=None):

@@ -120,6 +120,53 @@ def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
     np.testing.assert_array_equal(got.cpu().numpy(), want_keep)
 
 
+@pytest.mark.parametrize('n,pre,normal', [(1, None, False), (63, None, False), (64, 10, False), (65, None, True), (1000, 500, False),
+                                          (2049, None, False), (4096, None, False), (4096, 1000, True), (3000, 0, False),
+                                          (9000, 4096, False), (16384, 2000, False), (16385, 2000, False)])
+def test_nms_fused_score_sort_equals_torch_sort_path(amd, n, pre, normal):
+    """Up to 16384 candidates the library orders the scores itself (rank by counting, prep scattered to the rank): the kept
+    indices must equal those of the torch.sort(descending, stable) + rnms_*_ordered path, for ties, +-0, infinities and
+    NaN scores too; one box more takes the torch.sort path inside nms_gpu."""
+    import ctypes
+    lib = amd.load_library()
+    boxes, scores = nms_boxes(n, seed=3 * n + 1)
+    rng = np.random.default_rng(n)
+    scores = np.round(scores, 2)                               # many exact ties
+    if n >= 64:
+        scores[rng.integers(0, n, 5)] = 0.0
+        scores[rng.integers(0, n, 5)] = -0.0
+        scores[rng.integers(0, n, 3)] = np.inf
+        scores[rng.integers(0, n, 3)] = -np.inf
+        scores[rng.integers(0, n, 4)] = np.nan
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    fn = amd.nms_normal_gpu if normal else amd.nms_gpu
+    got = fn(b, s, 0.3) if normal else fn(b, s, 0.3, pre_max_size=pre)
+    # reference path: torch's stable descending sort, then the ordered entry point
+    order = s.sort(dim=0, descending=True, stable=True)[1]
+    if pre is not None and not normal:
+        order = order[:pre]
+    order = order.contiguous()
+    m = order.shape[0]
+    if m == 0:
+        assert got.numel() == 0
+        return
+    keep = torch.empty(m, dtype=torch.int64, device='cuda'); num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    ws = torch.empty(lib.rnms_workspace_bytes(m), dtype=torch.uint8, device='cuda')
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    f2 = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
+    assert f2(vp(b), vp(order), m, 0.3, vp(keep), vp(num), vp(ws), None) == 0
+    want = keep[:int(num.item())]
+    assert torch.equal(got, want)
+
+
+def test_nms_float64_scores_keep_torch_sort(amd):
+    boxes, scores = nms_boxes(500, seed=9)
+    s64 = torch.from_numpy(scores.astype(np.float64)).cuda() + 1e-12 * torch.arange(500, device='cuda', dtype=torch.float64)
+    got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), s64, 0.25)
+    want = oracle.nms_gpu_oracle(boxes, s64.cpu().numpy(), 0.25)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
 def test_nms_normal(amd):
     boxes, scores = nms_boxes(2000, seed=4)
     want = oracle.nms_gpu_oracle(boxes, scores, 0.3, normal=True)
