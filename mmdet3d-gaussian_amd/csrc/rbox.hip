@@ -536,26 +536,46 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       const int cnt = __builtin_popcountll(kb);
       const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
       const int myl = (lane < m) ? klist[bk & 3][rank + SCAN_GW * lane] : 0;
+      if (wave == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SCAN_STAMP(13); }
       const unsigned long long* blk = mask + (size_t)(max(bk, 0) * 64) * cbs;
+      // Loads are unconditional per lane: the word index is clamped into the row (w < cb is the same for every row of a
+      // chunk, so the surplus lanes are masked ONCE, at consume time) — a per-row lane predicate cost ~100 cycles per
+      // row in exec-mask handling.
       unsigned long long v[U][CH];
+      unsigned int wcl[CH];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int ch = 0; ch < CH; ++ch) wcl[ch] = (unsigned int)min(first + ch * 64 + lane, cb - 1);
+      static_assert(U % 2 == 0, "rows are issued in pairs");
+      const int mlast = max(m - 1, 0);
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) v[u][ch] = 0ull;
+      for (int u = 0; u < U; u += 2) {  // pairs: half the uniform branches; an odd tail re-loads its last row (OR is idempotent)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) v[u][ch] = v[u + 1][ch] = 0ull;
         if (u < m) {  // uniform
-          const unsigned int off = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;  // < 64 * 1024
+          const unsigned int off0 = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;  // < 64 * 1024
+          const unsigned int off1 = (unsigned int)__builtin_amdgcn_readlane(myl, min(u + 1, mlast)) * (unsigned int)cbs;
 #pragma unroll
           for (int ch = 0; ch < CH; ++ch) {
-            const int w = first + ch * 64 + lane;
-            if (w < cb) v[u][ch] = blk[off + (unsigned int)w];
+            v[u][ch] = blk[off0 + wcl[ch]];
+            v[u + 1][ch] = blk[off1 + wcl[ch]];
           }
         }
       }
+      if (wave == 1) SCAN_STAMP(14);
       // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
       const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
       unsigned long long in[2];
-      in[0] = load_field(t0 + 3, fa);
-      in[1] = fb >= 0 ? load_field(t0 + 3, fb) : 0ull;
+      if (rank == 0) {  // one uniform branch, then constant field ids (a run-time id cost ~430 cycles per field)
+        in[0] = load_field(t0 + 3, 0);
+        in[1] = load_field(t0 + 3, 1 + SCAN_NU);
+      } else if (rank == 1) {
+        in[0] = load_field(t0 + 3, 1);
+        in[1] = load_field(t0 + 3, 2);
+      } else {
+        in[0] = load_field(t0 + 3, 3);
+        in[1] = 0ull;
+      }
+      if (wave == 1) SCAN_STAMP(15);
       if (m > U || (m > 0 && first + 64 * CH < cb)) {  // overflow: finish it now, synchronously (rare)
         for (int w0 = first; w0 < cb; w0 += 64) {
           const int w = w0 + lane;
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 #pragma unroll
         for (int u = 0; u < U; ++u) acc |= v[u][ch];
         const int w = first + ch * 64 + lane;
-        if (acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words (acc == 0 where w >= cb)
+        if (w < cb && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
       }
       if (t0 + 3 < cb) {
         const int slot = (t0 + 3) & (SCAN_RING - 1);
