@@ -375,8 +375,10 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
 
 #ifdef SCAN_PROFILE
 #define SCAN_STAMP(k) do { if (lane == 0) dbg[(size_t)c * 16 + (k)] = clock64(); } while (0)
+#define SCAN_STAMP_SYNC(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SCAN_STAMP(k); } while (0)
 #else
 #define SCAN_STAMP(k) do { } while (0)
+#define SCAN_STAMP_SYNC(k) do { } while (0)
 #endif
 
 // wave-wide OR on the DPP network (row_shr 1/2/4/8 inside each row of 16, row_bcast 15 / 31 across rows; lane 63 holds
@@ -536,8 +538,21 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       const int cnt = __builtin_popcountll(kb);
       const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
       const int myl = (lane < m) ? klist[bk & 3][rank + SCAN_GW * lane] : 0;
-      if (wave == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SCAN_STAMP(13); }
+      if (wave == 1) SCAN_STAMP_SYNC(13);
       const unsigned long long* blk = mask + (size_t)(max(bk, 0) * 64) * cbs;
+      // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
+      const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
+      unsigned long long in[2];
+      if (rank == 0) {  // one uniform branch, then constant field ids (a run-time id cost ~430 cycles per field)
+        in[0] = load_field(t0 + 3, 0);
+        in[1] = load_field(t0 + 3, 1 + SCAN_NU);
+      } else if (rank == 1) {
+        in[0] = load_field(t0 + 3, 1);
+        in[1] = load_field(t0 + 3, 2);
+      } else {
+        in[0] = load_field(t0 + 3, 3);
+        in[1] = 0ull;
+      }
       // Loads are unconditional per lane: the word index is clamped into the row (w < cb is the same for every row of a
       // chunk, so the surplus lanes are masked ONCE, at consume time) — a per-row lane predicate cost ~100 cycles per
       // row in exec-mask handling.
@@ -562,19 +577,6 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
         }
       }
       if (wave == 1) SCAN_STAMP(14);
-      // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
-      const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
-      unsigned long long in[2];
-      if (rank == 0) {  // one uniform branch, then constant field ids (a run-time id cost ~430 cycles per field)
-        in[0] = load_field(t0 + 3, 0);
-        in[1] = load_field(t0 + 3, 1 + SCAN_NU);
-      } else if (rank == 1) {
-        in[0] = load_field(t0 + 3, 1);
-        in[1] = load_field(t0 + 3, 2);
-      } else {
-        in[0] = load_field(t0 + 3, 3);
-        in[1] = 0ull;
-      }
       if (wave == 1) SCAN_STAMP(15);
       if (m > U || (m > 0 && first + 64 * CH < cb)) {  // overflow: finish it now, synchronously (rare)
         for (int w0 = first; w0 < cb; w0 += 64) {

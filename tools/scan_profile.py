@@ -23,4 +23,4 @@ for n, thr, clutter in ((1000, 0.2, True), (4096, 0.25, True), (4096, 0.25, Fals
     grp = slice(3, cb - 6, 3)                    # wave 1 (group 0, rank 0) stamps live at rows t0 = 0, 3, 6, ...
     print(f'n={n} clutter={clutter} kept={int(num)} blocks={cb}: interval {np.median(iv):.0f} cyc | resolver: lds-read {d(0,1):.0f} '
           f'solve {d(1,2):.0f} store+or {d(2,3):.0f} barrier {d(3,5):.0f} | group wave: issue {d(8,10,grp):.0f} 2 barriers {d(10,11,grp):.0f} '
-          f'wait+consume {d(11,9,grp):.0f} barrier {d(9,12,grp):.0f} || issue split: lds {d(8,13,grp):.0f} rows {d(13,14,grp):.0f} fields {d(14,15,grp):.0f} rest {d(15,10,grp):.0f}', flush=True)
+          f'wait+consume {d(11,9,grp):.0f} barrier {d(9,12,grp):.0f} || issue split: lds {d(8,13,grp):.0f} fields+rows {d(13,15,grp):.0f} rest {d(15,10,grp):.0f}', flush=True)
