@@ -2,15 +2,18 @@
 // (include/gd3d.h).  Geometry: rbox_device.h.  Compiled with -ffp-contract=off (see build.py).
 //
 // NMS (replaces mmdet3d iou3d_cuda.nms_gpu, whose mask goes D->H and is scanned on the host):
-//   1. obox_prep_kernel: one thread per box: sin/cos + rotated corners once -> 64-byte OBox records.
+//   0. (nms_gpu path, <= 16384 candidates) rank_count_kernel + rank_scatter_kernel: the score order by counting larger
+//      (score, -index) keys over the whole chip — no sort — with the per-box prep scattered straight to its rank.
+//   1. obox_prep_kernel (pre-sorted / caller-ordered paths): one thread per box: sin/cos + rotated corners once ->
+//      64-byte OBox records.
 //   2. nms_mask_compact_kernel (rotated) / nms_mask_kernel (axis-aligned, circle): one wave per (8..64 row boxes,
 //      64-box column block at or right of their own block).  Rotated: the cheap bounding-circle test for every pair
 //      first, survivors queued in LDS, then the full polygon-clipping predicate with the live lanes packed densely;
-//      per-thread polygon vertices live in LDS [slot][thread] (12 KiB per wave).  Compute/latency-bound integer+fp32
+//      per-thread polygon vertices live in LDS [slot][thread] (12 KiB per wave).  VALU-throughput-bound integer+fp32
 //      work (no HBM roofline: N=4096 reads 256 KB, writes 1 MB).
-//   3. nms_scan_kernel:  the greedy scan as ONE wave that never leaves the device: the 64-box
-//      diagonal word of each block is resolved with scalar readlane steps, then the mask rows of the
-//      boxes just kept are OR-ed into the removed-set (LDS) with independent, pipelined row loads.
+//   3. nms_scan_kernel: the greedy scan as ONE 10-wave workgroup that never leaves the device: a resolver wave solves
+//      each 64-box diagonal block wave-parallel from an LDS ring, three phase-shifted groups of loader waves OR the
+//      mask rows of the boxes just kept into the removed-set (LDS); one LDS-only barrier per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
