@@ -307,6 +307,17 @@ int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const i
                  int32_t groups, int64_t cap, const float* thresh, int64_t* keep, int64_t* num_keep,
                  void* workspace, void* stream);
 
+/* rnms_batched with the score order taken inside the library (rank by counting, as rnms_scored), so the caller needs no
+ * masked_fill / sum / sort passes:
+ *   scores (groups, n) fp32;  valid (groups, n) bytes, nullable — which boxes take part in group g;  pre_max < 0: none.
+ *   Group g runs NMS over its valid boxes by descending score (ties by ascending index), cut to cap = min(n, pre_max).
+ *   keep (groups, cap) int64 indices into `boxes`; num_keep (groups) int64; thresh (groups) fp32, DEVICE.
+ *   n <= rnms_scored_max_n(), else GD3D_E_TOOLARGE.  workspace: rnms_batched_scored_workspace_bytes(groups, n, cap). */
+size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t cap);
+int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups,
+                        int64_t n, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
+                        void* workspace, void* stream);
+
 /* Circle NMS (mmdet3d `circle_nms(dets, thresh, post_max_size)`, numba, CPU; the reference copies the detections
  * D->H for it, gd_centerpoint_head.py:256-272): centres xy (rows, 2) fp32, order (n) by descending score; box j is
  * suppressed by a kept i before it iff (x_i-x_j)^2 + (y_i-y_j)^2 <= thresh (fp32 distance, float64 compare; note

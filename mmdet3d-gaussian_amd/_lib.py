@@ -78,6 +78,8 @@ SYMBOLS = {
     'rnms_scored': (_int, [ctypes.c_int32, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     'rnms_batched_workspace_bytes': (_sz, [ctypes.c_int32, _i64]),
     'rnms_batched': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'rnms_batched_scored_workspace_bytes': (_sz, [ctypes.c_int32, _i64, _i64]),
+    'rnms_batched_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_circle_ordered': (_int, [_vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _vp]),
     'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_bev': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),

@@ -80,10 +80,17 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
 }
 
-__global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores, int n, int* __restrict__ prank) {
+// blockIdx.z = group (batched form): scores / valid are (G, n) rows, prank is (G, slices, n).  A box that is not `valid`
+// in its group (nullable mask) gets key 0: it is below every real key and is never scattered.
+__global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores_, const unsigned char* __restrict__ valid_,
+                                                        int n, int* __restrict__ prank_) {
   __shared__ int spart[4][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int part = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = quarter of the slice
+  const size_t grow = (size_t)blockIdx.z * n;
+  const float* scores = scores_ + grow;
+  const unsigned char* valid = valid_ != nullptr ? valid_ + grow : nullptr;
+  int* prank = prank_ + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * n;
   const int j0 = blockIdx.y * RANK_SLICE, j1 = min(j0 + RANK_SLICE, n);
   const int i = blockIdx.x * 64 + lane;
   const unsigned long long mine = i < n ? score_key(scores[i], (unsigned)i) : ~0ull;
@@ -94,7 +101,8 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
   // copy paid one dependent LDS round trip per key: 15 us per launch)
   for (int jb = b; jb < e; jb += 64) {
     const int j = jb + lane;
-    const unsigned long long kj = j < e ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
+    const bool use = j < e && (valid == nullptr || valid[j] != 0);
+    const unsigned long long kj = use ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
     const unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
 #pragma unroll
     for (int t = 0; t < 64; ++t) {
@@ -105,26 +113,38 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
   }
   spart[part][lane] = cnt;
   __syncthreads();
-  if (tid < 64 && i < n) prank[(size_t)blockIdx.y * n + i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
+  if (tid < 64 && i < n) prank[i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
 }
 
+// counts (nullable, zeroed by the caller): counts[group] += boxes placed, i.e. min(#valid, n_keep) — integer atomics
 template <bool PREP>
-__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const int* __restrict__ prank,
-                                                          int n, int slices, int n_keep, long long* __restrict__ order,
-                                                          OBox* __restrict__ ob) {
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ valid_,
+                                                          const int* __restrict__ prank_, int n, int slices, int n_keep,
+                                                          long long* __restrict__ order_, OBox* __restrict__ ob_,
+                                                          int* __restrict__ counts) {
+  const int g = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int r = 0;
-  for (int s2 = 0; s2 < slices; ++s2) r += prank[(size_t)s2 * n + i];
-  if (r >= n_keep) return;
-  order[r] = (long long)i;
-  if (PREP) {
-    float b[5];
+  const int* prank = prank_ + (size_t)g * slices * n;
+  bool placed = false;
+  if (i < n && (valid_ == nullptr || valid_[(size_t)g * n + i] != 0)) {
+    int r = 0;
+    for (int s2 = 0; s2 < slices; ++s2) r += prank[(size_t)s2 * n + i];
+    if (r < n_keep) {
+      placed = true;
+      order_[(size_t)g * n_keep + r] = (long long)i;
+      if (PREP) {
+        float b[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)i * 5 + q];
-    OBox o;
-    obox_make(b, o);
-    ob[r] = o;
+        for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)i * 5 + q];
+        OBox o;
+        obox_make(b, o);
+        ob_[(size_t)g * n_keep + r] = o;
+      }
+    }
+  }
+  if (counts != nullptr) {
+    const int c = __popcll(__ballot(placed));
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicAdd(&counts[g], c);
   }
 }
 
@@ -826,19 +846,61 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
   int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
   const int slices = (int)rank_slices(n_all);
-  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores, (int)n_all,
-                     prank);
+  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores,
+                     (const unsigned char*)nullptr, (int)n_all, prank);
   const dim3 sg((unsigned)((n_all + 255) / 256));
   if (normal)
-    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const int*)prank, (int)n_all, slices, (int)n,
-                       order, (OBox*)workspace);
+    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)prank,
+                       (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
   else
-    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const int*)prank, (int)n_all, slices, (int)n,
-                       order, (OBox*)workspace);
+    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)prank,
+                       (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
                      num_keep, workspace, stream, /*prepped=*/true);
+}
+
+size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t cap) {
+  if (groups < 1) groups = 1;
+  if (n < 1) n = 1;
+  if (cap < 1) cap = 1;
+  return align_up(rnms_batched_workspace_bytes(groups, cap), 256) + align_up((size_t)groups * cap * sizeof(int64_t), 256) +
+         align_up((size_t)groups * sizeof(int), 256) + (size_t)groups * rank_slices(n) * (size_t)n * sizeof(int);
+}
+
+int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,
+                        int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  if (mode < MODE_ROT || mode > MODE_CIRCLE || groups < 0 || n < 0) return GD3D_E_BADARG;
+  if (groups == 0) return 0;
+  if (num_keep == nullptr) return GD3D_E_BADARG;
+  if (n > RANK_MAX || groups > 65535) return GD3D_E_TOOLARGE;
+  const int64_t cap = (pre_max >= 0 && pre_max < n) ? pre_max : n;
+  hipStream_t s = (hipStream_t)stream;
+  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, s);
+  if (boxes == nullptr || scores == nullptr || thresh == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  char* p = (char*)workspace + align_up(rnms_batched_workspace_bytes(groups, cap), 256);
+  long long* order = (long long*)p;
+  p += align_up((size_t)groups * cap * sizeof(int64_t), 256);
+  int* counts = (int*)p;
+  p += align_up((size_t)groups * sizeof(int), 256);
+  int* prank = (int*)p;
+  const int slices = (int)rank_slices(n);
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)groups, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)slices, (unsigned)groups), dim3(256), 0, s, scores,
+                     (const unsigned char*)valid, (int)n, prank);
+  const dim3 sg((unsigned)((n + 255) / 256), (unsigned)groups);
+  if (mode == MODE_ROT)
+    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)prank, (int)n,
+                       slices, (int)cap, order, (OBox*)workspace, counts);
+  else
+    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)prank, (int)n,
+                       slices, (int)cap, order, (OBox*)workspace, counts);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
+                     workspace, stream, /*prepped=*/mode == MODE_ROT);
 }
 
 int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,

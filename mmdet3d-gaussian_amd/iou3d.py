@@ -143,6 +143,28 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
     if N == 0:
         return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
     lib = _lib.load()
+    mode = 2 if circle else (1 if normal else 0)
+    if N <= _scored_max(lib) and G <= 65535 and scores.dtype in (torch.float32, torch.float16, torch.bfloat16):
+        # the library takes the score order itself (rank by counting per group): no masked_fill / sum / sort passes here
+        cap = N if pre_max_size is None else max(min(N, int(pre_max_size)), 0)
+        if cap == 0:
+            return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
+        with torch.cuda.device(dev):
+            sc = (scores if scores.dtype == torch.float32 else scores.float()).contiguous()
+            vb = None if valid is None else valid.to(torch.bool).contiguous()   # 1 byte per flag
+            th = _thresh_tensor(thresh, G, dev)
+            keep = torch.empty((G, cap), dtype=torch.int64, device=dev)
+            num = torch.empty(G, dtype=torch.int64, device=dev)
+            ws = torch.empty(lib.rnms_batched_scored_workspace_bytes(G, N, cap), dtype=torch.uint8, device=dev)
+            _lib.check(lib.rnms_batched_scored(mode, boxes.data_ptr(), sc.data_ptr(), None if vb is None else vb.data_ptr(), G, N,
+                                               cap, th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream), name)
+        nums = num.tolist()  # the one sync: G data-dependent result lengths
+        out = []
+        for g in range(G):
+            k = keep[g, :nums[g]]
+            out.append(k if post_max_size is None else k[:post_max_size])
+        return out
     with torch.cuda.device(dev):
         if valid is None:
             key = scores
@@ -164,7 +186,6 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
         keep = torch.empty((G, cap), dtype=torch.int64, device=dev)
         num = torch.empty(G, dtype=torch.int64, device=dev)
         ws = torch.empty(lib.rnms_batched_workspace_bytes(G, cap), dtype=torch.uint8, device=dev)
-        mode = 2 if circle else (1 if normal else 0)
         _lib.check(lib.rnms_batched(mode, boxes.data_ptr(), order.data_ptr(), counts.data_ptr(), G, cap, th.data_ptr(),
                                     keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), name)

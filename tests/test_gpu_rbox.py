@@ -251,6 +251,44 @@ def test_batched_nms_equals_per_group_calls_and_oracle(amd, normal):
         assert np.array_equal(cut[g].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('mode', ['rot', 'normal', 'circle'])
+def test_library_score_order_equals_torch_sort_fallback(amd, mode):
+    """nms_gpu / nms_gpu_batched take the score order inside the library up to 16384 boxes and fall back to torch.sort
+    above: both routes must give the same kept indices (ties, invalid boxes, pre / post cuts, per-group thresholds)."""
+    import sys
+    iou3d = sys.modules[amd.nms_gpu.__module__]
+    n, G = 2100, 4
+    boxes, _ = nms_boxes(n, seed=33)
+    rng = np.random.default_rng(8)
+    scores = np.round(rng.uniform(0, 1, (G, n)), 2).astype(np.float32)             # many ties
+    valid = scores >= np.array([0.2, 0.0, 1.5, 0.6], np.float32)[:, None]           # group 2 empty
+    b = torch.from_numpy(boxes[:, :2].copy() if mode == 'circle' else boxes).cuda()
+    s, v = torch.from_numpy(scores).cuda(), torch.from_numpy(valid).cuda()
+    thr = [1.0, 4.0, 0.5, 2.0] if mode == 'circle' else [0.25, 0.5, 0.1, 0.7]
+    kw = dict(normal=(mode == 'normal'), circle=(mode == 'circle'))
+
+    def run():
+        a = amd.nms_gpu_batched(b, s, thr, v, pre_max_size=900, post_max_size=120, **kw)
+        c = amd.nms_gpu_batched(b, s, thr, None, **kw)
+        d = None if mode == 'circle' else (amd.nms_normal_gpu(b, s[0], 0.3) if mode == 'normal'
+                                           else amd.nms_gpu(b, s[0], 0.3, pre_max_size=1000, post_max_size=200))
+        return a, c, d
+    lib = amd.load_library()
+    assert iou3d._scored_max(lib) == 16384
+    fast = run()
+    saved = iou3d._SCORED_MAX
+    iou3d._SCORED_MAX = 0                         # force the torch.sort route
+    try:
+        slow = run()
+    finally:
+        iou3d._SCORED_MAX = saved
+    for x, y in zip(fast[0] + fast[1], slow[0] + slow[1]):
+        assert torch.equal(x, y)
+    if fast[2] is not None:
+        assert torch.equal(fast[2], slow[2])
+    assert fast[0][2].numel() == 0 and all(k.numel() <= 120 for k in fast[0])
+
+
 def test_multi_class_nms_matches_reference_loop(amd):
     """pvrcnn_bbox_head.py:438-480 restated as the loop it is (score mask -> nonzero -> nms -> original_idxs[selected]
     -> cat) on the oracle vs the one-shot batched call."""
