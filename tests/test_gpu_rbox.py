@@ -33,6 +33,27 @@ def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+def test_nms_randomised_sweep_bit_exact(amd):
+    """40 seeded random problems (size, threshold, clutter, extent, pre/post cuts drawn at random): keep indices equal to
+    the CPU oracle in every one — the mask compaction, the register clipping path, the score ranking and the scan are
+    all exercised at sizes that are not multiples of anything."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.integers(1, 3200))
+        thr = float(rng.choice([0.01, 0.1, 0.2, 0.25, 0.5, 0.7, 0.9]))
+        clutter = bool(rng.integers(0, 2))
+        extent = float(rng.choice([5.0, 30.0, 74.88]))
+        boxes, scores = nms_boxes(n, seed=1000 + case, extent=extent, clutter=clutter)
+        if rng.random() < 0.3:
+            scores = np.round(scores, 1)                       # heavy ties
+        pre = None if rng.random() < 0.5 else int(rng.integers(1, n + 1))
+        post = None if rng.random() < 0.5 else int(rng.integers(1, 600))
+        want = oracle.nms_gpu_oracle(boxes, scores, thr, pre, post)
+        got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr, pre_max_size=pre,
+                          post_max_size=post)
+        assert np.array_equal(got.cpu().numpy(), want), (case, n, thr, clutter, extent, pre, post)
+
+
 def test_nms_pre_post_cuts_and_alias(amd):
     boxes, scores = nms_boxes(3000, seed=1)
     b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
