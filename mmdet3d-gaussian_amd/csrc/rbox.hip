@@ -237,8 +237,9 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
 // test; on score-sorted detector output ~1 % of the pairs do, i.e. about every second (row, 64 columns) wave runs a pass
 // with one or two live lanes.  Here a wave owns `rows` (8..64) consecutive row boxes x one 64-box column block and works
 // in two phases per 16-row chunk:
-//   1. the circle test alone for every (row, lane) pair (~12 VALU per row; the row box's centre / extent are
-//      wave-uniform scalar loads), survivors appended to an LDS queue as (row << 6 | column) via ballot + mbcnt;
+//   1. the circle test alone for every (row, lane) pair (~12 VALU per row, straight-line; the row boxes' centre / extent
+//      are broadcast from lanes by v_readlane): every lane keeps the 16-bit candidate mask of ITS column, the survivors
+//      are then appended to an LDS queue as (row << 6 | column) in bulk (DPP scan of the per-lane counts);
 //   2. whenever >= 64 candidates are queued (and once more at the end) lane l takes candidate l: loads both 64-byte
 //      records, runs the FULL predicate (iou_bev, which repeats the circle test — one code path, bit-identical
 //      decisions) and ORs its bit into the row's word in LDS.  Every clipping pass but the last has 64 live lanes.
