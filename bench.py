@@ -63,10 +63,30 @@ def synthetic_pairs(n, seed, device):
     return pred.float().contiguous(), tgt.float().contiguous()
 
 
+def usable_cores():
+    """Threads worth starting: the scheduler affinity, capped by the cgroup CPU quota when there is one (a GPU box may
+    show 256 CPUs and grant a 16-core share; 256 OpenMP threads on such a share run slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:           # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:   # v1
+                quota, period = int(f.read()), int(g.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(n, 1)
+
+
 def cpu_baseline(sample_pairs, seed):
     """fp32 CPU oracle (oracle/gd_oracle.c) on a bounded sample of the same workload, all host cores."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     pred, tgt = synthetic_pairs(sample_pairs, seed, torch.device('cpu'))
     p, t = pred.numpy(), tgt.numpy()
     loss = np.empty(sample_pairs, np.float32)
@@ -82,16 +102,24 @@ def cpu_baseline(sample_pairs, seed):
         dt = time.perf_counter() - t0
         if dt >= 10.0 or reps >= 64:
             break
+    # the same code on ONE thread, on a 1/16 slice (SURVEY.md §8d asks for the scalar single-thread figure as well)
+    n1 = max(sample_pairs // 16, 1)
+    t1 = time.perf_counter()
+    for prm in prms:
+        oracle.gd_loss_timed(p[:n1], t[:n1], prm, 5.0 / sample_pairs, loss[:n1], gp[:n1], 1)
+    dt1 = time.perf_counter() - t1
     return {'value': round(3 * sample_pairs * reps / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
+            'single_thread_value': round(3 * n1 / dt1 / 1e6, 3),
             'sample': f'{reps} pass(es) over {sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle '
-                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall'}
+                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall; single thread: {n1} pairs x 3 '
+                      f'losses in {dt1:.2f} s'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--pairs', type=int, default=10_000_000, help='pairs per GPU (default: BASELINE config 3)')
     ap.add_argument('--strong', action='store_true',
                     help='strong scaling: --pairs is the TOTAL, split into contiguous row ranges over the ranks '
