@@ -30,11 +30,25 @@ def time_ptrs(p, t, gp):
     return e0.elapsed_time(e1) / 20 * 1e3
 
 
+def time_add(p, t, gp):
+    """the same three buffers through a plain elementwise kernel (torch.add, 2 streams read : 1 written)"""
+    for _ in range(5): torch.add(p, t, out=gp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): torch.add(p, t, out=gp)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 20 * 1e3
+
+
 keep = []
 for k in range(8):
     p, t, gp = src_p.clone(), src_t.clone(), torch.empty_like(src_p)
     keep.append((p, t, gp))
-    print(f'torch allocation set {k}: {time_ptrs(p.data_ptr(), t.data_ptr(), gp.data_ptr()):6.1f} us', flush=True)
+    tk = time_ptrs(p.data_ptr(), t.data_ptr(), gp.data_ptr())
+    ta = time_add(p, t, gp)
+    p.copy_(src_p); t.copy_(src_t)
+    print(f'torch allocation set {k}: {tk:6.1f} us   (torch.add on the same buffers: {ta:6.1f} us)', flush=True)
 # re-time the first sets: is the time a stable property of the set?
 for k in (0, 1, 2):
     p, t, gp = keep[k]
