@@ -141,3 +141,20 @@ def test_head_slices_validate_shapes_before_touching_the_gpu():
                                            good['labels'], good['anchor_list'], 3, 1.0, None)
     with pytest.raises(RuntimeError, match='same number of rows'):
         amd.anchor_decoded_gd_loss(m, torch.zeros(5, 7), torch.zeros(4, 7), torch.zeros(4, 7))
+
+
+def test_bench_core_count_respects_the_cgroup_quota():
+    """bench.py's cpu_baseline must start as many threads as the box GRANTS (a GPU box shows 256 CPUs and a 16-core
+    quota): never more than the affinity mask, never less than 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            assert n <= max(1, int(int(quota) / int(period) + 0.5))
+    except OSError:
+        pass
