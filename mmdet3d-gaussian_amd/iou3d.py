@@ -119,7 +119,7 @@ def _thresh_tensor(thresh, groups, dev):
 
 
 def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_max_size=None, normal=False,
-                    circle=False):
+                    circle=False, _offsets=None):
     """G independent NMS problems over ONE box array in one set of launches and one host sync.
 
     boxes (N,5) [x1,y1,x2,y2,ry] (circle=True: (N,2) centres); scores (G,N); valid (G,N) bool or None — which boxes take
@@ -159,6 +159,8 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
             _lib.check(lib.rnms_batched_scored(mode, boxes.data_ptr(), sc.data_ptr(), None if vb is None else vb.data_ptr(), G, N,
                                                cap, th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), name)
+        if _offsets is not None:   # nms_gpu_multi: indices local to each entry, one launch for all groups
+            keep = keep - _offsets.unsqueeze(1)
         nums = num.tolist()  # the one sync: G data-dependent result lengths
         out = []
         for g in range(G):
@@ -189,12 +191,47 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
         _lib.check(lib.rnms_batched(mode, boxes.data_ptr(), order.data_ptr(), counts.data_ptr(), G, cap, th.data_ptr(),
                                     keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), name)
+    if _offsets is not None:
+        keep = keep - _offsets.unsqueeze(1)
     nums = num.tolist()  # the one sync: G data-dependent result lengths
     out = []
     for g in range(G):
         k = keep[g, :nums[g]]
         out.append(k if post_max_size is None else k[:post_max_size])
     return out
+
+
+def nms_gpu_multi(boxes_list, scores_list, thresh, pre_max_size=None, post_max_size=None, normal=False):
+    """`[nms_gpu(b, s, thresh, pre_max_size, post_max_size) for b, s in zip(boxes_list, scores_list)]` in ONE batched call
+    and ONE host sync: the per-sample loop of CenterHeadRev.get_task_detections (gd_centerpoint_head.py:329-345) and the
+    per-task loop around it (:233-282) — B samples x T tasks small NMS problems per inference step, each with its own
+    sort, launches and `.item()` — become a single `nms_gpu_batched` over the concatenated boxes (group g = entry g, its
+    boxes selected by the `valid` mask).  boxes_list[g] (n_g,5) [x1,y1,x2,y2,ry], scores_list[g] (n_g,); thresh: float or
+    one per entry.  Returns a list of LongTensors: kept indices LOCAL to each entry, by descending score."""
+    G = len(boxes_list)
+    if len(scores_list) != G:
+        raise RuntimeError(f'nms_gpu_multi: {G} box sets but {len(scores_list)} score sets')
+    if G == 0:
+        return []
+    sizes = [int(b.shape[0]) for b in boxes_list]
+    for b, s2, n in zip(boxes_list, scores_list, sizes):
+        if s2.shape[0] != n:
+            raise RuntimeError(f'nms_gpu_multi: {n} boxes but {s2.shape[0]} scores')
+    dev = boxes_list[0].device
+    total = sum(sizes)
+    if total == 0:
+        return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
+    boxes = torch.cat([b.reshape(-1, 5).to(torch.float32) for b in boxes_list], dim=0)
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    # (G, total) score / membership matrices: entry g owns columns offs[g] .. offs[g+1] (a handful of torch ops, not 2G)
+    flat = torch.cat([s2.reshape(-1).to(torch.float32) for s2 in scores_list], dim=0)
+    gid = torch.repeat_interleave(torch.arange(G, device=dev), torch.tensor(sizes, device=dev), output_size=total)
+    valid = gid.unsqueeze(0) == torch.arange(G, device=dev).unsqueeze(1)
+    scores = flat.unsqueeze(0).expand(G, total).contiguous()
+    return nms_gpu_batched(boxes, scores, thresh, valid, pre_max_size=pre_max_size, post_max_size=post_max_size, normal=normal,
+                           _offsets=torch.tensor(offs[:G], dtype=torch.int64, device=dev))
 
 
 def multi_class_nms(box_probs, boxes_for_nms, score_thr, nms_thr, use_rotate_nms=True):

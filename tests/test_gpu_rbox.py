@@ -310,6 +310,24 @@ def test_library_score_order_equals_torch_sort_fallback(amd, mode):
     assert fast[0][2].numel() == 0 and all(k.numel() <= 120 for k in fast[0])
 
 
+def test_nms_gpu_multi_equals_the_per_entry_loop(amd):
+    """B samples x T tasks of CenterHeadRev.get_bboxes (gd_centerpoint_head.py:233-345) as one batched call: every entry's
+    keep list equals nms_gpu on that entry alone — incl. empty entries and per-entry thresholds."""
+    rng = np.random.default_rng(17)
+    sizes = [500, 0, 37, 500, 1, 264, 64, 129, 0, 480, 333, 12]          # 2 samples x 6 tasks
+    bl, sl = [], []
+    for k, n in enumerate(sizes):
+        b, s = nms_boxes(max(n, 1), seed=400 + k, extent=20.0)
+        bl.append(torch.from_numpy(b[:n]).cuda()); sl.append(torch.from_numpy(np.round(s[:n], 2)).cuda())
+    thr = [float(rng.choice([0.1, 0.2, 0.5])) for _ in sizes]
+    got = amd.nms_gpu_multi(bl, sl, thr, pre_max_size=400, post_max_size=83)
+    assert len(got) == len(sizes)
+    for k, n in enumerate(sizes):
+        want = amd.nms_gpu(bl[k], sl[k], thr[k], pre_max_size=400, post_max_size=83) if n else torch.zeros(0, dtype=torch.int64).cuda()
+        assert torch.equal(got[k], want), k
+    assert amd.nms_gpu_multi([], [], 0.2) == []
+
+
 def test_multi_class_nms_matches_reference_loop(amd):
     """pvrcnn_bbox_head.py:438-480 restated as the loop it is (score mask -> nonzero -> nms -> original_idxs[selected]
     -> cat) on the oracle vs the one-shot batched call."""
