@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Loss/NMS-level stand-ins for BASELINE.json configs 2, 4 and 5 on ONE MI355X (SURVEY.md §8d maps each config to the
 nearest shipped reference config).  Per-GPU work of one training / inference step of the hot path only (the network body
-is out of scope); every value is checked against the oracle once before timing.
+is out of scope).  TIMING ONLY: the oracle checks of these three geometries are the -m gpu tests in
+tests/test_gpu_configs.py; here only config 5's NMS keep indices are re-checked (the `keep_bit_exact` field).
   config 2: PointPillars KITTI 3-class, KLD (tau=0, log1p): anchor head decoded-box branch from raw NCHW output,
             B=6 samples x 321 408 anchors, ~60 positives per sample (gd_anchor3d_head.py:95-141).
   config 4: nuScenes CenterPoint (nearest shipped; BASELINE says PointPillars), BCD: 6 tasks x samples_per_gpu=8 x <=500
