@@ -49,6 +49,7 @@ import torch.distributed as dist  # noqa: E402
 
 LOSSES = ('gwd3d', 'kld3d', 'bd3d')
 BYTES_PER_PAIR = 88          # read pred 28 + target 28, write loss 4 + grad_pred 28
+MOVED_BYTES_PER_PAIR = 84    # what the kernel moves under reduction='mean': the per-pair loss is summed, not stored
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -61,6 +62,21 @@ def synthetic_pairs(n, seed, device):
     tgt = torch.rand(n, 7, generator=g, device=device) * (hi - lo) + lo
     pred = tgt + torch.randn(n, 7, generator=g, device=device) * sigma
     return pred.float().contiguous(), tgt.float().contiguous()
+
+
+def shard_rows(pairs, rank, world, strong):
+    """Rows of rank `rank`: weak scaling keeps `pairs` per GPU; strong scaling splits `pairs` in total into the contiguous
+    ranges [r N/G, (r+1) N/G).  Returns (first_row, n_rows) in the global numbering."""
+    if not strong:
+        return rank * pairs, pairs
+    lo, hi = pairs * rank // world, pairs * (rank + 1) // world
+    return lo, hi - lo
+
+
+def job_value(pairs, world, strong, steps, elapsed_s, losses=len(LOSSES)):
+    """Whole-job throughput in M box-pairs/s: every loss counts its pairs once per step (fwd + bwd together)."""
+    total_pairs = losses * (pairs if strong else pairs * world) * steps
+    return total_pairs / elapsed_s / 1e6
 
 
 def usable_cores():
@@ -152,10 +168,7 @@ def main():
     from mmdet3d_gaussian_amd import gd_loss as gdl
     amd.load_library()
 
-    if args.strong:   # contiguous row range [r N/G, (r+1) N/G) of the total
-        n = args.pairs * (rank + 1) // world - args.pairs * rank // world
-    else:
-        n = args.pairs
+    _, n = shard_rows(args.pairs, rank, world, args.strong)
     pred0, tgt = synthetic_pairs(n, seed=rank, device=dev)
     # one leaf per loss (same values): the step calls backward() ONCE on the sum of the three losses, as a training
     # step does with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations
@@ -286,12 +299,34 @@ def main():
         vals = [v.item() for v in last['outs']]
     losses = dict(zip(LOSSES, vals))
 
+    # The box's own ceiling for this access mix, measured in this process right after the timed region: z = x + y with
+    # nontemporal 16-byte accesses over the fused kernel's OWN buffers (pred and target read, the gradient written:
+    # 2 x 280 MB in, 280 MB out at 10 M pairs), dispatch-bound events as for the fused kernel.
+    probe_ms = None
+    if rank == 0 and n > 0 and (7 * n) % 4 == 0:
+        lt0 = LOSSES[0]
+        x, y, z = preds[lt0].detach(), tgt, preds[lt0].grad
+        if z is not None:
+            lib = amd.load_library()
+            stream = torch.cuda.current_stream().cuda_stream
+            tms = []
+            for it in range(25):
+                tm = gdl.DispatchTimer()
+                rc = lib.gd3d_probe_stream(x.data_ptr(), y.data_ptr(), z.data_ptr(), 7 * n, stream, tm.start, tm.stop)
+                assert rc == 0, rc
+                if it >= 5:
+                    tms.append(tm)
+            torch.cuda.synchronize(dev)
+            d = sorted(t.elapsed_ms() for t in tms)
+            probe_ms = sum(d) / len(d)
+
     if rank == 0:
-        total_pairs = 3 * (args.pairs if args.strong else n * world) * args.steps
-        value = total_pairs / elapsed / 1e6
+        value = job_value(args.pairs, world, args.strong, args.steps, elapsed)
         dom = max(LOSSES, key=lambda k: kern_ms[k])          # slowest of the three fused kernels
         dom_s = kern_ms[dom] * 1e-3
         achieved = BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
+        moved = MOVED_BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
+        ceiling = MOVED_BYTES_PER_PAIR * n / (probe_ms * 1e-3) / 1e9 if probe_ms else None
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.isfile(tpath):
@@ -318,7 +353,18 @@ def main():
                        'graph_replay_ms_per_step': round(replay_ms, 4) if replay_ms is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
-                         'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR, 'timing': timing,
+                         'traffic_source': 'static: PMC passes of an earlier run of this command (profiles/traffic.json, '
+                                           'profiles/r02_pmc_summary.txt); not re-measured in this run',
+                         'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
+                         # what the kernel really moves under reduction=mean|sum (no per-pair loss store): 84 B/pair
+                         'moved_bytes_per_pair': MOVED_BYTES_PER_PAIR, 'achieved_moved_GBps': round(moved, 1),
+                         'frac_actual_bytes': round(moved / HBM_PEAK_GBPS, 4),
+                         # z = x + y (nontemporal, 16 B/lane) over the same three buffers, same process, after the region
+                         'copy_ceiling_GBps': round(ceiling, 1) if ceiling else None,
+                         'copy_ceiling_ms': round(probe_ms, 4) if probe_ms else None,
+                         'copy_ceiling_frac_of_peak': round(ceiling / HBM_PEAK_GBPS, 4) if ceiling else None,
+                         'frac_of_ceiling': round(moved / ceiling, 4) if ceiling else None,
+                         'timing': timing,
                          'kernel_ms': {k: round(v, 4) for k, v in kern_ms.items()},
                          'kernel_ms_median': {k: round(v, 4) for k, v in kern_med.items()},
                          'kernel_ms_min': {k: round(v, 4) for k, v in kern_min.items()},

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD3D_ABI_VERSION 1
+#define GD3D_ABI_VERSION 2
 
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
@@ -80,7 +80,7 @@ typedef struct gd3d_params {
  * loss_weight / (avg_factor | N | 1) so that the kernel writes final gradients.
  * n == 0 is legal (loss_sum = 0).  workspace: gd3d_loss_workspace_bytes(n) bytes,
  * 16-byte aligned; required when loss_sum != NULL; whenever it is given the kernel leaves one
- * fp32 partial sum per 256-pair tile in it.
+ * fp32 partial sum per 256-pair tile at its start.
  * ---------------------------------------------------------------------------------- */
 size_t gd3d_loss_workspace_bytes(int64_t n);
 
@@ -205,8 +205,9 @@ int gd3d_anchor_head_bbox_loss(const gd3d_params* params, const gd3d_smooth_l1* 
  * outputs where they lie.  Per task (host struct, device pointers):
  *   maps[6]   : reg (B,2,H,W) | height (B,1,H,W) | dim (B,3,H,W) | yaw (B,1,H,W) | dir (B,2,H,W) | vel (B,2,H,W), NCHW
  *               fp32; reg may be NULL (0.5 is used, :377-378), vel NULL when n_l1 == 2, dir NULL when n_l1 == 0;
- *   grads[6]  : gradient maps of the same shapes, ZERO-FILLED by the caller (any may be NULL); the kernel accumulates
- *               with float atomics (two objects may share a cell);
+ *   grads[6]  : gradient maps of the same shapes, ZERO-FILLED by the caller (any may be NULL).  Two objects may share a
+ *               cell: contributions are added in ascending object index by one thread per cell — deterministic, no
+ *               float atomics; cell_count receives the number of objects per cell (integer atomics);
  *   pos_ind   : (n,3) int64 [batch, x, y] (:72-80);  anno : (n, anno_cols) fp32 boxes [x,y,z,w,l,h,yaw(,vx,vy)];
  *   gd_scale  : loss_weight / avg_factor of loss_gd,  l1_scale: the same for loss_bbox (L1Loss).
  * coder: kind GD3D_PRO_CENTER (norm_bbox, out_size_factor, voxel_size, pc_range; aux ignored).
@@ -220,6 +221,7 @@ typedef struct gd3d_center_task {
   float* grads[6];
   const int64_t* pos_ind;
   const float* anno;
+  int32_t* cell_count; /* (B*H*W) int32, ZERO-FILLED by the caller; required when any grads[] is non-NULL */
   int64_t n;
   int32_t B, H, W, anno_cols;
   float gd_scale, l1_scale;
@@ -234,6 +236,36 @@ int gd3d_center_head_loss(const gd3d_params* params, const gd3d_prologue* coder,
 
 int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks,
                            const float* grad_losses, void* stream);
+
+/* GDLoss.forward with an (n,7) weight and a reduced result, INCLUDING its early-out, without a host sync.  The reference
+ * begins with `if not torch.any(weight > 0): return (pred * weight).sum()` (gaussian_distance_loss.py:290-292) — a full
+ * pass over the weights and a device-to-host wait on every training call.  Here the fused kernel leaves, per tile, the
+ * loss partial, sum(pred * weight7) and "some weight > 0"; the reduce stage adds them and selects on the device:
+ *     *any_positive = any(weight7 > 0)                  (int32, device; NaN weights are not > 0)
+ *     *loss_sum     = *any_positive ? scale * sum_i mean(weight7[i,:]) L_i : sum(dec(pred) * weight7)
+ * grad_pred / grad_target receive the gradient of the FIRST branch; gd3d_grad_finish (below) puts the second branch's
+ * gradient there when *any_positive == 0.  `prologue` as in gd3d_loss_fused_decoded (the early-out's `pred` is then the
+ * decoded row); start_event / stop_event as in gd3d_loss_fused_timed (NULL: none).  n == 0: *loss_sum = 0, flag 0. */
+int gd3d_loss_fused_select(const gd3d_params* params, const gd3d_prologue* prologue, const float* pred,
+                           const float* target, const float* weight7, int64_t n, float scale,
+                           float* loss_sum, int32_t* any_positive, float* grad_pred, float* grad_target,
+                           void* workspace, void* stream, void* start_event, void* stop_event);
+
+/* Autograd backward of a reduced call; g is the upstream gradient (device scalar).
+ *   any_positive == NULL or *any_positive != 0 : grad_pred *= g, grad_target *= g (the grid leaves after two scalar loads
+ *       when g == 1: one empty launch, no HBM traffic, no host sync — gd3d_scale_rows for both arrays at once);
+ *   *any_positive == 0 : grad_pred = g * d sum(dec(pred) * weight7) / d pred (= g * weight7 without a prologue),
+ *       grad_target = 0.  weight7 (and pred / prologue when the forward had a prologue) must be the forward's. */
+int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64_t n,
+                     const int32_t* any_positive, const float* weight7, const float* pred,
+                     const gd3d_prologue* prologue, void* stream);
+
+/* HBM ceiling probe with the fused kernel's access mix (two streams read, one written): z = x + y over n_floats fp32
+ * (multiple of 4, 16-byte aligned arrays), nontemporal 16-byte loads and stores, one vector per thread.  The two events
+ * (nullable) are bound to the dispatch as in gd3d_loss_fused_timed.  bench.py runs it on the fused kernel's own buffers
+ * to report the box's copy ceiling next to roofline.frac.  (Measurement aid; no reference counterpart.) */
+int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats, void* stream,
+                      void* start_event, void* stop_event);
 
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.

@@ -34,7 +34,8 @@ class SmoothL1(ctypes.Structure):
 class CenterTask(ctypes.Structure):
     """gd3d_center_task (include/gd3d.h)."""
     _fields_ = [('maps', ctypes.c_void_p * 6), ('grads', ctypes.c_void_p * 6), ('pos_ind', ctypes.c_void_p),
-                ('anno', ctypes.c_void_p), ('n', ctypes.c_int64), ('B', ctypes.c_int32), ('H', ctypes.c_int32),
+                ('anno', ctypes.c_void_p), ('cell_count', ctypes.c_void_p), ('n', ctypes.c_int64), ('B', ctypes.c_int32),
+                ('H', ctypes.c_int32),
                 ('W', ctypes.c_int32), ('anno_cols', ctypes.c_int32), ('gd_scale', ctypes.c_float),
                 ('l1_scale', ctypes.c_float)]
 
@@ -49,6 +50,10 @@ SYMBOLS = {
                                        _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_fused_timed': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_loss_fused_select': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _i64, _f32, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_grad_finish': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(Prologue), _vp]),
+    'gd3d_probe_stream': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'gd3d_prof_event_create': (_int, [ctypes.POINTER(_vp)]),
     'gd3d_prof_event_destroy': (_int, [_vp]),
     'gd3d_prof_event_elapsed_ms': (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
@@ -97,38 +102,44 @@ def lib_path():
     return _build.LIB_PATH
 
 
-def load():
-    """Load (building first if the in-tree .so is missing or stale and hipcc is available)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    override = os.environ.get('GD3D_LIB')  # A/B runs of experimental builds (tools/build_variants.py)
-    if override:
-        L = ctypes.CDLL(override)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
-        return _lib
-    if _build.is_stale():
-        try:
-            _build.build()
-        except Exception as e:  # noqa: BLE001
-            if not os.path.isfile(_build.LIB_PATH):
-                raise RuntimeError(
-                    'libgd3d.so (HIP kernels for gfx950) is missing and could not be built; '
-                    'there is no CPU fallback for this package') from e
-    L = ctypes.CDLL(_build.LIB_PATH)
+ABI_VERSION = 2
+
+
+def _bind(path):
+    L = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
     arch = ctypes.c_char_p()
     ver = L.gd3d_abi_version(ctypes.byref(arch))
-    if ver != 1:
-        raise RuntimeError(f'libgd3d.so ABI version {ver} != 1')
-    _lib = L
+    if ver != ABI_VERSION:
+        raise RuntimeError(f'{path}: ABI version {ver} != {ABI_VERSION}')
+    return L
+
+
+def load():
+    """Load libgd3d.so, building it first when the in-tree binary is missing or older than its sources.
+    A failed compile is an error (it never falls back to an older binary); only a machine WITHOUT hipcc may run a
+    binary whose source hash no longer matches, and says so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    override = os.environ.get('GD3D_LIB')  # A/B runs of experimental builds (tools/build_variants.py)
+    if override:
+        _lib = _bind(override)
+        return _lib
+    if _build.is_stale():
+        if os.path.exists(_build.hipcc_path()):
+            _build.build()                  # compile or link errors propagate
+        elif os.path.isfile(_build.LIB_PATH):
+            import warnings
+            warnings.warn(f'libgd3d.so does not match its sources (source hash {_build.source_hash()[:12]}) and hipcc is '
+                          'not available to rebuild it: running the binary as it is')
+        else:
+            raise RuntimeError('libgd3d.so (HIP kernels for gfx950) is missing and hipcc is not available to build it; '
+                               'there is no CPU fallback for this package')
+    _lib = _bind(_build.LIB_PATH)
     return _lib
 
 

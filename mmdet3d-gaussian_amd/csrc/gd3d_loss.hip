@@ -47,6 +47,10 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
                        // (measured r01, 10 M pairs: nt loads + nt stores 129 us vs 151 us plain; a persistent
                        //  double-buffered grid-stride variant was 143-160 us and was dropped)
 #endif
+#ifndef GD_TICKET
+#define GD_TICKET 0    // 1: the loss sum is finished inside the fused kernel (sc1 partial + arrival tickets);
+                       // 0: separate reduce_partials_kernel launch
+#endif
 #ifndef GD_NT_STORE
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
 #endif
@@ -89,6 +93,16 @@ struct LossArgs {
   float* gp;         // nullable
   float* gt;         // nullable (only read when the kernel is instantiated with GT)
   float* partials;   // nullable
+  // GDLoss.forward's early-out when no weight entry is > 0 (gaussian_distance_loss.py:290-292), resolved on the device:
+  // with wsel the block also leaves sum(pred * weight7) in partials[nbp + b] and "any weight > 0" in partials[2 nbp + b]
+  int wsel;
+  long long nbp;     // partial-array stride (number of tiles rounded up to 4)
+#if GD_TICKET
+  float* out;        // loss sum written by the last workgroup (two-level ticket tree), nullable
+  unsigned* gticket; // per 64-tile group arrival counters, zero before the launch, left zero
+  double* gsum;      // per group sums
+  unsigned* top;     // arrival counter of the groups
+#endif
   long long n;
   float scale, alpha, tau;
   float c0, c1, c2;
@@ -160,13 +174,14 @@ GD_DEV float wave_sum(float v) {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
-  // dynamic LDS (16-byte aligned base, every carve offset a multiple of 16): two tiles + 4 wave sums, plus a
-  // third tile only when (N,7) weights are given, so that the common launch keeps 8 workgroups per CU
+  // dynamic LDS (16-byte aligned base, every carve offset a multiple of 16): two tiles + 32 floats of per-wave sums
+  // (loss | pred*weight | any weight > 0), plus a third tile only when (N,7) weights are given, so that the common
+  // launch keeps 8 workgroups per CU
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sp = smem;
   float* const st = smem + TILE_F;
   float* const swave = smem + 2 * TILE_F;
-  float* const sw7 = smem + 2 * TILE_F + 16;
+  float* const sw7 = smem + 2 * TILE_F + 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -235,6 +250,16 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
       }
     }
   }
+  float alt = 0.0f;      // wsel: this row's share of (pred * weight).sum() (ref :292; pred = the DECODED row)
+  bool anyp = false;     //       and of torch.any(weight > 0) (ref :290; a NaN weight is not > 0)
+  if (a.wsel && valid) { // uniform && per-thread
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const float wk = sw7[tid * 7 + k];
+      anyp |= wk > 0.0f;
+      alt = fmaf(pv[k], wk, alt);
+    }
+  }
   const float L = pair_loss<LOSS, FUN, FLAG, GT>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
   const float fl = valid ? f * L : 0.0f;
   if (a.pro != GD3D_PRO_NONE) {
@@ -257,12 +282,32 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   if (a.partials != nullptr) {
     const float ws = wave_sum(fl);  // uniform (readlane 63)
     if (lane == 0) swave[wave] = ws;
+    if (a.wsel) {                   // uniform
+      const float wa = wave_sum(alt);
+      const bool any_w = __builtin_amdgcn_ballot_w64(anyp) != 0ull;
+      if (lane == 0) {
+        swave[NWAVE + wave] = wa;
+        swave[2 * NWAVE + wave] = any_w ? 1.0f : 0.0f;
+      }
+    }
   }
   __syncthreads();
   if (a.partials != nullptr && tid == 0) {
 #pragma unroll
     for (int w4 = 0; w4 < NWAVE; w4 += 4) bsum += (swave[w4] + swave[w4 + 1]) + (swave[w4 + 2] + swave[w4 + 3]);
+#if !GD_TICKET
     a.partials[blockIdx.x] = bsum;
+#endif
+    if (a.wsel) {
+      float asum = 0.0f, fany = 0.0f;
+#pragma unroll
+      for (int w4 = 0; w4 < NWAVE; ++w4) {
+        asum += swave[NWAVE + w4];
+        fany += swave[2 * NWAVE + w4];
+      }
+      a.partials[a.nbp + blockIdx.x] = asum;
+      a.partials[2 * a.nbp + blockIdx.x] = fany;   // > 0: some weight of this tile is > 0
+    }
   }
 
   if (fast) {
@@ -281,6 +326,48 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
     if (GT)
       for (int i = tid; i < fl7; i += TILE) a.gt[base * 7 + i] = st[i];
   }
+#if GD_TICKET
+  // Loss sum finished in this launch, fixed order, no float atomics: tile partial -> sum of a 64-tile group (by the
+  // group's last arriver) -> sum of the group sums (by the last group).  Only wave 0 takes part; the other waves have
+  // left.  Hand-off form (MI355X_MICROARCH.md, valid forms, row 1): every handed-off word is stored sc1 (write-through)
+  // by one lane, that wave drains vmcnt, then its agent-scope ticket add; the wave whose add returned last loads the
+  // words with sc1 loads.  Tickets return to zero, so the workspace needs zeroing once, not per call.
+  if (a.out != nullptr && wave == 0) {
+    const unsigned nb = gridDim.x, grp = blockIdx.x >> 6, ngroups = (nb + 63) >> 6;
+    const unsigned gsize = (nb - (grp << 6)) < 64u ? (nb - (grp << 6)) : 64u;
+    if (lane == 0) __hip_atomic_store(a.partials + blockIdx.x, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.gticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t == gsize - 1) {
+      double v = 0.0;
+      if ((unsigned)lane < gsize)
+        v = (double)__hip_atomic_load(a.partials + (grp << 6) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) {
+        __hip_atomic_store(a.gticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.gsum + grp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned tt = 0;
+      if (lane == 0) tt = __hip_atomic_fetch_add(a.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tt = __builtin_amdgcn_readfirstlane(tt);
+      if (tt == ngroups - 1) {
+        double acc = 0.0;
+        for (unsigned g = lane; g < ngroups; g += 64)
+          acc += __hip_atomic_load(a.gsum + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) {
+          *a.out = (float)acc;
+          __hip_atomic_store(a.top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -422,8 +509,10 @@ static void launch_head_fun(int fun, bool flag, unsigned grid, hipStream_t s, co
 //   the gather never materialise: a thread reads its 9/11 values straight from the NCHW head maps), pred_gd =
 //   coder.decode(locs, pred)[:7] (:422-423), target = coder.encode(anno) (:409-411: [anno[:7], sin yaw, cos yaw, vel]),
 //   loss_gd = GDLoss(pred_gd, target[:7], avg_factor) (:433-434), loss_l1 = L1Loss(pred[7:], target[7:], code_weights,
-//   avg_factor) (:426-432).  Gradients are accumulated into the (zero-filled) per-head gradient maps with float atomics
-//   (two objects of a task may share a cell; the reference's index backward accumulates as well).
+//   avg_factor) (:426-432).  Two objects of a task may share a cell (the reference's index backward accumulates), so the
+//   gradient takes two steps, deterministic and without float atomics: this kernel stages every object's 11 gradient
+//   values and counts the objects per cell (integer atomics); center_accum_kernel then writes single-object cells
+//   directly and lets the lowest-index object of a shared cell add the cell's contributions in ascending object order.
 // blockIdx.y = task; partials[(task * 2 + term) * pstride + block], term 0 = l1, 1 = gd.
 constexpr int CENTER_MAX_TASKS = 8;
 struct CenterTask {
@@ -431,6 +520,9 @@ struct CenterTask {
   float* grads[6];       // nullable
   const long long* pos_ind;
   const float* anno;
+  int* count;            // (B*H*W) objects per cell, zero-filled by the caller; nullptr = no gradient wanted
+  int* keys;             // (n) workspace: cell index of object i, -1 = not live
+  float* og;             // (n, 11) workspace: object i's gradient contributions, map order reg|height|dim|yaw|dir|vel
   long long n;
   int B, H, W, anno_cols;
   float gd_scale, l1_scale;
@@ -456,6 +548,7 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
   if ((long long)blockIdx.x * HEAD_T >= T.n) return;  // uniform: this task has fewer positives than the largest one
   float fgd = 0.0f, fl1 = 0.0f;
   bool live = i < T.n;
+  int key = -1;
   long long b = 0, x = 0, y = 0;
   if (live) {
     b = T.pos_ind[i * 3];
@@ -513,26 +606,18 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
       }
     }
     fl1 *= T.l1_scale;
-    // scatter: GD gradient -> reg / height / dim / yaw maps, L1 gradient -> dir / vel maps
-    if (T.grads[0] != nullptr) {
-      atomicAdd(&T.grads[0][(b * 2 + 0) * plane + off], g1[0] * jac[0]);
-      atomicAdd(&T.grads[0][(b * 2 + 1) * plane + off], g1[1] * jac[1]);
-    }
-    if (T.grads[1] != nullptr) atomicAdd(&T.grads[1][b * plane + off], g1[2]);
-    if (T.grads[2] != nullptr) {
+    // stage: GD gradient -> reg / height / dim / yaw slots, L1 gradient -> dir / vel slots
+    if (T.count != nullptr) {
+      float* o = T.og + i * 11;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) atomicAdd(&T.grads[2][(b * 3 + k) * plane + off], g1[3 + k] * jac[3 + k]);
-    }
-    if (T.grads[3] != nullptr) atomicAdd(&T.grads[3][b * plane + off], g1[6]);
-    if (T.grads[4] != nullptr) {
-      atomicAdd(&T.grads[4][(b * 2 + 0) * plane + off], gl1[0]);
-      atomicAdd(&T.grads[4][(b * 2 + 1) * plane + off], gl1[1]);
-    }
-    if (T.grads[5] != nullptr && a.n_l1 > 2) {
-      atomicAdd(&T.grads[5][(b * 2 + 0) * plane + off], gl1[2]);
-      atomicAdd(&T.grads[5][(b * 2 + 1) * plane + off], gl1[3]);
+      for (int k = 0; k < 7; ++k) o[k] = g1[k] * jac[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[7 + k] = gl1[k];
+      key = (int)(b * plane + off);
+      atomicAdd(&T.count[key], 1);
     }
   }
+  if (T.count != nullptr && i < T.n) T.keys[i] = key;
   const float w0 = wave_sum(fl1), w1 = wave_sum(fgd);
   if (lane == 0) {
     swave[0][wave] = w0;
@@ -544,22 +629,87 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
         (swave[tid][0] + swave[tid][1]) + (swave[tid][2] + swave[tid][3]);
 }
 
-// one workgroup per (task, term): fixed-order fp64 sum of that slice of partials -> losses[task * 2 + term]
-__global__ __launch_bounds__(256) void center_reduce_kernel(const CenterArgs a, float* __restrict__ losses) {
-  __shared__ double sd[256];
-  const int ti = blockIdx.x >> 1, term = blockIdx.x & 1, tid = threadIdx.x;
-  const long long nb = (a.t[ti].n + HEAD_T - 1) / HEAD_T;
-  const float* p = a.partials + ((long long)ti * 2 + term) * a.pstride;
-  double acc = 0.0;
-  for (long long k = tid; k < nb; k += 256) acc += (double)p[k];
-  sd[tid] = acc;
-  __syncthreads();
+// Second step of the CenterGDHead launch pair.  grid = (pstride, tasks), same geometry as head_center_kernel.
+//  (1) gradient: thread i owns object i.  count[cell] == 1: its 11 staged values go straight to the maps.  Shared cells:
+//      one such lane at a time, the wave scans the task's keys in ascending object order (64 per step, ballot); the lane
+//      is the cell's OWNER iff the first match is itself, and then lanes 0..10 add the matching objects' staged values
+//      in that order and write the cell.  Sums are in ascending object index whatever the launch geometry.
+//  (2) block (0, task): fixed-order fp64 sum of the task's loss partials -> losses[task * 2 + {l1, gd}].
+GD_DEV float* center_slot(const CenterTask& T, int k, long long b, long long off, long long plane, int n_l1) {
+  // slot k of the staged row -> address in the gradient maps (nullptr: that map wants no gradient)
+  if (k < 2) return T.grads[0] != nullptr ? T.grads[0] + (b * 2 + k) * plane + off : nullptr;
+  if (k == 2) return T.grads[1] != nullptr ? T.grads[1] + b * plane + off : nullptr;
+  if (k < 6) return T.grads[2] != nullptr ? T.grads[2] + (b * 3 + (k - 3)) * plane + off : nullptr;
+  if (k == 6) return T.grads[3] != nullptr ? T.grads[3] + b * plane + off : nullptr;
+  if (k < 9) return (T.grads[4] != nullptr && n_l1 >= 2) ? T.grads[4] + (b * 2 + (k - 7)) * plane + off : nullptr;
+  return (T.grads[5] != nullptr && n_l1 > 2) ? T.grads[5] + (b * 2 + (k - 9)) * plane + off : nullptr;
+}
+
+__global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a, float* __restrict__ losses) {
+  __shared__ double sd[HEAD_T];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ti = blockIdx.y;
+  const CenterTask& T = a.t[ti];
+  const long long plane = (long long)T.H * T.W;
+  if (T.count != nullptr && (long long)blockIdx.x * HEAD_T < T.n) {  // uniform
+    const long long i = (long long)blockIdx.x * HEAD_T + tid;
+    const int key = i < T.n ? T.keys[i] : -1;
+    const int c = key >= 0 ? T.count[key] : 0;
+    if (c == 1) {
+      const long long b = key / plane, off = key - b * plane;
 #pragma unroll
-  for (int s2 = 128; s2 > 0; s2 >>= 1) {
-    if (tid < s2) sd[tid] += sd[tid + s2];
-    __syncthreads();
+      for (int k = 0; k < 11; ++k) {
+        float* dst = center_slot(T, k, b, off, plane, a.n_l1);
+        if (dst != nullptr) *dst = T.og[i * 11 + k];
+      }
+    }
+    unsigned long long dup = __builtin_amdgcn_ballot_w64(c > 1);
+    while (dup != 0ull) {                                             // wave-uniform
+      const int L = __builtin_ctzll(dup);
+      dup &= dup - 1;
+      const int kL = __builtin_amdgcn_readlane(key, L);
+      const long long iL = i - lane + L;
+      float acc = 0.0f;
+      bool owner = true, first = true;
+      for (long long j0 = 0; j0 < T.n && owner; j0 += 64) {
+        const long long j = j0 + lane;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(j < T.n && T.keys[j] == kL);
+        while (m != 0ull) {
+          const long long jj = j0 + __builtin_ctzll(m);
+          m &= m - 1;
+          if (first) {
+            first = false;
+            if (jj != iL) {                                           // an earlier object owns this cell
+              owner = false;
+              break;
+            }
+          }
+          if (lane < 11) acc += T.og[jj * 11 + lane];
+        }
+      }
+      if (owner && lane < 11) {
+        const long long b = kL / plane, off = kL - b * plane;
+        float* dst = center_slot(T, lane, b, off, plane, a.n_l1);
+        if (dst != nullptr) *dst = acc;
+      }
+    }
   }
-  if (tid == 0) losses[ti * 2 + term] = (float)sd[0];
+  if (blockIdx.x != 0) return;
+  const long long nb = (T.n + HEAD_T - 1) / HEAD_T;
+  for (int term = 0; term < 2; ++term) {
+    const float* p = a.partials + ((long long)ti * 2 + term) * a.pstride;
+    double acc = 0.0;
+    for (long long k = tid; k < nb; k += HEAD_T) acc += (double)p[k];
+    __syncthreads();
+    sd[tid] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s2 = HEAD_T / 2; s2 > 0; s2 >>= 1) {
+      if (tid < s2) sd[tid] += sd[tid + s2];
+      __syncthreads();
+    }
+    if (tid == 0) losses[ti * 2 + term] = (float)sd[0];
+  }
 }
 
 // backward of the same call when the upstream gradient is not all ones: grads of task t are scaled by
@@ -633,6 +783,124 @@ __global__ __launch_bounds__(1024) void scale_rows_kernel(float* __restrict__ gr
   for (long long i = i0; i < nflt; i += stride) grad[i] *= per_row ? g[i / 7] : gs;
 }
 
+// The same second stage for a weighted call that must honour GDLoss.forward's early-out (ref :290-292) without a host
+// sync: besides the loss partials the fused kernel left sum(pred * weight) and "some weight > 0" per tile.  One launch
+// adds all three in a fixed order and SELECTS on the device:
+//   *out = any weight > 0 ? scale * sum_i w_i L_i : sum(pred * weight)          *any_pos = that predicate (for backward)
+__global__ __launch_bounds__(1024) void reduce_select_kernel(const float* __restrict__ partials, long long nb, long long nbp,
+                                                             float* __restrict__ out, int* __restrict__ any_pos) {
+  __shared__ double sd[3][1024];
+  const int tid = threadIdx.x;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (long long i = tid; i < nb; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += (double)partials[k * nbp + i];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sd[k][tid] = acc[k];
+  __syncthreads();
+  if (tid < 64) {
+    double s3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double s2 = 0.0;
+      for (int j = 0; j < 16; ++j) s2 += sd[k][tid * 16 + j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s2 += __shfl_down(s2, off, 64);
+      s3[k] = s2;
+    }
+    if (tid == 0) {
+      const bool any = s3[2] > 0.0;
+      *out = (float)(any ? s3[0] : s3[1]);
+      if (any_pos != nullptr) *any_pos = any ? 1 : 0;
+    }
+  }
+}
+
+// Autograd backward of a reduced call (replaces scale_rows_kernel there):
+//   any weight > 0 (or no selection):  grad *= g            (the whole grid leaves after two scalar loads when g == 1)
+//   otherwise (ref :290-292 took `(pred * weight).sum()`):  grad_pred = g * d(sum(dec(pred) * weight7)) / d pred,
+//                                                           grad_target = 0
+// One thread per row on the rare path; it is not a bandwidth path.
+struct FinishArgs {
+  float* gp;             // (n,7) nullable
+  float* gt;             // (n,7) nullable
+  const float* g;        // device scalar: upstream gradient
+  const int* any_pos;    // device flag written by reduce_select_kernel; nullptr = no selection
+  const float* w7;       // (n,7) weights      (selection only)
+  const float* pred;     // (n,7) encoded rows (selection with a prologue only)
+  const float* aux;
+  long long n;
+  int pro, norm_bbox;
+  float osf, vs0, vs1;
+};
+
+__global__ __launch_bounds__(1024) void grad_finish_kernel(const FinishArgs a) {
+  const float gs = a.g[0];
+  const bool normal = a.any_pos == nullptr || a.any_pos[0] != 0;
+  if (normal && gs == 1.0f) return;  // uniform across the grid
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nflt = a.n * 7;
+  if (normal) {
+    for (int which = 0; which < 2; ++which) {
+      float* grad = which == 0 ? a.gp : a.gt;
+      if (grad == nullptr) continue;
+      if (((uintptr_t)grad & 15) == 0) {
+        v4f* g4 = reinterpret_cast<v4f*>(grad);
+        const long long nv = nflt >> 2;
+        for (long long i = i0; i < nv; i += stride) g4[i] = g4[i] * gs;
+        for (long long i = (nv << 2) + i0; i < nflt; i += stride) grad[i] *= gs;
+      } else {
+        for (long long i = i0; i < nflt; i += stride) grad[i] *= gs;
+      }
+    }
+    return;
+  }
+  for (long long i = i0; i < a.n; i += stride) {
+    float w[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w[k] = a.w7[i * 7 + k];
+    if (a.pro == GD3D_PRO_ANCHOR_DELTA) {
+      float enc[7], an[7], dec[7];
+      DecodeJac J;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        enc[k] = a.pred[i * 7 + k];
+        an[k] = a.aux[i * 7 + k];
+      }
+      decode_anchor(enc, an, dec, J);
+      encode_grad(w, J, true);
+    } else if (a.pro == GD3D_PRO_CENTER) {
+      w[0] *= a.osf * a.vs0;
+      w[1] *= a.osf * a.vs1;
+      if (a.norm_bbox) {
+#pragma unroll
+        for (int k = 3; k < 6; ++k) w[k] *= expf(a.pred[i * 7 + k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      if (a.gp != nullptr) a.gp[i * 7 + k] = gs * w[k];
+      if (a.gt != nullptr) a.gt[i * 7 + k] = 0.0f;
+    }
+  }
+}
+
+// HBM ceiling probe for the access mix of the fused kernel: c = a + b over float4 vectors, nontemporal loads and
+// stores, one vector per thread, full grid (the fastest of the shapes tools/hbm_probe.hip measures).  bench.py runs it
+// on the fused kernel's OWN three buffers right after the timed region, so that `roofline.copy_ceiling_GBps` is the
+// ceiling of that box and of that buffer placement.
+__global__ __launch_bounds__(256) void probe_add_kernel(const v4f* __restrict__ x, const v4f* __restrict__ y,
+                                                        v4f* __restrict__ z, long long nv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < nv) {
+    const v4f p = __builtin_nontemporal_load(x + i);
+    const v4f q = __builtin_nontemporal_load(y + i);
+    __builtin_nontemporal_store(p + q, z + i);
+  }
+}
+
 struct Geometry {
   unsigned tgrid;  // one workgroup per 256-pair tile
   // profiling only (gd3d_loss_fused_timed): events bound to THIS dispatch, see launch_one
@@ -641,7 +909,7 @@ struct Geometry {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
-  const size_t lds = (size_t)(2 * TILE_F + 16 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+  const size_t lds = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
   if (g.ev_start != nullptr || g.ev_stop != nullptr) {
     // hipExtLaunchKernel binds the two events to the begin / end timestamps of this dispatch packet itself: no marker
     // packets enter the stream, and hipEventElapsedTime(start, stop) is the kernel's execution time as rocprofv3 reports
@@ -685,11 +953,15 @@ using namespace gd3d;
 
 extern "C" {
 
+// workspace layout (all offsets multiples of 16 bytes), nb = tiles of 256 rows, nbp = nb rounded up to 4, ng = 64-tile groups:
+//   float  partials[3][nbp]   loss | sum(pred * weight7) | any weight > 0   (rows 1, 2 only for gd3d_loss_fused_select)
+//   double gsum[ngp]; unsigned gticket[ngp]; unsigned top[4]                (in-kernel finish builds only, GD_TICKET)
+static inline int64_t ws_nbp(int64_t n) { return (((n + 255) / 256) + 3) & ~(int64_t)3; }
+static inline int64_t ws_ngp(int64_t n) { return ((((n + 255) / 256) + 63) / 64 + 3) & ~(int64_t)3; }
+
 size_t gd3d_loss_workspace_bytes(int64_t n) {
-  // one fp32 partial per workgroup; sized for 256-row workgroups (the finest geometry any kernel here uses)
-  if (n <= 0) return 16;
-  const int64_t nb = (n + 255) / 256;
-  return (size_t)(((nb + 1) * 4 + 15) / 16 * 16);
+  if (n <= 0) return 64;
+  return (size_t)(12 * ws_nbp(n) + 12 * ws_ngp(n) + 16);
 }
 
 int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
@@ -706,17 +978,39 @@ int gd3d_loss_fused_w7(const gd3d_params* p, const float* pred, const float* tar
                                  grad_target, workspace, stream);
 }
 
+static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
+                       const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
+                       float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream,
+                       void* start_event, void* stop_event, int32_t* any_positive, bool select);
+
 int gd3d_loss_fused_decoded(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
                             const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
                             float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream) {
-  return gd3d_loss_fused_timed(p, pro, pred, target, row_weight, weight7, n, scale, loss, loss_sum, grad_pred, grad_target,
-                               workspace, stream, nullptr, nullptr);
+  return loss_launch(p, pro, pred, target, row_weight, weight7, n, scale, loss, loss_sum, grad_pred, grad_target,
+                     workspace, stream, nullptr, nullptr, nullptr, false);
 }
 
 int gd3d_loss_fused_timed(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
                           const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
                           float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream,
                           void* start_event, void* stop_event) {
+  return loss_launch(p, pro, pred, target, row_weight, weight7, n, scale, loss, loss_sum, grad_pred, grad_target,
+                     workspace, stream, start_event, stop_event, nullptr, false);
+}
+
+int gd3d_loss_fused_select(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
+                           const float* weight7, int64_t n, float scale, float* loss_sum, int32_t* any_positive,
+                           float* grad_pred, float* grad_target, void* workspace, void* stream, void* start_event,
+                           void* stop_event) {
+  if (weight7 == nullptr || loss_sum == nullptr || any_positive == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  return loss_launch(p, pro, pred, target, nullptr, weight7, n, scale, nullptr, loss_sum, grad_pred, grad_target,
+                     workspace, stream, start_event, stop_event, any_positive, true);
+}
+
+static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
+                       const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
+                       float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream,
+                       void* start_event, void* stop_event, int32_t* any_positive, bool select) {
   if (row_weight != nullptr && weight7 != nullptr) return GD3D_E_BADARG;
   if (pro != nullptr && pro->kind != GD3D_PRO_NONE) {
     if (pro->kind != GD3D_PRO_ANCHOR_DELTA && pro->kind != GD3D_PRO_CENTER) return GD3D_E_BADARG;
@@ -737,12 +1031,25 @@ int gd3d_loss_fused_timed(const gd3d_params* p, const gd3d_prologue* pro, const 
   const int64_t nb = (n + TILE - 1) / TILE;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   if (n == 0) {
+    // no rows: sum 0; torch.any() of an empty weight is False, so a selecting call takes the early-out, whose value is 0 too
+    if (any_positive != nullptr) {
+      const hipError_t e0 = hipMemsetAsync(any_positive, 0, sizeof(int32_t), s);
+      if (e0 != hipSuccess) return (int)e0;
+    }
     if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
     return 0;
   }
   if (loss_sum == nullptr && loss == nullptr && grad_pred == nullptr && grad_target == nullptr && workspace == nullptr)
     return 0;  // nothing requested
   LossArgs a;
+  a.wsel = select ? 1 : 0;
+  a.nbp = ws_nbp(n);
+#if GD_TICKET
+  a.out = select ? nullptr : loss_sum;
+  a.gsum = workspace != nullptr ? (double*)((char*)workspace + 12 * ws_nbp(n)) : nullptr;
+  a.gticket = workspace != nullptr ? (unsigned*)((char*)workspace + 12 * ws_nbp(n) + 8 * ws_ngp(n)) : nullptr;
+  a.top = workspace != nullptr ? (unsigned*)((char*)workspace + 12 * ws_nbp(n) + 12 * ws_ngp(n)) : nullptr;
+#endif
   a.pred = pred;
   a.target = target;
   a.w = row_weight;
@@ -786,8 +1093,61 @@ int gd3d_loss_fused_timed(const gd3d_params* p, const gd3d_prologue* pro, const 
     default: e = launch_kfiou(p->fun, gt, grid, s, a); break;
   }
   if (e != hipSuccess) return (int)e;
+  if (select) {
+    hipLaunchKernelGGL(reduce_select_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, (long long)nb,
+                       (long long)ws_nbp(n), loss_sum, (int*)any_positive);
+    return (int)hipGetLastError();
+  }
+#if GD_TICKET
+  return 0;  // the last workgroup of the fused kernel wrote *loss_sum
+#else
   if (loss_sum != nullptr) return gd3d_loss_reduce(workspace, n, loss_sum, stream);
   return 0;
+#endif
+}
+
+int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64_t n, const int32_t* any_positive,
+                     const float* weight7, const float* pred, const gd3d_prologue* pro, void* stream) {
+  if (n < 0 || g == nullptr) return GD3D_E_BADARG;
+  if (n == 0 || (grad_pred == nullptr && grad_target == nullptr)) return 0;
+  FinishArgs a;
+  a.gp = grad_pred;
+  a.gt = grad_target;
+  a.g = g;
+  a.any_pos = (const int*)any_positive;
+  a.w7 = weight7;
+  a.pred = pred;
+  a.n = n;
+  a.pro = (pro != nullptr) ? pro->kind : GD3D_PRO_NONE;
+  a.norm_bbox = (pro != nullptr) ? pro->norm_bbox : 0;
+  a.aux = (pro != nullptr) ? pro->aux : nullptr;
+  a.osf = (pro != nullptr) ? pro->out_size_factor : 1.0f;
+  a.vs0 = (pro != nullptr) ? pro->voxel_size[0] : 1.0f;
+  a.vs1 = (pro != nullptr) ? pro->voxel_size[1] : 1.0f;
+  if (any_positive != nullptr) {
+    if (weight7 == nullptr) return GD3D_E_BADARG;
+    if (a.pro != GD3D_PRO_NONE && pred == nullptr) return GD3D_E_BADARG;
+    if (a.pro == GD3D_PRO_ANCHOR_DELTA && a.aux == nullptr) return GD3D_E_BADARG;
+  }
+  // few, large workgroups: the common case is the g == 1 early exit, whose cost is the dispatch itself
+  long long blocks = ((long long)n * 7 + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats, void* stream, void* start_event,
+                      void* stop_event) {
+  if (n_floats < 0 || (n_floats & 3) != 0) return GD3D_E_BADARG;
+  if (n_floats == 0) return 0;
+  if (x == nullptr || y == nullptr || z == nullptr) return GD3D_E_BADARG;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) != 0) return GD3D_E_BADARG;
+  const long long nv = n_floats >> 2;
+  const long long nb = (nv + 255) / 256;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipExtLaunchKernelGGL(probe_add_kernel, dim3((unsigned)nb), dim3(256), 0u, (hipStream_t)stream, (hipEvent_t)start_event,
+                        (hipEvent_t)stop_event, 0u, (const v4f*)x, (const v4f*)y, (v4f*)z, nv);
+  return (int)hipGetLastError();
 }
 
 int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* stream) {
@@ -914,6 +1274,11 @@ int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, in
                           labels, num_classes, M, scale, loss_sum, grad_bbox_pred, workspace, stream);
 }
 
+static size_t center_partial_bytes(int32_t num_tasks, int64_t max_n) {
+  const int64_t nb = (max_n + HEAD_T - 1) / HEAD_T;
+  return (size_t)((2 * (int64_t)num_tasks * nb * 4 + 15) / 16 * 16);
+}
+
 static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
                        const float* code_weights, int32_t n_l1, void* workspace, CenterArgs& a, long long& max_n) {
   if (p == nullptr || coder == nullptr || tasks == nullptr || num_tasks <= 0 || num_tasks > CENTER_MAX_TASKS)
@@ -952,6 +1317,12 @@ static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const g
     }
     d.pos_ind = (const long long*)s.pos_ind;
     d.anno = s.anno;
+    bool wants = false;
+    for (int m = 0; m < 6; ++m) wants |= s.grads[m] != nullptr;
+    if (wants && s.cell_count == nullptr) return GD3D_E_BADARG;
+    d.count = wants ? (int*)s.cell_count : nullptr;
+    d.keys = nullptr;
+    d.og = nullptr;
     d.n = s.n;
     d.B = s.B;
     d.H = s.H;
@@ -963,13 +1334,20 @@ static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const g
   }
   a.partials = (float*)workspace;
   a.pstride = (max_n + HEAD_T - 1) / HEAD_T;
+  // workspace: partials (2 * tasks * pstride floats, padded to 16 B) | per task: keys (max_n int32) | og (max_n * 11 fp32)
+  if (workspace != nullptr) {
+    char* base = (char*)workspace + center_partial_bytes(num_tasks, max_n);
+    for (int t = 0; t < num_tasks; ++t) {
+      a.t[t].keys = (int*)(base + (size_t)t * 48 * (size_t)max_n);
+      a.t[t].og = (float*)(base + (size_t)t * 48 * (size_t)max_n + 4 * (size_t)max_n);
+    }
+  }
   return 0;
 }
 
 size_t gd3d_center_head_workspace_bytes(int32_t num_tasks, int64_t max_n) {
   if (num_tasks <= 0 || max_n <= 0) return 16;
-  const int64_t nb = (max_n + HEAD_T - 1) / HEAD_T;
-  return (size_t)((2 * (int64_t)num_tasks * nb * 4 + 15) / 16 * 16);
+  return center_partial_bytes(num_tasks, max_n) + (size_t)num_tasks * 48 * (size_t)max_n;
 }
 
 int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
@@ -1017,8 +1395,9 @@ int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, cons
 #undef GD3D_CENTER_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  // tasks without positives: their partial slices are never written; the reduce reads nb = 0 entries -> 0
-  hipLaunchKernelGGL(center_reduce_kernel, dim3(2 * (unsigned)num_tasks), dim3(256), 0, s, a, losses);
+  // second step: gradient accumulation (deterministic) + the loss sums.  Tasks without positives: their partial slices
+  // are never written; the sum reads nb = 0 entries -> 0
+  hipLaunchKernelGGL(center_accum_kernel, grid, dim3(HEAD_T), 0, s, a, losses);
   return (int)hipGetLastError();
 }
 
@@ -1036,6 +1415,9 @@ int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks, con
     a.t[t].H = tasks[t].H;
     a.t[t].W = tasks[t].W;
     a.t[t].n = 0;
+    a.t[t].count = nullptr;
+    a.t[t].keys = nullptr;
+    a.t[t].og = nullptr;
   }
   hipLaunchKernelGGL(center_scale_kernel, dim3(64, 6 * (unsigned)num_tasks), dim3(256), 0, (hipStream_t)stream, a,
                      grad_losses);

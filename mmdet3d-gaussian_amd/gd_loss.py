@@ -107,10 +107,26 @@ def _rows(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None):
-    """One launch of gd3d_loss_fused(_decoded) on the current stream of pred's device.
+_WS_FLOATS = {}
+
+
+def _ws_floats(n):
+    """gd3d_loss_workspace_bytes(n) / 4, memoised (one ctypes call less per forward)."""
+    k = _WS_FLOATS.get(n)
+    if k is None:
+        if len(_WS_FLOATS) > 4096:
+            _WS_FLOATS.clear()
+        k = _WS_FLOATS[n] = _library().gd3d_loss_workspace_bytes(n) // 4
+    return k
+
+
+def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None,
+               select=False):
+    """One launch of the fused kernel (+ its reduce stage) on the current stream of pred's device.
     `prologue`: None or a _lib.Prologue (bbox-coder decode fused into the kernel, head_loss.py).
-    Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None)."""
+    `select`  : row_weight is (N,7) and the reference's no-positive-weight early-out is resolved on the device
+                (gd3d_loss_fused_select); the returned `any_pos` is the int32 device flag backward needs.
+    Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None, any_pos|None)."""
     lib = _library()
     n = pred.shape[0]
     dev = pred.device
@@ -122,60 +138,72 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
         loss = torch.empty(n, dtype=torch.float32, device=dev) if want_loss else None
         gp = torch.empty_like(pred) if want_gp else None
         gt = torch.empty_like(target) if want_gt else None
-        total = ws = None
+        total = ws = any_pos = None
         if want_sum:
-            # one allocation: [0] = the fp32 result, [4:] = the per-workgroup partials (16-byte aligned)
-            buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(n) // 4, dtype=torch.float32, device=dev)
-            total, ws = buf[0], buf[4:]
+            # one allocation: [0] = the fp32 result, [1] = the int32 any-positive flag, [4:] = workspace (16-byte aligned)
+            buf = torch.empty(4 + _ws_floats(n), dtype=torch.float32, device=dev)
+            total, ws = buf[0], buf.data_ptr() + 16
         ev = PROFILE_EVENTS
         stream = _raw_stream(dev.index)
-        w1 = w7 = None
-        if row_weight is not None:  # (N,) row weights, or (N,7) whose row mean the kernel takes itself
-            if row_weight.dim() == 2:
-                w7 = row_weight.data_ptr()
-            else:
-                w1 = row_weight.data_ptr()
-        if ev is None:
-            rc = lib.gd3d_loss_fused_decoded(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
-                                             _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream)
-        else:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
+        tm = None
+        if ev is not None:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
             tm = DispatchTimer()
-            rc = lib.gd3d_loss_fused_timed(params, prologue, _ptr(pred), _ptr(target), w1, w7, n, scale,
-                                           _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), _ptr(ws), stream,
-                                           tm.start, tm.stop)
             ev.append(tm)
+        if select:
+            any_pos = buf[1:2].view(torch.int32)
+            rc = lib.gd3d_loss_fused_select(params, prologue, pred.data_ptr(), target.data_ptr(), row_weight.data_ptr(), n,
+                                            scale, total.data_ptr(), any_pos.data_ptr(), _ptr(gp), _ptr(gt), ws, stream,
+                                            tm.start if tm else None, tm.stop if tm else None)
+        else:
+            w1 = w7 = None
+            if row_weight is not None:  # (N,) row weights, or (N,7) whose row mean the kernel takes itself
+                if row_weight.dim() == 2:
+                    w7 = row_weight.data_ptr()
+                else:
+                    w1 = row_weight.data_ptr()
+            if tm is None:
+                rc = lib.gd3d_loss_fused_decoded(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
+                                                 _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), ws, stream)
+            else:
+                rc = lib.gd3d_loss_fused_timed(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
+                                               _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), ws, stream, tm.start, tm.stop)
     finally:
         if switch:
             _set_device(prev)
     if rc != 0:
         _lib.check(rc, 'gd3d_loss_fused')
-    return loss, total, gp, gt
+    return loss, total, gp, gt, any_pos
 
 
 class _GDReduced(torch.autograd.Function):
-    """scale * sum_i w_i L_i  with the final gradients produced by the SAME launch."""
+    """scale * sum_i w_i L_i  with the final gradients produced by the SAME launch.  With `select` the value and the
+    gradient are those of the reference's early-out `(pred * weight).sum()` when no weight entry is > 0."""
 
     @staticmethod
-    def forward(ctx, pred, target, row_weight, params, scale, prologue=None):
+    def forward(ctx, pred, target, row_weight, params, scale, prologue=None, select=False):
         need_gp, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        _, total, gp, gt = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt, prologue)
-        ctx.gp, ctx.gt = gp, gt
+        _, total, gp, gt, any_pos = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt,
+                                               prologue, select)
+        ctx.gp, ctx.gt, ctx.any_pos = gp, gt, any_pos
         ctx.used = False
-        ctx.replay = (pred, target, row_weight, params, scale, prologue)
-        return total
+        ctx.replay = (pred, target, row_weight, params, scale, prologue, select)
+        if select:
+            ctx.mark_non_differentiable(any_pos)
+        return total, any_pos
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_flag=None):
         lib = _library()
-        pred = ctx.replay[0]
+        pred, target, row_weight, params, scale, prologue, select = ctx.replay
         if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
-            r_pred, r_target, r_w, r_params, r_scale, r_pro = ctx.replay
-            _, _, gp, gt = fused_call(r_params, r_pred, r_target, r_w, r_scale, False, False, ctx.gp is not None,
-                                      ctx.gt is not None, r_pro)
+            _, _, gp, gt, _ = fused_call(params, pred, target, row_weight, scale, False, False, ctx.gp is not None,
+                                         ctx.gt is not None, prologue)
         else:
             gp, gt = ctx.gp, ctx.gt
             ctx.used = True
+        if gp is None and gt is None:
+            return (None,) * 7
         g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         dev = pred.device
         prev = _get_device()
@@ -183,17 +211,18 @@ class _GDReduced(torch.autograd.Function):
         if switch:
             _set_device(dev.index)
         try:
-            stream = _raw_stream(dev.index)
-            for buf in (gp, gt):
-                if buf is not None:
-                    # reads g on the device, exits without touching memory when g == 1 (no host sync)
-                    rc = lib.gd3d_scale_rows(buf.data_ptr(), g.data_ptr(), 0, buf.shape[0], stream)
-                    if rc != 0:
-                        _lib.check(rc, 'gd3d_scale_rows')
+            # one launch for both arrays: reads g (and the any-positive flag) on the device; leaves without touching
+            # memory when g == 1 and the normal branch was taken (no host sync)
+            rc = lib.gd3d_grad_finish(_ptr(gp), _ptr(gt), g.data_ptr(), pred.shape[0], _ptr(ctx.any_pos),
+                                      row_weight.data_ptr() if select else None,
+                                      pred.data_ptr() if (select and prologue is not None) else None,
+                                      prologue if select else None, _raw_stream(dev.index))
         finally:
             if switch:
                 _set_device(prev)
-        return gp, gt, None, None, None, None
+        if rc != 0:
+            _lib.check(rc, 'gd3d_grad_finish')
+        return gp, gt, None, None, None, None, None
 
 
 class _GDPerPair(torch.autograd.Function):
@@ -201,7 +230,7 @@ class _GDPerPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target, row_weight, params, scale, prologue=None):
-        loss, _, _, _ = fused_call(params, pred, target, row_weight, scale, True, False, False, False, prologue)
+        loss = fused_call(params, pred, target, row_weight, scale, True, False, False, False, prologue)[0]
         ctx.replay = (pred, target, row_weight, params, scale, prologue)
         return loss
 
@@ -213,8 +242,8 @@ class _GDPerPair(torch.autograd.Function):
         if row_weight is not None:
             rw = rw * (row_weight.mean(dim=-1) if row_weight.dim() == 2 else row_weight)
         rw = rw.contiguous()
-        _, _, gp, gt = fused_call(params, pred, target, rw, scale, False, False, ctx.needs_input_grad[0],
-                                  ctx.needs_input_grad[1], prologue)
+        _, _, gp, gt, _ = fused_call(params, pred, target, rw, scale, False, False, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[1], prologue)
         return gp, gt, None, None, None, None
 
 
@@ -264,10 +293,20 @@ class GDLoss(nn.Module):
         prologue = kwargs.pop('_prologue', None)
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
-        if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
-            return (pred * weight).sum()  # ref :290-292 (keeps the graph; raises for an (N,) weight, as there)
+        # ref :290-292: `if weight is not None and not torch.any(weight > 0) and reduction != 'none':
+        #                    return (pred * weight).sum()`
+        # For the (N,7) weights the heads pass, that test, both results and both gradients are evaluated by the fused
+        # launch itself and selected on the device (`select`): no extra pass over the weights, no host sync.  Any other
+        # weight shape keeps the reference's host-side test: its early-out expression only broadcasts (or raises, as
+        # there) for particular shapes, which cannot be decided from the device.
+        select = False
+        if weight is not None and reduction != 'none':
+            if weight.shape == pred.shape and weight.is_cuda:
+                select = True
+            elif not torch.any(weight > 0):
+                return (pred * weight).sum()
         params = self._params(kwargs)
-        # ref :295-296 `weight.mean(dim=-1)` for an (N,7) weight: done inside the kernel (gd3d_loss_fused_w7)
+        # ref :295-296 `weight.mean(dim=-1)` for an (N,7) weight: done inside the kernel
         weight7 = weight is not None and weight.shape == pred.shape
 
         out_dtype = pred.dtype
@@ -279,7 +318,8 @@ class GDLoss(nn.Module):
         w = None
         if weight is not None:
             w = weight.reshape(-1, 7) if weight7 else weight.reshape(-1)
-            w = w.to(device=p.device, dtype=torch.float32).contiguous()
+            if w.dtype != torch.float32 or w.device != p.device or not w.is_contiguous():
+                w = w.to(device=p.device, dtype=torch.float32).contiguous()
             if w.shape[0] != n:
                 raise RuntimeError(f'weight has {w.shape[0]} rows for {n} boxes')
 
@@ -300,10 +340,12 @@ class GDLoss(nn.Module):
         if reduction == 'none':
             out = _GDPerPair.apply(p, t, w, params, float(scale), prologue)
         else:
-            out = _GDReduced.apply(p, t, w, params, float(scale), prologue)
+            out, any_pos = _GDReduced.apply(p, t, w, params, float(scale), prologue, select)
             if post_div is not None:
+                if select:  # the early-out value is not divided by avg_factor (it returns before the loss is called)
+                    post_div = torch.where(any_pos.reshape(()) != 0, post_div.to(torch.float32), 1.0)
                 out = out / post_div
-            if n == 0 and reduction == 'mean' and avg_factor is None:
+            if n == 0 and reduction == 'mean' and avg_factor is None and not select:
                 out = out + float('nan')  # torch: mean of an empty tensor is nan
         return out if out_dtype == torch.float32 else out.to(out_dtype)
 

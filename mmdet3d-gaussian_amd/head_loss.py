@@ -66,6 +66,29 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
                                   avg_factor=num_total_samples)
 
 
+def _anchor_head_launch(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense,
+                        num_classes, sl1, need_grad):
+    """One gd3d_anchor_head_bbox_loss launch -> (loss scalar tensor, zero-filled-then-scattered NCHW gradient | None)."""
+    lib = _lib.load()
+    B, C, H, W = bbox_pred.shape
+    A = C // 7
+    P = pos_or_labels.numel()
+    dev = bbox_pred.device
+    grad = torch.zeros_like(bbox_pred) if need_grad else None
+    buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
+    dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
+    wp = None if bbox_weights is None else bbox_weights.data_ptr()
+    sel = pos_or_labels.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
+                                            dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
+                                            int(num_classes), scale, buf[0].data_ptr(),
+                                            None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'gd3d_anchor_head_bbox_loss')
+    return buf[0], grad
+
+
 class _AnchorHeadFused(torch.autograd.Function):
     """selection/gather of the positives + decode x2 + loss(es) + gradient scatter into the NCHW head output: one launch.
     `pos_or_labels` is either the (P,) int64 positive list (dense=False) or the (M,) int64 label map (dense=True)."""
@@ -73,32 +96,19 @@ class _AnchorHeadFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
                 num_classes=0, sl1=None):
-        lib = _lib.load()
-        B, C, H, W = bbox_pred.shape
-        A = C // 7
-        P = pos_or_labels.numel()
-        dev = bbox_pred.device
-        need_grad = ctx.needs_input_grad[0]
-        grad = torch.zeros_like(bbox_pred) if need_grad else None
-        buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
-        dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
-        wp = None if bbox_weights is None else bbox_weights.data_ptr()
-        sel = pos_or_labels.data_ptr()
-        with torch.cuda.device(dev):
-            rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
-                                                dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
-                                                int(num_classes), scale, buf[0].data_ptr(),
-                                                None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, 'gd3d_anchor_head_bbox_loss')
-        ctx.grad = grad
-        return buf[0]
+        args = (bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense, num_classes, sl1)
+        loss, grad = _anchor_head_launch(*args, ctx.needs_input_grad[0])
+        ctx.grad, ctx.used, ctx.replay = grad, False, args
+        return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.load()
-        g = ctx.grad
+        if ctx.used:  # retain_graph replay: the saved gradient was scaled in place (and may have become .grad): recompute
+            g = _anchor_head_launch(*ctx.replay, True)[1]
+        else:
+            g, ctx.used = ctx.grad, True
         go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         with torch.cuda.device(g.device):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
@@ -164,6 +174,8 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
     sel = _select(labels, num_classes, dense)
     if not dense and sel.numel() == 0:
         return bbox_pred.sum() * 0
+    if num_total_samples is None:
+        num_total_samples = int(bbox_pred.shape[0])      # loss_single: `int(cls_score.shape[0])`, the batch size (:85-86)
     den = num_total_samples if loss_module.reduction == 'mean' else 1.0
     scale = float(loss_module.loss_weight) / float(den)
     return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_module._params({}), dw, scale, bool(dense),
@@ -209,6 +221,8 @@ def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets,
     sel = _select(labels, num_classes, dense)
     if not dense and sel.numel() == 0:
         return bbox_pred.sum() * 0
+    if num_total_samples is None:
+        num_total_samples = int(bbox_pred.shape[0])      # loss_single: `int(cls_score.shape[0])`, the batch size (:85-86)
     sl1 = _lib.SmoothL1()
     sl1.beta = beta
     sl1.scale = lw / float(num_total_samples)
@@ -236,7 +250,9 @@ def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
                     voxel_size=coder.voxel_size, pc_range=coder.pc_range)
     pred7 = pred[..., :7].reshape(-1, 7)
     if pred7.numel() == 0:
-        return pred.new_zeros((1,))
+        # the reference returns new_zeros((1,)) (:436-438); same value and shape here, but attached to `pred` so that the
+        # head's parameters still receive a (zero) gradient on a step without objects
+        return (pred.sum() * 0).reshape(1)
     return loss_module(pred7, target_gd, avg_factor=max(num_pos, 1), _prologue=pro)
 
 
@@ -244,60 +260,79 @@ _CENTER_HEADS = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
 _CENTER_CH = (2, 1, 3, 1, 2, 2)
 
 
+def _center_head_launch(meta, maps, need):
+    """gd3d_center_head_loss on all tasks -> (losses (T,2), per-map gradient views | None, task table)."""
+    lib = _lib.load()
+    params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta
+    T = len(layout)
+    dev = maps[0].device
+    tasks = (_lib.CenterTask * T)()
+    # ONE zero fill covers every gradient map of every task (36 maps at 6 tasks) and the per-task cell counters
+    # (B*H*W int32 each, all-zero bits): views into a single flat buffer
+    sizes = [m.numel() if nd else 0 for m, nd in zip(maps, need)]
+    wants = [any(need[k] for k in layout[t] if k >= 0) for t in range(T)]
+    cells = []
+    for t in range(T):
+        ref = maps[layout[t][1]]
+        cells.append(ref.shape[0] * ref.shape[2] * ref.shape[3] if wants[t] else 0)
+    flat = torch.zeros(sum(sizes) + sum(cells), dtype=torch.float32, device=dev) if any(need) else None
+    grads, off = [], 0
+    for m, nd, sz in zip(maps, need, sizes):
+        grads.append(flat[off:off + sz].view_as(m) if nd else None)
+        off += sz
+    max_n = 0
+    for t in range(T):
+        tk = tasks[t]
+        for h in range(6):
+            k = layout[t][h]
+            tk.maps[h] = maps[k].data_ptr() if k >= 0 else None
+            tk.grads[h] = grads[k].data_ptr() if (k >= 0 and grads[k] is not None) else None
+        ref = maps[layout[t][1]]
+        tk.B, tk.H, tk.W = ref.shape[0], ref.shape[2], ref.shape[3]
+        tk.cell_count = flat.data_ptr() + 4 * off if wants[t] else None
+        off += cells[t]
+        tk.n = pos_inds[t].shape[0]
+        tk.pos_ind = pos_inds[t].data_ptr()
+        tk.anno = annos[t].data_ptr()
+        tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
+        tk.gd_scale, tk.l1_scale = scales[t]
+        max_n = max(max_n, tk.n)
+    losses = torch.empty((T, 2), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
+    cwp = (ctypes.c_float * max(n_l1, 1))(*[float(x) for x in cw[:n_l1]])
+    with torch.cuda.device(dev):
+        rc = lib.gd3d_center_head_loss(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'gd3d_center_head_loss')
+    return losses, grads, tasks
+
+
 class _CenterHeadFused(torch.autograd.Function):
-    """All tasks' loss_l1 / loss_gd straight from the NCHW head maps: one launch forward (+ one reduce), one launch
-    backward.  `layout[t][h]` = index into `maps` of head h of task t, or -1."""
+    """All tasks' loss_l1 / loss_gd straight from the NCHW head maps: two launches forward (loss + staged gradients, then
+    the deterministic per-cell accumulation + loss sums), one launch backward.  `layout[t][h]` = index into `maps` of
+    head h of task t, or -1."""
 
     @staticmethod
     def forward(ctx, meta, *maps):
-        lib = _lib.load()
-        params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta
-        T = len(layout)
-        dev = maps[0].device
-        tasks = (_lib.CenterTask * T)()
-        # one zero fill for every gradient map of every task (36 maps at 6 tasks): views into a single flat buffer
         need = [bool(ctx.needs_input_grad[1 + k]) for k in range(len(maps))]
-        sizes = [m.numel() if nd else 0 for m, nd in zip(maps, need)]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev) if any(need) else None
-        grads, off = [], 0
-        for m, nd, sz in zip(maps, need, sizes):
-            grads.append(flat[off:off + sz].view_as(m) if nd else None)
-            off += sz
-        max_n = 0
-        for t in range(T):
-            tk = tasks[t]
-            for h in range(6):
-                k = layout[t][h]
-                tk.maps[h] = maps[k].data_ptr() if k >= 0 else None
-                tk.grads[h] = grads[k].data_ptr() if (k >= 0 and grads[k] is not None) else None
-            ref = maps[layout[t][1]]
-            tk.B, tk.H, tk.W = ref.shape[0], ref.shape[2], ref.shape[3]
-            tk.n = pos_inds[t].shape[0]
-            tk.pos_ind = pos_inds[t].data_ptr()
-            tk.anno = annos[t].data_ptr()
-            tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
-            tk.gd_scale, tk.l1_scale = scales[t]
-            max_n = max(max_n, tk.n)
-        losses = torch.empty((T, 2), dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
-        cwp = (ctypes.c_float * max(n_l1, 1))(*[float(x) for x in cw[:n_l1]])
-        with torch.cuda.device(dev):
-            rc = lib.gd3d_center_head_loss(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, 'gd3d_center_head_loss')
-        ctx.tasks, ctx.grads, ctx.keep = tasks, grads, (pos_inds, annos, maps)
+        losses, grads, tasks = _center_head_launch(meta, maps, need)
+        ctx.tasks, ctx.grads, ctx.used, ctx.replay = tasks, grads, False, (meta, maps, need)
         return losses
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_losses):
         lib = _lib.load()
+        if ctx.used:  # retain_graph replay: the saved maps were scaled in place: recompute them
+            _, grads, tasks = _center_head_launch(*ctx.replay)
+        else:
+            grads, tasks, ctx.used = ctx.grads, ctx.tasks, True
         go = grad_losses.contiguous().float()
         dev = go.device
         with torch.cuda.device(dev):
-            rc = lib.gd3d_center_head_scale(ctx.tasks, len(ctx.tasks), go.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            rc = lib.gd3d_center_head_scale(tasks, len(tasks), go.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'gd3d_center_head_scale')
-        return (None,) + tuple(ctx.grads)
+        return (None,) + tuple(grads)
 
 
 def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_boxes, num_pos, code_weights):

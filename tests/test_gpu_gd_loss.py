@@ -240,3 +240,114 @@ def test_full_size_properties_10m(amd, lt):
     p2 = p.detach().clone(); p2[:, 6] += np.pi
     out2 = mod(p2, t)
     assert abs(out2.item() - out.item()) <= 1e-5 * (1 + abs(out.item()))
+
+
+def _ref_forward(pred, target, weight, mod_kw, avg_factor, reduction, lt):
+    """Reference GDLoss.forward control flow (gaussian_distance_loss.py:286-310) on top of the eager torch restatement
+    of the loss functions (oracle/gd_torch.py, pinned by test_oracle_torch.py), fp64, autograd backward."""
+    from oracle import gd_torch
+    if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
+        return (pred * weight).sum()
+    return gd_torch.gd_loss(pred, target, lt, weight=weight, avg_factor=avg_factor, reduction=reduction, **mod_kw)
+
+
+@pytest.mark.parametrize('wkind', ['zero', 'negative', 'nan', 'one_positive', 'mixed'])
+@pytest.mark.parametrize('n', [300, 70_001])
+def test_weight7_early_out_resolved_on_device(amd, wkind, n):
+    """`if not torch.any(weight > 0): return (pred * weight).sum()` (ref :290-292) for (N,7) weights is decided inside the
+    fused launch (no host sync): value, gradient wrt pred and the missing gradient wrt target equal the reference's
+    control flow for all-zero, all-negative, NaN-only, exactly-one-positive (in the last tile) and ordinary weights,
+    also under an upstream gradient != 1."""
+    pred, tgt = _synthetic(n, seed=7)
+    g = torch.Generator().manual_seed(n)
+    if wkind == 'zero':
+        w = torch.zeros(n, 7)
+    elif wkind == 'negative':
+        w = -torch.rand(n, 7, generator=g)
+    elif wkind == 'nan':
+        w = torch.full((n, 7), float('nan'))
+    elif wkind == 'one_positive':
+        w = -torch.rand(n, 7, generator=g)
+        w[n - 2, 3] = 0.25
+    else:
+        w = torch.rand(n, 7, generator=g) - 0.3
+    lt, kw = 'kld3d', dict(fun='log1p', tau=1.0, loss_weight=5.0)
+    mod = amd.GDLoss(lt, **kw)
+    p = pred.cuda().requires_grad_(True)
+    t = tgt.cuda().requires_grad_(True)
+    out = mod(p, t, w.cuda(), avg_factor=37.0)
+    (out * 3.0).backward()
+    p64 = pred.double().requires_grad_(True)
+    t64 = tgt.double().requires_grad_(True)
+    ref = _ref_forward(p64, t64, w.double(), kw, 37.0, 'mean', lt)
+    (ref * 3.0).backward()
+    if wkind == 'nan':
+        assert torch.isnan(out).item() and torch.isnan(ref).item()
+        assert torch.isnan(p.grad).all()
+        return
+    assert abs(out.item() - ref.item()) <= 2e-5 * (1 + abs(ref.item())), (out.item(), ref.item())
+    sc = p64.grad.abs().max().item()
+    assert (p.grad.cpu().double() - p64.grad).abs().max().item() <= 5e-5 * (1 + sc)
+    gt_ref = t64.grad if t64.grad is not None else torch.zeros_like(t64)
+    gt_got = t.grad if t.grad is not None else torch.zeros_like(t)
+    assert (gt_got.cpu().double() - gt_ref).abs().max().item() <= 5e-5 * (1 + gt_ref.abs().max().item())
+    if wkind in ('zero', 'negative'):          # early-out branch: the gradient is exactly 3 * weight
+        assert torch.equal(p.grad.cpu(), 3.0 * w)
+
+
+def test_weight7_early_out_with_tensor_avg_factor_and_decode_prologue(amd):
+    """Early-out value is NOT divided by a tensor avg_factor, and with a fused bbox-coder decode `pred` of the early-out
+    is the DECODED row (gradient chained back to the encoded prediction)."""
+    n = 515
+    pred, tgt = _synthetic(n, seed=9)
+    w = -torch.rand(n, 7)
+    mod = amd.GDLoss('gwd3d', loss_weight=5.0)
+    p = pred.cuda().requires_grad_(True)
+    out = mod(p, tgt.cuda(), w.cuda(), avg_factor=torch.tensor(11.0, device='cuda'))
+    out.backward()
+    want = (pred.double() * w.double()).sum().item()
+    assert abs(out.item() - want) <= 1e-5 * (1 + abs(want))
+    assert torch.equal(p.grad.cpu(), w)
+    # ordinary weights with the same tensor avg_factor: divided as usual
+    w2 = torch.rand(n, 7)
+    a = mod(pred.cuda(), tgt.cuda(), w2.cuda(), avg_factor=torch.tensor(11.0, device='cuda')).item()
+    b = mod(pred.cuda(), tgt.cuda(), w2.cuda(), avg_factor=11.0).item()
+    assert abs(a - b) <= 1e-6 * (1 + abs(b))
+    # anchor-delta prologue
+    rng = np.random.default_rng(0)
+    anchors = np.stack([rng.uniform(0, 70, n), rng.uniform(-40, 40, n), rng.uniform(-2, 0, n), rng.uniform(.6, 2, n),
+                        rng.uniform(.8, 4, n), rng.uniform(1.4, 1.8, n), rng.choice([0, np.pi / 2], n)], -1).astype(np.float32)
+    enc_t = rng.normal(0, 0.3, (n, 7)).astype(np.float32)
+    enc_p = (enc_t + rng.normal(0, 0.1, (n, 7))).astype(np.float32)
+    pe = torch.from_numpy(enc_p).cuda().requires_grad_(True)
+    out = amd.anchor_decoded_gd_loss(mod, torch.from_numpy(anchors).cuda(), pe, torch.from_numpy(enc_t).cuda(), w.cuda(),
+                                     avg_factor=5.0)
+    out.backward()
+    from oracle import head_torch
+    pe64 = torch.from_numpy(enc_p).double().requires_grad_(True)
+    ref = (head_torch.delta_decode(torch.from_numpy(anchors).double(), pe64) * w.double()).sum()
+    ref.backward()
+    assert abs(out.item() - ref.item()) <= 1e-5 * (1 + abs(ref.item()))
+    assert (pe.grad.cpu().double() - pe64.grad).abs().max().item() <= 1e-5 * (1 + pe64.grad.abs().max().item())
+
+
+def test_weighted_call_path_has_no_host_sync(amd):
+    """The (N,7)-weight path must not wait for the device: the forward + backward calls return while a long kernel
+    queued in front of them is still running."""
+    n = 4096
+    pred, tgt = _synthetic(n, seed=1)
+    p = pred.cuda().requires_grad_(True)
+    t, w = tgt.cuda(), torch.rand(n, 7).cuda()
+    mod = amd.GDLoss('bd3d', loss_weight=5.0)
+    mod(p, t, w, avg_factor=float(n)).backward()       # warm (library load, allocator)
+    torch.cuda.synchronize()
+    big = torch.empty(1 << 28, device='cuda')           # 1 GiB of fills: tens of milliseconds of queued GPU work
+    done = torch.cuda.Event()
+    for _ in range(40):
+        big.fill_(1.0)
+    out = mod(p, t, w, avg_factor=float(n))
+    out.backward()
+    done.record()
+    assert not done.query(), 'the weighted GDLoss call waited for the device (host sync on the call path)'
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).item()
