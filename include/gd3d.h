@@ -267,6 +267,28 @@ int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64
 int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats, void* stream,
                       void* start_event, void* stop_event);
 
+/* ------------------------------------------------------------------------------------
+ * CenterPointBBoxYawCoder on the device.  Replaces the elementwise torch ops (and their autograd nodes) of
+ *   /root/reference/mmdet3d_gaussian/core/bbox/coders/centerpoint_bbox_yaw_coders.py:18-56 (decode), :11-16 (encode);
+ * decode is what CenterGDHead.get_bboxes runs at inference (gd_centerpoint_head.py:244, correct_yaw=True).
+ *   coder : kind GD3D_PRO_CENTER fields (norm_bbox, out_size_factor, voxel_size, pc_range; aux ignored)
+ *   locs (n,2) fp32 grid coordinates, preds (n,c) fp32 rows [dx, dy, z, dim x3, yaw, sin, cos, others...], c >= 7
+ *   (c >= 9 when correct_yaw);  out (n, 7 + max(c-9, 0)) = [x, y, z, dim x3, yaw, others...].
+ *   correct_yaw != 0: k = floor((atan2(sin, cos) - yaw) / (pi/2) + 0.5), yaw += k pi/2, w <-> l swapped when k is odd.
+ *   num_rot_parity (n) int32, nullable: receives k & 1 (what the backward needs).
+ * coder_center_decode_backward: grad_preds (n,c) from grad_out (n, out cols), `out` of the forward and the parity
+ *   flags (NULL = no swap); the sin / cos columns receive 0 (k is computed under no_grad in the reference).
+ * coder_center_encode: boxes (n,c) [x,y,z,w,l,h,yaw, others] -> out (n,c+2) [first 7, sin yaw, cos yaw, others].
+ * ---------------------------------------------------------------------------------- */
+int coder_center_decode(const gd3d_prologue* coder, const float* locs, const float* preds, int64_t n,
+                        int32_t c, int32_t correct_yaw, float* out, int32_t* num_rot_parity, void* stream);
+
+int coder_center_decode_backward(const gd3d_prologue* coder, const float* grad_out, const float* out,
+                                 const int32_t* num_rot_parity, int64_t n, int32_t c,
+                                 float* grad_preds, void* stream);
+
+int coder_center_encode(const float* boxes, int64_t n, int32_t c, float* out, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can
@@ -349,6 +371,18 @@ size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t ca
 int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups,
                         int64_t n, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
                         void* workspace, void* stream);
+
+/* The same for G problems that each own a CONTIGUOUS run of one flat box / score array (the per-sample x per-task NMS
+ * calls of CenterHeadRev.get_bboxes, gd_centerpoint_head.py:233-345, concatenated): group g = boxes [seg[g], seg[g+1]).
+ * Every group ranks only its own slice — O(sum n_g^2) key compares and O(G * n_max^2 / 256) workspace, where the dense
+ * (G, N) form above would compare every key in every group.
+ *   scores (N_total) fp32;  seg (groups+1) int32 on the DEVICE, ascending;  max_seg >= every group size (host value:
+ *   the caller knows the sizes from its tensor shapes), <= rnms_scored_max_n();  cap = min(max_seg, pre_max).
+ *   keep (groups, cap) int64 GLOBAL indices into `boxes`; num_keep (groups) int64.
+ *   workspace: rnms_batched_scored_workspace_bytes(groups, max_seg, cap). */
+int rnms_segmented_scored(int32_t mode, const float* boxes, const float* scores, const int32_t* seg, int32_t groups,
+                          int64_t max_seg, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
+                          void* workspace, void* stream);
 
 /* Circle NMS (mmdet3d `circle_nms(dets, thresh, post_max_size)`, numba, CPU; the reference copies the detections
  * D->H for it, gd_centerpoint_head.py:256-272): centres xy (rows, 2) fp32, order (n) by descending score; box j is

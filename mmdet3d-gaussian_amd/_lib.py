@@ -71,6 +71,9 @@ SYMBOLS = {
     'gd3d_center_head_loss': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
                                      ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp]),
     'gd3d_center_head_scale': (_int, [ctypes.POINTER(CenterTask), ctypes.c_int32, _vp, _vp]),
+    'coder_center_decode': (_int, [ctypes.POINTER(Prologue), _vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
+    'coder_center_decode_backward': (_int, [ctypes.POINTER(Prologue), _vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp]),
+    'coder_center_encode': (_int, [_vp, _i64, ctypes.c_int32, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),
     'rnms_workspace_bytes': (_sz, [_i64]),
@@ -85,6 +88,7 @@ SYMBOLS = {
     'rnms_batched': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_batched_scored_workspace_bytes': (_sz, [ctypes.c_int32, _i64, _i64]),
     'rnms_batched_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'rnms_segmented_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_circle_ordered': (_int, [_vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _vp]),
     'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'riou_eval_bev': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),

@@ -23,6 +23,7 @@ SOURCES = {
     'rbox.hip': ['-ffp-contract=off'],
     'voxel_scatter.hip': [],
     'eval_match.hip': ['-ffp-contract=off'],
+    'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,184 @@
+// coders.hip — CenterPointBBoxYawCoder on the device.
+//
+// Replaces the ~15 elementwise ATen ops (+ their autograd nodes) of
+//   /root/reference/mmdet3d_gaussian/core/bbox/coders/centerpoint_bbox_yaw_coders.py:11-16 (encode), :18-56 (decode)
+// by one launch each.  One thread per box; rows are short (9-11 floats), the calls are latency-bound (K <= 500 per
+// sample), so there is no LDS tiling: every thread reads its row and writes its row.
+//   decode: x = (p0 + loc0) * out_size_factor * voxel_size[0] + pc_range[0], y likewise, z = p2,
+//           dim = exp(p3..p5) if norm_bbox else p3..p5, yaw = p6;
+//           correct_yaw: k = floor((atan2(p7, p8) - yaw) / (pi/2) + 0.5) (no gradient), yaw += k * pi/2, and w <-> h when k
+//           is odd; the remaining columns p9.. are passed through.
+//   The training-time decode that feeds GDLoss does not come through here: it runs inside the fused loss kernel
+//   (gd3d_loss.hip, GD3D_PRO_CENTER).  This file serves inference (CenterGDHead.get_bboxes :244) and target encoding.
+#include <hip/hip_runtime.h>
+
+#include "../../include/gd3d.h"
+
+namespace gdcoder {
+
+constexpr int T = 256;
+constexpr float HALF_PI = 1.57079632679489661923f;
+
+struct DecArgs {
+  const float* locs;   // (n,2)
+  const float* preds;  // (n,c)
+  float* out;          // (n,co) co = 7 + max(c - 9, 0)
+  int* swapk;          // (n) nullable: num_rot90 of the forward, for the backward
+  long long n;
+  int c, co, norm_bbox, correct_yaw;
+  float osf, vs0, vs1, pc0, pc1;
+};
+
+__global__ __launch_bounds__(T) void center_decode_kernel(const DecArgs a) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= a.n) return;
+  const float* p = a.preds + i * a.c;
+  float* o = a.out + i * a.co;
+  o[0] = (p[0] + a.locs[i * 2]) * a.osf * a.vs0 + a.pc0;
+  o[1] = (p[1] + a.locs[i * 2 + 1]) * a.osf * a.vs1 + a.pc1;
+  o[2] = p[2];
+  float d0 = p[3], d1 = p[4], d2 = p[5];
+  if (a.norm_bbox) {
+    d0 = expf(d0);
+    d1 = expf(d1);
+    d2 = expf(d2);
+  }
+  float yaw = p[6];
+  int k = 0;
+  if (a.correct_yaw) {
+    const float dir = atan2f(p[7], p[8]);
+    const float nr = floorf((dir - yaw) / HALF_PI + 0.5f);
+    // `num_rot90.long() % 2 == 0`: parity of the truncated integer (Python % on tensors follows the divisor's sign: -1 % 2 = 1)
+    const long long kl = (long long)nr;
+    k = (int)(kl & 1);
+    yaw = yaw + nr * HALF_PI;
+    if (k) {
+      const float t = d0;
+      d0 = d1;
+      d1 = t;
+    }
+  }
+  o[3] = d0;
+  o[4] = d1;
+  o[5] = d2;
+  o[6] = yaw;
+  for (int j = 9; j < a.c; ++j) o[7 + (j - 9)] = p[j];
+  if (a.swapk != nullptr) a.swapk[i] = k;
+}
+
+// backward of decode wrt preds: gp (n,c) from go (n,co), the decoded output and the swap flags
+struct DecBwdArgs {
+  const float* go;    // (n,co)
+  const float* out;   // (n,co) decoded rows of the forward (dims = exp(p) when norm_bbox)
+  const int* swapk;   // (n) nullable
+  float* gp;          // (n,c)
+  long long n;
+  int c, co, norm_bbox;
+  float osf, vs0, vs1;
+};
+
+__global__ __launch_bounds__(T) void center_decode_bwd_kernel(const DecBwdArgs a) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= a.n) return;
+  const float* g = a.go + i * a.co;
+  const float* o = a.out + i * a.co;
+  float* gp = a.gp + i * a.c;
+  gp[0] = g[0] * a.osf * a.vs0;
+  gp[1] = g[1] * a.osf * a.vs1;
+  gp[2] = g[2];
+  const bool sw = a.swapk != nullptr && a.swapk[i] != 0;
+  // out[3] = dim[sw ? 1 : 0], out[4] = dim[sw ? 0 : 1]
+  const float g3 = sw ? g[4] : g[3], g4 = sw ? g[3] : g[4];
+  const float e3 = sw ? o[4] : o[3], e4 = sw ? o[3] : o[4];
+  gp[3] = a.norm_bbox ? g3 * e3 : g3;
+  gp[4] = a.norm_bbox ? g4 * e4 : g4;
+  gp[5] = a.norm_bbox ? g[5] * o[5] : g[5];
+  gp[6] = g[6];
+  if (a.c > 7) gp[7] = 0.0f;
+  if (a.c > 8) gp[8] = 0.0f;
+  for (int j = 9; j < a.c; ++j) gp[j] = g[7 + (j - 9)];
+}
+
+// encode: (n,c) boxes [x,y,z,w,l,h,yaw, others...] -> (n,c+2) [first 7, sin yaw, cos yaw, others]
+__global__ __launch_bounds__(T) void center_encode_kernel(const float* __restrict__ boxes, float* __restrict__ out,
+                                                         long long n, int c) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= n) return;
+  const float* b = boxes + i * c;
+  float* o = out + i * (c + 2);
+  for (int j = 0; j < 7; ++j) o[j] = b[j];
+  float s, co;
+  sincosf(b[6], &s, &co);
+  o[7] = s;
+  o[8] = co;
+  for (int j = 7; j < c; ++j) o[j + 2] = b[j];
+}
+
+}  // namespace gdcoder
+
+using namespace gdcoder;
+
+extern "C" {
+
+int coder_center_decode(const gd3d_prologue* coder, const float* locs, const float* preds, int64_t n, int32_t c,
+                        int32_t correct_yaw, float* out, int32_t* num_rot_parity, void* stream) {
+  if (coder == nullptr || n < 0 || c < 7) return GD3D_E_BADARG;
+  if (correct_yaw && c < 9) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (locs == nullptr || preds == nullptr || out == nullptr) return GD3D_E_BADARG;
+  DecArgs a;
+  a.locs = locs;
+  a.preds = preds;
+  a.out = out;
+  a.swapk = (int*)num_rot_parity;
+  a.n = n;
+  a.c = c;
+  a.co = 7 + (c > 9 ? c - 9 : 0);
+  a.norm_bbox = coder->norm_bbox;
+  a.correct_yaw = correct_yaw;
+  a.osf = coder->out_size_factor;
+  a.vs0 = coder->voxel_size[0];
+  a.vs1 = coder->voxel_size[1];
+  a.pc0 = coder->pc_range[0];
+  a.pc1 = coder->pc_range[1];
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(center_decode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int coder_center_decode_backward(const gd3d_prologue* coder, const float* grad_out, const float* out,
+                                 const int32_t* num_rot_parity, int64_t n, int32_t c, float* grad_preds, void* stream) {
+  if (coder == nullptr || n < 0 || c < 7) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (grad_out == nullptr || out == nullptr || grad_preds == nullptr) return GD3D_E_BADARG;
+  DecBwdArgs a;
+  a.go = grad_out;
+  a.out = out;
+  a.swapk = (const int*)num_rot_parity;
+  a.gp = grad_preds;
+  a.n = n;
+  a.c = c;
+  a.co = 7 + (c > 9 ? c - 9 : 0);
+  a.norm_bbox = coder->norm_bbox;
+  a.osf = coder->out_size_factor;
+  a.vs0 = coder->voxel_size[0];
+  a.vs1 = coder->voxel_size[1];
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(center_decode_bwd_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int coder_center_encode(const float* boxes, int64_t n, int32_t c, float* out, void* stream) {
+  if (n < 0 || c < 7) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (boxes == nullptr || out == nullptr) return GD3D_E_BADARG;
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(center_encode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, boxes, out, (long long)n,
+                     (int)c);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -15,7 +15,10 @@
 //   * after one barrier the tile leaves as 448 coalesced 16-B stores; the per-pair loss as one
 //     coalesced dword store; the tile's loss sum goes wave-shuffle -> LDS -> one fp32 partial per
 //     block, and a second tiny kernel adds the partials in a fixed order in fp64 (deterministic,
-//     no float atomics).
+//     no float atomics).  Finishing the sum INSIDE this kernel (sc1-stored partial, drained, agent-scope arrival
+//     ticket per 64-tile group, last arriver adds) was built and measured in round 2: 516 us per 3-loss step against
+//     421 us with the separate launch (profiles/r02_ticket_ab.txt) — the drain + ticket round trip keeps one wave of
+//     every workgroup resident ~30 % longer; removed.
 //   * tiles that are partial (the last one) or whose base pointers are not 16-B aligned take a
 //     guarded scalar load/store path around the same compute code.
 #include <hip/hip_runtime.h>
@@ -46,10 +49,6 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
 #define GD_NT_LOAD 1   // LDS-DMA loads with the nt cache policy: every input byte is read exactly once
                        // (measured r01, 10 M pairs: nt loads + nt stores 129 us vs 151 us plain; a persistent
                        //  double-buffered grid-stride variant was 143-160 us and was dropped)
-#endif
-#ifndef GD_TICKET
-#define GD_TICKET 0    // 1: the loss sum is finished inside the fused kernel (sc1 partial + arrival tickets);
-                       // 0: separate reduce_partials_kernel launch
 #endif
 #ifndef GD_NT_STORE
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
@@ -97,12 +96,6 @@ struct LossArgs {
   // with wsel the block also leaves sum(pred * weight7) in partials[nbp + b] and "any weight > 0" in partials[2 nbp + b]
   int wsel;
   long long nbp;     // partial-array stride (number of tiles rounded up to 4)
-#if GD_TICKET
-  float* out;        // loss sum written by the last workgroup (two-level ticket tree), nullable
-  unsigned* gticket; // per 64-tile group arrival counters, zero before the launch, left zero
-  double* gsum;      // per group sums
-  unsigned* top;     // arrival counter of the groups
-#endif
   long long n;
   float scale, alpha, tau;
   float c0, c1, c2;
@@ -295,9 +288,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   if (a.partials != nullptr && tid == 0) {
 #pragma unroll
     for (int w4 = 0; w4 < NWAVE; w4 += 4) bsum += (swave[w4] + swave[w4 + 1]) + (swave[w4 + 2] + swave[w4 + 3]);
-#if !GD_TICKET
     a.partials[blockIdx.x] = bsum;
-#endif
     if (a.wsel) {
       float asum = 0.0f, fany = 0.0f;
 #pragma unroll
@@ -326,48 +317,6 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
     if (GT)
       for (int i = tid; i < fl7; i += TILE) a.gt[base * 7 + i] = st[i];
   }
-#if GD_TICKET
-  // Loss sum finished in this launch, fixed order, no float atomics: tile partial -> sum of a 64-tile group (by the
-  // group's last arriver) -> sum of the group sums (by the last group).  Only wave 0 takes part; the other waves have
-  // left.  Hand-off form (MI355X_MICROARCH.md, valid forms, row 1): every handed-off word is stored sc1 (write-through)
-  // by one lane, that wave drains vmcnt, then its agent-scope ticket add; the wave whose add returned last loads the
-  // words with sc1 loads.  Tickets return to zero, so the workspace needs zeroing once, not per call.
-  if (a.out != nullptr && wave == 0) {
-    const unsigned nb = gridDim.x, grp = blockIdx.x >> 6, ngroups = (nb + 63) >> 6;
-    const unsigned gsize = (nb - (grp << 6)) < 64u ? (nb - (grp << 6)) : 64u;
-    if (lane == 0) __hip_atomic_store(a.partials + blockIdx.x, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.gticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t == gsize - 1) {
-      double v = 0.0;
-      if ((unsigned)lane < gsize)
-        v = (double)__hip_atomic_load(a.partials + (grp << 6) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) {
-        __hip_atomic_store(a.gticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.gsum + grp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned tt = 0;
-      if (lane == 0) tt = __hip_atomic_fetch_add(a.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tt = __builtin_amdgcn_readfirstlane(tt);
-      if (tt == ngroups - 1) {
-        double acc = 0.0;
-        for (unsigned g = lane; g < ngroups; g += 64)
-          acc += __hip_atomic_load(a.gsum + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) {
-          *a.out = (float)acc;
-          __hip_atomic_store(a.top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -955,13 +904,11 @@ extern "C" {
 
 // workspace layout (all offsets multiples of 16 bytes), nb = tiles of 256 rows, nbp = nb rounded up to 4, ng = 64-tile groups:
 //   float  partials[3][nbp]   loss | sum(pred * weight7) | any weight > 0   (rows 1, 2 only for gd3d_loss_fused_select)
-//   double gsum[ngp]; unsigned gticket[ngp]; unsigned top[4]                (in-kernel finish builds only, GD_TICKET)
 static inline int64_t ws_nbp(int64_t n) { return (((n + 255) / 256) + 3) & ~(int64_t)3; }
-static inline int64_t ws_ngp(int64_t n) { return ((((n + 255) / 256) + 63) / 64 + 3) & ~(int64_t)3; }
 
 size_t gd3d_loss_workspace_bytes(int64_t n) {
   if (n <= 0) return 64;
-  return (size_t)(12 * ws_nbp(n) + 12 * ws_ngp(n) + 16);
+  return (size_t)(12 * ws_nbp(n) + 16);
 }
 
 int gd3d_loss_fused(const gd3d_params* p, const float* pred, const float* target, const float* row_weight,
@@ -1044,12 +991,7 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
   LossArgs a;
   a.wsel = select ? 1 : 0;
   a.nbp = ws_nbp(n);
-#if GD_TICKET
-  a.out = select ? nullptr : loss_sum;
-  a.gsum = workspace != nullptr ? (double*)((char*)workspace + 12 * ws_nbp(n)) : nullptr;
-  a.gticket = workspace != nullptr ? (unsigned*)((char*)workspace + 12 * ws_nbp(n) + 8 * ws_ngp(n)) : nullptr;
-  a.top = workspace != nullptr ? (unsigned*)((char*)workspace + 12 * ws_nbp(n) + 12 * ws_ngp(n)) : nullptr;
-#endif
+
   a.pred = pred;
   a.target = target;
   a.w = row_weight;
@@ -1098,12 +1040,8 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
                        (long long)ws_nbp(n), loss_sum, (int*)any_positive);
     return (int)hipGetLastError();
   }
-#if GD_TICKET
-  return 0;  // the last workgroup of the fused kernel wrote *loss_sum
-#else
   if (loss_sum != nullptr) return gd3d_loss_reduce(workspace, n, loss_sum, stream);
   return 0;
-#endif
 }
 
 int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64_t n, const int32_t* any_positive,

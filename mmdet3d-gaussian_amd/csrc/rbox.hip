@@ -82,19 +82,25 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
 
 // blockIdx.z = group (batched form): scores / valid are (G, n) rows, prank is (G, slices, n).  A box that is not `valid`
 // in its group (nullable mask) gets key 0: it is below every real key and is never scattered.
+// Segmented form (seg != nullptr, (G+1) int32 on the device): group g owns the boxes [seg[g], seg[g+1]) of ONE flat score
+// array and ranks only those — O(sum n_g^2) compares and O(G * slices * n_max) workspace instead of the dense (G, G n)
+// matrices; `n` is then the LARGEST group size (grid extent, prank stride), indices inside a group are local.
 __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores_, const unsigned char* __restrict__ valid_,
-                                                        int n, int* __restrict__ prank_) {
+                                                        const int* __restrict__ seg, int n, int* __restrict__ prank_) {
   __shared__ int spart[4][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int part = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = quarter of the slice
+  const int base = seg != nullptr ? seg[blockIdx.z] : 0;
+  const int ng = seg != nullptr ? seg[blockIdx.z + 1] - base : n;
+  if ((int)blockIdx.x * 64 >= ng) return;                       // uniform: no box of this group in this lane block
   const size_t grow = (size_t)blockIdx.z * n;
-  const float* scores = scores_ + grow;
-  const unsigned char* valid = valid_ != nullptr ? valid_ + grow : nullptr;
+  const float* scores = seg != nullptr ? scores_ + base : scores_ + grow;
+  const unsigned char* valid = (valid_ != nullptr && seg == nullptr) ? valid_ + grow : nullptr;
   int* prank = prank_ + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * n;
-  const int j0 = blockIdx.y * RANK_SLICE, j1 = min(j0 + RANK_SLICE, n);
+  const int j0 = blockIdx.y * RANK_SLICE, j1 = min(j0 + RANK_SLICE, ng);
   const int i = blockIdx.x * 64 + lane;
-  const unsigned long long mine = i < n ? score_key(scores[i], (unsigned)i) : ~0ull;
-  const int len = j1 - j0, q = (len + 3) >> 2;
+  const unsigned long long mine = i < ng ? score_key(scores[i], (unsigned)i) : ~0ull;
+  const int len = max(j1 - j0, 0), q = (len + 3) >> 2;
   const int b = j0 + part * q, e = min(b + q, j1);
   int cnt = 0;
   // 64 keys at a time: lane l builds key b+l in registers, the 64 of them are broadcast by v_readlane (a loop over an LDS
@@ -113,29 +119,33 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
   }
   spart[part][lane] = cnt;
   __syncthreads();
-  if (tid < 64 && i < n) prank[i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
+  if (tid < 64 && i < ng) prank[i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
 }
 
-// counts (nullable, zeroed by the caller): counts[group] += boxes placed, i.e. min(#valid, n_keep) — integer atomics
+// counts (nullable, zeroed by the caller): counts[group] += boxes placed, i.e. min(#valid, n_keep) — integer atomics.
+// Segmented form: thread i is box seg[g] + i of the flat arrays; `order` receives that GLOBAL index.
 template <bool PREP>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ valid_,
-                                                          const int* __restrict__ prank_, int n, int slices, int n_keep,
-                                                          long long* __restrict__ order_, OBox* __restrict__ ob_,
-                                                          int* __restrict__ counts) {
+                                                          const int* __restrict__ seg, const int* __restrict__ prank_, int n,
+                                                          int slices, int n_keep, long long* __restrict__ order_,
+                                                          OBox* __restrict__ ob_, int* __restrict__ counts) {
   const int g = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const int base = seg != nullptr ? seg[g] : 0;
+  const int ng = seg != nullptr ? seg[g + 1] - base : n;
   const int* prank = prank_ + (size_t)g * slices * n;
   bool placed = false;
-  if (i < n && (valid_ == nullptr || valid_[(size_t)g * n + i] != 0)) {
+  if (i < ng && (valid_ == nullptr || seg != nullptr || valid_[(size_t)g * n + i] != 0)) {
     int r = 0;
-    for (int s2 = 0; s2 < slices; ++s2) r += prank[(size_t)s2 * n + i];
+    const int used = (ng + RANK_SLICE - 1) / RANK_SLICE;         // slices beyond the group's own keys were never written
+    for (int s2 = 0; s2 < used; ++s2) r += prank[(size_t)s2 * n + i];
     if (r < n_keep) {
       placed = true;
-      order_[(size_t)g * n_keep + r] = (long long)i;
+      order_[(size_t)g * n_keep + r] = (long long)(base + i);
       if (PREP) {
         float b[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)i * 5 + q];
+        for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)(base + i) * 5 + q];
         OBox o;
         obox_make(b, o);
         ob_[(size_t)g * n_keep + r] = o;
@@ -848,14 +858,14 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
   const int slices = (int)rank_slices(n_all);
   hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores,
-                     (const unsigned char*)nullptr, (int)n_all, prank);
+                     (const unsigned char*)nullptr, (const int*)nullptr, (int)n_all, prank);
   const dim3 sg((unsigned)((n_all + 255) / 256));
   if (normal)
-    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)prank,
-                       (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
+    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
   else
-    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)prank,
-                       (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
+    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
@@ -870,8 +880,9 @@ size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t ca
          align_up((size_t)groups * sizeof(int), 256) + (size_t)groups * rank_slices(n) * (size_t)n * sizeof(int);
 }
 
-int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,
-                        int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+static int batched_scored_impl(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, const int32_t* seg,
+                               int32_t groups, int64_t n, int64_t pre_max, const float* thresh, int64_t* keep,
+                               int64_t* num_keep, void* workspace, void* stream) {
   if (mode < MODE_ROT || mode > MODE_CIRCLE || groups < 0 || n < 0) return GD3D_E_BADARG;
   if (groups == 0) return 0;
   if (num_keep == nullptr) return GD3D_E_BADARG;
@@ -890,18 +901,31 @@ int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, c
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)groups, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)slices, (unsigned)groups), dim3(256), 0, s, scores,
-                     (const unsigned char*)valid, (int)n, prank);
+                     (const unsigned char*)valid, (const int*)seg, (int)n, prank);
   const dim3 sg((unsigned)((n + 255) / 256), (unsigned)groups);
   if (mode == MODE_ROT)
-    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)prank, (int)n,
-                       slices, (int)cap, order, (OBox*)workspace, counts);
+    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts);
   else
-    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)prank, (int)n,
-                       slices, (int)cap, order, (OBox*)workspace, counts);
+    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
                      workspace, stream, /*prepped=*/mode == MODE_ROT);
+}
+
+int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,
+                        int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  return batched_scored_impl(mode, boxes, scores, valid, nullptr, groups, n, pre_max, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_segmented_scored(int32_t mode, const float* boxes, const float* scores, const int32_t* seg, int32_t groups,
+                          int64_t max_seg, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
+                          void* workspace, void* stream) {
+  if (groups > 0 && seg == nullptr) return GD3D_E_BADARG;
+  return batched_scored_impl(mode, boxes, scores, nullptr, seg, groups, max_seg, pre_max, thresh, keep, num_keep, workspace,
+                             stream);
 }
 
 int rnms_bev_ordered(const float* boxes, const int64_t* order, int64_t n, float thresh, int64_t* keep, int64_t* num_keep,

@@ -119,7 +119,7 @@ def _thresh_tensor(thresh, groups, dev):
 
 
 def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_max_size=None, normal=False,
-                    circle=False, _offsets=None):
+                    circle=False):
     """G independent NMS problems over ONE box array in one set of launches and one host sync.
 
     boxes (N,5) [x1,y1,x2,y2,ry] (circle=True: (N,2) centres); scores (G,N); valid (G,N) bool or None — which boxes take
@@ -142,6 +142,19 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
         return []
     if N == 0:
         return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
+    if pre_max_size is not None and pre_max_size < 0:
+        # `order[:pre_max_size]` with a negative bound keeps (group size + bound) boxes: a different cut per group, so the
+        # promise "equal to nms_gpu per group" is kept by making exactly those calls
+        ths = list(thresh) if isinstance(thresh, (list, tuple)) else [thresh] * G
+        out = []
+        for g in range(G):
+            idx = torch.arange(N, device=dev) if valid is None else valid[g].nonzero(as_tuple=False).reshape(-1)
+            sub = boxes[idx]
+            if circle:
+                raise RuntimeError('nms_gpu_batched: a negative pre_max_size is not defined for circle NMS')
+            k = _nms(sub, scores[g][idx], ths[g], pre_max_size, post_max_size, normal)
+            out.append(idx[k])
+        return out
     lib = _lib.load()
     mode = 2 if circle else (1 if normal else 0)
     if N <= _scored_max(lib) and G <= 65535 and scores.dtype in (torch.float32, torch.float16, torch.bfloat16):
@@ -159,8 +172,6 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
             _lib.check(lib.rnms_batched_scored(mode, boxes.data_ptr(), sc.data_ptr(), None if vb is None else vb.data_ptr(), G, N,
                                                cap, th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), name)
-        if _offsets is not None:   # nms_gpu_multi: indices local to each entry, one launch for all groups
-            keep = keep - _offsets.unsqueeze(1)
         nums = num.tolist()  # the one sync: G data-dependent result lengths
         out = []
         for g in range(G):
@@ -191,8 +202,6 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
         _lib.check(lib.rnms_batched(mode, boxes.data_ptr(), order.data_ptr(), counts.data_ptr(), G, cap, th.data_ptr(),
                                     keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), name)
-    if _offsets is not None:
-        keep = keep - _offsets.unsqueeze(1)
     nums = num.tolist()  # the one sync: G data-dependent result lengths
     out = []
     for g in range(G):
@@ -202,12 +211,15 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
 
 
 def nms_gpu_multi(boxes_list, scores_list, thresh, pre_max_size=None, post_max_size=None, normal=False):
-    """`[nms_gpu(b, s, thresh, pre_max_size, post_max_size) for b, s in zip(boxes_list, scores_list)]` in ONE batched call
-    and ONE host sync: the per-sample loop of CenterHeadRev.get_task_detections (gd_centerpoint_head.py:329-345) and the
-    per-task loop around it (:233-282) — B samples x T tasks small NMS problems per inference step, each with its own
-    sort, launches and `.item()` — become a single `nms_gpu_batched` over the concatenated boxes (group g = entry g, its
-    boxes selected by the `valid` mask).  boxes_list[g] (n_g,5) [x1,y1,x2,y2,ry], scores_list[g] (n_g,); thresh: float or
-    one per entry.  Returns a list of LongTensors: kept indices LOCAL to each entry, by descending score."""
+    """`[nms_gpu(b, s, thresh, pre_max_size, post_max_size) for b, s in zip(boxes_list, scores_list)]` in ONE set of
+    launches and ONE host sync: the per-sample loop of CenterHeadRev.get_task_detections (gd_centerpoint_head.py:329-345)
+    and the per-task loop around it (:233-282) — B samples x T tasks small NMS problems per inference step, each with its
+    own sort, launches and `.item()`.  The entries are concatenated and every entry ranks and suppresses only ITS OWN
+    run of boxes (rnms_segmented_scored: work and workspace grow with sum n_g^2, not with (sum n_g)^2).
+    boxes_list[g] (n_g,5) [x1,y1,x2,y2,ry], scores_list[g] (n_g,); thresh: float or one per entry.
+    Returns a list of LongTensors: kept indices LOCAL to each entry, by descending score.
+    Entries larger than the library's rank limit, float64 scores, or a negative pre_max_size (a slice bound that means a
+    different cut per entry) take the per-entry calls."""
     G = len(boxes_list)
     if len(scores_list) != G:
         raise RuntimeError(f'nms_gpu_multi: {G} box sets but {len(scores_list)} score sets')
@@ -218,20 +230,41 @@ def nms_gpu_multi(boxes_list, scores_list, thresh, pre_max_size=None, post_max_s
         if s2.shape[0] != n:
             raise RuntimeError(f'nms_gpu_multi: {n} boxes but {s2.shape[0]} scores')
     dev = boxes_list[0].device
-    total = sum(sizes)
+    total, nmax = sum(sizes), max(sizes)
     if total == 0:
         return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
-    boxes = torch.cat([b.reshape(-1, 5).to(torch.float32) for b in boxes_list], dim=0)
+    lib = _lib.load()
+    ths = list(thresh) if isinstance(thresh, (list, tuple)) else [thresh] * G
+    if len(ths) != G:
+        raise RuntimeError(f'{len(ths)} thresholds for {G} groups')
+    per_entry = (nmax > _scored_max(lib) or G > 65535 or (pre_max_size is not None and pre_max_size < 0) or
+                 any(s2.dtype not in (torch.float32, torch.float16, torch.bfloat16) for s2 in scores_list))
+    if per_entry:
+        return [_nms(b, s2, t, pre_max_size, post_max_size, normal) for b, s2, t in zip(boxes_list, scores_list, ths)]
+    cap = nmax if pre_max_size is None else min(nmax, int(pre_max_size))
+    if cap == 0:
+        return [torch.zeros((0,), dtype=torch.int64, device=dev) for _ in range(G)]
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n)
-    # (G, total) score / membership matrices: entry g owns columns offs[g] .. offs[g+1] (a handful of torch ops, not 2G)
-    flat = torch.cat([s2.reshape(-1).to(torch.float32) for s2 in scores_list], dim=0)
-    gid = torch.repeat_interleave(torch.arange(G, device=dev), torch.tensor(sizes, device=dev), output_size=total)
-    valid = gid.unsqueeze(0) == torch.arange(G, device=dev).unsqueeze(1)
-    scores = flat.unsqueeze(0).expand(G, total).contiguous()
-    return nms_gpu_batched(boxes, scores, thresh, valid, pre_max_size=pre_max_size, post_max_size=post_max_size, normal=normal,
-                           _offsets=torch.tensor(offs[:G], dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        boxes = _check_boxes(torch.cat([b.reshape(-1, 5) for b in boxes_list], dim=0), 5, 'nms_gpu_multi')
+        flat = torch.cat([s2.reshape(-1) for s2 in scores_list], dim=0).to(torch.float32).contiguous()
+        seg = torch.tensor(offs, dtype=torch.int32, device=dev)
+        th = _thresh_tensor(ths, G, dev)
+        keep = torch.empty((G, cap), dtype=torch.int64, device=dev)
+        num = torch.empty(G, dtype=torch.int64, device=dev)
+        ws = torch.empty(lib.rnms_batched_scored_workspace_bytes(G, nmax, cap), dtype=torch.uint8, device=dev)
+        _lib.check(lib.rnms_segmented_scored(1 if normal else 0, boxes.data_ptr(), flat.data_ptr(), seg.data_ptr(), G, nmax, cap,
+                                             th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), 'nms_gpu_multi')
+        keep = keep - seg[:G].to(torch.int64).unsqueeze(1)          # indices local to each entry
+    nums = num.tolist()  # the one sync: G data-dependent result lengths
+    out = []
+    for g in range(G):
+        k = keep[g, :nums[g]]
+        out.append(k if post_max_size is None else k[:post_max_size])
+    return out
 
 
 def multi_class_nms(box_probs, boxes_for_nms, score_thr, nms_thr, use_rotate_nms=True):

@@ -1,14 +1,13 @@
-"""Dynamic point-to-voxel scatter ops — host mirror of /root/reference/mmdet3d_gaussian/ops/voxel/scatter.py
+"""Dynamic point-to-voxel scatter ops — the call surface of /root/reference/mmdet3d_gaussian/ops/voxel/scatter.py
 (`scatter_index` :10-26, `scatter_reduce` :29-72, `Scatter` :75-144) on top of the HIP kernels of
 csrc/voxel_scatter.hip.
 
-`scatter_index` is ATen-level plumbing in the reference as well (masked_fill + unique_dim,
-src/scatter_points_cuda.cu:221-251) and is restated with the same torch ops.  `scatter_reduce` keeps the reference's
-signature; the grouping of points by voxel (a stable argsort of the map) that the atomic-free kernels need is computed
-once per `Scatter` and reused by every reduce call on it.
+The reference indexes with masked_fill + unique_dim per SAMPLE (src/scatter_points_cuda.cu:221-251, scatter.py:101-117).
+Here one mixed-radix int64 key per point, one stable sort and one unique_consecutive index the whole batch and produce
+the by-voxel grouping of the points that the atomic-free reduce / backward kernels walk; nothing reads a value back to
+the host (`_index_and_grouping`).  `scatter_reduce` keeps the reference's signature.
 """
 import torch
-from torch import nn
 from torch.autograd import Function
 
 from . import _lib
@@ -37,6 +36,45 @@ class _on_device:
         return False
 
 
+def _index_and_grouping(coors):
+    """One pass from point coordinates to everything the scatter ops need, batched or not, without a per-sample loop
+    and without a host read of any VALUE (the only wait is the one inside torch.unique_consecutive: the number of
+    voxels is data dependent).
+
+    A point row (any number of integer columns; a leading batch column is just one more) becomes ONE int64 key, mixed
+    radix over the per-column extents taken on the device; a row with a negative entry gets key -1 (dropped point,
+    scatter_points_cuda.cu:236-246).  A stable sort of the keys is at once
+      * the order of the voxels: ascending keys = lexicographically sorted unique rows = what the reference's
+        unique_dim yields per sample, samples in batch order (ops/voxel/scatter.py:101-117);
+      * the grouping of the points by voxel in ascending point id that the atomic-free kernels walk (`order`, `seg`).
+    A sentinel key -1 is put in front so that the dropped-points bucket always exists and can be cut off without asking
+    the device whether it is there."""
+    n, ndim = coors.shape
+    dev = coors.device
+    c64 = coors.to(torch.int64)
+    ext = c64.amax(0).clamp_(min=0).add_(1)                                   # (ndim,) per-column extent, on the device
+    stride = torch.ones(ndim, dtype=torch.int64, device=dev)
+    if ndim > 1:
+        stride[:-1] = ext[1:].flip(0).cumprod(0).flip(0)
+    key = (c64 * stride).sum(-1)
+    key = torch.where((c64 < 0).any(-1), key.new_full((), -1), key)
+    key = torch.cat((key.new_full((1,), -1), key))                            # sentinel FIRST: bucket 0 = dropped points
+    skey, order = torch.sort(key, stable=True)                                # order[0] == 0: the sentinel itself
+    ukey, inv, cnt = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
+    pmap = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    pmap[order] = (inv - 1).to(torch.int32)                                   # voxel id per point, -1 = dropped
+    pmap = pmap[1:]
+    vkey = ukey[1:]
+    counts = cnt[1:].to(torch.int32)
+    voxel_coors = ((vkey.unsqueeze(-1) // stride) % ext).to(coors.dtype)
+    order = (order[1:] - 1).to(torch.int32)                                   # point ids, ascending inside every voxel
+    seg = torch.empty(counts.numel() + 1, dtype=torch.int32, device=dev)
+    seg[0] = 0
+    torch.cumsum(counts, 0, out=seg[1:])
+    seg += (cnt[0] - 1).to(torch.int32)                                        # dropped points come first in `order`
+    return voxel_coors, pmap.contiguous(), counts.contiguous(), (order.contiguous(), seg)
+
+
 def scatter_index(coors):
     """coors (N, ndim) int -> (voxel_coors (M, ndim), point2voxel_map (N,) int32 with -1 for dropped points,
     voxel_points_count (M,) int32).  Voxels are the sorted unique rows; a point with ANY negative coordinate is
@@ -44,23 +82,16 @@ def scatter_index(coors):
     if coors.size(0) == 0:
         return (coors.clone().detach(), coors.new_empty((0,), dtype=torch.int32),
                 coors.new_empty((0,), dtype=torch.int32))
-    clean = coors.masked_fill(coors.lt(0).any(-1, True), -1)
-    out_coors, coors_map, reduce_count = torch.unique(clean, dim=0, sorted=True, return_inverse=True,
-                                                      return_counts=True)
-    if bool(out_coors[0, 0].lt(0)):
-        out_coors = out_coors[1:]
-        reduce_count = reduce_count[1:]
-        coors_map = coors_map - 1
-    return out_coors, coors_map.to(torch.int32), reduce_count.to(torch.int32)
+    return _index_and_grouping(coors.contiguous())[:3]
 
 
 def group_points(point2voxel_map, voxel_points_count):
-    """(order, seg): point ids grouped by voxel in ascending id, and the (M+1) segment bounds into `order`."""
+    """(order, seg) from an existing map: point ids grouped by voxel in ascending id, and the (M+1) segment bounds into
+    `order` (the dropped points, map -1, come first).  No host read."""
     order = torch.sort(point2voxel_map, stable=True)[1].to(torch.int32)
-    n_invalid = int(point2voxel_map.numel()) - int(voxel_points_count.sum())   # leading -1 entries
     seg = torch.zeros(voxel_points_count.numel() + 1, dtype=torch.int32, device=point2voxel_map.device)
-    seg[1:] = torch.cumsum(voxel_points_count, 0)
-    seg += n_invalid
+    torch.cumsum(voxel_points_count, 0, out=seg[1:])
+    seg += (point2voxel_map.numel() - seg[-1:]).to(torch.int32)              # leading -1 entries, taken on the device
     return order.contiguous(), seg.contiguous()
 
 
@@ -123,39 +154,29 @@ def scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce_type='max'
 
 
 class Scatter(object):
-    """Reference `Scatter` (scatter.py:75-144): voxelise once, reduce / map back many times."""
+    """Voxelise once, reduce / map back many times — the reference's `Scatter` surface
+    (/root/reference/mmdet3d_gaussian/ops/voxel/scatter.py:75-144: `voxel_coors`, `pts_voxel_maps`,
+    `voxel_pts_counts`, `pts_coors`, `batch_size`, `reduce`, `mapback`, `reduce_mapback`).
+
+    The reference walks the batch in Python (one unique_dim + index_put per sample, and `.max().item()` to learn the
+    batch size).  Here batched (b, z, y, x) rows are indexed in ONE device pass: the batch column is simply the most
+    significant digit of the voxel key, which orders the voxels exactly as the per-sample loop does.  The same pass
+    yields the by-voxel grouping every `reduce` needs."""
 
     def __init__(self, coors):
         self._pts_coors = coors
+        self._batched = coors.size(-1) != 3
+        self._batch_size = None
         self._grouping = None
         if coors.numel() == 0:
-            self._batch_size = None if coors.size(-1) == 3 else 1
+            if self._batched:
+                self._batch_size = 1
             self.voxel_coors = coors.clone().detach()
             self.pts_voxel_maps = coors.new_empty((0,), dtype=torch.int32)
             self.voxel_pts_counts = coors.new_empty((0,), dtype=torch.int32)
             return
-        if coors.size(-1) == 3:
-            self._batch_size = None
-            voxel_coors, pts_voxel_maps, voxel_pts_counts = scatter_index(coors.contiguous())
-        else:
-            batch_size = coors[:, 0].max().item() + 1
-            self._batch_size = batch_size
-            previous_voxels = 0
-            pts_voxel_maps = coors.new_full((coors.size(0),), -1, dtype=torch.int32)
-            voxel_pts_counts, voxel_coors = [], []
-            for i in range(batch_size):
-                inds = torch.where(coors[:, 0] == i)
-                voxel_coor, pts_voxel_map, voxel_pts_count = scatter_index(coors[inds][:, 1:].contiguous())
-                pts_voxel_map[pts_voxel_map.ge(0)] += previous_voxels
-                pts_voxel_maps[inds] = pts_voxel_map
-                previous_voxels += voxel_coor.size(0)
-                voxel_pts_counts.append(voxel_pts_count)
-                voxel_coors.append(nn.functional.pad(voxel_coor, (1, 0), mode='constant', value=i))
-            voxel_coors = torch.cat(voxel_coors, dim=0)
-            voxel_pts_counts = torch.cat(voxel_pts_counts, dim=0)
-        self.voxel_coors = voxel_coors
-        self.pts_voxel_maps = pts_voxel_maps
-        self.voxel_pts_counts = voxel_pts_counts
+        (self.voxel_coors, self.pts_voxel_maps, self.voxel_pts_counts,
+         self._grouping) = _index_and_grouping(coors.contiguous())
 
     @property
     def pts_coors(self):
@@ -163,23 +184,26 @@ class Scatter(object):
 
     @property
     def batch_size(self):
+        """None for (z, y, x) rows; otherwise 1 + the largest batch index (read from the device on first use only)."""
+        if self._batched and self._batch_size is None:
+            self._batch_size = int(self._pts_coors[:, 0].max()) + 1
         return self._batch_size
 
     def mapback(self, voxel_feats, default_feat=0):
-        invalid_mask = self.pts_voxel_maps.lt(0)
-        point_feats = voxel_feats[self.pts_voxel_maps.clamp(min=0).long()]
-        point_feats[invalid_mask] = default_feat
-        return point_feats
+        """(M, C) voxel rows -> (N, C) point rows; dropped points receive `default_feat`."""
+        if voxel_feats.size(0) == 0:
+            return voxel_feats.new_full((self.pts_voxel_maps.numel(),) + tuple(voxel_feats.shape[1:]), default_feat)
+        idx = self.pts_voxel_maps.long()
+        rows = voxel_feats.index_select(0, idx.clamp(min=0))
+        keep = (idx >= 0).reshape((-1,) + (1,) * (rows.dim() - 1))
+        return torch.where(keep, rows, rows.new_full((), default_feat))
 
     def reduce(self, pts_feats, reduce_op):
         assert reduce_op in ['max', 'mean', 'sum'], \
             f'For the arg "reduce", only "max", "mean" and "sum" are supported but got {reduce_op}'
-        if self._grouping is None and self.pts_voxel_maps.numel() > 0:
-            self._grouping = group_points(self.pts_voxel_maps, self.voxel_pts_counts)
         voxel_feats = scatter_reduce(pts_feats.contiguous(), self.pts_voxel_maps, self.voxel_pts_counts, reduce_op,
                                      self._grouping)
         return voxel_feats, self.voxel_coors
 
     def reduce_mapback(self, pts_feats, reduce_op, default_feat=0):
-        voxel_feats, _ = self.reduce(pts_feats, reduce_op)
-        return self.mapback(voxel_feats, default_feat)
+        return self.mapback(self.reduce(pts_feats, reduce_op)[0], default_feat)

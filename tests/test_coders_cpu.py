@@ -1,5 +1,6 @@
-"""§8f-2 host mirror of the CenterPoint yaw coder vs golden outputs of the REAL reference classes, and the
-head-level oracle (decode + GD loss + chain rule) vs the real reference composition.  CPU only."""
+"""§8f-2: the torch statement of the CenterPoint yaw coder (oracle/coder_torch.py, the checker of the device coder) vs
+golden outputs of the REAL reference classes, and the head-level oracle (decode + GD loss + chain rule) vs the real
+reference composition.  CPU only."""
 import os
 
 import numpy as np
@@ -7,25 +8,26 @@ import pytest
 import torch
 
 import oracle
-from mmdet3d_gaussian_amd.coders import CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
+from mmdet3d_gaussian_amd.coders import DeltaXYZWLHRBBoxCoder
+from oracle import coder_torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'coder_center.npz')
 CASES = (('gwd3d', dict(fun='log1p', tau=0.0)), ('bd3d', dict(fun='log1p', tau=1.0)), ('kld3d', dict(fun='none', tau=0.0)))
 
 
-def _coder(g):
-    return CenterPointBBoxYawCoder(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
-                                   voxel_size=g['cfg_voxel_size'].tolist(), code_size=9, norm_bbox=True)
+def _cfg(g):
+    return dict(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
+                voxel_size=g['cfg_voxel_size'].tolist(), norm_bbox=True)
 
 
-def test_center_coder_decode_encode_bit_exact_with_reference():
+def test_center_coder_statement_bit_exact_with_reference():
     g = np.load(GOLD)
-    c = _coder(g)
     locs, pred, anno = torch.from_numpy(g['locs']), torch.from_numpy(g['pred']), torch.from_numpy(g['anno'])
-    np.testing.assert_array_equal(c.decode(locs, pred, correct_yaw=False).numpy(), g['decode_noyaw32'])
-    np.testing.assert_array_equal(c.decode(locs, pred, correct_yaw=True).numpy(), g['decode_yaw32'])
-    np.testing.assert_array_equal(c.encode(anno)[..., :7].numpy(), g['enc7'])
-    assert c.encode(anno).shape[-1] == 11
+    np.testing.assert_array_equal(coder_torch.center_decode(locs, pred, correct_yaw=False, **_cfg(g)).numpy(), g['decode_noyaw32'])
+    np.testing.assert_array_equal(coder_torch.center_decode(locs, pred, correct_yaw=True, **_cfg(g)).numpy(), g['decode_yaw32'])
+    enc = coder_torch.center_encode(anno)
+    np.testing.assert_array_equal(enc[..., :7].numpy(), g['enc7'])
+    assert enc.shape[-1] == 11
 
 
 @pytest.mark.parametrize('lt,kw', CASES)

@@ -335,3 +335,44 @@ def test_center_head_losses_all_tasks_one_launch(amd, lt, kw, vel, reg):
     bad[0][3, 1] = W
     o2 = amd.center_head_losses(mod, dict(type='L1Loss', loss_weight=0.25), coder, dev_tasks, bad, [an.cuda() for _, _, an in tasks], ns, cw)
     assert torch.isnan(o2[0][0]) and torch.isnan(o2[0][1]) and torch.isfinite(o2[2][1])
+
+
+def test_device_center_coder_vs_reference_golden_and_autograd(amd):
+    """CenterPointBBoxYawCoder on the device (csrc/coders.hip): decode with and without correct_yaw and encode against
+    the outputs of the REAL reference classes (tests/golden/coder_center.npz; exp / sincos / atan2 differ from the CPU's
+    by ulps: 2e-6 relative, and the quarter-turn decision must agree wherever it is not within 1e-4 of a boundary),
+    the backward against autograd on the pinned torch statement (oracle/coder_torch.py)."""
+    from oracle import coder_torch
+    g = np.load(GOLD)
+    cfg = dict(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
+               voxel_size=g['cfg_voxel_size'].tolist(), norm_bbox=True)
+    coder = amd.CenterPointBBoxYawCoder(code_size=9, **cfg)
+    locs, pred, anno = torch.from_numpy(g['locs']).cuda(), torch.from_numpy(g['pred']).cuda(), torch.from_numpy(g['anno']).cuda()
+    d0 = coder.decode(locs, pred, correct_yaw=False).cpu().numpy()
+    np.testing.assert_allclose(d0, g['decode_noyaw32'], rtol=2e-6, atol=2e-6)
+    d1 = coder.decode(locs, pred).cpu().numpy()                      # correct_yaw=True is the default (ref :18)
+    p = g['pred']
+    frac = (np.arctan2(p[..., 7], p[..., 8]) - p[..., 6]) / (np.pi / 2) + 0.5
+    safe = np.abs(frac - np.round(frac)) > 1e-4
+    assert safe.mean() > 0.99
+    np.testing.assert_allclose(d1[safe], g['decode_yaw32'][safe], rtol=2e-6, atol=2e-6)
+    assert (d1[safe][:, 3] != d0[safe][:, 3]).any()                   # some rows did swap w / l
+    e = coder.encode(anno).cpu().numpy()
+    assert e.shape[-1] == 11
+    np.testing.assert_array_equal(e[..., :7], g['enc7'])
+    np.testing.assert_allclose(e[..., 7], np.sin(g['anno'][..., 6]), atol=2e-7)
+    np.testing.assert_allclose(e[..., 8], np.cos(g['anno'][..., 6]), atol=2e-7)
+    np.testing.assert_array_equal(e[..., 9:], g['anno'][..., 7:])
+    # backward, both modes, random upstream gradient
+    for cy in (False, True):
+        pd = pred.clone().requires_grad_(True)
+        out = coder.decode(locs, pd, correct_yaw=cy)
+        up = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        (out * up).sum().backward()
+        pr = torch.from_numpy(g['pred']).double().requires_grad_(True)
+        ref = coder_torch.center_decode(torch.from_numpy(g['locs']).double(), pr, correct_yaw=cy, **cfg)
+        (ref * up.cpu().double()).sum().backward()
+        sc = pr.grad.abs().max().item()
+        assert (pd.grad.cpu().double() - pr.grad)[torch.from_numpy(safe)].abs().max().item() <= 2e-6 * (1 + sc), cy
+    with pytest.raises(RuntimeError):
+        coder.decode(torch.zeros(1, 2), torch.zeros(1, 11))           # no CPU path

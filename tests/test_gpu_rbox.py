@@ -326,6 +326,29 @@ def test_nms_gpu_multi_equals_the_per_entry_loop(amd):
         want = amd.nms_gpu(bl[k], sl[k], thr[k], pre_max_size=400, post_max_size=83) if n else torch.zeros(0, dtype=torch.int64).cuda()
         assert torch.equal(got[k], want), k
     assert amd.nms_gpu_multi([], [], 0.2) == []
+    # a negative pre_max_size is a slice bound (order[:pre]): n_g + pre boxes survive per entry, in every path
+    neg = amd.nms_gpu_multi(bl, sl, thr, pre_max_size=-10)
+    for k, n in enumerate(sizes):
+        want = amd.nms_gpu(bl[k], sl[k], thr[k], pre_max_size=-10) if n else torch.zeros(0, dtype=torch.int64).cuda()
+        assert torch.equal(neg[k], want), k
+    allb = torch.cat(bl); N = allb.shape[0]
+    alls = torch.zeros(2, N).cuda(); allv = torch.zeros(2, N, dtype=torch.bool).cuda()
+    alls[0, :500] = sl[0]; allv[0, :500] = True
+    alls[1, 537:1037] = sl[3]; allv[1, 537:1037] = True
+    bat = amd.nms_gpu_batched(allb, alls, [thr[0], thr[3]], allv, pre_max_size=-10)
+    assert torch.equal(bat[0], amd.nms_gpu(bl[0], sl[0], thr[0], pre_max_size=-10))
+    assert torch.equal(bat[1] - 537, amd.nms_gpu(bl[3], sl[3], thr[3], pre_max_size=-10))
+
+
+def test_nms_gpu_multi_many_entries_stay_segmented(amd):
+    """48 entries x 500 boxes (8 samples x 6 tasks): each entry ranks only its own slice; results equal the loop."""
+    bl, sl = [], []
+    for k in range(48):
+        b, s = nms_boxes(500 - 7 * (k % 5), seed=900 + k, extent=25.0)
+        bl.append(torch.from_numpy(b).cuda()); sl.append(torch.from_numpy(s).cuda())
+    got = amd.nms_gpu_multi(bl, sl, 0.2, pre_max_size=1000, post_max_size=83)
+    for k in range(48):
+        assert torch.equal(got[k], amd.nms_gpu(bl[k], sl[k], 0.2, pre_max_size=1000, post_max_size=83)), k
 
 
 def test_multi_class_nms_matches_reference_loop(amd):

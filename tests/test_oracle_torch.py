@@ -47,9 +47,7 @@ def test_head_torch_restatements_against_independent_formulas():
     a, b = head_torch.add_sin_difference(p, t)
     assert torch.allclose(a[:, 6] - b[:, 6], torch.sin(p[:, 6] - t[:, 6]), atol=1e-14)
     assert torch.equal(a[:, :6], p[:, :6]) and torch.equal(b[:, :6], t[:, :6])
-    spec = importlib.util.spec_from_file_location(
-        'coders_mirror', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mmdet3d-gaussian_amd', 'coders.py'))
-    cm = importlib.util.module_from_spec(spec); spec.loader.exec_module(cm)
+    from mmdet3d_gaussian_amd import coders as cm
     anchors = torch.rand(200, 7, generator=g, dtype=torch.float64) + 0.5
     boxes = torch.rand(200, 7, generator=g, dtype=torch.float64) + 0.5
     enc = cm.DeltaXYZWLHRBBoxCoder.encode(anchors, boxes)

@@ -11,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PROBES = {
     'hbm_probe': ['-O3'],
+    'hbm_probe2': ['-O3'],
     'clip_probe': ['-O3', '-ffp-contract=off'],
     'mask_probe': ['-O3', '-ffp-contract=off', '-Wno-unused-value'],
 }

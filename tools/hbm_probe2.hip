@@ -1,0 +1,94 @@
+// hbm_probe2.hip — where do the last 3 % between the fused loss kernel and a flat copy go?
+// 2 streams read : 1 written over 3 x 280 MB (the fused kernel's traffic at 10 M pairs), nontemporal everywhere.
+//   flat<V,T>   : T threads, V float4 per thread, block chunk = V*T vectors (no LDS)           -> the ceiling
+//   tile<BAR>   : the fused kernel's data path without its math: 7-KiB tiles (448 vectors) per tensor brought in by
+//                 14 LDS-DMA pieces, (barrier), each thread reads "its rows" (7 dwords x 2), writes 7 dwords back to
+//                 LDS, (barrier), 448 16-byte stores.  BAR=0 drops both workgroup barriers (wave-local waits only;
+//                 the data is then garbage, only the time matters).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/hbm_probe2 tools/hbm_probe2.hip && tools/hbm_probe2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void gbl_cptr_t;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e, __FILE__, __LINE__); return 1; } } while (0)
+
+template <int V, int T>
+__global__ __launch_bounds__(T) void flat(const v4f* __restrict__ a, const v4f* __restrict__ b, v4f* __restrict__ c, long long n) {
+  const long long base = (long long)blockIdx.x * (V * T) + threadIdx.x;
+  v4f x[V], y[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const long long i = base + k * T;
+    if (i < n) { x[k] = __builtin_nontemporal_load(a + i); y[k] = __builtin_nontemporal_load(b + i); }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const long long i = base + k * T;
+    if (i < n) __builtin_nontemporal_store(x[k] + y[k], c + i);
+  }
+}
+
+template <bool BAR, int VALU>
+__global__ __launch_bounds__(256) void tile(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, long long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sp = smem; float* st = smem + 1792;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long t = blockIdx.x;
+  if (t >= ntiles) return;
+  const float* ga = a + t * 1792; const float* gb = b + t * 1792; float* gc = c + t * 1792;
+#pragma unroll
+  for (int j0 = 0; j0 < 14; j0 += 4) {
+    const int j = j0 + wave;
+    if (j < 7) __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(ga + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, 2);
+    else if (j < 14) __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gb + (j - 7) * 256 + lane * 4), (lds_ptr_t*)(st + (j - 7) * 256), 16, 0, 2);
+  }
+  if (BAR) __syncthreads(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float r[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) r[k] = sp[tid * 7 + k] + st[tid * 7 + k];
+#pragma unroll
+  for (int it = 0; it < VALU; ++it) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) r[k] = __builtin_fmaf(r[k], 1.0000001f, 1e-9f);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sp[tid * 7 + k] = r[k];
+  if (BAR) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const v4f v0 = reinterpret_cast<const v4f*>(sp)[tid];
+  __builtin_nontemporal_store(v0, reinterpret_cast<v4f*>(gc) + tid);
+  if (tid < 192) {
+    const v4f v1 = reinterpret_cast<const v4f*>(sp)[tid + 256];
+    __builtin_nontemporal_store(v1, reinterpret_cast<v4f*>(gc) + tid + 256);
+  }
+}
+
+int main() {
+  const long long n = 17500000;  // float4 per buffer = 280 MB
+  v4f *a, *b, *c;
+  CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMalloc(&c, n * 16));
+  CK(hipMemset(a, 1, n * 16)); CK(hipMemset(b, 1, n * 16)); CK(hipMemset(c, 0, n * 16));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int iters = 30;
+  const double bytes = 3.0 * n * 16;
+  auto run = [&](const char* name, auto launch) {
+    float best = 1e9f, sum = 0;
+    for (int r = 0; r < 3; ++r) {
+      for (int i = 0; i < 5; ++i) launch();
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int i = 0; i < iters; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      ms /= iters; sum += ms; if (ms < best) best = ms;
+    }
+    printf("%-44s best %7.1f us  mean %7.1f us  %7.1f GB/s\n", name, best * 1e3, sum / 3 * 1e3, bytes / (best * 1e-3) / 1e9);
+  };
+#define FLAT(V, T) run("flat V=" #V " T=" #T, [&] { flat<V, T><<<(unsigned)((n + (V) * (T) - 1) / ((V) * (T))), T>>>(a, b, c, n); })
+  FLAT(1, 256); FLAT(2, 256); FLAT(4, 256); FLAT(1, 512); FLAT(2, 512); FLAT(1, 1024); FLAT(1, 128); FLAT(1, 64); FLAT(2, 64); FLAT(4, 64);
+  const long long ntiles = n / 448;
+#define TILE(B, VL) run("tile448 LDS-DMA bar=" #B " valu=" #VL "x7fma", [&] { tile<B, VL><<<(unsigned)ntiles, 256, 2 * 1792 * 4>>>((const float*)a, (const float*)b, (float*)c, ntiles); })
+  TILE(true, 0); TILE(false, 0); TILE(true, 16); TILE(true, 32); TILE(true, 48); TILE(false, 32);
+  FLAT(1, 256);
+  return 0;
+}
