@@ -10,6 +10,7 @@ loss AND the final gradient(s) in a single pass over the (N,7) rows (csrc/gd3d_l
 through the C ABI of include/gd3d.h.  There is no CPU path: CPU tensors raise.
 """
 import ctypes
+import os
 from copy import deepcopy
 
 import torch
@@ -24,6 +25,9 @@ FUNS = {'none': 0, 'log1p': 1, 'expm1': 2, 'nlog': 3}
 # bench.py sets this to a list; every fused launch then appends a DispatchTimer: a pair of HIP events bound to the
 # begin / end timestamps of that kernel's own dispatch (gd3d_loss_fused_timed), inside the timed region.
 PROFILE_EVENTS = None
+# measurement switch (tests/perf/small_p_latency.py): 1 = decide the no-positive-weight early-out on the HOST as the
+# reference does (torch.any + a device-to-host wait per call) instead of inside the fused launch
+_HOST_WEIGHT_CHECK = os.environ.get('GD3D_HOST_WEIGHT_CHECK', '0') == '1'
 
 
 class DispatchTimer:
@@ -301,7 +305,7 @@ class GDLoss(nn.Module):
         # there) for particular shapes, which cannot be decided from the device.
         select = False
         if weight is not None and reduction != 'none':
-            if weight.shape == pred.shape and weight.is_cuda:
+            if weight.shape == pred.shape and weight.is_cuda and not _HOST_WEIGHT_CHECK:
                 select = True
             elif not torch.any(weight > 0):
                 return (pred * weight).sum()

@@ -84,22 +84,42 @@ def grad_bound(g64, g32, tol=GRAD_TOL):
     return _bound(g64, g32, tol, rowwise=True)
 
 
-# Sampling allowance: the yardstick is a maximum over a finite family (128-256 rows), so an independent fp32
-# evaluation exceeds it now and then by a small factor.  Up to FRAC_OUT of the elements may lie between
-# bound and HARD x bound; none beyond.
+# Sampling allowance, ONLY where the reference's own fp32 evaluation is not trustworthy (the near-identical and identical
+# families: catastrophic cancellation, the yardstick there is a maximum over 128 noisy rows): up to FRAC_OUT of the
+# elements may lie between bound and HARD x bound; none beyond.  Everywhere else (kitti / large / delta families, seeded
+# oracle comparisons, head slices) the bound is strict: no element may exceed it.
 FRAC_OUT = 0.002
 HARD = 4.0
+NOISY_FAMILIES = ('near', 'ident')
+
+# (name, max |ours - ref64| / (1 + scale), max |ours - ref32| / (1 + scale), max |ref32 - ref64| / (1 + scale)) rows
+# collected by check_close(..., report=...); tests/test_gpu_gd_loss.py writes them out as the accuracy report
+REPORT = []
 
 
-def check_close(name, ours, ref64, bound):
+def _relerr(a, b, ref64, rowwise):
+    sc = 1 + _scale(np.asarray(ref64, np.float64), rowwise)
+    with np.errstate(all='ignore'):
+        e = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / sc
+    fin = np.isfinite(e)
+    return float(e[fin].max()) if fin.any() else float('nan')
+
+
+def check_close(name, ours, ref64, bound, noisy=False, report=None):
+    """`noisy`: the sampling allowance above applies (near / ident families only).
+    `report`: (ref32, rowwise) -> also record this comparison's error figures in REPORT."""
     ours = np.asarray(ours, np.float64)
     ref64 = np.asarray(ref64, np.float64)
+    if report is not None:
+        ref32, rowwise = report
+        REPORT.append((name, _relerr(ours, ref64, ref64, rowwise), _relerr(ours, ref32, ref64, rowwise),
+                       _relerr(ref32, ref64, ref64, rowwise)))
     bound = np.broadcast_to(np.asarray(bound, np.float64), ref64.shape)
     fin = np.isfinite(ref64) & np.isfinite(bound)
     assert np.isfinite(ours[fin]).all(), f'{name}: non-finite where the reference is finite'
     err = np.abs(ours - ref64)
     bad = fin & (err > bound)
-    if bad.any() and bad.sum() <= FRAC_OUT * bad.size and not (fin & (err > HARD * bound)).any():
+    if noisy and bad.any() and bad.sum() <= FRAC_OUT * bad.size and not (fin & (err > HARD * bound)).any():
         return
     if bad.any():
         k = np.argmax(np.where(bad, err / np.maximum(bound, 1e-300), 0))

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""SURVEY.md §8d config 2 stand-in: loss-level train-step slice of the PointPillars/KITTI KLD config (tau=0, log1p,
-loss_weight=5): P positives, weight (P,7)=1, avg_factor=P; forward + backward per step.
-Compares the fused HIP path (GDLoss) with the reference-style eager PyTorch op chain on the same MI355X
-(oracle/gd_torch.py — written in entry form, fewer kernels than the reference's own bmm chain, so conservative)."""
+"""Host-side cost of GDLoss at training sizes (SURVEY.md §8d config 2 stand-in: KLD tau=0 log1p loss_weight=5, P positives,
+weight (P,7) = 1, avg_factor = P).  Per P:
+  isolated_us   : one forward + its own backward() per step (includes torch's autograd-engine thread hand-off, which any
+                  op chain pays once per backward() call);
+  amortised_us  : 8 GDLoss calls summed, ONE backward() — the shape of a real training step, where the loss is one of
+                  many nodes of a single backward pass; per-call cost = step / 8;
+  forward_us    : forward only;
+  eager_torch_us: the reference-style eager PyTorch op chain on the same GPU (oracle/gd_torch.py), isolated.
+Run twice for the weight-path A/B: GD3D_HOST_WEIGHT_CHECK=1 decides the early-out on the host as the reference does."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import math, torch
 import mmdet3d_gaussian_amd as amd
+from mmdet3d_gaussian_amd import gd_loss as gdl
 from oracle import gd_torch
 dev = torch.device('cuda:0')
-def pairs(n):
-    g = torch.Generator(device=dev).manual_seed(0)
+def pairs(n, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
     lo = torch.tensor([0, -40, -3, 0.5, 0.5, 0.5, -math.pi], device=dev); hi = torch.tensor([70, 40, 1, 2.5, 4.5, 2.0, math.pi], device=dev)
     t = torch.rand(n, 7, generator=g, device=dev) * (hi - lo) + lo
     p = t + torch.randn(n, 7, generator=g, device=dev) * torch.tensor([0.3, 0.3, 0.1, 0.1, 0.1, 0.1, 0.1], device=dev)
@@ -21,17 +27,30 @@ def timeit(fn, iters):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e6
-rows = []
-for lt in ('kld3d', 'gwd3d', 'bd3d'):
-    mod = amd.GDLoss(lt, fun='log1p', tau=0.0, loss_weight=5.0)
+mode = 'host torch.any check (reference control flow)' if gdl._HOST_WEIGHT_CHECK else 'early-out resolved in the fused launch'
+lt = 'kld3d'
+mod = amd.GDLoss(lt, fun='log1p', tau=0.0, loss_weight=5.0)
+for weighted in (True, False):
     for P in (64, 512, 4096, 100_000, 1_000_000, 10_000_000):
-        p, t = pairs(P); w = torch.ones(P, 7, device=dev)
-        def ours():
+        sets = [pairs(P, s) for s in range(8 if P <= 100_000 else 1)]
+        w = torch.ones(P, 7, device=dev) if weighted else None
+        p, t = sets[0]
+        def iso():
             p.grad = None; mod(p, t, w, avg_factor=P).backward()
+        def fwd():
+            mod(p, t, w, avg_factor=P)
+        def amort():
+            tot = 0
+            for pp, tt in sets:
+                pp.grad = None
+                tot = tot + mod(pp, tt, w, avg_factor=P)
+            tot.backward()
         def ref():
             p.grad = None; gd_torch.gd_loss(p, t, lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).backward()
-        iters = 200 if P <= 100_000 else 20
-        a = timeit(ours, iters); b = timeit(ref, max(5, iters // 4))
-        l1 = mod(p, t, w, avg_factor=P).item(); l2 = gd_torch.gd_loss(p, t, lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).item()
-        rows.append(dict(loss=lt, P=P, fused_us=round(a, 1), eager_torch_us=round(b, 1), speedup=round(b / a, 1), loss_fused=l1, loss_eager=l2))
-        print(json.dumps(rows[-1]), flush=True)
+        iters = 300 if P <= 100_000 else 20
+        row = dict(mode=mode, weight='(P,7)' if weighted else None, P=P, isolated_us=round(timeit(iso, iters), 1),
+                   forward_us=round(timeit(fwd, iters), 1))
+        if len(sets) == 8:
+            row['amortised_us_per_call'] = round(timeit(amort, max(iters // 4, 10)) / 8, 1)
+        row['eager_torch_us'] = round(timeit(ref, max(5, iters // 10)), 1)
+        print(json.dumps(row), flush=True)
