@@ -124,11 +124,52 @@ def cpu_baseline(sample_pairs, seed):
     for prm in prms:
         oracle.gd_loss_timed(p[:n1], t[:n1], prm, 5.0 / sample_pairs, loss[:n1], gp[:n1], 1)
     dt1 = time.perf_counter() - t1
-    return {'value': round(3 * sample_pairs * reps / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
-            'single_thread_value': round(3 * n1 / dt1 / 1e6, 3),
-            'sample': f'{reps} pass(es) over {sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle '
-                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall; single thread: {n1} pairs x 3 '
-                      f'losses in {dt1:.2f} s'}
+    out = {'value': round(3 * sample_pairs * reps / dt / 1e6, 3), 'unit': 'M box-pairs/s', 'cores': cores, 'kind': 'port',
+           'single_thread_value': round(3 * n1 / dt1 / 1e6, 3), 'cpu_model': cpu_model(),
+           'sample': f'{reps} pass(es) over {sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle '
+                     f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall; single thread: {n1} pairs x 3 '
+                     f'losses in {dt1:.2f} s'}
+    out['torch_chain'] = torch_chain_baseline(min(sample_pairs, 1_000_000), seed, cores)
+    return out
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def torch_chain_baseline(sample_pairs, seed, cores):
+    """SURVEY.md §8d CPU baseline (2): the op-for-op PyTorch-CPU statement of a1-a9 (oracle/gd_torch.py, checked against
+    the reference's golden vectors in tests/test_oracle_torch.py), forward + autograd backward, fp32, on this host with
+    torch.set_num_threads(1) and (all granted cores).  This is the shape of the reference's own CPU path: ~110-145 ATen
+    ops per loss call plus autograd."""
+    from oracle import gd_torch
+    pred, tgt = synthetic_pairs(sample_pairs, seed, torch.device('cpu'))
+    res = {}
+    keep = torch.get_num_threads()
+    try:
+        for label, nt in (('threads_1', 1), (f'threads_{cores}', cores)):
+            torch.set_num_threads(nt)
+            p = pred.clone().requires_grad_(True)
+            for lt in LOSSES:   # untimed warm pass on a slice
+                gd_torch.gd_loss(p[:50_000], tgt[:50_000], lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
+            t0 = time.perf_counter()
+            for lt in LOSSES:
+                p.grad = None
+                gd_torch.gd_loss(p, tgt, lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
+            res[label] = round(3 * sample_pairs / (time.perf_counter() - t0) / 1e6, 3)
+    finally:
+        torch.set_num_threads(keep)
+    res['unit'] = 'M box-pairs/s'
+    res['sample'] = f'{sample_pairs} pairs x 3 losses, forward + autograd backward, fp32, eager PyTorch-CPU op chain (oracle/gd_torch.py)'
+    return res
 
 
 def main():

@@ -184,20 +184,20 @@ class _GDReduced(torch.autograd.Function):
     gradient are those of the reference's early-out `(pred * weight).sum()` when no weight entry is > 0."""
 
     @staticmethod
-    def forward(ctx, pred, target, row_weight, params, scale, prologue=None, select=False):
+    def forward(ctx, pred, target, row_weight, params, scale, prologue=None, select=False, flag_box=None):
         need_gp, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         _, total, gp, gt, any_pos = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt,
                                                prologue, select)
         ctx.gp, ctx.gt, ctx.any_pos = gp, gt, any_pos
         ctx.used = False
         ctx.replay = (pred, target, row_weight, params, scale, prologue, select)
-        if select:
-            ctx.mark_non_differentiable(any_pos)
-        return total, any_pos
+        if flag_box is not None:   # the any-positive flag leaves through a side door: a second autograd OUTPUT that is a
+            flag_box.append(any_pos)   # view of the same buffer as `total` makes every backward pay view bookkeeping
+        return total
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_out, _grad_flag=None):
+    def backward(ctx, grad_out):
         lib = _library()
         pred, target, row_weight, params, scale, prologue, select = ctx.replay
         if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
@@ -207,7 +207,7 @@ class _GDReduced(torch.autograd.Function):
             gp, gt = ctx.gp, ctx.gt
             ctx.used = True
         if gp is None and gt is None:
-            return (None,) * 7
+            return (None,) * 8
         g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         dev = pred.device
         prev = _get_device()
@@ -226,7 +226,7 @@ class _GDReduced(torch.autograd.Function):
                 _set_device(prev)
         if rc != 0:
             _lib.check(rc, 'gd3d_grad_finish')
-        return gp, gt, None, None, None, None, None
+        return gp, gt, None, None, None, None, None, None
 
 
 class _GDPerPair(torch.autograd.Function):
@@ -344,10 +344,11 @@ class GDLoss(nn.Module):
         if reduction == 'none':
             out = _GDPerPair.apply(p, t, w, params, float(scale), prologue)
         else:
-            out, any_pos = _GDReduced.apply(p, t, w, params, float(scale), prologue, select)
+            box = [] if (select and post_div is not None) else None
+            out = _GDReduced.apply(p, t, w, params, float(scale), prologue, select, box)
             if post_div is not None:
                 if select:  # the early-out value is not divided by avg_factor (it returns before the loss is called)
-                    post_div = torch.where(any_pos.reshape(()) != 0, post_div.to(torch.float32), 1.0)
+                    post_div = torch.where(box[0].reshape(()) != 0, post_div.to(torch.float32), 1.0)
                 out = out / post_div
             if n == 0 and reduction == 'mean' and avg_factor is None and not select:
                 out = out + float('nan')  # torch: mean of an empty tensor is nan

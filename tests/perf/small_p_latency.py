@@ -30,8 +30,9 @@ def timeit(fn, iters):
 mode = 'host torch.any check (reference control flow)' if gdl._HOST_WEIGHT_CHECK else 'early-out resolved in the fused launch'
 lt = 'kld3d'
 mod = amd.GDLoss(lt, fun='log1p', tau=0.0, loss_weight=5.0)
-for weighted in (True, False):
-    for P in (64, 512, 4096, 100_000, 1_000_000, 10_000_000):
+for weighted, sizes in ((True, (64, 512, 4096, 100_000, 1_000_000, 10_000_000)), (False, (64, 512, 4096, 100_000, 1_000_000, 10_000_000)),
+                        (True, (4096,)), (False, (4096,))):     # the last two repeat one size in the other order
+    for P in sizes:
         sets = [pairs(P, s) for s in range(8 if P <= 100_000 else 1)]
         w = torch.ones(P, 7, device=dev) if weighted else None
         p, t = sets[0]

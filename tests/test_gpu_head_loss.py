@@ -356,7 +356,23 @@ def test_device_center_coder_vs_reference_golden_and_autograd(amd):
     safe = np.abs(frac - np.round(frac)) > 1e-4
     assert safe.mean() > 0.99
     np.testing.assert_allclose(d1[safe], g['decode_yaw32'][safe], rtol=2e-6, atol=2e-6)
-    assert (d1[safe][:, 3] != d0[safe][:, 3]).any()                   # some rows did swap w / l
+    # the golden predictions carry a direction consistent with their yaw (no quarter turns): a second input set turns
+    # the (sin, cos) channels by k quarter turns, k = -3..3, checked against the pinned torch statement
+    rng = np.random.default_rng(5)
+    n2 = 700
+    p2 = rng.normal(0, 0.5, (n2, 11)).astype(np.float32)
+    k2 = rng.integers(-3, 4, n2)
+    ang = p2[:, 6] + k2 * (np.pi / 2) + rng.uniform(-0.6, 0.6, n2)
+    p2[:, 7], p2[:, 8] = np.sin(ang), np.cos(ang)
+    l2 = rng.integers(0, 128, (n2, 2)).astype(np.float32)
+    want2 = coder_torch.center_decode(torch.from_numpy(l2), torch.from_numpy(p2), correct_yaw=True, **cfg).numpy()
+    got2 = coder.decode(torch.from_numpy(l2).cuda(), torch.from_numpy(p2).cuda(), correct_yaw=True).cpu().numpy()
+    fr2 = (np.arctan2(p2[:, 7], p2[:, 8]) - p2[:, 6]) / (np.pi / 2) + 0.5
+    safe2 = np.abs(fr2 - np.round(fr2)) > 1e-4
+    np.testing.assert_allclose(got2[safe2], want2[safe2], rtol=2e-6, atol=2e-6)
+    plain2 = coder.decode(torch.from_numpy(l2).cuda(), torch.from_numpy(p2).cuda(), correct_yaw=False).cpu().numpy()
+    swapped = got2[:, 3] != plain2[:, 3]
+    assert 0.3 < swapped.mean() < 0.7 and (np.abs(got2[:, 6] - plain2[:, 6]) > 1.0).mean() > 0.6
     e = coder.encode(anno).cpu().numpy()
     assert e.shape[-1] == 11
     np.testing.assert_array_equal(e[..., :7], g['enc7'])
@@ -365,14 +381,14 @@ def test_device_center_coder_vs_reference_golden_and_autograd(amd):
     np.testing.assert_array_equal(e[..., 9:], g['anno'][..., 7:])
     # backward, both modes, random upstream gradient
     for cy in (False, True):
-        pd = pred.clone().requires_grad_(True)
-        out = coder.decode(locs, pd, correct_yaw=cy)
+        pd = torch.from_numpy(p2).cuda().requires_grad_(True)
+        out = coder.decode(torch.from_numpy(l2).cuda(), pd, correct_yaw=cy)
         up = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).cuda()
         (out * up).sum().backward()
-        pr = torch.from_numpy(g['pred']).double().requires_grad_(True)
-        ref = coder_torch.center_decode(torch.from_numpy(g['locs']).double(), pr, correct_yaw=cy, **cfg)
+        pr = torch.from_numpy(p2).double().requires_grad_(True)
+        ref = coder_torch.center_decode(torch.from_numpy(l2).double(), pr, correct_yaw=cy, **cfg)
         (ref * up.cpu().double()).sum().backward()
         sc = pr.grad.abs().max().item()
-        assert (pd.grad.cpu().double() - pr.grad)[torch.from_numpy(safe)].abs().max().item() <= 2e-6 * (1 + sc), cy
+        assert (pd.grad.cpu().double() - pr.grad)[torch.from_numpy(safe2)].abs().max().item() <= 2e-6 * (1 + sc), cy
     with pytest.raises(RuntimeError):
         coder.decode(torch.zeros(1, 2), torch.zeros(1, 11))           # no CPU path

@@ -63,6 +63,42 @@ __global__ __launch_bounds__(256) void tile(const float* __restrict__ a, const f
   }
 }
 
+// Wave-owned sub-tiles: every wave moves and owns 64 rows (1792 B per tensor = 2 x 768-B dwordx3 DMA pieces + one 256-B
+// dword piece, all 64 lanes active), no workgroup barrier at all; NW waves per workgroup (NW = 1: 64-thread workgroups).
+template <int NW, int VALU>
+__global__ __launch_bounds__(64 * NW) void tilew(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, long long nsub) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long t = (long long)blockIdx.x * NW + wave;
+  if (t >= nsub) return;
+  float* sp = smem + wave * 896; float* st = sp + 448;
+  const float* ga = a + t * 448; const float* gb = b + t * 448; float* gc = c + t * 448;
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(ga + lane * 3), (lds_ptr_t*)sp, 12, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gb + lane * 3), (lds_ptr_t*)st, 12, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(ga + 192 + lane * 3), (lds_ptr_t*)(sp + 192), 12, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gb + 192 + lane * 3), (lds_ptr_t*)(st + 192), 12, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(ga + 384 + lane), (lds_ptr_t*)(sp + 384), 4, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gb + 384 + lane), (lds_ptr_t*)(st + 384), 4, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float r[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) r[k] = sp[lane * 7 + k] + st[lane * 7 + k];
+#pragma unroll
+  for (int it = 0; it < VALU; ++it) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) r[k] = __builtin_fmaf(r[k], 1.0000001f, 1e-9f);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sp[lane * 7 + k] = r[k];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in-order LDS pipe of one wave: the writes above are visible below
+  const v4f v0 = reinterpret_cast<const v4f*>(sp)[lane];
+  __builtin_nontemporal_store(v0, reinterpret_cast<v4f*>(gc) + lane);
+  if (lane < 48) {
+    const v4f v1 = reinterpret_cast<const v4f*>(sp)[lane + 64];
+    __builtin_nontemporal_store(v1, reinterpret_cast<v4f*>(gc) + lane + 64);
+  }
+}
+
 int main() {
   const long long n = 17500000;  // float4 per buffer = 280 MB
   v4f *a, *b, *c;
@@ -89,6 +125,9 @@ int main() {
   const long long ntiles = n / 448;
 #define TILE(B, VL) run("tile448 LDS-DMA bar=" #B " valu=" #VL "x7fma", [&] { tile<B, VL><<<(unsigned)ntiles, 256, 2 * 1792 * 4>>>((const float*)a, (const float*)b, (float*)c, ntiles); })
   TILE(true, 0); TILE(false, 0); TILE(true, 16); TILE(true, 32); TILE(true, 48); TILE(false, 32);
-  FLAT(1, 256);
+  const long long nsub = n / 112;   // 64-row sub-tiles (112 float4 each)
+#define TILEW(NW, VL) run("wave-owned 64-row subtiles waves/WG=" #NW " valu=" #VL "x7fma", [&] { tilew<NW, VL><<<(unsigned)((nsub + (NW) - 1) / (NW)), 64 * (NW), (NW) * 896 * 4>>>((const float*)a, (const float*)b, (float*)c, nsub); })
+  TILEW(1, 0); TILEW(1, 32); TILEW(1, 48); TILEW(2, 0); TILEW(2, 32); TILEW(4, 0); TILEW(4, 32); TILEW(8, 32); TILEW(16, 32);
+  FLAT(1, 256); FLAT(1, 64); TILE(true, 32); TILEW(1, 32); TILEW(2, 32);
   return 0;
 }
