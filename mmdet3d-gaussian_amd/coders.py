@@ -61,7 +61,6 @@ class _CenterDecode(torch.autograd.Function):
         return res if preds.dtype == torch.float32 else res.to(preds.dtype)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.load()
         out, parity = ctx.saved_tensors

@@ -196,7 +196,6 @@ class _GDReduced(torch.autograd.Function):
         return total
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _library()
         pred, target, row_weight, params, scale, prologue, select = ctx.replay
@@ -239,7 +238,6 @@ class _GDPerPair(torch.autograd.Function):
         return loss
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         pred, target, row_weight, params, scale, prologue = ctx.replay
         rw = grad_out.reshape(-1).to(torch.float32)
@@ -284,12 +282,15 @@ class GDLoss(nn.Module):
             _kwargs = deepcopy(self.kwargs)
             _kwargs.update(call_kwargs)  # ref :293-294
             return make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset, _kwargs)
+        # the attributes are plain and may be reassigned by the user: cheap identity / value key, rebuilt when it changes
         co = self.center_offset
-        key = (self.loss_type, self.fun, tau, self.alpha,
-               tuple(co.tolist()) if isinstance(co, torch.Tensor) else tuple(co), tuple(sorted(self.kwargs.items())))
-        if self._params_cache is None or self._params_cache[0] != key:
-            self._params_cache = (key, make_params(self.loss_type, self.fun, tau, self.alpha, co, self.kwargs))
-        return self._params_cache[1]
+        key = (self.loss_type, self.fun, tau, self.alpha, id(co) if isinstance(co, torch.Tensor) else tuple(co),
+               id(self.kwargs), len(self.kwargs))
+        cache = self._params_cache
+        if cache is None or cache[0] != key:
+            cache = self._params_cache = (key, make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset,
+                                                           self.kwargs))
+        return cache[1]
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
         # `_prologue` is internal (head_loss.py): a bbox-coder decode fused into the kernel; `pred` (and `target`

@@ -102,7 +102,6 @@ class _AnchorHeadFused(torch.autograd.Function):
         return loss
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved gradient was scaled in place (and may have become .grad): recompute
@@ -320,7 +319,6 @@ class _CenterHeadFused(torch.autograd.Function):
         return losses
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_losses):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved maps were scaled in place: recompute them

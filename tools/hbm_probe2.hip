@@ -63,6 +63,45 @@ __global__ __launch_bounds__(256) void tile(const float* __restrict__ a, const f
   }
 }
 
+// flat copy whose loads go through LDS-DMA: each wave DMAs 1 KiB of a and of b into its own LDS slots, waits, reads them
+// back (ds_read_b128), adds, stores.  Separates "LDS-DMA instead of register loads" from "7-KiB transposing tiles".
+__global__ __launch_bounds__(256) void flat_dma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, long long nv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long v0 = ((long long)blockIdx.x * 4 + wave) * 64;       // first float4 of this wave
+  if (v0 + 64 > nv) return;
+  float* sa = smem + wave * 512; float* sb = sa + 256;
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(a + (v0 + lane) * 4), (lds_ptr_t*)sa, 16, 0, 2);
+  __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(b + (v0 + lane) * 4), (lds_ptr_t*)sb, 16, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const v4f x = reinterpret_cast<const v4f*>(sa)[lane], y = reinterpret_cast<const v4f*>(sb)[lane];
+  __builtin_nontemporal_store(x + y, reinterpret_cast<v4f*>(c) + v0 + lane);
+}
+
+// the 7-KiB tile structure with REGISTER loads (nontemporal global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
+__global__ __launch_bounds__(256) void tile_reg(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, long long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sp = smem; float* st = smem + 1792;
+  const int tid = threadIdx.x;
+  const long long t = blockIdx.x;
+  if (t >= ntiles) return;
+  const v4f* ga = reinterpret_cast<const v4f*>(a + t * 1792); const v4f* gb = reinterpret_cast<const v4f*>(b + t * 1792);
+  float* gc = c + t * 1792;
+  v4f x0 = __builtin_nontemporal_load(ga + tid), y0 = __builtin_nontemporal_load(gb + tid), x1 = x0, y1 = y0;
+  if (tid < 192) { x1 = __builtin_nontemporal_load(ga + tid + 256); y1 = __builtin_nontemporal_load(gb + tid + 256); }
+  reinterpret_cast<v4f*>(sp)[tid] = x0; reinterpret_cast<v4f*>(st)[tid] = y0;
+  if (tid < 192) { reinterpret_cast<v4f*>(sp)[tid + 256] = x1; reinterpret_cast<v4f*>(st)[tid + 256] = y1; }
+  __syncthreads();
+  float r[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) r[k] = sp[tid * 7 + k] + st[tid * 7 + k];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sp[tid * 7 + k] = r[k];
+  __syncthreads();
+  __builtin_nontemporal_store(reinterpret_cast<const v4f*>(sp)[tid], reinterpret_cast<v4f*>(gc) + tid);
+  if (tid < 192) __builtin_nontemporal_store(reinterpret_cast<const v4f*>(sp)[tid + 256], reinterpret_cast<v4f*>(gc) + tid + 256);
+}
+
 // Wave-owned sub-tiles: every wave moves and owns 64 rows (1792 B per tensor = 2 x 768-B dwordx3 DMA pieces + one 256-B
 // dword piece, all 64 lanes active), no workgroup barrier at all; NW waves per workgroup (NW = 1: 64-thread workgroups).
 template <int NW, int VALU>
@@ -129,5 +168,13 @@ int main() {
 #define TILEW(NW, VL) run("wave-owned 64-row subtiles waves/WG=" #NW " valu=" #VL "x7fma", [&] { tilew<NW, VL><<<(unsigned)((nsub + (NW) - 1) / (NW)), 64 * (NW), (NW) * 896 * 4>>>((const float*)a, (const float*)b, (float*)c, nsub); })
   TILEW(1, 0); TILEW(1, 32); TILEW(1, 48); TILEW(2, 0); TILEW(2, 32); TILEW(4, 0); TILEW(4, 32); TILEW(8, 32); TILEW(16, 32);
   FLAT(1, 256); FLAT(1, 64); TILE(true, 32); TILEW(1, 32); TILEW(2, 32);
+  run("flat T=256 loads via LDS-DMA (1 KiB per wave)", [&] { flat_dma<<<(unsigned)(n / 256), 256, 4 * 512 * 4>>>((const float*)a, (const float*)b, (float*)c, n); });
+  run("tile448 register loads + ds_write_b128", [&] { tile_reg<<<(unsigned)ntiles, 256, 2 * 1792 * 4>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+  // occupancy cap by LDS size: workgroups per CU = min(8, 160 KiB / lds)
+  for (int lds : {14336, 20480, 23400, 27300, 32768, 40960, 54600}) {
+    char nm[96]; snprintf(nm, 96, "tile448 LDS-DMA bar valu=32  lds=%d B (%d WG/CU)", lds, (163840 / lds) < 8 ? (163840 / lds) : 8);
+    run(nm, [&] { tile<true, 32><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+  }
+  FLAT(1, 256);
   return 0;
 }
