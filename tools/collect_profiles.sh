@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence for the round into gpurun_out/<round>/.
-#   tools/collect_profiles.sh r01
+#   tools/collect_profiles.sh r02
 # kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
 # and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -22,6 +22,13 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SAL
   --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
 # context measurements (not bench lines): HBM ceilings, NMS, small-P / head-level train-step slices
 python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
+[ -x tools/hbm_probe2 ] && ./tools/hbm_probe2 > $OUT/${R}_hbm_probe2.txt 2>&1
+# multi-GPU rehearsal with ONE rank under torch.distributed.run (RCCL backend, hipGraph replay + per-step all_gather): the
+# N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
+python3 tests/perf/multi_nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_multi_nms_time.jsonl
+GD3D_HOST_WEIGHT_CHECK=1 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_hostcheck.jsonl
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
 python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
@@ -31,6 +38,6 @@ python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_conf
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
 python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
-python3 tools/accuracy_report.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_accuracy_report.txt
+python3 -m pytest tests/test_gpu_gd_loss.py -m gpu -q -k 'pairs_against_reference_golden or config0' > $OUT/accuracy_pytest.log 2>&1; cp gpurun_out/r02_accuracy_report.txt $OUT/${R}_accuracy_report.txt 2>/dev/null
 python3 tools/profile_summary.py $OUT $R
 ls -la $OUT
