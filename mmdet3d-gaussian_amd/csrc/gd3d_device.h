@@ -18,8 +18,20 @@ namespace gd3d {
 #define GD_DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------ scalar helpers
+#ifndef GD_PRECISE
+#define GD_PRECISE 0   // 1: correctly rounded rcp / sqrt / rsq and library log2 / exp2 (accuracy experiments only)
+#endif
+#if GD_PRECISE
+GD_DEV float frcp(float x) { return __fdiv_rn(1.0f, x); }
+GD_DEV float fsqrt(float x) { return __fsqrt_rn(x); }
+GD_DEV float frsq(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
+GD_DEV float fexp2(float x) { return exp2f(x); }
+#else
 GD_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
 GD_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
+GD_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32, 1 ulp
+GD_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32
+#endif
 
 // sin & cos.  Cody-Waite reduction by pi/2 with FMAs + Cephes minimax polynomials on
 // [-pi/4, pi/4] (abs error < 1.5e-7 for |x| <= 8192).  Beyond that (never in practice for a
@@ -45,7 +57,11 @@ GD_DEV void sincos_f(float x, float& s, float& c) {
   c = ((n + 1) & 2) ? -cv : cv;
 }
 
+#if GD_PRECISE
+GD_DEV float flog2(float x) { return log2f(x); }
+#else
 GD_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (base 2), 1 ulp
+#endif
 constexpr float LN2 = 0.6931471805599453f;
 
 // log1p with the (1+d) rounding error folded back in; *inv_u returns 1/(1+d) (= d log1p / dd) from the same v_rcp
@@ -161,7 +177,7 @@ GD_DEV float post(float d, float tau, float& deriv) {
 // u * 0 keeps a NaN a NaN where clamp(0) would (torch.clamp propagates NaN) and is 0 otherwise.
 // One v_rsq_f32 serves both: sqrt(u) = u * rsq(u), 1/(2 sqrt(u)) = rsq(u)/2 (rsq(0) = +inf as required).
 GD_DEV float sqrt0(float u, float& dsu) {
-  const float r = __builtin_amdgcn_rsqf(u);
+  const float r = frsq(u);
   const float s = (u > 0.0f) ? u * r : u * 0.0f;
   dsu = (u >= 0.0f) ? 0.5f * r : 0.0f;
   return s;
@@ -191,7 +207,7 @@ GD_DEV float gwd(const Box& p, const Box& t, float dr, float alpha, float tau, A
   const float K = dAp * dAt;
   const float Ks2 = K * s2;
   const float q = fmaf(r0, r0, -Ks2);  // >= (ap bt + bp at)^2 > 0 for clamped dims; NaN inputs stay NaN
-  const float rq = __builtin_amdgcn_rsqf(q);
+  const float rq = frsq(q);
   const float sq = q * rq;
   const float irs = frcp(r0 + sq);
   const float da = p.a - t.a, db = p.b - t.b, de = p.e - t.e;
@@ -205,7 +221,7 @@ GD_DEV float gwd(const Box& p, const Box& t, float dr, float alpha, float tau, A
   if (NORMALIZE) {
     // 2 exp((ln D + ln ep + ln et)/6) = 2 * 2^((log2 D + log2(ep et))/6)
     const float L2 = flog2(Dp * Dt) + flog2(p.e * t.e);
-    iscale = 0.5f * __builtin_amdgcn_exp2f(L2 * (-1.0f / 6.0f));
+    iscale = 0.5f * fexp2(L2 * (-1.0f / 6.0f));
     dn = dist * iscale;
   }
   float dpost;
@@ -440,7 +456,7 @@ GD_DEV float kfiou(const Box& p, const Box& t, float nanp, Adj& gp, Adj& gt) {
   const float m = det >= 1e-7f ? 1.0f : 0.0f;
   float detc = det >= 1e-7f ? det : 1e-7f;
   detc = (det != det) ? det : detc;
-  const float isq = __builtin_amdgcn_rsqf(detc);
+  const float isq = frsq(detc);
   const float inter = vp * vt * isq;
   const float un_raw = vp + vt - inter;
   const float mu = un_raw >= 1e-7f ? 1.0f : 0.0f;
