@@ -18,20 +18,10 @@ namespace gd3d {
 #define GD_DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------ scalar helpers
-#ifndef GD_PRECISE
-#define GD_PRECISE 0   // 1: correctly rounded rcp / sqrt / rsq and library log2 / exp2 (accuracy experiments only)
-#endif
-#if GD_PRECISE
-GD_DEV float frcp(float x) { return __fdiv_rn(1.0f, x); }
-GD_DEV float fsqrt(float x) { return __fsqrt_rn(x); }
-GD_DEV float frsq(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
-GD_DEV float fexp2(float x) { return exp2f(x); }
-#else
 GD_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
 GD_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }    // v_sqrt_f32, 1 ulp
 GD_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32, 1 ulp
 GD_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32
-#endif
 
 // sin & cos.  Cody-Waite reduction by pi/2 with FMAs + Cephes minimax polynomials on
 // [-pi/4, pi/4] (abs error < 1.5e-7 for |x| <= 8192).  Beyond that (never in practice for a
@@ -57,11 +47,7 @@ GD_DEV void sincos_f(float x, float& s, float& c) {
   c = ((n + 1) & 2) ? -cv : cv;
 }
 
-#if GD_PRECISE
-GD_DEV float flog2(float x) { return log2f(x); }
-#else
 GD_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (base 2), 1 ulp
-#endif
 constexpr float LN2 = 0.6931471805599453f;
 
 // log1p with the (1+d) rounding error folded back in; *inv_u returns 1/(1+d) (= d log1p / dd) from the same v_rcp

@@ -50,6 +50,15 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
                        // (measured r01, 10 M pairs: nt loads + nt stores 129 us vs 151 us plain; a persistent
                        //  double-buffered grid-stride variant was 143-160 us and was dropped)
 #endif
+#ifndef GD_MIN_LDS
+#define GD_MIN_LDS 27300  // bytes of dynamic LDS the fused launch requests AT LEAST = an occupancy cap of
+#endif                    // floor(160 KiB / 27300) = 6 workgroups per CU instead of the 8 its 14.4 KiB would admit.
+                          // r02, tools/hbm_probe2 (the kernel's data path without its math) on one box: 8 WG/CU 131.0 us,
+                          // 7: 131.3, 6: 130.2, 5: 126.7, 4: 126.8, 3: 162 (a flat copy of the same bytes: 127.5): fewer
+                          // tiles in flight per CU stream better.  With the real math the cap costs VALU latency hiding:
+                          // inside bench.py (profiles/r02_lds_sweep.txt) gwd3d / kld3d / bd3d ran 133.5 / 134.3 / 133.7 us
+                          // at 8 WG/CU, 132.1 / 131.8 / 130.6 at 7, 130.8 / 130.1 / 130.1 at 6 and 131.2 / 136.2 / 138.1
+                          // at 5 (217 / 270 / 296 VALU instructions per pair).  6 is the best for all three.
 #ifndef GD_NT_STORE
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
 #endif
@@ -858,7 +867,8 @@ struct Geometry {
 
 template <int LOSS, int FUN, bool FLAG, bool GT>
 static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
-  const size_t lds = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+  size_t lds = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+  if (lds < (size_t)GD_MIN_LDS) lds = (size_t)GD_MIN_LDS;   // occupancy cap (see GD_MIN_LDS above)
   if (g.ev_start != nullptr || g.ev_stop != nullptr) {
     // hipExtLaunchKernel binds the two events to the begin / end timestamps of this dispatch packet itself: no marker
     // packets enter the stream, and hipEventElapsedTime(start, stop) is the kernel's execution time as rocprofv3 reports
