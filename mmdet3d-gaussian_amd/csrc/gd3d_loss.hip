@@ -23,6 +23,7 @@
 //     guarded scalar load/store path around the same compute code.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 #include "gd3d_device.h"
 
@@ -50,15 +51,29 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
                        // (measured r01, 10 M pairs: nt loads + nt stores 129 us vs 151 us plain; a persistent
                        //  double-buffered grid-stride variant was 143-160 us and was dropped)
 #endif
+// Occupancy cap.  The fused launch requests AT LEAST this much dynamic LDS, i.e. floor(160 KiB / bytes) workgroups per CU
+// instead of the 8 that its own 14.4 KiB would admit: fewer tiles in flight per CU stream better (tools/hbm_probe2, the
+// kernel's data path without its math: 8 WG/CU 131.0 us, 6: 130.2, 5: 126.7, 4: 126.8, 3: 162; flat copy 127.5), but
+// fewer waves hide less VALU latency, so the best cap depends on the loss.  Measured per loss at FIXED buffer placement
+// (tools/lds_fixed_placement.py, profiles/r02_lds_fixed_placement.txt; 10 M pairs, us per launch, good / bad placement):
+//   WG/CU   gwd3d (217 VALU/pair)   kld3d (270)      bd3d (296)
+//     8     134.1 / 137.6           134.2 / 139.5    134.5 / 139.1
+//     7     133.1 / 137.1           131.2 / 138.8    133.0 / 138.3
+//     6     131.7 / 136.4           129.6 / 138.0    130.1 / 137.6
+//     5     131.4 / 134.7           135.8 / 137.6    140.0 / 140.9
+//     4     132.2 / 134.6           136.0 / 136.8    139.9 / 140.3
 #ifndef GD_MIN_LDS
-#define GD_MIN_LDS 27300  // bytes of dynamic LDS the fused launch requests AT LEAST = an occupancy cap of
-#endif                    // floor(160 KiB / 27300) = 6 workgroups per CU instead of the 8 its 14.4 KiB would admit.
-                          // r02, tools/hbm_probe2 (the kernel's data path without its math) on one box: 8 WG/CU 131.0 us,
-                          // 7: 131.3, 6: 130.2, 5: 126.7, 4: 126.8, 3: 162 (a flat copy of the same bytes: 127.5): fewer
-                          // tiles in flight per CU stream better.  With the real math the cap costs VALU latency hiding:
-                          // inside bench.py (profiles/r02_lds_sweep.txt) gwd3d / kld3d / bd3d ran 133.5 / 134.3 / 133.7 us
-                          // at 8 WG/CU, 132.1 / 131.8 / 130.6 at 7, 130.8 / 130.1 / 130.1 at 6 and 131.2 / 136.2 / 138.1
-                          // at 5 (217 / 270 / 296 VALU instructions per pair).  6 is the best for all three.
+#define GD_MIN_LDS 27300      // 6 workgroups per CU
+#endif
+#ifndef GD_MIN_LDS_GWD
+#define GD_MIN_LDS_GWD 32768  // 5
+#endif
+#ifndef GD_MIN_LDS_KLD
+#define GD_MIN_LDS_KLD GD_MIN_LDS
+#endif
+#ifndef GD_MIN_LDS_BD
+#define GD_MIN_LDS_BD GD_MIN_LDS
+#endif
 #ifndef GD_NT_STORE
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
 #endif
@@ -868,7 +883,16 @@ struct Geometry {
 template <int LOSS, int FUN, bool FLAG, bool GT>
 static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
   size_t lds = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
-  if (lds < (size_t)GD_MIN_LDS) lds = (size_t)GD_MIN_LDS;   // occupancy cap (see GD_MIN_LDS above)
+  constexpr int min_lds = LOSS == GD3D_GWD3D ? GD_MIN_LDS_GWD : (LOSS == GD3D_KLD3D ? GD_MIN_LDS_KLD :
+                          (LOSS == GD3D_BD3D ? GD_MIN_LDS_BD : GD_MIN_LDS));
+  if (lds < (size_t)min_lds) lds = (size_t)min_lds;   // occupancy cap (see GD_MIN_LDS above)
+#ifdef GD_LDS_ENV   // experiment builds only (tools/lds_fixed_placement.py): the cap is re-read from the environment per launch
+  if (const char* e = getenv("GD3D_MIN_LDS")) {
+    const size_t base = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);
+    const size_t want = (size_t)atoi(e);
+    lds = want > base ? want : base;
+  }
+#endif
   if (g.ev_start != nullptr || g.ev_stop != nullptr) {
     // hipExtLaunchKernel binds the two events to the begin / end timestamps of this dispatch packet itself: no marker
     // packets enter the stream, and hipEventElapsedTime(start, stop) is the kernel's execution time as rocprofv3 reports
