@@ -400,7 +400,7 @@ def main():
                          # what the kernel really moves under reduction=mean|sum (no per-pair loss store): 84 B/pair
                          'moved_bytes_per_pair': MOVED_BYTES_PER_PAIR, 'achieved_moved_GBps': round(moved, 1),
                          'frac_actual_bytes': round(moved / HBM_PEAK_GBPS, 4),
-                         # z = x + y (nontemporal, 16 B/lane) over the same three buffers, same process, after the region
+                         # z = x + y (nontemporal, 16 B/lane, 64-thread workgroups) over the same three buffers, same process, after the region
                          'copy_ceiling_GBps': round(ceiling, 1) if ceiling else None,
                          'copy_ceiling_ms': round(probe_ms, 4) if probe_ms else None,
                          'copy_ceiling_frac_of_peak': round(ceiling / HBM_PEAK_GBPS, 4) if ceiling else None,

@@ -261,7 +261,8 @@ int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64
                      const gd3d_prologue* prologue, void* stream);
 
 /* HBM ceiling probe with the fused kernel's access mix (two streams read, one written): z = x + y over n_floats fp32
- * (multiple of 4, 16-byte aligned arrays), nontemporal 16-byte loads and stores, one vector per thread.  The two events
+ * (multiple of 4, 16-byte aligned arrays), nontemporal 16-byte loads and stores, one vector per thread, 64-thread
+ * workgroups (the fastest and most repeatable flat-copy shape measured on MI355X).  The two events
  * (nullable) are bound to the dispatch as in gd3d_loss_fused_timed.  bench.py runs it on the fused kernel's own buffers
  * to report the box's copy ceiling next to roofline.frac.  (Measurement aid; no reference counterpart.) */
 int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats, void* stream,

@@ -861,12 +861,14 @@ __global__ __launch_bounds__(1024) void grad_finish_kernel(const FinishArgs a) {
 }
 
 // HBM ceiling probe for the access mix of the fused kernel: c = a + b over float4 vectors, nontemporal loads and
-// stores, one vector per thread, full grid (the fastest of the shapes tools/hbm_probe.hip measures).  bench.py runs it
-// on the fused kernel's OWN three buffers right after the timed region, so that `roofline.copy_ceiling_GBps` is the
-// ceiling of that box and of that buffer placement.
-__global__ __launch_bounds__(256) void probe_add_kernel(const v4f* __restrict__ x, const v4f* __restrict__ y,
-                                                        v4f* __restrict__ z, long long nv) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+// stores, one vector per thread, full grid of 64-THREAD workgroups — the fastest and the most repeatable of the shapes
+// tools/hbm_probe2.hip measures (126.1-129 us over five processes for 3 x 280 MB; 256-thread workgroups: 126.8-133).
+// bench.py runs it on the fused kernel's OWN three buffers right after the timed region, so that
+// `roofline.copy_ceiling_GBps` is the ceiling of that box and of that buffer placement.
+constexpr int PROBE_T = 64;
+__global__ __launch_bounds__(PROBE_T) void probe_add_kernel(const v4f* __restrict__ x, const v4f* __restrict__ y,
+                                                            v4f* __restrict__ z, long long nv) {
+  const long long i = (long long)blockIdx.x * PROBE_T + threadIdx.x;
   if (i < nv) {
     const v4f p = __builtin_nontemporal_load(x + i);
     const v4f q = __builtin_nontemporal_load(y + i);
@@ -1115,9 +1117,9 @@ int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats
   if (x == nullptr || y == nullptr || z == nullptr) return GD3D_E_BADARG;
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) != 0) return GD3D_E_BADARG;
   const long long nv = n_floats >> 2;
-  const long long nb = (nv + 255) / 256;
+  const long long nb = (nv + PROBE_T - 1) / PROBE_T;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
-  hipExtLaunchKernelGGL(probe_add_kernel, dim3((unsigned)nb), dim3(256), 0u, (hipStream_t)stream, (hipEvent_t)start_event,
+  hipExtLaunchKernelGGL(probe_add_kernel, dim3((unsigned)nb), dim3(PROBE_T), 0u, (hipStream_t)stream, (hipEvent_t)start_event,
                         (hipEvent_t)stop_event, 0u, (const v4f*)x, (const v4f*)y, (v4f*)z, nv);
   return (int)hipGetLastError();
 }
