@@ -133,10 +133,9 @@ NodeParams unpack(const c10::IValue& v, const at::Tensor& aux) {
 class GDReducedNode : public torch::autograd::Function<GDReducedNode> {
  public:
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& pred,
-                                                const at::Tensor& target, const c10::optional<at::Tensor>& weight_,
-                                                const NodeParams* np, double scale, bool select, bool need_gp,
-                                                bool need_gt, int64_t stream, int64_t ev0, int64_t ev1) {
-    const at::Tensor weight = weight_.has_value() ? *weight_ : at::Tensor();
+                                                const at::Tensor& target, const at::Tensor& weight, const NodeParams* np,
+                                                double scale, bool select, bool need_gp, bool need_gt, int64_t stream,
+                                                int64_t ev0, int64_t ev1) {
     c10::DeviceGuard guard(pred.device());
     Launch L = run_forward(pred, target, weight, *np, scale, select, true, need_gp, need_gt, stream, ev0, ev1);
     auto& sd = ctx->saved_data;
@@ -203,8 +202,9 @@ std::vector<at::Tensor> gd_reduced(const at::Tensor& pred, const at::Tensor& tar
   TORCH_CHECK(pred.dim() == 2 && pred.size(1) == 7 && pred.scalar_type() == at::kFloat && pred.is_contiguous() &&
                   target.sizes() == pred.sizes() && target.scalar_type() == at::kFloat && target.is_contiguous(),
               "gd3d node: pred / target must be contiguous fp32 (N,7)");
+  const at::Tensor w = weight.has_value() ? *weight : at::Tensor();
   const bool grad_on = at::GradMode::is_enabled();   // (inside forward() it is always off)
-  return GDReducedNode::apply(pred, target, weight, &np, scale, select, grad_on && pred.requires_grad(),
+  return GDReducedNode::apply(pred, target, w, &np, scale, select, grad_on && pred.requires_grad(),
                               grad_on && target.requires_grad(), stream, ev0, ev1);
 }
 
