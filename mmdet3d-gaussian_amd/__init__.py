@@ -30,13 +30,8 @@ def build(force=False, verbose=False):
     return _build_mod.build(force=force, verbose=verbose)
 
 
-def build_node(force=False, verbose=False):
-    """Compile csrc_torch/gd3d_node.cpp (the C++ autograd node above the C ABI) into mmdet3d-gaussian_amd/_gd3d_node.so."""
-    return _build_mod.build_node(force=force, verbose=verbose)
-
-
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'circle_nms',
-           'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'build_node', 'load_library', 'lib_path',
+           'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
            'trans_bev', 'match_coco', 'MatcherCoCo', 'LidarCenterTransBEV', 'LidarIOU3D', 'LidarIOUBEV']

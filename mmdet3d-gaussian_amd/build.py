@@ -97,69 +97,5 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# The C++ autograd node (csrc_torch/gd3d_node.cpp): a torch extension (plain C++, no HIP / CUDA headers, no hipify) that
-# sits ABOVE the C ABI and replaces the Python autograd.Function of the reduced GDLoss call.  Built in-tree next to
-# libgd3d.so; optional: without it gd_loss.py uses its Python node (same kernels, ~20 us more host time per call).
-NODE_SRC = os.path.join(PKG_DIR, 'csrc_torch', 'gd3d_node.cpp')
-NODE_PATH = os.path.join(PKG_DIR, '_gd3d_node.so')
-NODE_HASH = NODE_PATH + '.srchash'
-
-
-def node_source_hash():
-    import torch
-    h = hashlib.sha256()
-    for d in (NODE_SRC, os.path.join(PKG_DIR, '..', 'include', 'gd3d.h')):
-        with open(d, 'rb') as f:
-            h.update(f.read())
-    h.update(torch.__version__.encode())
-    return h.hexdigest()
-
-
-def node_is_stale():
-    if not os.path.isfile(NODE_PATH) or not os.path.isfile(NODE_HASH):
-        return True
-    with open(NODE_HASH) as f:
-        return f.read().strip() != node_source_hash()
-
-
-def build_node(force=False, verbose=False):
-    """Compile csrc_torch/gd3d_node.cpp with torch.utils.cpp_extension (g++, ~30 s) into _gd3d_node.so.  Returns the path."""
-    if not force and not node_is_stale():
-        return NODE_PATH
-    from torch.utils.cpp_extension import load
-    bdir = os.path.join(PKG_DIR, 'build', f'node_{os.getpid()}')
-    os.makedirs(bdir, exist_ok=True)
-    mod = load(name='_gd3d_node', sources=[NODE_SRC], build_directory=bdir, extra_ldflags=['-ldl'], verbose=verbose)
-    tmp = f'{NODE_PATH}.{os.getpid()}.tmp'
-    shutil.copyfile(mod.__file__, tmp)
-    os.replace(tmp, NODE_PATH)
-    with open(NODE_HASH + f'.{os.getpid()}', 'w') as f:
-        f.write(node_source_hash())
-    os.replace(NODE_HASH + f'.{os.getpid()}', NODE_HASH)
-    shutil.rmtree(bdir, ignore_errors=True)
-    return NODE_PATH
-
-
-def load_node():
-    """Import the in-tree _gd3d_node.so (building it first when missing or stale and a C++ toolchain is there)."""
-    import importlib.util
-    import sys
-    if '_gd3d_node' in sys.modules:
-        return sys.modules['_gd3d_node']
-    if node_is_stale():
-        if shutil.which('g++') or shutil.which('c++'):
-            build_node()
-        elif not os.path.isfile(NODE_PATH):
-            raise RuntimeError('_gd3d_node.so is missing and there is no C++ compiler to build it')
-    import torch  # noqa: F401  (libtorch must be loaded before the extension)
-    spec = importlib.util.spec_from_file_location('_gd3d_node', NODE_PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    sys.modules['_gd3d_node'] = mod
-    return mod
-
-
 if __name__ == '__main__':
     print(build(force=True, verbose=True))
-    print(build_node(force=True, verbose=True))

@@ -120,10 +120,6 @@ struct LossArgs {
   // with wsel the block also leaves sum(pred * weight7) in partials[nbp + b] and "any weight > 0" in partials[2 nbp + b]
   int wsel;
   long long nbp;     // partial-array stride (number of tiles rounded up to 4)
-#ifdef GD_LDS_ENV
-  int order_k;
-  long long order_s, nb_tiles;
-#endif
   long long n;
   float scale, alpha, tau;
   float c0, c1, c2;
@@ -207,14 +203,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
-#ifdef GD_LDS_ENV   // experiment builds: tile order = K interleaved contiguous segments (block b -> segment b % K)
-  const long long tile_i = a.order_k > 1 ? (long long)(blockIdx.x % a.order_k) * a.order_s + blockIdx.x / a.order_k
-                                         : (long long)blockIdx.x;
-  if (tile_i >= a.nb_tiles) return;
-#else
-  const long long tile_i = blockIdx.x;
-#endif
-  const long long base = tile_i * TILE;
+  const long long base = (long long)blockIdx.x * TILE;
   const long long rows_left = a.n - base;
   const bool full = rows_left >= TILE;
   const bool fast = full && a.vec_ok;  // workgroup-uniform
@@ -323,7 +312,7 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   if (a.partials != nullptr && tid == 0) {
 #pragma unroll
     for (int w4 = 0; w4 < NWAVE; w4 += 4) bsum += (swave[w4] + swave[w4 + 1]) + (swave[w4 + 2] + swave[w4 + 3]);
-    a.partials[tile_i] = bsum;
+    a.partials[blockIdx.x] = bsum;
     if (a.wsel) {
       float asum = 0.0f, fany = 0.0f;
 #pragma unroll
@@ -331,8 +320,8 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
         asum += swave[NWAVE + w4];
         fany += swave[2 * NWAVE + w4];
       }
-      a.partials[a.nbp + tile_i] = asum;
-      a.partials[2 * a.nbp + tile_i] = fany;   // > 0: some weight of this tile is > 0
+      a.partials[a.nbp + blockIdx.x] = asum;
+      a.partials[2 * a.nbp + blockIdx.x] = fany;   // > 0: some weight of this tile is > 0
     }
   }
 
@@ -1069,13 +1058,6 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
   const bool flag = p->flag != 0;
   Geometry grid;
   grid.tgrid = (unsigned)nb;
-#ifdef GD_LDS_ENV
-  a.order_k = 1;
-  if (const char* e = getenv("GD3D_TILE_K")) a.order_k = atoi(e) > 1 ? atoi(e) : 1;
-  a.order_s = (nb + a.order_k - 1) / a.order_k;
-  a.nb_tiles = nb;
-  grid.tgrid = (unsigned)(a.order_s * a.order_k);
-#endif
   grid.ev_start = (hipEvent_t)start_event;
   grid.ev_stop = (hipEvent_t)stop_event;
   hipError_t e;

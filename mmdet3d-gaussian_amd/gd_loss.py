@@ -17,7 +17,6 @@ import torch
 from torch import nn
 
 from . import _lib
-from . import build as _build_mod
 from .registry import LOSSES, register_with_mmdet
 
 LOSS_TYPES = {'gwd3d': 0, 'kld3d': 1, 'bd3d': 2, 'jd3d': 3, 'kld3d_symmax': 4, 'kld3d_symmin': 5, 'kfiou3d': 6}
@@ -180,73 +179,6 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
     return loss, total, gp, gt, any_pos
 
 
-_NODE = None   # the C++ autograd node (csrc_torch/gd3d_node.cpp); False = not available, use the Python node below
-
-
-def _node():
-    global _NODE
-    if _NODE is None:
-        if os.environ.get('GD3D_PY_AUTOGRAD', '0') == '1':
-            _NODE = False
-        else:
-            try:
-                _library()
-                mod = _build_mod.load_node()
-                mod.bind_library(_lib.lib_path() if not os.environ.get('GD3D_LIB') else os.environ['GD3D_LIB'])
-                _NODE = mod
-            except Exception as e:  # noqa: BLE001 — the Python node below does the same work, only slower on the host
-                import warnings
-                warnings.warn(f'gd3d: C++ autograd node unavailable ({type(e).__name__}: {e}); using the Python node')
-                _NODE = False
-    return _NODE
-
-
-def _node_params(node, params, prologue):
-    """_lib.Params (+ optional _lib.Prologue) -> the node's NodeParams object."""
-    co = params.center_offset
-    np_ = node.NodeParams(params.loss_type, params.fun, params.tau, params.alpha, co[0], co[1], co[2], params.flag)
-    if prologue is not None:
-        np_.set_prologue(prologue.kind, bool(prologue.norm_bbox), prologue._keepalive, prologue.out_size_factor,
-                         prologue.voxel_size[0], prologue.voxel_size[1], prologue.pc_range[0], prologue.pc_range[1])
-    return np_
-
-
-def _reduced_call(p, t, w, params, scale, prologue, select, box, cache_owner=None):
-    """scale * sum_i w_i L_i as a 0-dim tensor with the gradient attached: the C++ node when it is available, else the
-    Python autograd.Function.  `box` (a list or None) receives the any-positive flag of a selecting call."""
-    node = _node()
-    if not node:
-        return _GDReduced.apply(p, t, w, params, scale, prologue, select, box)
-    np_ = None
-    if prologue is None and cache_owner is not None:   # module-level cache: (params object identity) -> NodeParams
-        c = cache_owner._node_cache
-        if c is not None and c[0] is params:
-            np_ = c[1]
-    if np_ is None:
-        np_ = _node_params(node, params, prologue)
-        if prologue is None and cache_owner is not None:
-            cache_owner._node_cache = (params, np_)
-    dev = p.device
-    ev = PROFILE_EVENTS
-    e0 = e1 = 0
-    if ev is not None:
-        tm = DispatchTimer()
-        ev.append(tm)
-        e0, e1 = tm.start, tm.stop
-    prev = _get_device()
-    switch = prev != dev.index
-    if switch:
-        _set_device(dev.index)
-    try:
-        outs = node.gd_reduced(p, t, w, np_, scale, select, _raw_stream(dev.index), e0, e1)
-    finally:
-        if switch:
-            _set_device(prev)
-    if box is not None:
-        box.append(outs[1])
-    return outs[0]
-
-
 class _GDReduced(torch.autograd.Function):
     """scale * sum_i w_i L_i  with the final gradients produced by the SAME launch.  With `select` the value and the
     gradient are those of the reference's early-out `(pred * weight).sum()` when no weight entry is > 0."""
@@ -342,7 +274,6 @@ class GDLoss(nn.Module):
         self.loss_weight = loss_weight
         self.kwargs = kwargs
         self._params_cache = None  # (key, gd3d_params) for calls without per-call kwargs
-        self._node_cache = None    # (gd3d_params object, NodeParams) for the C++ autograd node
 
     def _params(self, call_kwargs):
         # kfiou3d ignores tau (ref :247) — the kernel is told tau = 0
@@ -415,7 +346,7 @@ class GDLoss(nn.Module):
             out = _GDPerPair.apply(p, t, w, params, float(scale), prologue)
         else:
             box = [] if (select and post_div is not None) else None
-            out = _reduced_call(p, t, w, params, float(scale), prologue, select, box, self if not kwargs else None)
+            out = _GDReduced.apply(p, t, w, params, float(scale), prologue, select, box)
             if post_div is not None:
                 if select:  # the early-out value is not divided by avg_factor (it returns before the loss is called)
                     post_div = torch.where(box[0].reshape(()) != 0, post_div.to(torch.float32), 1.0)

@@ -52,20 +52,6 @@ for r in range(4):
             run(lt, 3)
         for lt in lts:
             res[(lt, c)].append(run(lt, 12))
-# tile order at the shipped caps: K interleaved contiguous segments (K = 8: one segment per XCD under round-robin placement)
-os.environ.pop('GD3D_MIN_LDS', None)
-ores = {(lt, k): [] for lt in lts for k in (1, 2, 4, 8, 64)}
-for r in range(3):
-    for k in (1, 2, 4, 8, 64):
-        os.environ['GD3D_TILE_K'] = str(k)
-        for lt in lts:
-            run(lt, 3)
-        for lt in lts:
-            ores[(lt, k)].append(run(lt, 12))
-os.environ['GD3D_TILE_K'] = '1'
-print('tile order K   ' + '   '.join(f'{lt:>8s}' for lt in lts))
-for k in (1, 2, 4, 8, 64):
-    print(f'{k:12d}  ' + '   '.join(f'{sum(ores[(lt, k)]) / len(ores[(lt, k)]):8.1f}' for lt in lts))
 print('copy probe per buffer set (us):', {lt: round(probe(lt), 1) for lt in lts})
 print('WG/CU  ' + '   '.join(f'{lt:>8s}' for lt in lts))
 for c in caps:
