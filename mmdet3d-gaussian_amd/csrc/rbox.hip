@@ -470,29 +470,49 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 
 // U rows x CH 64-word chunks in flight per propagate lane (registers: 2*U*CH VGPRs); rows / chunks beyond that are OR-ed
 // in synchronously during the issue interval (correct, slower; only very dense keeps or n > 64*(64*CH+4)).
+// Two-level form (win.gremv != nullptr; n > 8448): the box range is cut into super-blocks of SCAN_SB 64-box blocks.  One
+// launch of this kernel resolves ONE super-block [c_begin, c_end): its removed-set starts from the global words gremv
+// (what earlier super-blocks suppressed), rows are propagated only to words inside the super-block (<= SCAN_SB words per
+// row: short loads, one chunk), the kept words of its blocks go to gkept, the running keep count lives in num_keep.
+// nms_propagate_kernel then ORs the kept rows into gremv for all words right of the super-block with the whole chip.
+struct ScanWindow {
+  int c_begin, c_end;               // blocks; c_end is clamped to the group's block count
+  unsigned long long* gremv;        // (G, cbs) global removed-set, nullptr = single-level scan over all blocks
+  unsigned long long* gkept;        // (G, cbs) kept word per block
+};
+constexpr int SCAN_SB = 64;         // blocks per super-block (4096 boxes): rows inside it fit the one-chunk scan variant
+
 template <int U, int CH>
 __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
                                                           const unsigned long long* __restrict__ colm_,
                                                           long long* __restrict__ keep_, long long* __restrict__ num_keep,
-                                                          long long* __restrict__ dbg) {
+                                                          long long* __restrict__ dbg, const ScanWindow win) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
   __shared__ unsigned long long skept[4];
   __shared__ int klist[4][64];  // lane indices of the boxes kept in a block, compacted (k-th kept box -> lane)
   __shared__ unsigned long long rin[SCAN_RING][2 + SCAN_NU][64];  // [slot][col, urgent 1..3, id][lane]
   const int g = blockIdx.x;  // one workgroup per group
   const int n = group_n(a, g);
-  const int cb = (n + 63) >> 6;
+  const int cb_all = (n + 63) >> 6;
+  const bool windowed = win.gremv != nullptr;
+  const int c_begin = windowed ? win.c_begin : 0;
+  const int cb = windowed ? min(win.c_end, cb_all) : cb_all;   // every "< cb" below means "inside this launch's range"
   const size_t cbs = (size_t)a.cbs;
+  unsigned long long* gremv = windowed ? win.gremv + (size_t)g * cbs : nullptr;
+  unsigned long long* gkept = windowed ? win.gkept + (size_t)g * cbs : nullptr;
+  if (windowed && c_begin >= cb_all) return;                    // uniform: this group ends before the super-block
   const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
   const unsigned long long* mask = mask_ + (size_t)g * a.cap * cbs;
   const unsigned long long* colm = colm_ + (size_t)g * a.cap;
   long long* keep = keep_ + (size_t)g * a.cap;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int w = tid; w < cb; w += SCAN_T) remv[w] = 0ull;
+  for (int w = c_begin + tid; w < cb; w += SCAN_T) remv[w] = (windowed && c_begin > 0) ? gremv[w] : 0ull;
+  if (windowed && c_begin == 0)   // the first super-block opens the global removed-set for everything right of it
+    for (int w = cb + tid; w < cb_all; w += SCAN_T) gremv[w] = 0ull;
   if (tid < 4) skept[tid] = 0ull;
   lds_barrier();
-  const int NB = cb;  // intervals = barriers every wave executes in the main phase
+  const int NB = cb - c_begin;  // intervals = barriers every wave executes in the main phase
 
   // resolver inputs of block B for this lane (0 where the box or the word does not exist)
   // field f of block B for this lane: 0 = column word, 1..3 = urgent words mask[i][B+f], 4 = box id.  (Contiguous
@@ -507,12 +527,12 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 
   if (wave == 0) {
     // ---------------------------------------------------------------- resolver
-    for (int B = 0; B < 3; ++B) {  // blocks 0..2: nobody runs ahead of them
+    for (int B = c_begin; B < c_begin + 3; ++B) {  // the first three blocks: nobody runs ahead of them
 #pragma unroll
-      for (int f = 0; f < 2 + SCAN_NU; ++f) rin[B][f][lane] = load_field(B, f);
+      for (int f = 0; f < 2 + SCAN_NU; ++f) rin[B & (SCAN_RING - 1)][f][lane] = load_field(B, f);
     }
-    int count = 0;
-    for (int c = 0; c < NB; ++c) {
+    int count = (windowed && c_begin > 0) ? (int)num_keep[g] : 0;
+    for (int c = c_begin; c < cb; ++c) {
       SCAN_STAMP(0);
       const int slot = c & (SCAN_RING - 1);
       const unsigned long long col = rin[slot][0][lane];
@@ -540,11 +560,14 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 #pragma unroll
       for (int k = 0; k < SCAN_NU; ++k) {
         const unsigned long long o = wave_or_u64(mine ? urg[k] : 0ull);  // uniform; 0 past the last block
-        if (lane == 0 && o) atomicOr(&remv[c + 1 + k], o);
+        if (lane == 0 && o && c + 1 + k < cb) atomicOr(&remv[c + 1 + k], o);
       }
       if (mine) klist[c & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = lane;
       count += __builtin_popcountll(kept);
-      if (lane == 0) skept[c & 3] = kept;
+      if (lane == 0) {
+        skept[c & 3] = kept;
+        if (windowed) gkept[c] = kept;
+      }
       SCAN_STAMP(3);
       lds_barrier();
       SCAN_STAMP(5);
@@ -558,14 +581,14 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
     const int trail = NB - lead - 3 * S;
     for (int q = 0; q < lead; ++q) lds_barrier();
     for (int s2 = 0; s2 < S; ++s2) {
-      const int t0 = grp + 3 * s2;
+      const int t0 = c_begin + grp + 3 * s2;
       [[maybe_unused]] const int c = t0;  // (SCAN_STAMP index)
       if (wave == 1) SCAN_STAMP(8);
       // ---- interval t0: issue
       const int bk = t0 - 1;             // block whose kept rows this group spreads
       const int first = t0 + SCAN_NU;    // = bk + 1 + SCAN_NU: first word not covered by the urgent words
       unsigned long long kb = 0ull;
-      if (bk >= 0 && first < cb) kb = uniform_u64(skept[bk & 3]);
+      if (bk >= c_begin && first < cb) kb = uniform_u64(skept[bk & 3]);
       // this wave's share: every SCAN_GW-th kept box, read from the compacted list the resolver left in LDS: lane u
       // fetches the row of slot u, the slots then cost a v_readlane + multiply + load each (a lone wave pays ~5 cycles
       // per instruction: walking the kept bits with ffbl / and / compare cost more than the memory round trip)
@@ -573,7 +596,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
       const int myl = (lane < m) ? klist[bk & 3][rank + SCAN_GW * lane] : 0;
       if (wave == 1) SCAN_STAMP_SYNC(13);
-      const unsigned long long* blk = mask + (size_t)(max(bk, 0) * 64) * cbs;
+      const unsigned long long* blk = mask + (size_t)(max(bk, c_begin) * 64) * cbs;
       // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
       const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
       unsigned long long in[2];
@@ -657,6 +680,34 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   }
 }
 
+// Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
+// boxes further right; those mask rows are OR-ed into the global removed-set by the whole chip instead of by the one scan
+// workgroup.  One wave per (64-box row block of the super-block, 64-word chunk right of it): lane = word, the wave walks
+// the kept boxes of its block (independent 512-byte row loads), one atomicOr (integer: deterministic) per word.
+__global__ __launch_bounds__(64) void nms_propagate_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
+                                                           const ScanWindow win, int wchunks) {
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const int c_end = win.c_end;
+  if (c_end >= cb) return;                                     // nothing right of the super-block in this group
+  const size_t cbs = (size_t)a.cbs;
+  const int rb = win.c_begin + (int)(blockIdx.x / wchunks), wc = (int)(blockIdx.x % wchunks);
+  const int w = c_end + wc * 64 + (int)threadIdx.x;
+  if (c_end + wc * 64 >= cb) return;                           // uniform
+  unsigned long long kept = win.gkept[(size_t)g * cbs + rb];   // uniform
+  if (kept == 0ull) return;
+  const unsigned long long* rows = mask_ + ((size_t)g * a.cap + (size_t)rb * 64) * cbs;
+  const unsigned int wcl = (unsigned int)min(w, cb - 1);
+  unsigned long long acc = 0ull;
+  while (kept != 0ull) {
+    const int i = __builtin_ctzll(kept);
+    kept &= kept - 1ull;
+    acc |= rows[(size_t)i * cbs + wcl];
+  }
+  if (w < cb && acc != 0ull) atomicOr(&win.gremv[(size_t)g * cbs + w], acc);
+}
+
 // pairwise IoU matrices ------------------------------------------------------------------
 constexpr int IOU_T = 256;
 __global__ __launch_bounds__(IOU_T) void riou_xyxyr_kernel(const float* __restrict__ a, long long na,
@@ -736,7 +787,7 @@ size_t rnms_workspace_bytes(int64_t n) {
   if (n <= 0) return 16;
   const size_t cb = (size_t)((n + 63) / 64);
   return align_up((size_t)n * sizeof(OBox), 256) + align_up((size_t)n * cb * sizeof(unsigned long long), 256) +
-         (size_t)n * sizeof(unsigned long long);
+         align_up((size_t)n * sizeof(unsigned long long), 256) + 2 * cb * sizeof(unsigned long long);
 }
 
 size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
@@ -744,7 +795,7 @@ size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
   const size_t cb = (size_t)((cap + 63) / 64);
   return align_up((size_t)groups * cap * sizeof(OBox), 256) +
          align_up((size_t)groups * cap * cb * sizeof(unsigned long long), 256) +
-         (size_t)groups * cap * sizeof(unsigned long long);
+         align_up((size_t)groups * cap * sizeof(unsigned long long), 256) + 2 * (size_t)groups * cb * sizeof(unsigned long long);
 }
 
 // shared by the single and the batched entry points: G groups of up to `cap` boxes
@@ -793,15 +844,38 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   }
   const dim3 sgrid((unsigned)G), sblk(SCAN_T);
   const size_t slds = (size_t)a.cbs * sizeof(unsigned long long);
-  if (a.cbs <= 64 + 1 + SCAN_NU)  // one 64-word chunk right of any block (n <= 4352): 22 rows x 1 chunk in flight
+  ScanWindow win;
+  win.c_begin = 0;
+  win.c_end = a.cbs;
+  win.gremv = win.gkept = nullptr;
+  // n <= 8448: one launch resolves everything.  Beyond that the single workgroup's row propagation (three 64-word chunks
+  // per kept row, one CU's miss bandwidth) dominates and the two-level form wins: r02, kernels of rnms_bev, single ->
+  // two-level: n = 9000 339 -> 237 us (72 % kept), 208 -> 207 (25 % kept), 400 -> 237 (79 % kept); n = 16384 1052 -> 476 us;
+  // it loses below (n = 6000: 117 -> 128 us: five launches instead of one) — profiles/r02_nms_scan_levels.txt.
+  if (a.cbs <= 128 + 1 + SCAN_NU) {
+    if (a.cbs <= 64 + 1 + SCAN_NU)  // one 64-word chunk right of any block (n <= 4352): 22 rows x 1 chunk in flight
+      hipLaunchKernelGGL((nms_scan_kernel<22, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+    else
+      hipLaunchKernelGGL((nms_scan_kernel<22, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+    return (int)hipGetLastError();
+  }
+  // two-level scan: super-blocks of SCAN_SB blocks resolved one after the other by the scan workgroup (rows stay inside
+  // the super-block: one chunk), the rows of the kept boxes spread to everything right of it by nms_propagate_kernel
+  win.gremv = (unsigned long long*)((char*)colm + align_up((size_t)G * cap * sizeof(unsigned long long), 256));
+  win.gkept = win.gremv + (size_t)G * a.cbs;
+  for (int c0 = 0; c0 < a.cbs; c0 += SCAN_SB) {
+    win.c_begin = c0;
+    win.c_end = c0 + SCAN_SB < a.cbs ? c0 + SCAN_SB : a.cbs;
     hipLaunchKernelGGL((nms_scan_kernel<22, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
-  else if (a.cbs <= 128 + 1 + SCAN_NU)  // n <= 8448
-    hipLaunchKernelGGL((nms_scan_kernel<22, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
-  else
-    hipLaunchKernelGGL((nms_scan_kernel<16, 3>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob);
+                       (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+    if (win.c_end < a.cbs) {
+      const int wchunks = (a.cbs - win.c_end + 63) / 64;
+      hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)((win.c_end - c0) * wchunks), (unsigned)G), dim3(64), 0, s, a,
+                         (const unsigned long long*)mask, win, wchunks);
+    }
+  }
   return (int)hipGetLastError();
 }
 

@@ -33,6 +33,41 @@ def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('n,thr', [(8448, 0.6), (8449, 0.6), (12288, 0.3), (16384, 0.7)])
+def test_nms_two_level_scan_boundaries_bit_exact(amd, n, thr):
+    """n > 8448 takes the two-level scan (super-blocks of 4096 boxes resolved in turn, kept rows spread to the right by a
+    chip-wide kernel): the last single-level size, the first two-level size, an exact multiple of the super-block and
+    the rank-path maximum, against the CPU restatement."""
+    boxes, scores = nms_boxes(n, seed=n, clutter=True)
+    want = oracle.nms_gpu_oracle(boxes, scores, thr)
+    got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('mode', ['rot', 'normal'])
+def test_batched_nms_ragged_groups_across_super_blocks(amd, mode):
+    """Three groups over one 11 000-box array with 11 000 / 4 500 / 8 700 valid boxes: the group sizes are only known on
+    the device, so every group runs the two-level launch sequence and leaves it where ITS boxes end; each keep list
+    equals the single call on the compacted group (which takes the one- or two-level scan by its own size)."""
+    n = 11000
+    boxes, _ = nms_boxes(n, seed=33, clutter=True)
+    rng = np.random.default_rng(9)
+    scores = rng.uniform(0, 1, (3, n)).astype(np.float32)
+    valid = np.ones((3, n), bool)
+    valid[1, rng.permutation(n)[:n - 4500]] = False
+    valid[2, rng.permutation(n)[:n - 8700]] = False
+    b = torch.from_numpy(boxes).cuda(); s = torch.from_numpy(scores).cuda(); v = torch.from_numpy(valid).cuda()
+    normal = mode == 'normal'
+    got = amd.nms_gpu_batched(b, s, [0.6, 0.3, 0.7], v, normal=normal)
+    single = amd.nms_normal_gpu if normal else (lambda bb, ss, t: amd.nms_gpu(bb, ss, t))
+    for g, thr in enumerate([0.6, 0.3, 0.7]):
+        one = single(b[v[g]], s[g][v[g]], thr)
+        assert torch.equal(got[g], v[g].nonzero().reshape(-1)[one]), g
+    idx = np.nonzero(valid[1])[0]
+    want = idx[oracle.nms_gpu_oracle(boxes[idx], scores[1, idx], 0.3, normal=normal)]
+    assert np.array_equal(got[1].cpu().numpy(), want)
+
+
 def test_nms_randomised_sweep_bit_exact(amd):
     """40 seeded random problems (size, threshold, clutter, extent, pre/post cuts drawn at random): keep indices equal to
     the CPU oracle in every one — the mask compaction, the register clipping path, the score ranking and the scan are
