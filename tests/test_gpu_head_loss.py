@@ -392,3 +392,58 @@ def test_device_center_coder_vs_reference_golden_and_autograd(amd):
         assert (pd.grad.cpu().double() - pr.grad)[torch.from_numpy(safe2)].abs().max().item() <= 2e-6 * (1 + sc), cy
     with pytest.raises(RuntimeError):
         coder.decode(torch.zeros(1, 2), torch.zeros(1, 11))           # no CPU path
+
+
+def test_head_functions_second_backward_on_a_retained_graph(amd):
+    """the head-level nodes scale their saved gradient buffers in place; a second backward through the same
+    node (retain_graph=True, upstream gradient != 1, e.g. an AMP loss scale) must recompute instead of scaling twice."""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(21)
+    mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    bp = bbox_pred.cuda().requires_grad_(True)
+    out = amd.anchor_head_bbox_loss(mod, dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), bp, bbox_targets.cuda(),
+                                    bbox_weights.cuda(), labels.cuda(), anchors.cuda(), C, 31.0, code_weight=[1.0] * 7, decode_weight=1)
+    (out * 4.0).backward(retain_graph=True)
+    g4 = bp.grad.clone(); bp.grad = None
+    (out * 4.0).backward(retain_graph=True)
+    assert torch.equal(bp.grad, g4)
+    bp.grad = None
+    out.backward()
+    assert torch.allclose(bp.grad * 4.0, g4, rtol=1e-6, atol=0)
+    # CenterGDHead slice
+    g = torch.Generator().manual_seed(2)
+    coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+    maps = {k: (torch.randn(2, c, 16, 12, generator=g) * 0.3).cuda().requires_grad_(True)
+            for k, c in (('reg', 2), ('height', 1), ('dim', 3), ('yaw', 1), ('dir', 2), ('vel', 2))}
+    n = 50
+    pi = torch.stack([torch.randint(0, 2, (n,), generator=g), torch.randint(0, 12, (n,), generator=g),
+                      torch.randint(0, 16, (n,), generator=g)], -1).cuda()
+    an = torch.cat([torch.randn(n, 3, generator=g), torch.rand(n, 3, generator=g) + 0.5, torch.randn(n, 3, generator=g)], -1).cuda()
+    l1, gd = amd.center_head_losses(mod, dict(type='L1Loss', loss_weight=0.25), coder, [maps], [pi], [an], [n], [1.0, 1.0, 0.2, 0.2])[0]
+    tot = 3.0 * l1 + 2.0 * gd
+    tot.backward(retain_graph=True)
+    first = {k: v.grad.clone() for k, v in maps.items()}
+    for v in maps.values():
+        v.grad = None
+    tot.backward()
+    for k, v in maps.items():
+        assert torch.equal(v.grad, first[k]), k
+
+
+def test_anchor_head_num_total_samples_none_is_the_batch_size(amd):
+    """loss_single substitutes int(cls_score.shape[0]) — the batch size — for num_total_samples=None
+    (gd_anchor3d_head.py:85-86); the empty CenterGDHead slice returns a zero that still reaches `pred`."""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(5)
+    mod = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    args = (bbox_pred.cuda(), bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(), anchors.cuda(), C)
+    a = amd.anchor_head_bbox_loss(mod, dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), *args, None, code_weight=[1.0] * 7)
+    b = amd.anchor_head_bbox_loss(mod, dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0), *args, bbox_pred.shape[0],
+                                  code_weight=[1.0] * 7)
+    assert a.item() == b.item()
+    c = amd.anchor_head_decoded_loss_fused(mod, *args, None, [1.0] * 7)
+    d = amd.anchor_head_decoded_loss_fused(mod, *args, float(bbox_pred.shape[0]), [1.0] * 7)
+    assert c.item() == d.item()
+    coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+    pred = torch.zeros(2, 0, 11, device='cuda', requires_grad=True)
+    z = amd.center_head_gd_loss(mod, coder, torch.zeros(2, 0, 3, dtype=torch.long, device='cuda'), pred,
+                                torch.zeros(2, 0, 9, device='cuda'), num_pos=0)
+    assert tuple(z.shape) == (1,) and z.item() == 0.0 and z.requires_grad
