@@ -47,10 +47,21 @@ __global__ __launch_bounds__(256) void tile(const float* __restrict__ a, const f
   float r[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) r[k] = sp[tid * 7 + k] + st[tid * 7 + k];
+  if (VALU >= 0) {
 #pragma unroll
-  for (int it = 0; it < VALU; ++it) {
+    for (int it = 0; it < VALU; ++it) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) r[k] = __builtin_fmaf(r[k], 1.0000001f, 1e-9f);
+      for (int k = 0; k < 7; ++k) r[k] = __builtin_fmaf(r[k], 1.0000001f, 1e-9f);
+    }
+  } else {   // one dependent chain of (-VALU % 1000) FMAs per thread; below -1000: every 13th step is a v_rcp_f32
+    const int len = (-VALU) % 1000;
+    float x = r[0];
+#pragma unroll
+    for (int it = 0; it < len; ++it) {
+      x = __builtin_fmaf(x, 1.0000001f, r[1 + it % 6]);
+      if (VALU < -1000 && it % 13 == 12) x = __builtin_amdgcn_rcpf(x);
+    }
+    r[0] = x;
   }
 #pragma unroll
   for (int k = 0; k < 7; ++k) sp[tid * 7 + k] = r[k];
@@ -174,6 +185,14 @@ int main() {
   for (int lds : {14336, 20480, 23400, 27300, 32768, 40960, 54600}) {
     char nm[96]; snprintf(nm, 96, "tile448 LDS-DMA bar valu=32  lds=%d B (%d WG/CU)", lds, (163840 / lds) < 8 ? (163840 / lds) : 8);
     run(nm, [&] { tile<true, 32><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+  }
+  // VALU count under the occupancy cap: independent FMAs (7 chains) vs the same count as ONE dependent chain per thread
+  for (int lds : {14336, 27300, 32768}) {
+    char nm[96];
+    snprintf(nm, 96, "tile448 valu=48x7 indep   lds=%d", lds); run(nm, [&] { tile<true, 48><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+    snprintf(nm, 96, "tile448 valu=64x7 indep   lds=%d", lds); run(nm, [&] { tile<true, 64><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+    snprintf(nm, 96, "tile448 270 dependent fma lds=%d", lds); run(nm, [&] { tile<true, -270><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+    snprintf(nm, 96, "tile448 270 dep, 20 rcp   lds=%d", lds); run(nm, [&] { tile<true, -1270><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
   }
   FLAT(1, 256);
   return 0;
