@@ -684,8 +684,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 // boxes further right; those mask rows are OR-ed into the global removed-set by the whole chip instead of by the one scan
 // workgroup.  One wave per (64-box row block of the super-block, 64-word chunk right of it): lane = word, the wave walks
 // the kept boxes of its block (independent 512-byte row loads), one atomicOr (integer: deterministic) per word.
-__global__ __launch_bounds__(64) void nms_propagate_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
-                                                           const ScanWindow win, int wchunks) {
+__global__ __launch_bounds__(256) void nms_propagate_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
+                                                            const ScanWindow win, int wchunks) {
   const int g = blockIdx.y;
   const int n = group_n(a, g);
   const int cb = (n + 63) >> 6;
@@ -693,17 +693,30 @@ __global__ __launch_bounds__(64) void nms_propagate_kernel(const NmsArgs a, cons
   if (c_end >= cb) return;                                     // nothing right of the super-block in this group
   const size_t cbs = (size_t)a.cbs;
   const int rb = win.c_begin + (int)(blockIdx.x / wchunks), wc = (int)(blockIdx.x % wchunks);
-  const int w = c_end + wc * 64 + (int)threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = c_end + wc * 64 + lane;
   if (c_end + wc * 64 >= cb) return;                           // uniform
-  unsigned long long kept = win.gkept[(size_t)g * cbs + rb];   // uniform
-  if (kept == 0ull) return;
+  const unsigned long long kept = win.gkept[(size_t)g * cbs + rb];   // uniform
+  // the four waves of the workgroup share the block's kept rows round-robin (k-th kept row -> wave k % 4)
+  unsigned long long mine = 0ull;
+  int k = 0;
+  for (unsigned long long t = kept; t != 0ull; t &= t - 1ull, ++k)
+    if ((k & 3) == wave) mine |= t & (~t + 1ull);
+  if (mine == 0ull) return;
   const unsigned long long* rows = mask_ + ((size_t)g * a.cap + (size_t)rb * 64) * cbs;
   const unsigned int wcl = (unsigned int)min(w, cb - 1);
   unsigned long long acc = 0ull;
-  while (kept != 0ull) {
-    const int i = __builtin_ctzll(kept);
-    kept &= kept - 1ull;
-    acc |= rows[(size_t)i * cbs + wcl];
+  while (mine != 0ull) {   // four independent 512-byte row loads per round trip (a duplicate row is harmless: OR)
+    int idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      idx[u] = mine != 0ull ? __builtin_ctzll(mine) : idx[u > 0 ? u - 1 : 0];
+      mine &= mine - (mine != 0ull ? 1ull : 0ull);
+    }
+    const unsigned long long v0 = rows[(size_t)idx[0] * cbs + wcl], v1 = rows[(size_t)idx[1] * cbs + wcl];
+    const unsigned long long v2 = rows[(size_t)idx[2] * cbs + wcl], v3 = rows[(size_t)idx[3] * cbs + wcl];
+    acc |= (v0 | v1) | (v2 | v3);
   }
   if (w < cb && acc != 0ull) atomicOr(&win.gremv[(size_t)g * cbs + w], acc);
 }
@@ -872,7 +885,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
                        (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     if (win.c_end < a.cbs) {
       const int wchunks = (a.cbs - win.c_end + 63) / 64;
-      hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)((win.c_end - c0) * wchunks), (unsigned)G), dim3(64), 0, s, a,
+      hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)((win.c_end - c0) * wchunks), (unsigned)G), dim3(256), 0, s, a,
                          (const unsigned long long*)mask, win, wchunks);
     }
   }
