@@ -199,8 +199,8 @@ class Scatter(object):
         return torch.where(keep, rows, rows.new_full((), default_feat))
 
     def reduce(self, pts_feats, reduce_op):
-        assert reduce_op in ['max', 'mean', 'sum'], \
-            f'For the arg "reduce", only "max", "mean" and "sum" are supported but got {reduce_op}'
+        if reduce_op not in REDUCE:
+            raise AssertionError(f'reduce_op must be one of {sorted(REDUCE)}, got {reduce_op!r}')
         voxel_feats = scatter_reduce(pts_feats.contiguous(), self.pts_voxel_maps, self.voxel_pts_counts, reduce_op,
                                      self._grouping)
         return voxel_feats, self.voxel_coors
