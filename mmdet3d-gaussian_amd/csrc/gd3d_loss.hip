@@ -985,7 +985,8 @@ int gd3d_loss_fused_select(const gd3d_params* p, const gd3d_prologue* pro, const
                            const float* weight7, int64_t n, float scale, float* loss_sum, int32_t* any_positive,
                            float* grad_pred, float* grad_target, void* workspace, void* stream, void* start_event,
                            void* stop_event) {
-  if (weight7 == nullptr || loss_sum == nullptr || any_positive == nullptr || workspace == nullptr) return GD3D_E_BADARG;
+  if ((n > 0 && weight7 == nullptr) || loss_sum == nullptr || any_positive == nullptr || workspace == nullptr)
+    return GD3D_E_BADARG;   // (an empty weight array has no address)
   return loss_launch(p, pro, pred, target, nullptr, weight7, n, scale, nullptr, loss_sum, grad_pred, grad_target,
                      workspace, stream, start_event, stop_event, any_positive, true);
 }
