@@ -251,6 +251,18 @@ int gd3d_loss_fused_select(const gd3d_params* params, const gd3d_prologue* prolo
                            float* loss_sum, int32_t* any_positive, float* grad_pred, float* grad_target,
                            void* workspace, void* stream, void* start_event, void* stop_event);
 
+/* Training-size form (n <= gd3d_one_launch_max_n() = 16384 pairs): the same result in ONE launch.  The workgroup whose
+ * arrival ticket comes last adds the per-tile partials itself (lane order, fp64) and writes *loss_sum (and, when
+ * any_positive != NULL, selects as gd3d_loss_fused_select does; weight7 is then required and row_weight must be NULL).
+ *   ticket: device int32 that is 0 when the call is launched and is 0 again when it has completed; calls that share a
+ *   ticket must be ordered on one stream (allocate one zeroed word per stream once).  hipGraph-replay safe.
+ * The two-stage form above stays the general one: in the streaming regime the arrival ticket costs 20 %. */
+int64_t gd3d_one_launch_max_n(void);
+int gd3d_loss_fused_one_launch(const gd3d_params* params, const gd3d_prologue* prologue, const float* pred,
+                               const float* target, const float* row_weight, const float* weight7, int64_t n,
+                               float scale, float* loss_sum, int32_t* any_positive, float* grad_pred,
+                               float* grad_target, void* workspace, int32_t* ticket, void* stream);
+
 /* Autograd backward of a reduced call; g is the upstream gradient (device scalar).
  *   any_positive == NULL or *any_positive != 0 : grad_pred *= g, grad_target *= g (the grid leaves after two scalar loads
  *       when g == 1: one empty launch, no HBM traffic, no host sync — gd3d_scale_rows for both arrays at once);

@@ -52,6 +52,9 @@ SYMBOLS = {
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_loss_fused_select': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _i64, _f32, _vp, _vp,
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_one_launch_max_n': (_i64, []),
+    'gd3d_loss_fused_one_launch': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp]),
     'gd3d_grad_finish': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(Prologue), _vp]),
     'gd3d_probe_stream': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'gd3d_prof_event_create': (_int, [ctypes.POINTER(_vp)]),

@@ -120,6 +120,12 @@ struct LossArgs {
   // with wsel the block also leaves sum(pred * weight7) in partials[nbp + b] and "any weight > 0" in partials[2 nbp + b]
   int wsel;
   long long nbp;     // partial-array stride (number of tiles rounded up to 4)
+  // single-launch form for small problems (<= FIN_MAX_TILES tiles): the workgroup whose arrival ticket comes last adds
+  // the partials itself (fixed order, fp64) and writes the result — no reduce launch.  fin: device int32, 0 at launch,
+  // left 0; fin_out: the loss sum; fin_any: the any-positive flag of a selecting call (nullable).
+  int* fin;
+  float* fin_out;
+  int* fin_any;
   long long n;
   float scale, alpha, tau;
   float c0, c1, c2;
@@ -312,16 +318,26 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
   if (a.partials != nullptr && tid == 0) {
 #pragma unroll
     for (int w4 = 0; w4 < NWAVE; w4 += 4) bsum += (swave[w4] + swave[w4 + 1]) + (swave[w4 + 2] + swave[w4 + 3]);
-    a.partials[blockIdx.x] = bsum;
+    float asum = 0.0f, fany = 0.0f;
     if (a.wsel) {
-      float asum = 0.0f, fany = 0.0f;
 #pragma unroll
       for (int w4 = 0; w4 < NWAVE; ++w4) {
         asum += swave[NWAVE + w4];
         fany += swave[2 * NWAVE + w4];
       }
-      a.partials[a.nbp + blockIdx.x] = asum;
-      a.partials[2 * a.nbp + blockIdx.x] = fany;   // > 0: some weight of this tile is > 0
+    }
+    if (a.fin == nullptr) {
+      a.partials[blockIdx.x] = bsum;
+      if (a.wsel) {
+        a.partials[a.nbp + blockIdx.x] = asum;
+        a.partials[2 * a.nbp + blockIdx.x] = fany;   // > 0: some weight of this tile is > 0
+      }
+    } else {   // handed to the last workgroup: write-through (sc1) stores, see the finish below
+      __hip_atomic_store(a.partials + blockIdx.x, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.wsel) {
+        __hip_atomic_store(a.partials + a.nbp + blockIdx.x, asum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.partials + 2 * a.nbp + blockIdx.x, fany, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 
@@ -340,6 +356,36 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
       for (int i = tid; i < fl7; i += TILE) a.gp[base * 7 + i] = sp[i];
     if (GT)
       for (int i = tid; i < fl7; i += TILE) a.gt[base * 7 + i] = st[i];
+  }
+
+  // Single-launch finish (small grids only; the same hand-off cost 20 % in the streaming regime and is not used there,
+  // profiles/r02_ticket_ab.txt).  Form: MI355X_MICROARCH.md, valid forms, row 1 — every handed-off word was stored sc1 by
+  // lane 0 of its workgroup; that wave drains vmcnt, then takes an agent-scope ticket; the wave whose add returned last
+  // loads the words with sc1 loads, one per lane, and adds them in lane order in fp64.  The ticket returns to 0.
+  if (a.fin != nullptr && wave == 0) {   // uniform
+    const int nb = (int)gridDim.x;       // <= 64: one partial per lane
+    int t = 0;
+    if (lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t = __hip_atomic_fetch_add(a.fin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t == nb - 1) {
+      double v[3] = {0.0, 0.0, 0.0};
+      const int terms = a.wsel ? 3 : 1;
+      for (int k = 0; k < terms; ++k) {
+        if (lane < nb)
+          v[k] = (double)__hip_atomic_load(a.partials + (long long)k * a.nbp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+      }
+      if (lane == 0) {
+        const bool any = !a.wsel || v[2] > 0.0;
+        *a.fin_out = (float)(any ? v[0] : v[1]);
+        if (a.fin_any != nullptr) *a.fin_any = any ? 1 : 0;
+        __hip_atomic_store(a.fin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -964,7 +1010,7 @@ int gd3d_loss_fused_w7(const gd3d_params* p, const float* pred, const float* tar
 static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
                        const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
                        float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream,
-                       void* start_event, void* stop_event, int32_t* any_positive, bool select);
+                       void* start_event, void* stop_event, int32_t* any_positive, bool select, int32_t* ticket = nullptr);
 
 int gd3d_loss_fused_decoded(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
                             const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
@@ -991,10 +1037,22 @@ int gd3d_loss_fused_select(const gd3d_params* p, const gd3d_prologue* pro, const
                      workspace, stream, start_event, stop_event, any_positive, true);
 }
 
+int gd3d_loss_fused_one_launch(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
+                               const float* row_weight, const float* weight7, int64_t n, float scale, float* loss_sum,
+                               int32_t* any_positive, float* grad_pred, float* grad_target, void* workspace,
+                               int32_t* ticket, void* stream) {
+  if (loss_sum == nullptr || workspace == nullptr || ticket == nullptr || n > gd3d_one_launch_max_n()) return GD3D_E_BADARG;
+  if (any_positive != nullptr && (row_weight != nullptr || (n > 0 && weight7 == nullptr))) return GD3D_E_BADARG;
+  return loss_launch(p, pro, pred, target, row_weight, weight7, n, scale, nullptr, loss_sum, grad_pred, grad_target,
+                     workspace, stream, nullptr, nullptr, any_positive, any_positive != nullptr, ticket);
+}
+
+int64_t gd3d_one_launch_max_n(void) { return 64 * (int64_t)TILE; }
+
 static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const float* pred, const float* target,
                        const float* row_weight, const float* weight7, int64_t n, float scale, float* loss,
                        float* loss_sum, float* grad_pred, float* grad_target, void* workspace, void* stream,
-                       void* start_event, void* stop_event, int32_t* any_positive, bool select) {
+                       void* start_event, void* stop_event, int32_t* any_positive, bool select, int32_t* ticket) {
   if (row_weight != nullptr && weight7 != nullptr) return GD3D_E_BADARG;
   if (pro != nullptr && pro->kind != GD3D_PRO_NONE) {
     if (pro->kind != GD3D_PRO_ANCHOR_DELTA && pro->kind != GD3D_PRO_CENTER) return GD3D_E_BADARG;
@@ -1028,6 +1086,9 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
   LossArgs a;
   a.wsel = select ? 1 : 0;
   a.nbp = ws_nbp(n);
+  a.fin = (int*)ticket;
+  a.fin_out = loss_sum;
+  a.fin_any = (int*)any_positive;
 
   a.pred = pred;
   a.target = target;
@@ -1072,6 +1133,7 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
     default: e = launch_kfiou(p->fun, gt, grid, s, a); break;
   }
   if (e != hipSuccess) return (int)e;
+  if (ticket != nullptr) return 0;   // the last workgroup of the fused kernel wrote the result
   if (select) {
     hipLaunchKernelGGL(reduce_select_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, (long long)nb,
                        (long long)ws_nbp(n), loss_sum, (int*)any_positive);

@@ -112,6 +112,28 @@ def _rows(t):
 
 
 _WS_FLOATS = {}
+_ONE_MAX = None
+_TICKETS = {}
+
+
+def _one_launch_max():
+    global _ONE_MAX
+    if _ONE_MAX is None:
+        _ONE_MAX = int(_library().gd3d_one_launch_max_n()) if os.environ.get('GD3D_TWO_STAGE', '0') != '1' else -1
+    return _ONE_MAX
+
+
+def _ticket(dev_index, stream):
+    """The arrival-ticket word of gd3d_loss_fused_one_launch for this (device, stream): a zeroed int32 allocated once;
+    every call leaves it zero again, and calls on one stream are ordered, so they can share it."""
+    t = _TICKETS.get((dev_index, stream))
+    if t is None:
+        if len(_TICKETS) > 256:
+            _TICKETS.clear()
+        t = _TICKETS[(dev_index, stream)] = torch.zeros(4, dtype=torch.int32, device=torch.device('cuda', dev_index))
+    return t.data_ptr()
+
+
 
 
 def _ws_floats(n):
@@ -153,7 +175,21 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
         if ev is not None:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
             tm = DispatchTimer()
             ev.append(tm)
-        if select:
+        one = want_sum and ev is None and n <= _one_launch_max()
+        if one:
+            # training-size call: ONE launch, the last workgroup finishes the sum (per-stream arrival ticket, zeroed once)
+            w1 = w7 = None
+            if row_weight is not None:
+                if row_weight.dim() == 2:
+                    w7 = row_weight.data_ptr()
+                else:
+                    w1 = row_weight.data_ptr()
+            if select:
+                any_pos = buf[1:2].view(torch.int32)
+            rc = lib.gd3d_loss_fused_one_launch(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
+                                                total.data_ptr(), _ptr(any_pos), _ptr(gp), _ptr(gt), ws,
+                                                _ticket(dev.index, stream), stream)
+        elif select:
             any_pos = buf[1:2].view(torch.int32)
             rc = lib.gd3d_loss_fused_select(params, prologue, pred.data_ptr(), target.data_ptr(), row_weight.data_ptr(), n,
                                             scale, total.data_ptr(), any_pos.data_ptr(), _ptr(gp), _ptr(gt), ws, stream,
