@@ -225,7 +225,7 @@ class _GDReduced(torch.autograd.Function):
         _, total, gp, gt, any_pos = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt,
                                                prologue, select)
         ctx.gp, ctx.gt, ctx.any_pos = gp, gt, any_pos
-        ctx.used = False
+        ctx.used, ctx.want = False, (need_gp, need_gt)
         ctx.replay = (pred, target, row_weight, params, scale, prologue, select)
         if flag_box is not None:   # the any-positive flag leaves through a side door: a second autograd OUTPUT that is a
             flag_box.append(any_pos)   # view of the same buffer as `total` makes every backward pay view bookkeeping
@@ -236,10 +236,11 @@ class _GDReduced(torch.autograd.Function):
         lib = _library()
         pred, target, row_weight, params, scale, prologue, select = ctx.replay
         if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
-            _, _, gp, gt, _ = fused_call(params, pred, target, row_weight, scale, False, False, ctx.gp is not None,
-                                         ctx.gt is not None, prologue)
-        else:
+            _, _, gp, gt, _ = fused_call(params, pred, target, row_weight, scale, False, False, ctx.want[0], ctx.want[1],
+                                         prologue)
+        else:  # hand the buffers over: with no reference left here a leaf's AccumulateGrad keeps them instead of cloning
             gp, gt = ctx.gp, ctx.gt
+            ctx.gp = ctx.gt = None
             ctx.used = True
         if gp is None and gt is None:
             return (None,) * 8

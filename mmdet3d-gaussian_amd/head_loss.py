@@ -106,8 +106,8 @@ class _AnchorHeadFused(torch.autograd.Function):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved gradient was scaled in place (and may have become .grad): recompute
             g = _anchor_head_launch(*ctx.replay, True)[1]
-        else:
-            g, ctx.used = ctx.grad, True
+        else:  # hand the buffer over (no reference left here: a leaf's AccumulateGrad then keeps it instead of cloning it)
+            g, ctx.grad, ctx.used = ctx.grad, None, True
         go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         with torch.cuda.device(g.device):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
@@ -323,8 +323,9 @@ class _CenterHeadFused(torch.autograd.Function):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved maps were scaled in place: recompute them
             _, grads, tasks = _center_head_launch(*ctx.replay)
-        else:
+        else:  # hand the maps over (no reference left here: a leaf's AccumulateGrad then keeps its map instead of cloning it)
             grads, tasks, ctx.used = ctx.grads, ctx.tasks, True
+            ctx.grads = ctx.tasks = None
         go = grad_losses.contiguous().float()
         dev = go.device
         with torch.cuda.device(dev):
