@@ -267,7 +267,9 @@ def main():
             outs = compute(record)
         else:
             graph.replay()   # nothing else enters the stream: no event brackets (marker packets) in the timed region
-            outs = graph_outs
+            # the collective reads its input on RCCL's stream while the next replay may already run: give it a private
+            # copy of the graph's static output (12 bytes) instead of the buffer the next replay writes
+            outs = graph_outs.clone() if use_dist else graph_outs
         if use_dist:  # one tiny collective per step: (3,) shard losses -> (world, 3)
             last['pending'] = amd.sharded.gather_shard_losses(outs, async_op=True)
         else:

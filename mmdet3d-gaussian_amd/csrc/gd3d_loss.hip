@@ -68,6 +68,9 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
 #ifndef GD_MIN_LDS_GWD
 #define GD_MIN_LDS_GWD 32768  // 5
 #endif
+#ifndef GD_MIN_LDS_W7
+#define GD_MIN_LDS_W7 32768   // 5, launches with (N,7) weights (any loss)
+#endif
 #ifndef GD_MIN_LDS_KLD
 #define GD_MIN_LDS_KLD GD_MIN_LDS
 #endif
@@ -934,6 +937,9 @@ static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
   constexpr int min_lds = LOSS == GD3D_GWD3D ? GD_MIN_LDS_GWD : (LOSS == GD3D_KLD3D ? GD_MIN_LDS_KLD :
                           (LOSS == GD3D_BD3D ? GD_MIN_LDS_BD : GD_MIN_LDS));
   if (lds < (size_t)min_lds) lds = (size_t)min_lds;   // occupancy cap (see GD_MIN_LDS above)
+  // with (N,7) weights a workgroup keeps three tiles in flight: 5 per CU for every loss (10 M pairs, fixed placement,
+  // 7/6/5/4/3 per CU: kld3d 185.5/185.4/179.8/180.9/202.7 us, bd3d 185.8/184.7/178.0/177.9/204.9, gwd3d 185.0/185.2/182.3/182.7/201.4)
+  if (a.w7 != nullptr && lds < (size_t)GD_MIN_LDS_W7) lds = (size_t)GD_MIN_LDS_W7;
 #ifdef GD_LDS_ENV   // experiment builds only (tools/lds_fixed_placement.py): the cap is re-read from the environment per launch
   if (const char* e = getenv("GD3D_MIN_LDS")) {
     const size_t base = (size_t)(2 * TILE_F + 32 + (a.w7 != nullptr ? TILE_F : 0)) * sizeof(float);

@@ -21,12 +21,14 @@ total = torch.zeros((), device=dev)
 ws = torch.empty(lib.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
 prm = {lt: amd.make_params(lt, 'log1p', 1.0, 1.0, (0, 0, 0.5), {}) for lt in lts}
 stream = torch.cuda.current_stream().cuda_stream
-caps = {8: 0, 7: 23400, 6: 27300, 5: 32768, 4: 40960}
+WEIGHTED = '--weighted' in sys.argv   # (N,7) weights: a third tile per workgroup (21.6 KB of LDS: 7 workgroups per CU uncapped)
+w7 = torch.rand(n, 7, device=dev) if WEIGHTED else None
+caps = {7: 0, 6: 27300, 5: 32768, 4: 40960, 3: 54600} if WEIGHTED else {8: 0, 7: 23400, 6: 27300, 5: 32768, 4: 40960}
 def run(lt, iters):
     tms = []
     for _ in range(iters):
         tm = gdl.DispatchTimer()
-        rc = lib.gd3d_loss_fused_timed(prm[lt], None, preds[lt].data_ptr(), tgt.data_ptr(), None, None, n, 5.0 / n, None,
+        rc = lib.gd3d_loss_fused_timed(prm[lt], None, preds[lt].data_ptr(), tgt.data_ptr(), None, w7.data_ptr() if WEIGHTED else None, n, 5.0 / n, None,
                                        total.data_ptr(), grads[lt].data_ptr(), None, ws.data_ptr(), stream, tm.start, tm.stop)
         assert rc == 0
         tms.append(tm)
