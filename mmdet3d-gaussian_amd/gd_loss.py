@@ -114,6 +114,9 @@ def _rows(t):
 _WS_FLOATS = {}
 _ONE_MAX = None
 _TICKETS = {}
+_GRAPH_TICKETS = {}      # device index -> [int32 pool, slots handed out]
+_GRAPH_SLOTS = 4096
+_capturing = torch._C._cuda_isCurrentStreamCapturing
 
 
 def _one_launch_max():
@@ -124,16 +127,25 @@ def _one_launch_max():
 
 
 def _ticket(dev_index, stream):
-    """The arrival-ticket word of gd3d_loss_fused_one_launch for this (device, stream): a zeroed int32 allocated once;
-    every call leaves it zero again, and calls on one stream are ordered, so they can share it."""
+    """The arrival-ticket word of gd3d_loss_fused_one_launch.  Eager calls: one zeroed int32 per (device, stream),
+    allocated once; every call leaves it zero again and calls on one stream are ordered, so they share it.  A call that is
+    being CAPTURED into a hipGraph gets a word of its own from a per-device pool allocated outside the capture (a replay
+    may run while eager calls use the capture stream's word); None when no such word is available -> two-stage form."""
+    if _capturing():
+        pool = _GRAPH_TICKETS.get(dev_index)
+        if pool is None or pool[1] >= _GRAPH_SLOTS:
+            return None
+        pool[1] += 1
+        return pool[0].data_ptr() + 16 * (pool[1] - 1)
     t = _TICKETS.get((dev_index, stream))
     if t is None:
         if len(_TICKETS) > 256:
             _TICKETS.clear()
-        t = _TICKETS[(dev_index, stream)] = torch.zeros(4, dtype=torch.int32, device=torch.device('cuda', dev_index))
+        dev = torch.device('cuda', dev_index)
+        t = _TICKETS[(dev_index, stream)] = torch.zeros(4, dtype=torch.int32, device=dev)
+        if dev_index not in _GRAPH_TICKETS:
+            _GRAPH_TICKETS[dev_index] = [torch.zeros(4 * _GRAPH_SLOTS, dtype=torch.int32, device=dev), 0]
     return t.data_ptr()
-
-
 
 
 def _ws_floats(n):
@@ -175,8 +187,8 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
         if ev is not None:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
             tm = DispatchTimer()
             ev.append(tm)
-        one = want_sum and ev is None and n <= _one_launch_max()
-        if one:
+        ticket = _ticket(dev.index, stream) if (want_sum and ev is None and n <= _one_launch_max()) else None
+        if ticket is not None:
             # training-size call: ONE launch, the last workgroup finishes the sum (per-stream arrival ticket, zeroed once)
             w1 = w7 = None
             if row_weight is not None:
@@ -187,8 +199,7 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
             if select:
                 any_pos = buf[1:2].view(torch.int32)
             rc = lib.gd3d_loss_fused_one_launch(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
-                                                total.data_ptr(), _ptr(any_pos), _ptr(gp), _ptr(gt), ws,
-                                                _ticket(dev.index, stream), stream)
+                                                total.data_ptr(), _ptr(any_pos), _ptr(gp), _ptr(gt), ws, ticket, stream)
         elif select:
             any_pos = buf[1:2].view(torch.int32)
             rc = lib.gd3d_loss_fused_select(params, prologue, pred.data_ptr(), target.data_ptr(), row_weight.data_ptr(), n,
