@@ -18,18 +18,21 @@ lts = ('gwd3d', 'kld3d', 'bd3d')
 preds = {lt: pred0.clone() for lt in lts}; grads = {lt: torch.empty_like(pred0) for lt in lts}
 del pred0
 total = torch.zeros((), device=dev)
-ws = torch.empty(lib.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+ws = torch.empty(16 * lib.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)   # 16x: room for the partial-layout experiment builds
 prm = {lt: amd.make_params(lt, 'log1p', 1.0, 1.0, (0, 0, 0.5), {}) for lt in lts}
 stream = torch.cuda.current_stream().cuda_stream
+NOSUM = '--nosum' in sys.argv         # no loss sum: the kernel's partial-sum tail is skipped (gradient only)
 WEIGHTED = '--weighted' in sys.argv   # (N,7) weights: a third tile per workgroup (21.6 KB of LDS: 7 workgroups per CU uncapped)
 w7 = torch.rand(n, 7, device=dev) if WEIGHTED else None
 caps = {7: 0, 6: 27300, 5: 32768, 4: 40960, 3: 54600} if WEIGHTED else {8: 0, 7: 23400, 6: 27300, 5: 32768, 4: 40960}
+if os.environ.get('GD_CAPS'):   # restrict the sweep, e.g. GD_CAPS=6,5
+    caps = {int(c): caps[int(c)] for c in os.environ['GD_CAPS'].split(',')}
 def run(lt, iters):
     tms = []
     for _ in range(iters):
         tm = gdl.DispatchTimer()
         rc = lib.gd3d_loss_fused_timed(prm[lt], None, preds[lt].data_ptr(), tgt.data_ptr(), None, w7.data_ptr() if WEIGHTED else None, n, 5.0 / n, None,
-                                       total.data_ptr(), grads[lt].data_ptr(), None, ws.data_ptr(), stream, tm.start, tm.stop)
+                                       None if NOSUM else total.data_ptr(), grads[lt].data_ptr(), None, ws.data_ptr(), stream, tm.start, tm.stop)
         assert rc == 0
         tms.append(tm)
     torch.cuda.synchronize()

@@ -1,40 +1,57 @@
 #!/usr/bin/env python3
-"""A/B of experimental libgd3d builds (tools/variants/libgd3d_<name>.so) on the SAME buffer sets in one process: the fused
-bd3d kernel at 10 M pairs, kernel-only timing, on 8 independently allocated sets.  usage: variant_probe.py base <name> ..."""
+"""A/B of experimental libgd3d builds (tools/variants/libgd3d_<name>.so, tools/build_variants.py) on the SAME buffer sets in
+one process: the fused kernels at 10 M pairs, events bound to the dispatch, variants interleaved in rounds, on several
+independently allocated buffer sets.  usage: variant_probe.py [--sets K] base <name> ..."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import mmdet3d_gaussian_amd as amd
 from mmdet3d_gaussian_amd import _lib, gd_loss as gdl
-names = sys.argv[1:]
+import bench
+argv = sys.argv[1:]
+sets = 3
+if argv and argv[0] == '--sets':
+    sets = int(argv[1]); argv = argv[2:]
+names = argv
 libs = {}
 for nm in names:
     L = ctypes.CDLL(os.path.join(ROOT, 'tools', 'variants', f'libgd3d_{nm}.so'))
-    res, args = _lib.SYMBOLS['gd3d_loss_fused']
-    L.gd3d_loss_fused.restype, L.gd3d_loss_fused.argtypes = res, args
+    res, args = _lib.SYMBOLS['gd3d_loss_fused_timed']
+    L.gd3d_loss_fused_timed.restype, L.gd3d_loss_fused_timed.argtypes = res, args
     libs[nm] = L
 base = amd.load_library()
 dev = torch.device('cuda:0')
 n = 10_000_000
-g = torch.Generator(device=dev).manual_seed(0)
-src_t = torch.rand(n, 7, generator=g, device=dev) * 2 + 0.5
-src_p = src_t + torch.randn(n, 7, generator=g, device=dev) * 0.1
+lts = ('gwd3d', 'kld3d', 'bd3d')
+prm = {lt: gdl.make_params(lt, 'log1p', 1.0, 1.0, (0, 0, 0.5), {}) for lt in lts}
 ws = torch.empty(base.gd3d_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
 out = torch.zeros(4, device=dev)
-prm = gdl.make_params('bd3d', 'log1p', 1.0, 1.0, (0, 0, 0.5), {})
-def t_one(L, p, t, gp):
-    call = lambda: L.gd3d_loss_fused(prm, p.data_ptr(), t.data_ptr(), None, n, 5.0 / n, None, out.data_ptr(), gp.data_ptr(), None, ws.data_ptr(), None)
-    for _ in range(3): call()
+stream = torch.cuda.current_stream().cuda_stream
+def run(L, lt, p, t, gp, iters):
+    tms = []
+    for _ in range(iters):
+        tm = gdl.DispatchTimer()
+        rc = L.gd3d_loss_fused_timed(prm[lt], None, p.data_ptr(), t.data_ptr(), None, None, n, 5.0 / n, None, out.data_ptr(),
+                                     gp.data_ptr(), None, ws.data_ptr(), stream, tm.start, tm.stop)
+        assert rc == 0
+        tms.append(tm)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): assert call() == 0
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / 20 * 1e3, out[0].item()
+    d = sorted(x.elapsed_ms() for x in tms)
+    return sum(d) / len(d) * 1e3
 keep = []
-for k in range(8):
-    p, t, gp = src_p.clone(), src_t.clone(), torch.empty_like(src_p)
+for k in range(sets):
+    p, t = bench.synthetic_pairs(n, k, dev)
+    gp = torch.empty_like(p)
     keep.append((p, t, gp))
-    r = {nm: t_one(L, p, t, gp) for nm, L in libs.items()}
-    print(f'set {k}: ' + '  '.join(f'{nm} {v[0]:6.1f} us' for nm, v in r.items()) + f'   (loss {list(r.values())[0][1]:.6f} / {list(r.values())[-1][1]:.6f})', flush=True)
+    res = {(nm, lt): [] for nm in names for lt in lts}
+    for nm in names:
+        for lt in lts:
+            run(libs[nm], lt, p, t, gp, 5)
+    for r in range(4):
+        for nm in names:
+            for lt in lts:
+                res[(nm, lt)].append(run(libs[nm], lt, p, t, gp, 10))
+    print(f'buffer set {k}   ' + '   '.join(f'{lt:>7s}' for lt in lts))
+    for nm in names:
+        print(f'  {nm:<10s}  ' + '   '.join(f'{sum(res[(nm, lt)]) / len(res[(nm, lt)]):7.1f}' for lt in lts), flush=True)
