@@ -105,7 +105,8 @@ def _rows(t):
     under @force_fp32, gd_anchor3d_head.py:167)."""
     if not t.is_cuda:
         raise RuntimeError('GDLoss: the MI355X implementation has no CPU path; tensors must be on the GPU')
-    t = t.reshape(-1, 7)
+    if t.dim() != 2 or t.shape[1] != 7:
+        t = t.reshape(-1, 7)
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
@@ -163,7 +164,8 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
     """One launch of the fused kernel (+ its reduce stage) on the current stream of pred's device.
     `prologue`: None or a _lib.Prologue (bbox-coder decode fused into the kernel, head_loss.py).
     `select`  : row_weight is (N,7) and the reference's no-positive-weight early-out is resolved on the device
-                (gd3d_loss_fused_select); the returned `any_pos` is the int32 device flag backward needs.
+                (gd3d_loss_fused_select); the returned `any_pos` is (buffer that owns it, address) of the int32 device
+                flag backward needs.
     Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None, any_pos|None)."""
     lib = _library()
     n = pred.shape[0]
@@ -197,13 +199,14 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
                 else:
                     w1 = row_weight.data_ptr()
             if select:
-                any_pos = buf[1:2].view(torch.int32)
+                any_pos = (buf, ws - 12)   # buf[1], read as int32
             rc = lib.gd3d_loss_fused_one_launch(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
-                                                total.data_ptr(), _ptr(any_pos), _ptr(gp), _ptr(gt), ws, ticket, stream)
+                                                ws - 16, any_pos[1] if select else None, _ptr(gp), _ptr(gt), ws, ticket,
+                                                stream)
         elif select:
-            any_pos = buf[1:2].view(torch.int32)
+            any_pos = (buf, ws - 12)
             rc = lib.gd3d_loss_fused_select(params, prologue, pred.data_ptr(), target.data_ptr(), row_weight.data_ptr(), n,
-                                            scale, total.data_ptr(), any_pos.data_ptr(), _ptr(gp), _ptr(gt), ws, stream,
+                                            scale, ws - 16, any_pos[1], _ptr(gp), _ptr(gt), ws, stream,
                                             tm.start if tm else None, tm.stop if tm else None)
         else:
             w1 = w7 = None
@@ -239,7 +242,8 @@ class _GDReduced(torch.autograd.Function):
         ctx.used, ctx.want = False, (need_gp, need_gt)
         ctx.replay = (pred, target, row_weight, params, scale, prologue, select)
         if flag_box is not None:   # the any-positive flag leaves through a side door: a second autograd OUTPUT that is a
-            flag_box.append(any_pos)   # view of the same buffer as `total` makes every backward pay view bookkeeping
+            # view of the same buffer as `total` makes every backward pay view bookkeeping
+            flag_box.append(any_pos[0][1:2].view(torch.int32))
         return total
 
     @staticmethod
@@ -264,7 +268,8 @@ class _GDReduced(torch.autograd.Function):
         try:
             # one launch for both arrays: reads g (and the any-positive flag) on the device; leaves without touching
             # memory when g == 1 and the normal branch was taken (no host sync)
-            rc = lib.gd3d_grad_finish(_ptr(gp), _ptr(gt), g.data_ptr(), pred.shape[0], _ptr(ctx.any_pos),
+            rc = lib.gd3d_grad_finish(_ptr(gp), _ptr(gt), g.data_ptr(), pred.shape[0],
+                                      ctx.any_pos[1] if ctx.any_pos is not None else None,
                                       row_weight.data_ptr() if select else None,
                                       pred.data_ptr() if (select and prologue is not None) else None,
                                       prologue if select else None, _raw_stream(dev.index))
@@ -370,7 +375,7 @@ class GDLoss(nn.Module):
         n = p.shape[0]
         w = None
         if weight is not None:
-            w = weight.reshape(-1, 7) if weight7 else weight.reshape(-1)
+            w = (weight if weight.dim() == 2 else weight.reshape(-1, 7)) if weight7 else weight.reshape(-1)
             if w.dtype != torch.float32 or w.device != p.device or not w.is_contiguous():
                 w = w.to(device=p.device, dtype=torch.float32).contiguous()
             if w.shape[0] != n:
