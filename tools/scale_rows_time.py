@@ -1,5 +1,6 @@
-import torch, time, sys
-sys.path.insert(0,'/root/repo')
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mmdet3d_gaussian_amd as amd
 lib = amd.load_library()
 n = 10_000_000
