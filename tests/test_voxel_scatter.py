@@ -146,3 +146,45 @@ def test_gpu_backward_voxel_order_equals_map_order(c, red):
     torch.cuda.synchronize()
     assert not torch.isnan(b).any() and torch.equal(a, b)
     assert (b[sc.pts_voxel_maps < 0] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('red', ['sum', 'max'])
+def test_gpu_scatter_feature_offsets_beyond_2_31(red):
+    """36 M points x 64 channels = 2.3e9 floats: element offsets beyond int32 in the point-feature array.  The 64-channel
+    result equals the two 32-channel halves reduced on their own (every channel is summed in ascending point order whatever
+    the channel count), forward and backward, and the rows of the LAST points carry the right voxel's gradient."""
+    from mmdet3d_gaussian_amd.scatter import Scatter
+    n, c = 36_000_000, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < (48 << 30):
+        pytest.skip('needs 48 GB of free HBM')
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(3)
+    coors = torch.stack([torch.randint(0, 10, (n,), generator=g, device=dev), torch.randint(0, 400, (n,), generator=g, device=dev),
+                         torch.randint(0, 400, (n,), generator=g, device=dev)], 1).int()
+    coors[::97, 1] = -1                                     # points outside every voxel
+    feats = torch.empty(n, c, device=dev)
+    for s in range(0, n, 4_000_000):
+        feats[s:s + 4_000_000] = torch.randn(4_000_000, c, generator=g, device=dev)
+    assert feats.numel() > 2 ** 31
+    sc = Scatter(coors)
+    f = feats.requires_grad_(True)
+    out, _ = sc.reduce(f, red)
+    halves = [sc.reduce(feats.detach()[:, k:k + 32].contiguous(), red)[0] for k in (0, 32)]
+    assert torch.equal(out.detach()[:, :32], halves[0]) and torch.equal(out.detach()[:, 32:], halves[1])
+    gv = torch.randn(out.shape, generator=g, device=dev)
+    out.backward(gv)
+    m = sc.pts_voxel_maps
+    tail = slice(n - 1000, n)                               # rows whose offsets are beyond 2^31
+    mt = m[tail].long()
+    if red == 'sum':
+        want = torch.where((mt >= 0)[:, None], gv[mt.clamp(min=0)], torch.zeros((), device=dev))
+        assert torch.equal(f.grad[tail], want)
+    else:
+        hit = out.detach()[mt.clamp(min=0)] == feats.detach()[tail]
+        got = f.grad[tail]
+        assert bool(((got != 0) <= (hit & (mt >= 0)[:, None])).all())          # gradient only where the point IS the max
+        assert torch.equal(got[got != 0], gv[mt.clamp(min=0)][got != 0])
+    del f, feats, out, gv
+    torch.cuda.empty_cache()
