@@ -463,3 +463,21 @@ def test_matcher_class_pipeline_iou_to_matches(amd):
     want = oracle.match_coco(-aff_o, -np.array([0.3, 0.5, 0.7], np.float32), ign, np.zeros(40, bool))
     assert np.array_equal(got.cpu().numpy(), want)
     assert amd.LidarCenterTransBEV.LARGER_CLOSER is False and amd.LidarIOUBEV.LARGER_CLOSER is True
+
+
+def test_pairwise_matrix_offsets_beyond_2_31(amd):
+    """50 000 x 45 000 centre distances = 2.25e9 outputs: the flat pair index and the output offset exceed int32."""
+    D, G = 50_000, 45_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < (24 << 30):
+        pytest.skip('needs 24 GB of free HBM')
+    g = torch.Generator(device='cuda').manual_seed(2)
+    det = torch.rand(D, 7, generator=g, device='cuda') * 100
+    gt = torch.rand(G, 9, generator=g, device='cuda') * 100
+    out = amd.trans_bev(det, gt)
+    assert out.numel() > 2 ** 31
+    for rows in (slice(0, 64), slice(D - 64, D)):           # first rows and the rows past offset 2^31
+        dx = det[rows, None, 0] - gt[None, :, 0]; dy = det[rows, None, 1] - gt[None, :, 1]
+        assert torch.equal(out[rows], torch.sqrt(dx * dx + dy * dy))
+    del out
+    torch.cuda.empty_cache()
