@@ -481,3 +481,46 @@ def test_pairwise_matrix_offsets_beyond_2_31(amd):
         assert torch.equal(out[rows], torch.sqrt(dx * dx + dy * dy))
     del out
     torch.cuda.empty_cache()
+
+
+def test_nms_at_the_maximum_size_closed_form(amd):
+    """n = 65 536 (RNMS_MAX_N): 32 768 separated sites on a 256 x 128 unit grid with two identical axis-aligned boxes each
+    (all coordinates exact in fp32 and below 256).  Whatever the order, exactly the higher-scored box of every site
+    survives, in descending score order.  One box more is refused, not truncated.
+    Beyond |coordinate| >= 256 the published overlap algorithm's in-box margin of 1e-5 is less than half an fp32 ulp,
+    `x1 - MARGIN` rounds back to x1 and a corner ON the boundary no longer counts as inside: identical boxes then have
+    IoU 0 and do not suppress each other (oracle: iou_bev_xyxyr of a box at (500, 20) with itself = 0).  That behaviour of
+    the algorithm is pinned against the CPU restatement on 8192 far-away duplicates (bit-exact), not 'fixed'."""
+    n = 65536
+    g = torch.Generator().manual_seed(11)
+    site = torch.arange(n // 2)
+
+    def problem(cx, cy, hx, hy, rot):
+        one = torch.stack([cx - hx, cy - hy, cx + hx, cy + hy, rot], 1)           # xyxyr
+        boxes = one.repeat_interleave(2, 0)
+        scores = torch.rand(n, generator=g)
+        perm = torch.randperm(n, generator=g)
+        return boxes[perm].contiguous(), scores[perm].contiguous(), perm // 2
+
+    boxes, scores, site_of = problem((site % 256).float(), (site // 256).float(), 0.25, 0.125, torch.zeros(n // 2))
+    keep = amd.nms_gpu(boxes.cuda(), scores.cuda(), 0.5).cpu()
+    order = torch.argsort(scores, descending=True, stable=True)
+    seen = torch.zeros(n // 2, dtype=torch.bool)
+    want = []
+    for i in order.tolist():                       # closed form: the first box of a site in score order
+        s = int(site_of[i])
+        if not seen[s]:
+            seen[s] = True; want.append(i)
+    assert keep.tolist() == want
+    with pytest.raises(RuntimeError):
+        amd.nms_gpu(torch.cat([boxes, boxes[:1]]).cuda(), torch.cat([scores, scores[:1]]).cuda(), 0.5)
+    # rotated duplicates up to 2500 m from the origin: whatever the algorithm decides there, GPU == CPU restatement
+    rb, rs, _ = problem((site % 256).float() * 10.0, (site // 256).float() * 10.0, 1.5, 0.8,
+                        torch.rand(n // 2, generator=g) * 6.0 - 3.0)
+    top = torch.argsort(rs, descending=True, stable=True)[:8192]
+    rb, rs = rb[top].contiguous(), rs[top].contiguous()
+    want_r = oracle.nms_gpu_oracle(rb.numpy(), rs.numpy(), 0.5)
+    got_r = amd.nms_gpu(rb.cuda(), rs.cuda(), 0.5).cpu().numpy()
+    assert np.array_equal(got_r, want_r)
+    far = np.array([[498.5, 19.0, 501.5, 21.0, 0.0]], np.float32)
+    assert oracle.iou_bev_xyxyr(far, far)[0, 0] == 0.0 and float(amd.boxes_iou_bev(torch.from_numpy(far).cuda(), torch.from_numpy(far).cuda())[0, 0]) == 0.0
