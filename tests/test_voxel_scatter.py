@@ -188,3 +188,32 @@ def test_gpu_scatter_feature_offsets_beyond_2_31(red):
         assert torch.equal(got[got != 0], gv[mt.clamp(min=0)][got != 0])
     del f, feats, out, gv
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_gpu_scatter_all_points_outside_and_single_voxel():
+    """Edge clouds: every point invalid (no voxel at all), and every point in ONE voxel (the longest possible segment)."""
+    from mmdet3d_gaussian_amd.scatter import Scatter
+    n, c = 5000, 16
+    feats = torch.randn(n, c, device='cuda', requires_grad=True)
+    none = Scatter(torch.full((n, 3), -1, dtype=torch.int32, device='cuda'))
+    assert none.voxel_coors.shape[0] == 0 and bool((none.pts_voxel_maps == -1).all())
+    out, vc = none.reduce(feats, 'max')
+    assert out.shape == (0, c) and vc.shape[0] == 0
+    back = none.reduce_mapback(feats.detach(), 'mean', default_feat=7.0)
+    assert back.shape == (n, c) and bool((back == 7.0).all())
+    one = Scatter(torch.tensor([[3, 2, 1]], dtype=torch.int32, device='cuda').expand(n, 3).contiguous())
+    assert one.voxel_coors.tolist() == [[3, 2, 1]] and one.voxel_pts_counts.tolist() == [n]
+    for red in ('sum', 'mean', 'max'):
+        feats.grad = None
+        o, _ = one.reduce(feats, red)
+        f64 = feats.detach().double()
+        want = {'sum': f64.sum(0), 'mean': f64.mean(0), 'max': f64.max(0).values}[red]
+        # 5000 fp32 terms added in ascending point order: |error| <~ n * eps * max|partial sum| ~ 2e-3 on the sum
+        atol = {'sum': 2e-3, 'mean': 2e-3 / n, 'max': 0.0}[red]
+        assert torch.allclose(o[0].double(), want, rtol=1e-6, atol=atol)
+        o.sum().backward()
+        if red == 'max':
+            assert int((feats.grad != 0).sum()) == c                  # exactly one winner per channel
+        else:
+            assert torch.allclose(feats.grad, torch.full_like(feats, 1.0 if red == 'sum' else 1.0 / n))
