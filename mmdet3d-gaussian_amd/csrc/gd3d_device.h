@@ -26,11 +26,16 @@ GD_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f3
 // sin & cos.  Cody-Waite reduction by pi/2 with FMAs + Cephes minimax polynomials on
 // [-pi/4, pi/4] (abs error < 1.5e-7 for |x| <= 8192).  Beyond that (never in practice for a
 // yaw) fall back to the full-range library routine.
+GD_DEV void sincos_poly(float x, float& s, float& c);
 GD_DEV void sincos_f(float x, float& s, float& c) {
   if (__builtin_expect(!(fabsf(x) <= 8192.0f), 0)) {
     sincosf(x, &s, &c);
     return;
   }
+  sincos_poly(x, s, c);
+}
+// the polynomial path alone, for callers that have already bounded |x| (<= 8192)
+GD_DEV void sincos_poly(float x, float& s, float& c) {
   const float q = rintf(x * 0.63661977236758134f);
   float r = fmaf(q, -1.5703125f, x);
   r = fmaf(q, -4.837512969970703125e-4f, r);
@@ -54,7 +59,8 @@ constexpr float LN2 = 0.6931471805599453f;
 GD_DEV float log1p_f(float d, float& inv_u) {
   const float u = 1.0f + d;
   inv_u = frcp(u);
-  const float corr = (d - (u - 1.0f)) * inv_u;
+  const float lost = d - (u - 1.0f);                 // d = +inf: inf - inf; torch.log1p(inf) = inf, so no correction there
+  const float corr = (inv_u == 0.0f) ? 0.0f : lost * inv_u;
   return fmaf(flog2(u), LN2, corr);
 }
 
@@ -164,7 +170,7 @@ GD_DEV float post(float d, float tau, float& deriv) {
 // One v_rsq_f32 serves both: sqrt(u) = u * rsq(u), 1/(2 sqrt(u)) = rsq(u)/2 (rsq(0) = +inf as required).
 GD_DEV float sqrt0(float u, float& dsu) {
   const float r = frsq(u);
-  const float s = (u > 0.0f) ? u * r : u * 0.0f;
+  const float s = (u > 0.0f) ? ((r == 0.0f) ? u : u * r) : u * 0.0f;   // rsq(+inf) = 0: sqrt(inf) = inf, not inf * 0
   dsu = (u >= 0.0f) ? 0.5f * r : 0.0f;
   return s;
 }
@@ -182,11 +188,21 @@ GD_DEV float sqrt0(float u, float& dsu) {
 //     d/d ap = 2 [(ap-at) + at m + ap (At-Bt) sin^2 d / sqrt q],  m = 1 - r0/sqrt q = -K sin^2 d / ((r0 + sqrt q) sqrt q)
 //     d/d bp = 2 [(bp-bt) + bt m - bp (At-Bt) sin^2 d / sqrt q],  d/d r_p = 2 K sin d cos d / sqrt q = - d/d r_t
 template <int FUN, bool NORMALIZE, bool GT>
-GD_DEV float gwd(const Box& p, const Box& t, float dr, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float gwd(const Box& p, const Box& t, float yaw_p, float yaw_t, float alpha, float tau, Adj& gp, Adj& gt) {
   const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
   const float dxyz = fmaf(dX, dX, fmaf(dY, dY, dZ * dZ));
   float sd, cd;
-  sincos_f(dr, sd, cd);
+  if (__builtin_expect(!(fabsf(yaw_p) <= 16.0f && fabsf(yaw_t) <= 16.0f), 0)) {
+    // fl(yaw_p - yaw_t) is off by up to ulp(yaw)/2 (1e-6 rad at 16, 0.03 rad at 1e6): for yaws that far out take the
+    // sine and cosine of the difference from the two angles themselves, as the reference's per-box rotations do
+    float sp, cp, st, ct;
+    sincos_f(yaw_p, sp, cp);
+    sincos_f(yaw_t, st, ct);
+    sd = fmaf(sp, ct, -cp * st);
+    cd = fmaf(cp, ct, sp * st);
+  } else {
+    sincos_poly(yaw_p - yaw_t, sd, cd);   // |difference| <= 32: no range check of its own (one branch on this path, as before)
+  }
   const float s2 = sd * sd;
   const float r0 = fmaf(p.a, t.a, p.b * t.b);
   const float dAp = (p.a - p.b) * (p.a + p.b), dAt = (t.a - t.b) * (t.a + t.b);
@@ -490,7 +506,7 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
   box_make<LOSS != GD3D_GWD3D>(pv, c, p);
   box_make<LOSS != GD3D_GWD3D>(tv, c, t);
   float out;
-  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6] - tv[6], alpha, tau, gp, gt);
+  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6], tv[6], alpha, tau, gp, gt);
   else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
   else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);

@@ -1,0 +1,105 @@
+"""The fused kernel's per-pair DEVICE math (csrc/gd3d_device.h), compiled for the host by g++ through the stand-in header
+tests/hostmath/hip/hip_runtime.h, against the golden vectors generated from the real reference.  CPU-only coverage of
+the arithmetic the GPU runs: closed forms, hand-derived gradients, clamp / tie / NaN / inf rules and the launch dispatch on
+(loss type, fun, flag).  The hardware's 1-ulp v_rcp / v_rsq / v_sqrt / v_log / v_exp are IEEE-exact here, everything
+else is the same source.  Test infrastructure only: nothing in the product can reach this build."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from gd_golden import (NOISY_FAMILIES, NONFINITE_CASES, check_close, check_nonfinite, families, grad_bound, index,
+                       loss_bound, nonfinite, pair_case_names, pairs)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope='module')
+def hostmath():
+    cxx = shutil.which('g++')
+    if cxx is None:
+        pytest.skip('g++ not available')
+    out_dir = os.path.join(HERE, 'hostmath', '_build')
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, f'libpairmath.{os.getpid()}.so')
+    cmd = [cxx, '-O1', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(HERE, 'hostmath'), '-I', ROOT,
+           os.path.join(HERE, 'hostmath', 'pair_math.cpp'), '-o', so]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = ctypes.CDLL(so)
+    lib.hostmath_pairs.restype = ctypes.c_int
+    yield lib
+    try:
+        os.remove(so)
+    except OSError:
+        pass
+
+
+def _run(lib, loss_type, kw, pred, target, scale=1.0):
+    import mmdet3d_gaussian_amd as amd          # host-side parameter mapping of the product (no GPU needed for it)
+    kw = dict(kw)
+    prm = amd.make_params(loss_type, kw.pop('fun', 'log1p'), kw.pop('tau', 1.0), kw.pop('alpha', 1.0),
+                          tuple(kw.pop('center_offset', (0, 0, 0.5))), kw)
+    pred = np.ascontiguousarray(pred, np.float32); target = np.ascontiguousarray(target, np.float32)
+    n = pred.shape[0]
+    loss = np.empty(n, np.float32); gp = np.empty((n, 7), np.float32); gt = np.empty((n, 7), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    with np.errstate(all='ignore'):
+        rc = lib.hostmath_pairs(ctypes.byref(prm), vp(pred), vp(target), ctypes.c_long(n), ctypes.c_float(scale), vp(loss),
+                                vp(gp), vp(gt))
+    assert rc == 0
+    return loss, gp, gt
+
+
+@pytest.mark.parametrize('case', pair_case_names())
+def test_device_math_on_host_against_reference_golden(hostmath, case):
+    """Same data, same tolerance policy as tests/test_gpu_gd_loss.py::test_pairs_against_reference_golden."""
+    c = index()['pairs']['cases'][case]
+    g = pairs()
+    for fam in families():
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c['kwargs'].items()}
+        loss, gp, gt = _run(hostmath, c['loss_type'], kw, g[f'in.{fam}.pred'], g[f'in.{fam}.target'])
+        key = f'{case}.{fam}'
+        l64, l32 = g[key + '.loss64'], g[key + '.loss32']
+        noisy = fam in NOISY_FAMILIES
+        if fam == 'ident':
+            check_close(key + '.loss', loss, l64, np.maximum(loss_bound(l64, l32), 2e-3), noisy=True)
+            continue
+        check_close(key + '.loss', loss, l64, loss_bound(l64, l32), noisy)
+        check_close(key + '.gp', gp, g[key + '.gp64'], grad_bound(g[key + '.gp64'], g[key + '.gp32']), noisy)
+        check_close(key + '.gt', gt, g[key + '.gt64'], grad_bound(g[key + '.gt64'], g[key + '.gt32']), noisy)
+
+
+def test_device_math_on_host_nonfinite_and_degenerate_rows(hostmath):
+    """NaN exactly where the reference has it; +inf centres / heights and an overflowing centre give the reference's 1.0
+    (sqrt(inf) and log1p(inf) are inf, not inf * 0); a yaw of 1e6 goes through the two-angle path of gwd3d."""
+    gold = nonfinite()
+    for lt, kw in NONFINITE_CASES:
+        loss, _, _ = _run(hostmath, lt, kw, gold['pred'], gold['target'])
+        check_nonfinite(lt, loss, gold[f'{lt}.loss32'], gold[f'{lt}.loss64'])
+
+
+def test_device_math_large_yaws_keep_the_reference_accuracy(hostmath):
+    """gwd3d takes sin / cos of the yaw DIFFERENCE; beyond |yaw| = 16 that difference is formed from the two angles'
+    own sines and cosines, so a common offset of 2 pi k (exact multiples are not representable: use the oracle on the
+    SAME rounded inputs) does not cost accuracy: kernel math vs fp64 oracle on yaws around 1e3 .. 1e5."""
+    import oracle
+    rng = np.random.default_rng(3)
+    n = 256
+    t = np.stack([rng.uniform(0, 70, n), rng.uniform(-40, 40, n), rng.uniform(-3, 1, n), rng.uniform(0.5, 2.5, n),
+                  rng.uniform(0.5, 4.5, n), rng.uniform(0.5, 2, n), rng.uniform(-3.14, 3.14, n)], -1)
+    p = t + rng.normal(0, 1, (n, 7)) * np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.1, 0.3])
+    off = rng.choice([1e3, -1e3, 1e4, 1e5, 17.0], n)
+    p[:, 6] += off
+    t[:, 6] += off + rng.choice([0.0, 2 * np.pi, -4 * np.pi], n)
+    p32, t32 = p.astype(np.float32), t.astype(np.float32)
+    loss, gp, _ = _run(hostmath, 'gwd3d', dict(fun='log1p', tau=1.0), p32, t32)
+    prm = oracle.make_params('gwd3d', fun='log1p', tau=1.0)
+    r64 = oracle.gd_loss(p32, t32, prm, scale=1.0, dtype=np.float64)
+    assert np.max(np.abs(loss - r64['loss']) / (1 + np.abs(r64['loss']))) <= 1e-5
+    sc = 1 + np.abs(r64['grad_pred']).max(-1, keepdims=True)
+    assert np.max(np.abs(gp - r64['grad_pred']) / sc) <= 3e-5
