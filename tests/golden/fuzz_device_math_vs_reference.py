@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised search for inputs on which the kernel's per-pair math is LESS accurate than the reference's own fp32
+(build container only: imports the real reference through _ref_loader and runs the device math through the host build of
+tests/hostmath).  Nine stress families x 7 loss types x 3 post-processing settings, 512 pairs each; a line is printed for
+every (family, loss, setting) with a NaN-pattern mismatch, or with rows whose error exceeds 1e-5 + 3 x the reference's
+fp32 error on the same row AND 10 x the family's median fp32 error.
+
+    python3 -B tests/golden/fuzz_device_math_vs_reference.py
+
+State at the end of round 2: no NaN mismatch anywhere; nothing at all on the aspect / far-centre / far-distance /
+big-yaw / negative-dim / quarter-turn / square families; isolated rows (<= 2 %) on boxes of 10 m .. 1 km with aspect
+ratios of 1:500 (bd3d, kfiou3d: errors of 2e-5 .. 8e-5 where the reference's fp32 has 1e-6 .. 7e-5 on its bad rows) and
+single gradient elements on 1e-9-scaled dims.  Nothing is written."""
+import ctypes, os, subprocess, sys, tempfile
+import numpy as np
+import torch
+HERE=os.path.dirname(os.path.abspath(__file__)); ROOT=os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.dirname(HERE)); sys.path.insert(0,HERE)
+from _ref_loader import load_reference_loss
+import mmdet3d_gaussian_amd as amd
+ref = load_reference_loss()
+so=os.path.join(tempfile.mkdtemp(),'libpairmath.so')
+subprocess.check_call(['g++','-O1','-std=c++17','-shared','-fPIC','-I',os.path.join(ROOT,'tests','hostmath'),'-I',ROOT,os.path.join(ROOT,'tests','hostmath','pair_math.cpp'),'-o',so])
+L=ctypes.CDLL(so)
+def host(lt, kw, p, t):
+    kw=dict(kw)
+    prm = amd.make_params(lt, kw.pop('fun','log1p'), kw.pop('tau',1.0), kw.pop('alpha',1.0), (0,0,0.5), kw)
+    n=len(p); loss=np.empty(n,np.float32); gp=np.empty((n,7),np.float32); gt=np.empty((n,7),np.float32)
+    vp=lambda a:a.ctypes.data_as(ctypes.c_void_p)
+    with np.errstate(all='ignore'):
+        L.hostmath_pairs(ctypes.byref(prm), vp(p), vp(t), ctypes.c_long(n), ctypes.c_float(1.0), vp(loss), vp(gp), vp(gt))
+    return loss, gp
+def refrun(lt, kw, p, t, dt):
+    pp=torch.from_numpy(p).to(dt).requires_grad_(True); tt=torch.from_numpy(t).to(dt)
+    with np.errstate(all='ignore'):
+        l=ref.GDLoss(lt, reduction='none', loss_weight=1.0, **kw)(pp,tt); l.sum().backward()
+    return l.detach().numpy().astype(np.float64), pp.grad.numpy().astype(np.float64)
+rng=np.random.default_rng(0)
+def gen(n, kind):
+    t=np.stack([rng.uniform(0,70,n),rng.uniform(-40,40,n),rng.uniform(-3,1,n),rng.uniform(0.5,2.5,n),rng.uniform(0.5,4.5,n),rng.uniform(0.5,2,n),rng.uniform(-3.14,3.14,n)],-1)
+    p=t+rng.normal(0,1,(n,7))*np.array([0.3,0.3,0.1,0.1,0.1,0.1,0.1])
+    if kind=='hugedim': p[:,3:6]*=10**rng.uniform(0,3,(n,3)); t[:,3:6]*=10**rng.uniform(0,3,(n,3))   # boxes up to kilometres
+    if kind=='tinydim': p[:,3:6]*=10**rng.uniform(-9,0,(n,3)); t[:,3:6]*=10**rng.uniform(-9,0,(n,3))
+    if kind=='aspect': p[:,3]*=1e3; t[:,4]*=1e3
+    if kind=='farcentre': off=10**rng.uniform(2,6,(n,1)); p[:,:3]+=off; t[:,:3]+=off
+    if kind=='fardist': p[:,:3]+=10**rng.uniform(1,8,(n,3))
+    if kind=='bigyaw': p[:,6]+=rng.uniform(-300,300,n); t[:,6]+=rng.uniform(-300,300,n)
+    if kind=='negdim': p[::3,3:6]*=-1; t[::5,4]*=-1
+    if kind=='yaw90': t[:,6]=p[:,6]+np.pi/2*rng.integers(-2,3,n)+rng.normal(0,1e-4,n)
+    if kind=='square': p[:,4]=p[:,3]; t[:,4]=t[:,3]*(1+rng.normal(0,1e-6,n))
+    return p.astype(np.float32), t.astype(np.float32)
+cases=[(lt,dict(fun=f,tau=tau)) for lt in ('gwd3d','kld3d','bd3d','jd3d','kld3d_symmax','kld3d_symmin') for f,tau in (('log1p',1.0),('none',0.0),('log1p',0.0))]+[('kfiou3d',dict(fun=f)) for f in ('none','expm1','nlog')]
+for kind in ('hugedim','tinydim','aspect','farcentre','fardist','bigyaw','negdim','yaw90','square'):
+    p,t=gen(512,kind)
+    for lt,kw in cases:
+        l,gp=host(lt,kw,p,t)
+        l64,g64=refrun(lt,kw,p,t,torch.float64); l32,g32=refrun(lt,kw,p,t,torch.float32)
+        with np.errstate(all='ignore'):
+            nanmis=(np.isnan(l)!=np.isnan(l64))&~(np.isnan(l32)!=np.isnan(l64))
+            sc=1+np.abs(l64); e=np.abs(l-l64)/sc; e32=np.abs(l32-l64)/sc
+            fin=np.isfinite(l64)&np.isfinite(l)&np.isfinite(l32)
+            worse=fin&(e>1e-5+3*e32)&(e>10*np.median(e32[fin])+1e-5)
+            gs=1+np.nanmax(np.abs(np.where(np.isfinite(g64),g64,0)),-1,keepdims=True)
+            ge=np.abs(gp-g64)/gs; ge32=np.abs(g32-g64)/gs
+            gfin=np.isfinite(g64)&np.isfinite(gp)&np.isfinite(g32)
+            gw=gfin&(ge>1e-5+3*ge32)&(ge>10*np.median(ge32[gfin])+1e-5)
+        if nanmis.any() or worse.any() or gw.any():
+            i=int(np.argmax(np.where(worse,e,0))); j=np.unravel_index(int(np.argmax(np.where(gw,ge,0))),ge.shape)
+            print(f'{kind:10s} {lt:13s} {str(kw):32s} nan-mismatch {int(nanmis.sum()):3d}  loss-worse {int(worse.sum()):3d} (max {e[i]:.2e} vs ref32 {e32[i]:.2e})  grad-worse {int(gw.sum()):4d} (max {ge[j]:.2e} vs {ge32[j]:.2e})')
