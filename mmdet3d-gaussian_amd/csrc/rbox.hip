@@ -758,32 +758,7 @@ __global__ __launch_bounds__(EVAL_T) void riou_eval_kernel(const float* __restri
     d[k] = det[di * 7 + k];
     g[k] = gt[gi * 7 + k];
   }
-  const RBox D = {d[0], d[1], d[3], d[4], d[6]}, G = {g[0], g[1], g[3], g[4], g[6]};
-  const float bev = rot_intersection<EVAL_T>(D, G, hs, threadIdx.x);
-  const float EPSF = 1.1920928955078125e-7f;
-  if (IS3D) {
-    const float dzb = d[2] + (z_offset - 0.5f) * d[5], gzb = g[2] + (z_offset - 0.5f) * g[5];
-    const float dzt = d[2] + (z_offset + 0.5f) * d[5], gzt = g[2] + (z_offset + 0.5f) * g[5];
-    const float zb = dzb > gzb ? dzb : gzb, zt = dzt < gzt ? dzt : gzt;
-    float zi = zt - zb;
-    zi = zi < 0.f ? 0.f : zi;
-    const float dv = d[3] * d[4] * d[5], gv = g[3] * g[4] * g[5];
-    float iv = bev * zi;
-    iv = iv < 0.f ? 0.f : iv;
-    iv = iv > dv ? dv : iv;
-    iv = iv > gv ? gv : iv;
-    float uv = dv + gv - iv;
-    uv = uv < EPSF ? EPSF : uv;
-    out[idx] = iv / uv;
-  } else {
-    const float da = d[3] * d[4], ga = g[3] * g[4];
-    float inter = bev < 0.f ? 0.f : bev;
-    inter = inter > da ? da : inter;
-    inter = inter > ga ? ga : inter;
-    float un = da + ga - inter;
-    un = un < EPSF ? EPSF : un;
-    out[idx] = inter / un;
-  }
+  out[idx] = eval_iou<IS3D, EVAL_T>(d, g, z_offset, hs, threadIdx.x);
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

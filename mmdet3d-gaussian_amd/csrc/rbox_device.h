@@ -452,4 +452,35 @@ RB_DEV float rot_intersection(const RBox& b1, const RBox& b2, HullScratch<NT>& h
   return area / 2.0f;
 }
 
+// IoU of one detection / ground-truth pair from the intersection above: affinity.cpp:8-81 (iou_bev :8-38, iou_3d :40-81).
+// Rows are [x, y, z, w, l, h, yaw]; z_offset places the box centre between its bottom (0) and top (1) face.
+template <bool IS3D, int NT>
+RB_DEV float eval_iou(const float (&d)[7], const float (&g)[7], float z_offset, HullScratch<NT>& hs, int t) {
+  const RBox D = {d[0], d[1], d[3], d[4], d[6]}, G = {g[0], g[1], g[3], g[4], g[6]};
+  const float bev = rot_intersection<NT>(D, G, hs, t);
+  const float EPSF = 1.1920928955078125e-7f;
+  if (IS3D) {
+    const float dzb = d[2] + (z_offset - 0.5f) * d[5], gzb = g[2] + (z_offset - 0.5f) * g[5];
+    const float dzt = d[2] + (z_offset + 0.5f) * d[5], gzt = g[2] + (z_offset + 0.5f) * g[5];
+    const float zb = dzb > gzb ? dzb : gzb, zt = dzt < gzt ? dzt : gzt;
+    float zi = zt - zb;
+    zi = zi < 0.f ? 0.f : zi;
+    const float dv = d[3] * d[4] * d[5], gv = g[3] * g[4] * g[5];
+    float iv = bev * zi;
+    iv = iv < 0.f ? 0.f : iv;
+    iv = iv > dv ? dv : iv;
+    iv = iv > gv ? gv : iv;
+    float uv = dv + gv - iv;
+    uv = uv < EPSF ? EPSF : uv;
+    return iv / uv;
+  }
+  const float da = d[3] * d[4], ga = g[3] * g[4];
+  float inter = bev < 0.f ? 0.f : bev;
+  inter = inter > da ? da : inter;
+  inter = inter > ga ? ga : inter;
+  float un = da + ga - inter;
+  un = un < EPSF ? EPSF : un;
+  return inter / un;
+}
+
 }  // namespace rbox

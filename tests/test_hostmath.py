@@ -103,3 +103,70 @@ def test_device_math_large_yaws_keep_the_reference_accuracy(hostmath):
     assert np.max(np.abs(loss - r64['loss']) / (1 + np.abs(r64['loss']))) <= 1e-5
     sc = 1 + np.abs(r64['grad_pred']).max(-1, keepdims=True)
     assert np.max(np.abs(gp - r64['grad_pred']) / sc) <= 3e-5
+
+
+# ------------------------------------------------------------------------------------------------ rotated-box geometry
+@pytest.fixture(scope='module')
+def rboxmath():
+    cxx = shutil.which('g++')
+    if cxx is None:
+        pytest.skip('g++ not available')
+    out_dir = os.path.join(HERE, 'hostmath', '_build')
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, f'librboxmath.{os.getpid()}.so')
+    # -ffp-contract=off as for csrc/rbox.hip: every step one IEEE fp32 operation, so the NMS part is bit-reproducible
+    cmd = [cxx, '-O1', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-I', os.path.join(HERE, 'hostmath'), '-I', ROOT,
+           os.path.join(HERE, 'hostmath', 'rbox_math.cpp'), '-o', so]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = ctypes.CDLL(so)
+    lib.hostmath_iou_xyxyr.restype = None
+    lib.hostmath_eval_iou.restype = None
+    yield lib
+    try:
+        os.remove(so)
+    except OSError:
+        pass
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _host_iou(lib, a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    out = np.empty((len(a), len(b)), np.float32)
+    lib.hostmath_iou_xyxyr(_vp(a), ctypes.c_long(len(a)), _vp(b), ctypes.c_long(len(b)), _vp(out))
+    return out
+
+
+@pytest.mark.parametrize('clutter', [True, False])
+def test_nms_overlap_math_on_host_is_bit_identical_to_the_oracle(rboxmath, clutter):
+    """The per-pair IoU the NMS mask kernels evaluate (rbox_device.h part 1), compiled for the host, against the CPU
+    restatement of mmdet3d's overlap: same bits on clustered and scattered boxes, degenerate ones included."""
+    import oracle
+    from rbox_inputs import nms_boxes
+    a, _ = nms_boxes(300, seed=5, clutter=clutter)
+    b, _ = nms_boxes(260, seed=6, clutter=clutter)
+    b[:40] = a[:40]                                          # identical pairs
+    b[40:50, 2] = b[40:50, 0]                                # zero width
+    b[50:60, 4] = a[50:60, 4] + np.float32(np.pi / 2)        # quarter turn of a near-copy
+    b[50:60, :4] = a[50:60, :4]
+    got = _host_iou(rboxmath, a, b)
+    want = oracle.iou_bev_xyxyr(a, b)
+    assert np.array_equal(got.view(np.int32), np.asarray(want, np.float32).view(np.int32))
+    far = np.array([[498.5, 19.0, 501.5, 21.0, 0.0]], np.float32)     # in-box margin below half an ulp: IoU with itself = 0
+    assert _host_iou(rboxmath, far, far)[0, 0] == 0.0 and _host_iou(rboxmath, far - np.float32([400, 0, 400, 0, 0]), far - np.float32([400, 0, 400, 0, 0]))[0, 0] == 1.0
+
+
+@pytest.mark.parametrize('fam', ['shift', 'dense', 'degen', 'ragged'])
+def test_eval_iou_math_on_host_against_reference_golden(rboxmath, fam):
+    """rbox_device.h part 2 + eval_iou on the host vs tests/golden/riou_eval.npz (from the reference's own affinity.cpp),
+    same tolerance as the GPU test."""
+    g = np.load(os.path.join(HERE, 'golden', 'riou_eval.npz'))
+    det = np.ascontiguousarray(g[fam + '.det'], np.float32); gt = np.ascontiguousarray(g[fam + '.gt'], np.float32)
+    for key, is3d, zo in (('iou_bev', 0, 0.5), ('iou_3d', 1, 0.5), ('iou_3d_z0', 1, 0.0)):
+        out = np.empty((len(det), len(gt)), np.float32)
+        rboxmath.hostmath_eval_iou(_vp(det), ctypes.c_long(len(det)), _vp(gt), ctypes.c_long(len(gt)), ctypes.c_int(is3d),
+                                   ctypes.c_float(zo), _vp(out))
+        np.testing.assert_allclose(out, g[f'{fam}.{key}'], atol=1e-5, rtol=0)
