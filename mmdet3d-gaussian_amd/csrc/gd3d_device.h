@@ -374,12 +374,22 @@ GD_DEV float sym(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Ad
     f1 = 0.0f;
     f2 = 1.0f;
   }
-  if (v1 != v1 || v2 != v2) {
+  const bool poisoned = (v1 != v1) || (v2 != v2);
+  if (poisoned) {
     m = v1 + v2;
     f1 = f2 = 0.0f;
   }
   float dpost;
   const float out = post<FUN>(m, tau, dpost);
+  if (poisoned) {
+    // torch.maximum / minimum backward: where(a == b, g/2, g).masked_fill(a < b, 0) — with a NaN operand neither mask
+    // is set, so BOTH inputs receive the upstream gradient, which is NaN here (postprocess of a NaN): every gradient
+    // entry of the row is NaN in the reference, not 0
+    const float qn = m * 0.0f;   // NaN
+    gp.gX = gp.gY = gp.gZ = gp.ga = gp.gb = gp.ge = gp.gr = qn;
+    gt = gp;
+    return out;
+  }
   adj_zero(gp);
   adj_zero(gt);
   // a zero factor must contribute exactly 0 (not 0 * inf): branch instead of multiply

@@ -164,3 +164,16 @@ def check_nonfinite(name, got, r32, r64):
     bound[NONFINITE_IDENT_ROW] = max(bound[NONFINITE_IDENT_ROW], 1e-3)
     bad = fin & (np.abs(got - r64) > bound)
     assert not bad.any(), (name, np.flatnonzero(bad), got[bad], r64[bad], bound[bad])
+
+
+def check_nonfinite_grad_rows(name, grad, nanrow32, nanrow64):
+    """A pair's gradient row contains a NaN exactly when the reference's does — on the rows where the reference's fp32
+    and fp64 agree about that (an overflowing centre and the identical pair are precision-dependent in the reference
+    itself).  The element pattern INSIDE such a row is an artefact of the reference's autograd graph (clamp masks zero
+    the upstream NaN, later products with NaN operands revive some entries) and is not part of the contract."""
+    got = np.isnan(np.asarray(grad)).any(1)
+    agree = np.asarray(nanrow32) == np.asarray(nanrow64)
+    # the identical pair sits ON the sqrt-at-zero singularity: the reference lands on 0, a finite value or NaN depending on
+    # the sign of its own rounding noise (gwd3d here: fp32 finite, fp64 zero); the closed forms land on exactly 0 -> NaN
+    agree[NONFINITE_IDENT_ROW] = False
+    assert np.array_equal(got[agree], np.asarray(nanrow32)[agree]), (name, np.flatnonzero(agree & (got != nanrow32)))

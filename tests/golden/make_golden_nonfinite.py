@@ -6,7 +6,7 @@
 24 KITTI-range pairs; rows 0-6: NaN in column k of pred; rows 7-13: +inf in column k; then zero / negative / huge /
 tiny dims, a yaw of 1e6, a centre at 1e20, -inf in a dim, and one identical pair.  For the 7 loss types (log1p, tau 1;
 kfiou3d: fun none) the reference's per-pair loss in fp32 and fp64 is stored: values where finite, and the NaN / inf
-pattern.  Only data is written."""
+pattern; and, per pair, whether its gradient row (wrt pred / wrt target) contains a NaN.  Only data is written."""
 import os
 import sys
 
@@ -52,8 +52,16 @@ def main():
     with np.errstate(all='ignore'):
         for lt, kw in CASES:
             m = ref.GDLoss(lt, reduction='none', loss_weight=1.0, **kw)
-            out[f'{lt}.loss32'] = m(torch.from_numpy(p), torch.from_numpy(t)).numpy()
-            out[f'{lt}.loss64'] = m(torch.from_numpy(p).double(), torch.from_numpy(t).double()).numpy()
+            for dt, tag in ((torch.float32, '32'), (torch.float64, '64')):
+                pp = torch.from_numpy(p).to(dt).requires_grad_(True)
+                tt = torch.from_numpy(t).to(dt).requires_grad_(True)
+                loss = m(pp, tt)
+                loss.sum().backward()
+                out[f'{lt}.loss{tag}'] = loss.detach().numpy()
+                # which gradient ROWS contain a NaN (the element pattern inside a row is an artefact of the autograd graph:
+                # clamp masks turn the upstream NaN into 0, later multiplications by NaN operands turn some 0s back)
+                out[f'{lt}.gp_nanrow{tag}'] = np.isnan(pp.grad.numpy()).any(1)
+                out[f'{lt}.gt_nanrow{tag}'] = np.isnan(tt.grad.numpy()).any(1)
     np.savez_compressed(os.path.join(HERE, 'gd_nonfinite.npz'), **out)
     for lt, _ in CASES:
         print(lt, ''.join('N' if np.isnan(x) else ('I' if np.isinf(x) else '.') for x in out[f'{lt}.loss32']))

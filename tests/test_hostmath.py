@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from gd_golden import (NOISY_FAMILIES, NONFINITE_CASES, check_close, check_nonfinite, families, grad_bound, index,
+from gd_golden import (NOISY_FAMILIES, NONFINITE_CASES, check_close, check_nonfinite, check_nonfinite_grad_rows, families, grad_bound, index,
                        loss_bound, nonfinite, pair_case_names, pairs)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,8 +79,10 @@ def test_device_math_on_host_nonfinite_and_degenerate_rows(hostmath):
     (sqrt(inf) and log1p(inf) are inf, not inf * 0); a yaw of 1e6 goes through the two-angle path of gwd3d."""
     gold = nonfinite()
     for lt, kw in NONFINITE_CASES:
-        loss, _, _ = _run(hostmath, lt, kw, gold['pred'], gold['target'])
+        loss, gp, gt = _run(hostmath, lt, kw, gold['pred'], gold['target'])
         check_nonfinite(lt, loss, gold[f'{lt}.loss32'], gold[f'{lt}.loss64'])
+        check_nonfinite_grad_rows(lt + '.gp', gp, gold[f'{lt}.gp_nanrow32'], gold[f'{lt}.gp_nanrow64'])
+        check_nonfinite_grad_rows(lt + '.gt', gt, gold[f'{lt}.gt_nanrow32'], gold[f'{lt}.gt_nanrow64'])
 
 
 def test_device_math_large_yaws_keep_the_reference_accuracy(hostmath):
