@@ -35,22 +35,11 @@ def refrun(lt, kw, p, t, dt):
     with np.errstate(all='ignore'):
         l=ref.GDLoss(lt, reduction='none', loss_weight=1.0, **kw)(pp,tt); l.sum().backward()
     return l.detach().numpy().astype(np.float64), pp.grad.numpy().astype(np.float64)
-rng=np.random.default_rng(0)
+from gd_stress import FAMILIES, stress_pairs
 def gen(n, kind):
-    t=np.stack([rng.uniform(0,70,n),rng.uniform(-40,40,n),rng.uniform(-3,1,n),rng.uniform(0.5,2.5,n),rng.uniform(0.5,4.5,n),rng.uniform(0.5,2,n),rng.uniform(-3.14,3.14,n)],-1)
-    p=t+rng.normal(0,1,(n,7))*np.array([0.3,0.3,0.1,0.1,0.1,0.1,0.1])
-    if kind=='hugedim': p[:,3:6]*=10**rng.uniform(0,3,(n,3)); t[:,3:6]*=10**rng.uniform(0,3,(n,3))   # boxes up to kilometres
-    if kind=='tinydim': p[:,3:6]*=10**rng.uniform(-9,0,(n,3)); t[:,3:6]*=10**rng.uniform(-9,0,(n,3))
-    if kind=='aspect': p[:,3]*=1e3; t[:,4]*=1e3
-    if kind=='farcentre': off=10**rng.uniform(2,6,(n,1)); p[:,:3]+=off; t[:,:3]+=off
-    if kind=='fardist': p[:,:3]+=10**rng.uniform(1,8,(n,3))
-    if kind=='bigyaw': p[:,6]+=rng.uniform(-300,300,n); t[:,6]+=rng.uniform(-300,300,n)
-    if kind=='negdim': p[::3,3:6]*=-1; t[::5,4]*=-1
-    if kind=='yaw90': t[:,6]=p[:,6]+np.pi/2*rng.integers(-2,3,n)+rng.normal(0,1e-4,n)
-    if kind=='square': p[:,4]=p[:,3]; t[:,4]=t[:,3]*(1+rng.normal(0,1e-6,n))
-    return p.astype(np.float32), t.astype(np.float32)
+    return stress_pairs(n, kind, seed=0)
 cases=[(lt,dict(fun=f,tau=tau)) for lt in ('gwd3d','kld3d','bd3d','jd3d','kld3d_symmax','kld3d_symmin') for f,tau in (('log1p',1.0),('none',0.0),('log1p',0.0))]+[('kfiou3d',dict(fun=f)) for f in ('none','expm1','nlog')]
-for kind in ('hugedim','tinydim','aspect','farcentre','fardist','bigyaw','negdim','yaw90','square'):
+for kind in FAMILIES:
     p,t=gen(512,kind)
     for lt,kw in cases:
         l,gp=host(lt,kw,p,t)

@@ -172,3 +172,23 @@ def test_eval_iou_math_on_host_against_reference_golden(rboxmath, fam):
         rboxmath.hostmath_eval_iou(_vp(det), ctypes.c_long(len(det)), _vp(gt), ctypes.c_long(len(gt)), ctypes.c_int(is3d),
                                    ctypes.c_float(zo), _vp(out))
         np.testing.assert_allclose(out, g[f'{fam}.{key}'], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize('kind', __import__('gd_stress').FAMILIES)
+def test_device_math_on_host_stress_families(hostmath, kind):
+    """tests/gd_stress.py families through the host build of the kernel math vs the fp64 oracle (same policy as the GPU
+    test test_stress_families_against_fp64_oracle)."""
+    import oracle
+    from gd_golden import oracle32_bounds
+    from gd_stress import ILL_CONDITIONED, stress_pairs
+    p, t = stress_pairs(1024, kind, seed=1)
+    noisy = kind in ILL_CONDITIONED
+    for lt in ('gwd3d', 'kld3d', 'bd3d', 'jd3d', 'kld3d_symmax', 'kld3d_symmin', 'kfiou3d'):
+        for fun, tau in ((('none', 0.0), ('expm1', 0.0)) if lt == 'kfiou3d' else (('log1p', 1.0), ('none', 0.0))):
+            prm = oracle.make_params(lt, fun=fun, tau=tau)
+            with np.errstate(all='ignore'):
+                ref = oracle.gd_loss(p, t, prm, scale=1.0)
+                lb, gb = oracle32_bounds(p, t, prm, ref, 1.0)
+            loss, gp, _ = _run(hostmath, lt, dict(fun=fun, tau=tau), p, t)
+            check_close(f'{kind}.{lt}.{fun}.loss', loss, ref['loss'], lb, noisy)
+            check_close(f'{kind}.{lt}.{fun}.gp', gp, ref['grad_pred'], gb, noisy)
