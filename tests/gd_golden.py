@@ -177,3 +177,37 @@ def check_nonfinite_grad_rows(name, grad, nanrow32, nanrow64):
     # the sign of its own rounding noise (gwd3d here: fp32 finite, fp64 zero); the closed forms land on exactly 0 -> NaN
     agree[NONFINITE_IDENT_ROW] = False
     assert np.array_equal(got[agree], np.asarray(nanrow32)[agree]), (name, np.flatnonzero(agree & (got != nanrow32)))
+
+
+# ---------------------------------------------------------------- extreme raw head outputs (coder_center_extreme.npz)
+EXTREME_CASES = (('gwd3d', dict(fun='log1p', tau=0.0)), ('bd3d', dict(fun='log1p', tau=1.0)),
+                 ('kld3d', dict(fun='none', tau=0.0)), ('kld3d_symmax', dict(fun='log1p', tau=1.0)))
+
+
+def coder_extreme():
+    return dict(np.load(os.path.join(GOLD, 'coder_center_extreme.npz')))
+
+
+def _category(a):
+    a = np.asarray(a, np.float64)
+    return np.where(np.isnan(a), 2, np.where(np.isinf(a), np.sign(a), 0))      # 0 finite, +-1 inf, 2 NaN
+
+
+def check_extreme(name, loss, gradrow_nan, gold, lt):
+    """Per object: NaN / +-inf / finite as the reference (where its fp32 and fp64 disagree — an fp32 overflow — either is
+    accepted), finite values within the per-row fp32 yardstick, and the gradient row contains a NaN iff the reference's
+    does (again only where its two precisions agree)."""
+    r32, r64 = gold[f'{lt}.loss32'], gold[f'{lt}.loss64']
+    c, c32, c64 = _category(loss), _category(r32), _category(r64)
+    ok = (c == c32) | (c == c64)
+    assert ok.all(), (name, np.flatnonzero(~ok), c[~ok], c32[~ok], c64[~ok])
+    fin = (c == 0) & (c64 == 0) & (c32 == 0)
+    with np.errstate(all='ignore'):
+        sc = 1 + np.abs(r64)
+        bound = (LOSS_TOL + YARD * np.abs(r32.astype(np.float64) - r64) / sc) * sc
+        bad = fin & (np.abs(np.asarray(loss, np.float64) - r64) > bound)
+    assert not bad.any(), (name, np.flatnonzero(bad), np.asarray(loss)[bad], r64[bad], bound[bad])
+    n32, n64 = gold[f'{lt}.gp_nanrow32'], gold[f'{lt}.gp_nanrow64']
+    agree = n32 == n64
+    got = np.asarray(gradrow_nan)
+    assert np.array_equal(got[agree], n32[agree]), (name, np.flatnonzero(agree & (got != n32)))

@@ -41,6 +41,27 @@ def test_center_head_gd_loss_vs_reference_golden(amd, lt, kw):
     assert np.abs(got[:, 7:]).max() == 0.0
 
 
+def test_center_head_gd_loss_on_extreme_head_outputs_vs_reference_golden(amd):
+    """tests/golden/coder_center_extreme.npz (real reference coder.decode + GDLoss, reduction 'none'): raw head outputs
+    far outside the trained regime — log-dims of +-20, +89 (exp overflows), -104 (underflows to the 1e-7 clamp), NaN / inf
+    entries, cell offsets of 1e4 / 1e30, yaws of 1e4.  The fused decode + loss gives NaN / inf / finite per object as the
+    reference does, finite values within the per-row yardstick, NaN gradient rows where the reference has them."""
+    from gd_golden import EXTREME_CASES, check_extreme, coder_extreme
+    g = coder_extreme()
+    coder = amd.CenterPointBBoxYawCoder(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
+                                        voxel_size=g['cfg_voxel_size'].tolist(), norm_bbox=True)
+    B, K = g['locs'].shape[:2]
+    pos_ind = torch.cat([torch.arange(B).reshape(B, 1, 1).expand(B, K, 1), torch.from_numpy(g['locs'])], -1).cuda()
+    anno = torch.from_numpy(g['anno']).cuda()
+    for lt, kw in EXTREME_CASES:
+        pred = torch.from_numpy(g['pred']).cuda().requires_grad_(True)
+        mod = amd.GDLoss(lt, loss_weight=1.0, reduction='none', **kw)
+        loss = amd.center_head_gd_loss(mod, coder, pos_ind, pred, anno, num_pos=1.0)
+        loss.sum().backward()
+        grow = torch.isnan(pred.grad.reshape(-1, 11)).any(1).cpu().numpy()
+        check_extreme(lt, loss.detach().cpu().numpy(), grow, g, lt)
+
+
 @pytest.mark.parametrize('lt', ['gwd3d', 'kld3d', 'bd3d'])
 @pytest.mark.parametrize('P', [1, 300, 5000])
 def test_anchor_decoded_loss_vs_oracle(amd, lt, P):
