@@ -358,6 +358,43 @@ def test_center_head_losses_all_tasks_one_launch(amd, lt, kw, vel, reg):
     assert torch.isnan(o2[0][0]) and torch.isnan(o2[0][1]) and torch.isfinite(o2[2][1])
 
 
+def test_center_head_losses_on_extreme_head_outputs_vs_reference_golden(amd):
+    """The all-task kernel pair (head_center_kernel + center_accum_kernel) on the objects of coder_center_extreme.npz, ONE
+    object per task (8 tasks per call) so that a task's loss_gd IS that object's loss: NaN / inf / finite and gradient NaN
+    rows as the real reference, values per row."""
+    from gd_golden import EXTREME_CASES, check_extreme, coder_extreme
+    g = coder_extreme()
+    coder = amd.CenterPointBBoxYawCoder(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
+                                        voxel_size=g['cfg_voxel_size'].tolist(), norm_bbox=True)
+    pred = torch.from_numpy(g['pred']).reshape(-1, 11); anno = torch.from_numpy(g['anno']).reshape(-1, 9)
+    locs = torch.from_numpy(g['locs']).reshape(-1, 2)
+    heads = (('reg', 0, 2), ('height', 2, 3), ('dim', 3, 6), ('yaw', 6, 7), ('dir', 7, 9), ('vel', 9, 11))
+    n = pred.shape[0]
+    for lt, kw in EXTREME_CASES:
+        mod = amd.GDLoss(lt, loss_weight=1.0, **kw)
+        loss = np.zeros(n); grow = np.zeros(n, bool)
+        for c0 in range(0, n, 8):
+            idx = list(range(c0, min(c0 + 8, n)))
+            tasks, pis, ans = [], [], []
+            for i in idx:
+                x, y = int(locs[i, 0]), int(locs[i, 1])
+                d = {}
+                for name, a, b in heads:
+                    m = torch.zeros(1, b - a, 128, 128)
+                    m[0, :, y, x] = pred[i, a:b]
+                    d[name] = m.cuda().requires_grad_(True)
+                tasks.append(d); pis.append(torch.tensor([[0, x, y]]).cuda()); ans.append(anno[i:i + 1].cuda())
+            out = amd.center_head_losses(mod, dict(type='L1Loss', reduction='mean', loss_weight=0.25), coder, tasks, pis, ans,
+                                         [1] * len(idx), [1.0, 1.0, 0.2, 0.2])
+            # loss_l1 only sees the dir / vel channels: it cannot mask a NaN of the GD part
+            torch.stack([o[1] for o in out]).nan_to_num(0.0, 0.0, 0.0).sum().backward()
+            for t, i in enumerate(idx):
+                x, y = int(locs[i, 0]), int(locs[i, 1])
+                loss[i] = out[t][1].item()
+                grow[i] = any(bool(torch.isnan(tasks[t][k].grad[0, :, y, x]).any()) for k in ('reg', 'height', 'dim', 'yaw'))
+        check_extreme(lt, loss, grow, g, lt)
+
+
 def test_device_center_coder_vs_reference_golden_and_autograd(amd):
     """CenterPointBBoxYawCoder on the device (csrc/coders.hip): decode with and without correct_yaw and encode against
     the outputs of the REAL reference classes (tests/golden/coder_center.npz; exp / sincos / atan2 differ from the CPU's
