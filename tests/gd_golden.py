@@ -211,3 +211,11 @@ def check_extreme(name, loss, gradrow_nan, gold, lt):
     agree = n32 == n64
     got = np.asarray(gradrow_nan)
     assert np.array_equal(got[agree], n32[agree]), (name, np.flatnonzero(agree & (got != n32)))
+
+
+ANCHOR_EXTREME_CASES = (('gwd3d', dict(fun='log1p', tau=1.0)), ('kld3d', dict(fun='log1p', tau=0.0)),
+                        ('bd3d', dict(fun='log1p', tau=1.0)), ('kld3d_symmin', dict(fun='none', tau=0.0)))
+
+
+def anchor_extreme():
+    return dict(np.load(os.path.join(GOLD, 'anchor_extreme.npz')))

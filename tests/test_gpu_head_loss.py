@@ -88,6 +88,22 @@ def test_anchor_decoded_loss_vs_oracle(amd, lt, P):
     check_close(f'{lt}.{P}.gp', p.grad.cpu().numpy(), ref['grad_pred'], grad_bound(ref['grad_pred'], r32['grad_pred']))
 
 
+def test_anchor_decoded_loss_on_extreme_encodings_vs_reference_golden(amd):
+    """tests/golden/anchor_extreme.npz (DeltaXYZWLHR decode restated in torch + the REAL reference GDLoss, reduction
+    'none'): encodings with size deltas of +-20 / +89 (exp overflows) / -104 (underflows to the clamp), NaN / inf, centre
+    deltas of 1e4 / 1e30, yaw deltas of 1e4, in pred, in target or in both.  The fused decode + loss gives NaN / inf /
+    finite per positive as the reference does, finite values per row, NaN gradient rows where the reference has them."""
+    from gd_golden import ANCHOR_EXTREME_CASES, anchor_extreme, check_extreme
+    g = anchor_extreme()
+    an = torch.from_numpy(g['anchors']).cuda(); t = torch.from_numpy(g['target']).cuda()
+    for lt, kw in ANCHOR_EXTREME_CASES:
+        p = torch.from_numpy(g['pred']).cuda().requires_grad_(True)
+        mod = amd.GDLoss(lt, loss_weight=1.0, reduction='none', **kw)
+        loss = amd.anchor_decoded_gd_loss(mod, an, p, t)
+        loss.sum().backward()
+        check_extreme(lt, loss.detach().cpu().numpy(), torch.isnan(p.grad).any(1).cpu().numpy(), g, lt)
+
+
 def test_anchor_head_slice_end_to_end(amd):
     """gd_anchor3d_head.py:95-141 from raw head tensors: permute/reshape, positive gather, decode_weight, fused loss;
     compared with the same slice assembled from the torch coder mirror + the plain (unfused) GDLoss."""
