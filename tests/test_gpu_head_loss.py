@@ -104,6 +104,35 @@ def test_anchor_decoded_loss_on_extreme_encodings_vs_reference_golden(amd):
         check_extreme(lt, loss.detach().cpu().numpy(), torch.isnan(p.grad).any(1).cpu().numpy(), g, lt)
 
 
+@pytest.mark.parametrize('dense', [True, False])
+def test_anchor_head_gather_fused_on_extreme_encodings_vs_reference_golden(amd, dense):
+    """The gather-fused anchor-head kernel (its own decode path: head_anchor_kernel) on anchor_extreme.npz: the 48 rows are
+    the 48 anchors of one 8 x 6 sample and exactly ONE of them is positive per call, so the reduced loss IS that positive's
+    loss (loss_weight 1, num_total_samples 1, weights 1)."""
+    from gd_golden import ANCHOR_EXTREME_CASES, anchor_extreme, check_extreme
+    g = anchor_extreme()
+    P, H, W, C = 48, 8, 6, 3
+    anchors = torch.from_numpy(g['anchors']).cuda()
+    targets = torch.from_numpy(g['target']).cuda().reshape(1, P, 7)
+    weights = torch.ones(1, P, 7).cuda()
+    pred_nchw = torch.from_numpy(g['pred']).reshape(H, W, 7).permute(2, 0, 1).reshape(1, 7, H, W).contiguous()
+    for lt, kw in ANCHOR_EXTREME_CASES:
+        mod = amd.GDLoss(lt, loss_weight=1.0, reduction='mean', **kw)
+        loss = np.zeros(P); grow = np.zeros(P, bool)
+        for i in range(P):
+            bp = pred_nchw.cuda().requires_grad_(True)
+            labels = torch.full((1, P), C, dtype=torch.long).cuda()
+            labels[0, i] = 1
+            out = amd.anchor_head_decoded_loss_fused(mod, bp, targets, weights, labels, anchors, C, 1.0, [1.0] * 7, dense=dense)
+            out.nan_to_num(0.0, 0.0, 0.0).backward()
+            loss[i] = out.item()
+            gi = bp.grad.reshape(7, H * W)[:, i]
+            grow[i] = bool(torch.isnan(gi).any())
+            others = torch.cat([bp.grad.reshape(7, H * W)[:, :i], bp.grad.reshape(7, H * W)[:, i + 1:]], 1)
+            assert bool((others == 0).all())                    # the negatives' gradient stays exactly zero
+        check_extreme(f'{lt}.dense{int(dense)}', loss, grow, g, lt)
+
+
 def test_anchor_head_slice_end_to_end(amd):
     """gd_anchor3d_head.py:95-141 from raw head tensors: permute/reshape, positive gather, decode_weight, fused loss;
     compared with the same slice assembled from the torch coder mirror + the plain (unfused) GDLoss."""
