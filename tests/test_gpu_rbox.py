@@ -524,3 +524,16 @@ def test_nms_at_the_maximum_size_closed_form(amd):
     assert np.array_equal(got_r, want_r)
     far = np.array([[498.5, 19.0, 501.5, 21.0, 0.0]], np.float32)
     assert oracle.iou_bev_xyxyr(far, far)[0, 0] == 0.0 and float(amd.boxes_iou_bev(torch.from_numpy(far).cuda(), torch.from_numpy(far).cuda())[0, 0]) == 0.0
+
+
+@pytest.mark.parametrize('n', [300, 5000, 20000])
+def test_nms_nan_and_infinite_scores_order_as_torch_sort(amd, n):
+    """mmdet3d's nms_gpu orders with `scores.sort(0, descending=True)`: NaN first, then +inf ... -inf.  The library's own
+    score ordering (n <= 16 384) and the torch.sort path above it do the same (stable among equals)."""
+    b, s = nms_boxes(n, seed=4)
+    s[::37] = np.nan; s[5] = np.inf; s[9] = -np.inf
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    order = torch.sort(st, descending=True, stable=True)[1].cpu().numpy()
+    want = order[oracle.nms_bev(b[order], 0.3)]
+    got = amd.nms_gpu(bt, st, 0.3).cpu().numpy()
+    assert np.array_equal(got, want)
