@@ -397,7 +397,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
                          'traffic_source': 'static: PMC passes of an earlier run of this command (profiles/traffic.json, '
-                                           'profiles/r02_pmc_summary.txt); not re-measured in this run',
+                                           'profiles/r02f_pmc_summary.txt); not re-measured in this run',
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
                          # what the kernel really moves under reduction=mean|sum (no per-pair loss store): 84 B/pair
                          'moved_bytes_per_pair': MOVED_BYTES_PER_PAIR, 'achieved_moved_GBps': round(moved, 1),
