@@ -64,6 +64,9 @@ def main():
            'cfg_pc_range': np.array(cfg['pc_range'], np.float64), 'cfg_voxel_size': np.array(cfg['voxel_size'], np.float64),
            'cfg_out_size_factor': np.array(cfg['out_size_factor'])}
     with np.errstate(all='ignore'):
+        # the coder on its own (inference path, gd_centerpoint_head.py:244): decode with and without correct_yaw, fp32
+        out['decode_noyaw32'] = coder.decode(locs, pred, correct_yaw=False).numpy()
+        out['decode_yaw32'] = coder.decode(locs, pred, correct_yaw=True).numpy()
         for lt, kw in CASES:
             for dtype, tag in ((torch.float32, '32'), (torch.float64, '64')):
                 p = pred.to(dtype).clone().requires_grad_(True)

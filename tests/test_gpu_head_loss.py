@@ -440,6 +440,31 @@ def test_center_head_losses_on_extreme_head_outputs_vs_reference_golden(amd):
         check_extreme(lt, loss, grow, g, lt)
 
 
+def test_device_center_coder_on_extreme_head_outputs_vs_reference_golden(amd):
+    """The device coder (csrc/coders.hip) on coder_center_extreme.npz: decode outputs of the REAL reference coder for raw
+    head outputs with exp overflow / underflow, NaN / inf and far offsets, with and without correct_yaw.  Element by element:
+    NaN / +-inf / finite as the reference, finite values to 2e-6 relative (a yaw of 1e4 to one ulp of 1e4), the quarter-turn
+    swap decided the same way on every row where the reference's own decision is not at a rounding boundary."""
+    from gd_golden import _category, coder_extreme
+    g = coder_extreme()
+    coder = amd.CenterPointBBoxYawCoder(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
+                                        voxel_size=g['cfg_voxel_size'].tolist(), norm_bbox=True, code_size=9)
+    locs, pred = torch.from_numpy(g['locs']).cuda(), torch.from_numpy(g['pred']).cuda()
+    p = g['pred'][0]
+    with np.errstate(all='ignore'):
+        frac = (np.arctan2(p[:, 7], p[:, 8]) - p[:, 6]) / (np.pi / 2) + 0.5
+        safe = ~(np.abs(frac - np.round(frac)) <= 1e-3) | ~np.isfinite(frac)     # NaN / inf rows have no decision to miss
+        safe &= ~(np.abs(p[:, 6]) > 1e3)                                          # yaw 1e4: k is ~6366, one ulp of yaw decides
+    for cy, key in ((False, 'decode_noyaw32'), (True, 'decode_yaw32')):
+        got = coder.decode(locs, pred, correct_yaw=cy).cpu().numpy()[0]
+        want = g[key][0]
+        rows = np.ones(len(p), bool) if not cy else safe
+        assert np.array_equal(_category(got[rows]), _category(want[rows])), key
+        fin = np.isfinite(want) & rows[:, None]
+        np.testing.assert_allclose(got[fin], want[fin], rtol=2e-6, atol=2e-6)
+    assert (~safe).sum() <= 2
+
+
 def test_device_center_coder_vs_reference_golden_and_autograd(amd):
     """CenterPointBBoxYawCoder on the device (csrc/coders.hip): decode with and without correct_yaw and encode against
     the outputs of the REAL reference classes (tests/golden/coder_center.npz; exp / sincos / atan2 differ from the CPU's
