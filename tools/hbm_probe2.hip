@@ -53,13 +53,16 @@ __global__ __launch_bounds__(256) void tile(const float* __restrict__ a, const f
 #pragma unroll
       for (int k = 0; k < 7; ++k) r[k] = __builtin_fmaf(r[k], 1.0000001f, 1e-9f);
     }
-  } else {   // one dependent chain of (-VALU % 1000) FMAs per thread; below -1000: every 13th step is a v_rcp_f32
+  } else {   // one dependent chain of (-VALU % 1000) FMAs per thread; below -1000: every 13th step is a v_rcp_f32;
+             // below -2000: a non-VALU issue slot (s_nop) after 4 of every 5 steps as well — the real kernels spend 43 % of
+             // their issue slots on scalar work, branches and waits (profiles/r02_pmc_issue_mix_by_cap.txt)
     const int len = (-VALU) % 1000;
     float x = r[0];
 #pragma unroll
     for (int it = 0; it < len; ++it) {
       x = __builtin_fmaf(x, 1.0000001f, r[1 + it % 6]);
       if (VALU < -1000 && it % 13 == 12) x = __builtin_amdgcn_rcpf(x);
+      if (VALU < -2000 && it % 5 != 4) asm volatile("s_nop 0");
     }
     r[0] = x;
   }
@@ -193,6 +196,7 @@ int main() {
     snprintf(nm, 96, "tile448 valu=64x7 indep   lds=%d", lds); run(nm, [&] { tile<true, 64><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
     snprintf(nm, 96, "tile448 270 dependent fma lds=%d", lds); run(nm, [&] { tile<true, -270><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
     snprintf(nm, 96, "tile448 270 dep, 20 rcp   lds=%d", lds); run(nm, [&] { tile<true, -1270><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
+    snprintf(nm, 96, "tile448 270 dep, 20 rcp, 216 s_nop lds=%d", lds); run(nm, [&] { tile<true, -2270><<<(unsigned)ntiles, 256, lds>>>((const float*)a, (const float*)b, (float*)c, ntiles); });
   }
   FLAT(1, 256);
   return 0;
