@@ -90,22 +90,31 @@ GD_DEV void store_v4(float* dst, const float* src_lds, int idx) {
   else reinterpret_cast<v4f*>(dst)[idx] = v;
 }
 
-// 14 LDS-DMA pieces of 1 KiB bring one 256-pair tile of pred and target into LDS; wave w issues
-// pieces w, w+4, w+8, w+12.
-// (an optional third tile, the (256,7) weights, adds pieces 14..20)
+// 14 LDS-DMA pieces of 1 KiB bring one 256-pair tile of pred and target into LDS; wave w issues pieces w, w+4, w+8, w+12.
+// The two tiles are adjacent in LDS (st = sp + TILE_F = sp + 7 pieces), so piece j of the 14 lands at sp + j * 256 and only
+// its SOURCE depends on which tensor it belongs to — a scalar select, no branch.  (Written as a loop over both tensors
+// with per-piece if / else-if, the compiler built a tree of ~60 scalar compares and branches in front of the first load:
+// issue slots on every workgroup's critical path, profiles/r02_pmc_issue_mix_by_cap.txt.)
+// (an optional third tile, the (256,7) weights, sits behind the wave sums and keeps its own loop)
 GD_DEV void issue_tile_dma(const float* gpred, const float* gtarget, float* sp, float* st, int wave, int lane,
                            const float* gw7, float* sw7) {
+  static_assert(TILE_F == NPIECE * 256, "pred and target tiles must be whole pieces for the adjacent-piece addressing");
+  (void)st;
+  const float* const t_shifted = gtarget - NPIECE * 256;   // so that piece j >= NPIECE reads target piece j - NPIECE
 #pragma unroll
-  for (int j0 = 0; j0 < 3 * NPIECE; j0 += NWAVE) {
-    const int j = j0 + wave;  // wave-uniform
-    if (j < NPIECE) {
-      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gpred + j * 256 + lane * 4), (lds_ptr_t*)(sp + j * 256), 16, 0, DMA_AUX);
-    } else if (j < 2 * NPIECE) {
-      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gtarget + (j - NPIECE) * 256 + lane * 4),
-                                       (lds_ptr_t*)(st + (j - NPIECE) * 256), 16, 0, DMA_AUX);
-    } else if (j < 3 * NPIECE && gw7 != nullptr) {
-      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gw7 + (j - 2 * NPIECE) * 256 + lane * 4),
-                                       (lds_ptr_t*)(sw7 + (j - 2 * NPIECE) * 256), 16, 0, DMA_AUX);
+  for (int k = 0; k * NWAVE < 2 * NPIECE; ++k) {
+    const int j = wave + k * NWAVE;  // wave-uniform
+    if ((k + 1) * NWAVE <= 2 * NPIECE || j < 2 * NPIECE) {   // only the last round needs the runtime test
+      const float* src = (j < NPIECE ? gpred : t_shifted) + j * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds((gbl_cptr_t*)src, (lds_ptr_t*)(sp + j * 256), 16, 0, DMA_AUX);
+    }
+  }
+  if (gw7 != nullptr) {
+#pragma unroll
+    for (int k = 0; k * NWAVE < NPIECE; ++k) {
+      const int j = wave + k * NWAVE;
+      if ((k + 1) * NWAVE <= NPIECE || j < NPIECE)
+        __builtin_amdgcn_global_load_lds((gbl_cptr_t*)(gw7 + j * 256 + lane * 4), (lds_ptr_t*)(sw7 + j * 256), 16, 0, DMA_AUX);
     }
   }
 }
@@ -198,8 +207,24 @@ GD_DEV float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int LOSS, int FUN, bool FLAG, bool GT>
-__global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a) {
+// PLAIN: the launcher has checked that none of the options is in use (no weights, no selection, no prologue, no per-pair
+// loss output, no single-launch finish); folding them to constants here removes their uniform tests and the kernarg loads
+// behind them from every wave's issue stream (profiles/r02_pmc_issue_mix_by_cap.txt: issue slots are what the streaming
+// launch has too many of).  Same code otherwise.
+template <int LOSS, int FUN, bool FLAG, bool GT, bool PLAIN = false>
+__global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a_in) {
+  LossArgs a = a_in;
+  if (PLAIN) {
+    a.w = nullptr;
+    a.w7 = nullptr;
+    a.wsel = 0;
+    a.pro = GD3D_PRO_NONE;
+    a.aux = nullptr;
+    a.loss = nullptr;
+    a.fin = nullptr;
+    a.fin_out = nullptr;
+    a.fin_any = nullptr;
+  }
   // dynamic LDS (16-byte aligned base, every carve offset a multiple of 16): two tiles + 32 floats of per-wave sums
   // (loss | pred*weight | any weight > 0), plus a third tile only when (N,7) weights are given, so that the common
   // launch keeps 8 workgroups per CU
@@ -947,15 +972,31 @@ static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
     lds = want > base ? want : base;
   }
 #endif
+  // The option-free instantiation, for calls that use none of the options — built and used for gwd3d only, without a
+  // target gradient.  Same buffers, 4 sets, us per 10 M pairs against the general instantiation (tools/variant_probe.py,
+  // profiles/r02_plain_and_dma_issue_ab.txt): gwd3d -2.5 -0.7 -1.8 -0.5 (issue units per wave 424 -> 340), but kld3d
+  // +1.0 +1.5 +1.2 +1.0 and bd3d +0.9 +0.7 +1.1 +1.9 at their cap of 6 workgroups per CU although their streams shrink
+  // as well (483 -> 415, 519 -> 433): with less to issue they keep more bytes in flight, which is what the cap exists to
+  // limit, and at 5 per CU they lose more than they gain on a fast box (133.0 vs 130.3 us).  gwd3d is the slowest of
+  // the three on fast boxes, i.e. the kernel roofline.frac is computed from.
+  const bool plain = LOSS == GD3D_GWD3D && !GT && a.w == nullptr && a.w7 == nullptr && !a.wsel && a.pro == GD3D_PRO_NONE &&
+                     a.loss == nullptr && a.fin == nullptr;
   if (g.ev_start != nullptr || g.ev_stop != nullptr) {
     // hipExtLaunchKernel binds the two events to the begin / end timestamps of this dispatch packet itself: no marker
     // packets enter the stream, and hipEventElapsedTime(start, stop) is the kernel's execution time as rocprofv3 reports
     // it (events recorded AROUND a launch add the ~3 us of two barrier packets to every bracket).
-    hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), (std::uint32_t)lds, s,
-                          g.ev_start, g.ev_stop, 0u, a);
+    if (plain)
+      hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, LOSS == GD3D_GWD3D>), dim3(g.tgrid), dim3(TILE),
+                            (std::uint32_t)lds, s, g.ev_start, g.ev_stop, 0u, a);
+    else
+      hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), (std::uint32_t)lds, s,
+                            g.ev_start, g.ev_stop, 0u, a);
     return;
   }
-  hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), lds, s, a);
+  if (plain)
+    hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, LOSS == GD3D_GWD3D>), dim3(g.tgrid), dim3(TILE), lds, s, a);
+  else
+    hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), lds, s, a);
 }
 
 template <int LOSS, int FUN>
