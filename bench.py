@@ -16,20 +16,28 @@ data-path collective; once per step the three per-shard loss values are all-gath
 asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs
 (`--strong`: 10 M pairs in TOTAL, contiguous row ranges per rank — SURVEY.md §8e asks for both).
 
-Launch mode.  N = 1 launches eagerly, so that every fused launch INSIDE the timed region carries its own HIP event pair
-(gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no marker packets):
-with one backward() per step the host needs 190-300 us per step against 440-460 us of GPU time (one backward per loss
-cost ~60 us of autograd-engine thread hand-off each and made the step host-bound on boxes with busy host cores).
+Launch mode.  N = 1 launches eagerly: every fused launch INSIDE the timed region then carries its own HIP event pair
+(gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no marker packets), and on
+one MI355X the eager step is the FASTER one: same process, same buffers, round 3 (profiles/r03_step_variants.jsonl):
+eager 423-427 us per step, hipGraph replay 430 us around 411 us of fused kernels; the host needs ~95 us per step.
+(Round 2's eager step cost 434-445 us: its backward added a ones-fill, two adds and three early-exit launches.)
 N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~20 us/step) so that the per-step collective call
-cannot make the host the limit; HIP events cannot be bound inside a captured graph on ROCm, so there the per-kernel
-durations come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says
-which), followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph`
-override; on one MI355X both modes give the same step time within 1 %.
+cannot make the host the limit with eight ranks sharing the host's cores; HIP events cannot be bound to a dispatch inside a
+captured graph on ROCm, so there the per-kernel durations come from an eager pass run right after the timed region, same
+stream, same process (`roofline.timing` says which), followed by a bracketed run of bare replays
+(`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph` override.
+The step: three GDLoss forwards, then ONE torch.autograd.backward over the three losses whose upstream gradients are the
+library's unit-gradient constant (gd_loss.unit_grad): backward then launches nothing, because the fused forward launch
+already wrote the final gradients (a plain `loss.backward()` costs a ones-fill plus one early-exit launch per loss).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(python -m torch.distributed.run, 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank failed.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
                  (88 B/pair) / average launch duration measured with a HIP event pair bound to
-                 every fused dispatch INSIDE the timed region, on the stream it is launched on.
+                 every fused dispatch, on the stream it is launched on.  `frac` is that kernel alone;
+                 `frac_step` prices the WHOLE timed step the same way (3 x 88 B x pairs / ms_per_step / peak:
+                 SURVEY.md §8d's protocol, reduce launches and the backward call included).
   cpu_baseline : the fp32 CPU oracle ("port") timed on this host's cores on a bounded sample.
 """
 import argparse
@@ -172,6 +180,59 @@ def torch_chain_baseline(sample_pairs, seed, cores):
     return res
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, visible, cmd=None, out=None, err=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched
+    the GPU and never replaces itself), relay rank 0's JSON line to stdout, everything else the children print to
+    stderr, and return their exit status (non-zero if any rank failed, or if no result line appeared).
+    Reference counterpart: /root/reference/tools/dist_train.sh:8-9."""
+    import subprocess
+    out = out or sys.stdout
+    err = err or sys.stderr
+    if visible < n:
+        print(f'bench.py: {n} GPUs requested, {visible} visible', file=err, flush=True)
+        return 2
+    cmd = cmd or launch_command(n, argv, free_port())
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on these hosts
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:
+        is_result = False
+        if line.lstrip().startswith('{'):
+            try:
+                is_result = 'metric' in json.loads(line)
+            except ValueError:
+                is_result = False
+        if is_result:
+            lines += 1
+            out.write(line)
+            out.flush()
+        else:
+            err.write(line)
+            err.flush()
+    rc = proc.wait()
+    if rc != 0:
+        print(f'bench.py: the {n}-rank job exited with status {rc}', file=err, flush=True)
+        return rc if 0 < rc < 256 else 1
+    if lines != 1:
+        print(f'bench.py: expected one result line from rank 0, saw {lines}', file=err, flush=True)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,14 +247,17 @@ def main():
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly, a HIP event pair bound to every fused dispatch in-region (default for N = 1)')
+    ap.add_argument('--sum-backward', action='store_true',
+                    help="round 2's step: (l0 + l1 + l2).backward() instead of one autograd.backward with unit gradients")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: be the launcher (device_count() does not initialise the GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], torch.cuda.device_count()))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
@@ -222,17 +286,23 @@ def main():
     events = {lt: [] for lt in LOSSES}
     last = {}
 
+    unit = [gdl.unit_grad(dev)] * len(LOSSES)
+
     def compute(record):
-        """gwd3d, kld3d, bd3d: GDLoss forward each, then autograd backward of their sum (every loss's fused kernel has
-        already produced its gradient; backward runs the three scale launches).  Returns the 3 detached loss scalars
-        (N > 1: stacked into the (3,) tensor the per-step collective sends — inside the captured graph)."""
+        """gwd3d, kld3d, bd3d: GDLoss forward each, then ONE autograd backward over the three losses (every loss's fused
+        kernel has already produced its gradient; with the library's unit gradient as upstream gradient backward launches
+        nothing).  Returns the 3 detached loss scalars (N > 1: stacked into the (3,) tensor the per-step collective
+        sends — inside the captured graph)."""
         losses_ = []
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if record else None
             preds[lt].grad = None
             losses_.append(mods[lt](preds[lt], tgt))
         gdl.PROFILE_EVENTS = None
-        (losses_[0] + losses_[1] + losses_[2]).backward()
+        if args.sum_backward:
+            (losses_[0] + losses_[1] + losses_[2]).backward()
+        else:
+            torch.autograd.backward(losses_, grad_tensors=unit)
         outs = [l.detach() for l in losses_]
         return torch.stack(outs) if use_dist else outs
 
@@ -315,8 +385,12 @@ def main():
               'begin/end timestamps of the dispatch itself, no marker packets)')
     replay_ms = None
     if graph is not None:  # events cannot be bound inside a captured graph on ROCm: eager pass right after
-        for _ in range(min(args.steps, 10)):
+        for it in range(25):
             compute(True)
+            if it == 4:   # the first passes re-warm the eager path (event creation, allocator); keep the last 20
+                torch.cuda.synchronize(dev)
+                for lt in LOSSES:
+                    events[lt].clear()
         torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -373,6 +447,7 @@ def main():
         dom = max(LOSSES, key=lambda k: kern_ms[k])          # slowest of the three fused kernels
         dom_s = kern_ms[dom] * 1e-3
         achieved = BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
+        step_gbps = BYTES_PER_PAIR * n * len(LOSSES) / (elapsed / args.steps) / 1e9   # per GPU: every rank runs n pairs x 3 losses a step
         moved = MOVED_BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
         ceiling = MOVED_BYTES_PER_PAIR * n / (probe_ms * 1e-3) / 1e9 if probe_ms else None
         traffic = None
@@ -392,15 +467,19 @@ def main():
                                     if args.strong else
                                     f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward over the whole batch '
-                                   '(one autograd backward() of the summed losses; fun=log1p, tau=1, reduction=mean, '
-                                   'loss_weight=5)',
+                                   + ('(one autograd backward() of the summed losses' if args.sum_backward else
+                                      '(one torch.autograd.backward over the three losses, upstream gradients = gd_loss.unit_grad')
+                                   + '; fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
                        'graph_replay_ms_per_step': round(replay_ms, 4) if replay_ms is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                         # the whole timed step priced like the kernel (reduce launches and backward included)
+                         'achieved_step': round(step_gbps, 1), 'frac_step': round(step_gbps / HBM_PEAK_GBPS, 4),
+                         'traffic': traffic,
                          'traffic_source': 'static: PMC passes of an earlier run of this command (profiles/traffic.json, '
                                            'profiles/r02f_pmc_summary.txt); not re-measured in this run',
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,

@@ -882,7 +882,10 @@ struct FinishArgs {
   float osf, vs0, vs1;
 };
 
-__global__ __launch_bounds__(1024) void grad_finish_kernel(const FinishArgs a) {
+constexpr int FINISH_T = 256;   // one wave per SIMD and CU on a 256-workgroup grid: the common case is the g == 1 early exit, whose cost
+constexpr int FINISH_U = 8;     // is the dispatch of the grid's waves (4096 waves: 4.4 us, 1024 waves: see profiles/r03); a real
+                                // scaling pass keeps FINISH_U 16-byte loads in flight per lane instead (32 KiB per CU)
+__global__ __launch_bounds__(FINISH_T) void grad_finish_kernel(const FinishArgs a) {
   const float gs = a.g[0];
   const bool normal = a.any_pos == nullptr || a.any_pos[0] != 0;
   if (normal && gs == 1.0f) return;  // uniform across the grid
@@ -896,7 +899,15 @@ __global__ __launch_bounds__(1024) void grad_finish_kernel(const FinishArgs a) {
       if (((uintptr_t)grad & 15) == 0) {
         v4f* g4 = reinterpret_cast<v4f*>(grad);
         const long long nv = nflt >> 2;
-        for (long long i = i0; i < nv; i += stride) g4[i] = g4[i] * gs;
+        for (long long i = i0; i < nv; i += FINISH_U * stride) {
+          v4f v[FINISH_U];
+#pragma unroll
+          for (int u = 0; u < FINISH_U; ++u)
+            if (i + u * stride < nv) v[u] = g4[i + u * stride];
+#pragma unroll
+          for (int u = 0; u < FINISH_U; ++u)
+            if (i + u * stride < nv) g4[i + u * stride] = v[u] * gs;
+        }
         for (long long i = (nv << 2) + i0; i < nflt; i += stride) grad[i] *= gs;
       } else {
         for (long long i = i0; i < nflt; i += stride) grad[i] *= gs;
@@ -1213,10 +1224,10 @@ int gd3d_grad_finish(float* grad_pred, float* grad_target, const float* g, int64
     if (a.pro != GD3D_PRO_NONE && pred == nullptr) return GD3D_E_BADARG;
     if (a.pro == GD3D_PRO_ANCHOR_DELTA && a.aux == nullptr) return GD3D_E_BADARG;
   }
-  // few, large workgroups: the common case is the g == 1 early exit, whose cost is the dispatch itself
-  long long blocks = ((long long)n * 7 + 1023) / 1024;
+  // few waves: the common case is the g == 1 early exit, whose cost is the dispatch itself
+  long long blocks = ((long long)n * 7 + 4 * FINISH_T - 1) / (4 * FINISH_T);
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)blocks), dim3(FINISH_T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -500,7 +500,12 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   const size_t cbs = (size_t)a.cbs;
   unsigned long long* gremv = windowed ? win.gremv + (size_t)g * cbs : nullptr;
   unsigned long long* gkept = windowed ? win.gkept + (size_t)g * cbs : nullptr;
-  if (windowed && c_begin >= cb_all) return;                    // uniform: this group ends before the super-block
+  if (windowed && c_begin >= cb_all) {                          // uniform: this group ends before the super-block
+    // an EMPTY group (cb_all == 0) never reaches a resolver: the first launch records its count here, as the
+    // single-level scan does (callers allocate num_keep uninitialised)
+    if (c_begin == 0 && threadIdx.x == 0) num_keep[g] = 0;
+    return;
+  }
   const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
   const unsigned long long* mask = mask_ + (size_t)g * a.cap * cbs;
   const unsigned long long* colm = colm_ + (size_t)g * a.cap;

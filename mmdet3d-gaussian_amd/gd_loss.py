@@ -15,6 +15,7 @@ from copy import deepcopy
 
 import torch
 from torch import nn
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from .registry import LOSSES, register_with_mmdet
@@ -55,6 +56,20 @@ class DispatchTimer:
             if h:
                 self._abi.gd3d_prof_event_destroy(h)
                 setattr(self, slot, None)
+
+
+def guard_double_backward(impl):
+    """The backward functions here return gradients that ctypes kernels wrote: no autograd graph hangs off them.  Under
+    `create_graph=True` (the only case in which grad mode is ON inside a backward) take torch's once_differentiable
+    route, which raises if that result is differentiated again instead of silently treating it as a constant; the plain
+    call otherwise, without the wrapper's per-call cost."""
+    guarded = once_differentiable(impl)
+
+    def backward(ctx, *grads):
+        if torch.is_grad_enabled():
+            return guarded(ctx, *grads)
+        return impl(ctx, *grads)
+    return backward
 
 
 def make_params(loss_type, fun, tau, alpha, center_offset, kwargs):
@@ -159,6 +174,32 @@ def _ws_floats(n):
     return k
 
 
+_UNIT_GRAD = {}
+
+
+def unit_grad(device):
+    """The upstream gradient 1.0 as a CONSTANT of this library: one read-only 0-dim fp32 tensor per device.
+
+    `loss.backward()` makes torch fill a fresh ones tensor (one launch) and our backward then has to READ it on the device
+    to learn that nothing needs scaling (one more launch, gd3d_grad_finish's early exit).  A training step that passes this
+    tensor instead -- `torch.autograd.backward([l0, l1, l2], grad_tensors=[unit_grad(dev)] * 3)` -- is recognised by
+    ADDRESS (no read, no sync): the gradients the fused forward launch wrote are already final and backward launches
+    nothing.  Never write to the returned tensor."""
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise RuntimeError('unit_grad: the MI355X implementation has no CPU path')
+    idx = dev.index if dev.index is not None else _get_device()
+    t = _UNIT_GRAD.get(idx)
+    if t is None:
+        t = _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=torch.device('cuda', idx))
+    return t
+
+
+def _is_unit_grad(g):
+    t = _UNIT_GRAD.get(g.device.index)
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0 and g.dtype == torch.float32
+
+
 def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None,
                select=False):
     """One launch of the fused kernel (+ its reduce stage) on the current stream of pred's device.
@@ -247,6 +288,7 @@ class _GDReduced(torch.autograd.Function):
         return total
 
     @staticmethod
+    @guard_double_backward
     def backward(ctx, grad_out):
         lib = _library()
         pred, target, row_weight, params, scale, prologue, select = ctx.replay
@@ -259,6 +301,9 @@ class _GDReduced(torch.autograd.Function):
             ctx.used = True
         if gp is None and gt is None:
             return (None,) * 8
+        if not select and _is_unit_grad(grad_out):
+            # the library's own constant 1.0 (unit_grad): known by address, nothing to read, nothing to scale
+            return gp, gt, None, None, None, None, None, None
         g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         dev = pred.device
         prev = _get_device()
@@ -291,6 +336,7 @@ class _GDPerPair(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @guard_double_backward
     def backward(ctx, grad_out):
         pred, target, row_weight, params, scale, prologue = ctx.replay
         rw = grad_out.reshape(-1).to(torch.float32)
@@ -337,8 +383,10 @@ class GDLoss(nn.Module):
             return make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset, _kwargs)
         # the attributes are plain and may be reassigned by the user: cheap identity / value key, rebuilt when it changes
         co = self.center_offset
-        key = (self.loss_type, self.fun, tau, self.alpha, id(co) if isinstance(co, torch.Tensor) else tuple(co),
-               id(self.kwargs), len(self.kwargs))
+        # (values, not identities: `loss.kwargs['sqrt'] = False` or an in-place write to a center_offset tensor must be
+        #  seen, as the reference re-reads both on every call, ref :293-299)
+        key = (self.loss_type, self.fun, tau, self.alpha,
+               (id(co), co._version) if isinstance(co, torch.Tensor) else tuple(co), tuple(self.kwargs.items()))
         cache = self._params_cache
         if cache is None or cache[0] != key:
             cache = self._params_cache = (key, make_params(self.loss_type, self.fun, tau, self.alpha, self.center_offset,

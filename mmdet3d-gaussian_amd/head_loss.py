@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .gd_loss import guard_double_backward
 
 
 def _prologue(kind, aux, norm_bbox=False, out_size_factor=1.0, voxel_size=(1.0, 1.0), pc_range=(0.0, 0.0)):
@@ -102,6 +103,7 @@ class _AnchorHeadFused(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @guard_double_backward
     def backward(ctx, grad_out):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved gradient was scaled in place (and may have become .grad): recompute
@@ -319,6 +321,7 @@ class _CenterHeadFused(torch.autograd.Function):
         return losses
 
     @staticmethod
+    @guard_double_backward
     def backward(ctx, grad_losses):
         lib = _lib.load()
         if ctx.used:  # retain_graph replay: the saved maps were scaled in place: recompute them

@@ -68,6 +68,40 @@ def test_batched_nms_ragged_groups_across_super_blocks(amd, mode):
     assert np.array_equal(got[1].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('mode', ['rot', 'normal'])
+def test_batched_nms_empty_group_beyond_the_single_level_size(amd, mode):
+    """with more than 8448 boxes per group the two-level scan runs, and a group WITHOUT any valid box never
+    reaches a resolver wave — its count must still come out 0 (the count buffer is allocated uninitialised).  Poison
+    the caching allocator first so that a stale count would be visible."""
+    n = 9500
+    boxes, _ = nms_boxes(n, seed=71, clutter=True)
+    rng = np.random.default_rng(3)
+    scores = rng.uniform(0, 1, (4, n)).astype(np.float32)
+    valid = np.ones((4, n), bool)
+    valid[1] = False                                   # empty group between two full ones
+    valid[3, rng.permutation(n)[:n - 100]] = False     # a small group, far below one super-block
+    b = torch.from_numpy(boxes).cuda(); s = torch.from_numpy(scores).cuda(); v = torch.from_numpy(valid).cuda()
+    normal = mode == 'normal'
+    single = amd.nms_normal_gpu if normal else (lambda bb, ss, t: amd.nms_gpu(bb, ss, t))
+    for _ in range(2):
+        junk = [torch.full((k,), 0x7f7f7f7f7f7f7f7f, dtype=torch.int64, device='cuda') for k in (4, 8, 64, 512, 4096)]
+        del junk
+        got = amd.nms_gpu_batched(b, s, 0.5, v, normal=normal)
+        assert got[1].numel() == 0
+        for g in (0, 2, 3):
+            assert torch.equal(got[g], v[g].nonzero().reshape(-1)[single(b[v[g]], s[g][v[g]], 0.5)]), g
+    # the same through the list form: an empty entry among entries above the single-level size
+    bl = [b, b[:0], b[:9000]]
+    sl = [s[0], s[0][:0], s[2][:9000]]
+    for _ in range(2):
+        junk = [torch.full((k,), 0x7f7f7f7f7f7f7f7f, dtype=torch.int64, device='cuda') for k in (4, 8, 64, 512, 4096)]
+        del junk
+        multi = amd.nms_gpu_multi(bl, sl, 0.5, normal=normal)
+        assert multi[1].numel() == 0
+        assert torch.equal(multi[0], single(bl[0], sl[0], 0.5))
+        assert torch.equal(multi[2], single(bl[2], sl[2], 0.5))
+
+
 def test_nms_randomised_sweep_bit_exact(amd):
     """40 seeded random problems (size, threshold, clutter, extent, pre/post cuts drawn at random): keep indices equal to
     the CPU oracle in every one — the mask compaction, the register clipping path, the score ranking and the scan are

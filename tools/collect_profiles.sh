@@ -4,7 +4,7 @@
 # kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
 # and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -38,6 +38,14 @@ python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_conf
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
 python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
-python3 -m pytest tests/test_gpu_gd_loss.py -m gpu -q -k 'pairs_against_reference_golden or config0' > $OUT/accuracy_pytest.log 2>&1; cp gpurun_out/r02_accuracy_report.txt $OUT/${R}_accuracy_report.txt 2>/dev/null
+# accuracy report of THIS build: the test module deletes any older file of that name before it runs and writes it only from
+# the rows it really compared; a failed or empty run leaves no report and is said so loudly
+rm -f $OUT/${R}_accuracy_report.txt
+GD3D_ACCURACY_REPORT=$PWD/$OUT/${R}_accuracy_report.txt python3 -m pytest tests/test_gpu_gd_loss.py -m gpu -q -k 'pairs_against_reference_golden or config0' > $OUT/accuracy_pytest.log 2>&1
+ACC_RC=$?
+if [ $ACC_RC -ne 0 ] || [ ! -s $OUT/${R}_accuracy_report.txt ]; then
+  echo "ACCURACY REPORT MISSING: pytest rc=$ACC_RC (see $OUT/accuracy_pytest.log)" | tee $OUT/${R}_accuracy_report.FAILED
+  rm -f $OUT/${R}_accuracy_report.txt
+fi
 python3 tools/profile_summary.py $OUT $R
 ls -la $OUT
