@@ -254,89 +254,171 @@ GD_DEV float gwd(const Box& p, const Box& t, float yaw_p, float yaw_t, float alp
   return out;
 }
 
-// ------------------------------------------------------------------ kld3d core (ref :109-137)
-struct KldI {
-  float iap, ibp, iep, iA, iB, iE, P11, P12, P22, dX, dY, dZ;
+// ------------------------------------------------------------------ shared pair geometry (kld / jd / sym / bd)
+// Everything below works in the frame of ONE box and in the yaw DIFFERENCE d = r_p - r_t, like gwd<> above: the
+// reference's covariance entries (R diag R^T, (N,2,2) bmm chains) only ever enter through rotation-invariant
+// combinations, and written in d and in differences of the extents those combinations have no cancellation left:
+// the reference's own fp32 loses 3-4 digits on near-identical boxes (1.5 - 1.5 + O(delta^2)), these forms do not.
+struct Geo {
+  float dX, dY, dZ;  // C_p - C_t (gravity centres)
+  float sd, cd;      // sin / cos of d = yaw_p - yaw_t
+  float sp, cp;      // sin / cos of yaw_p
 };
 
-GD_DEV float kld_fwd(const Box& p, const Box& t, float ia2, KldI& k) {
-  k.iap = frcp(p.a);
-  k.ibp = frcp(p.b);
-  k.iep = frcp(p.e);
-  k.iA = k.iap * k.iap;
-  k.iB = k.ibp * k.ibp;
-  k.iE = k.iep * k.iep;
-  rotdiag(k.iA, k.iB, p.co, p.si, k.P11, k.P12, k.P22);
-  k.dX = p.X - t.X;
-  k.dY = p.Y - t.Y;
-  k.dZ = p.Z - t.Z;
-  const float quad = fmaf(k.dX * k.dX, k.P11, fmaf(2.0f * k.dX * k.dY, k.P12, k.dY * k.dY * k.P22));
-  const float xyz = 0.5f * fmaf(k.dZ * k.dZ, k.iE, quad);
-  const float tr = fmaf(k.P11, t.S11, fmaf(2.0f * k.P12, t.S12, k.P22 * t.S22));
-  float whlr = 0.5f * fmaf(k.iE, t.e * t.e, tr);
-  // (ln ap + ln bp + ln ep) - (ln at + ln bt + ln et) as one log of a ratio would overflow for
-  // clamped dims; keep two logs of products (each product is within fp32 range: >= 1.25e-22)
-  const float lp = flog2(p.a * p.b * p.e);
-  const float lt = flog2(t.a * t.b * t.e);
-  whlr = fmaf(lp - lt, LN2, whlr) - 1.5f;
-  return fmaf(xyz, ia2, whlr);
+GD_DEV void geo_make(const Box& p, const Box& t, float yaw_p, float yaw_t, Geo& g) {
+  g.dX = p.X - t.X;
+  g.dY = p.Y - t.Y;
+  g.dZ = p.Z - t.Z;
+  if (__builtin_expect(!(fabsf(yaw_p) <= 16.0f && fabsf(yaw_t) <= 16.0f), 0)) {
+    // fl(yaw_p - yaw_t) is off by up to ulp(yaw)/2 (1e-6 rad at 16, 0.03 rad at 1e6): out there take the difference's sine
+    // and cosine from the two angles themselves, as the reference's per-box rotations do (cf. gwd<>)
+    float st, ct;
+    sincos_f(yaw_p, g.sp, g.cp);
+    sincos_f(yaw_t, st, ct);
+    g.sd = fmaf(g.sp, ct, -g.cp * st);
+    g.cd = fmaf(g.cp, ct, g.sp * st);
+  } else {
+    sincos_poly(yaw_p - yaw_t, g.sd, g.cd);   // exact difference when the yaws are close (Sterbenz)
+    sincos_poly(yaw_p, g.sp, g.cp);
+  }
 }
 
-// accumulates into gp (always) and gt (if GT) with upstream g
-template <bool GP, bool GT>
-GD_DEV void kld_bwd(const Box& p, const Box& t, float ia2, const KldI& k, float g, Adj& gp, Adj& gt) {
-  const float g_xyz = g * ia2, g_w = g;
-  const float g_quad = 0.5f * g_xyz;
-  const float g_dX = 2.0f * g_quad * fmaf(k.dX, k.P11, k.dY * k.P12);
-  const float g_dY = 2.0f * g_quad * fmaf(k.dX, k.P12, k.dY * k.P22);
-  const float g_dZ = g_xyz * k.dZ * k.iE;
-  if (GP) {
-    const float g_iE = 0.5f * fmaf(g_xyz, k.dZ * k.dZ, g_w * (t.e * t.e));
-    gp.gX += g_dX;
-    gp.gY += g_dY;
-    gp.gZ += g_dZ;
-    const float gP11 = fmaf(g_quad * k.dX, k.dX, 0.5f * g_w * t.S11);
-    const float gP12 = fmaf(2.0f * g_quad * k.dX, k.dY, g_w * t.S12);
-    const float gP22 = fmaf(g_quad * k.dY, k.dY, 0.5f * g_w * t.S22);
-    float g_iA, g_iB, g_r;
-    rotdiag_bwd(k.iA, k.iB, p.co, p.si, k.P12, gP11, gP12, gP22, g_iA, g_iB, g_r);
-    gp.gr += g_r;
-    gp.ga += fmaf(g_iA, -2.0f * k.iA * k.iap, g_w * k.iap);
-    gp.gb += fmaf(g_iB, -2.0f * k.iB * k.ibp, g_w * k.ibp);
-    gp.ge += fmaf(g_iE, -2.0f * k.iE * k.iep, g_w * k.iep);
+// the target box in the pred role: its own frame (yaw_t = yaw_p - d) and the mirrored offset and yaw difference
+struct GeoT {
+  float st, ct;
+};
+GD_DEV void geo_swap(const Geo& G, GeoT& o) {
+  o.ct = fmaf(G.cp, G.cd, G.sp * G.sd);
+  o.st = fmaf(G.sp, G.cd, -G.cp * G.sd);
+}
+
+// f(rho) = (rho^2 - 1)/2 - ln(rho) for rho = num / den, the per-extent term of KL between Gaussians: >= 0, zero and flat
+// at rho = 1, where (rho^2-1)/2 and ln(rho) cancel.  With delta = rho - 1 and z = (num-den)/(num+den) = delta/(2+delta):
+//     ln(rho) = 2 atanh(z) = 2z + 2z^3/3 + 2z^5/5 + ...,   delta - 2z = delta z   (exactly)
+//     f = delta^2/2 + delta z - 2 z^3 (1/3 + z^2/5 + z^4/7 + z^6/9 + z^8/11)
+// every term a product of differences.  Five series terms are good to 1.2e-7 of f for |z| <= 1/3 (rho in [1/2, 2]); lanes
+// outside take the direct expression (no cancellation there: |ln rho| > 0.69).  *delta returns rho - 1.
+GD_DEV float ratio_term(float num, float den, float iden, float& delta) {
+  const float d = num - den, sum = num + den;
+  delta = d * iden;
+  const float z = d * frcp(sum);
+  const float w = z * z;
+  float P = fmaf(w, 1.0f / 11.0f, 1.0f / 9.0f);
+  P = fmaf(w, P, 1.0f / 7.0f);
+  P = fmaf(w, P, 1.0f / 5.0f);
+  P = fmaf(w, P, 1.0f / 3.0f);
+  float f = fmaf(delta, fmaf(0.5f, delta, z), -2.0f * (z * w) * P);
+  if (__builtin_expect(!(3.0f * fabsf(d) <= sum), 0))   // also taken by NaN
+    f = fmaf(delta, fmaf(0.5f, delta, 1.0f), -LN2 * flog2(num * iden));
+  return f;
+}
+
+// The reference's own evaluation of [dX dY] M [dX dY]^T (two bmm's, ref :119-121, :168-170).  Used only when a centre offset
+// is not finite, to decide whether the reference's quadratic form is NaN (inf - inf or 0 * inf between ITS world-frame
+// terms) rather than +inf: the box-frame forms below group the same infinities differently.
+GD_DEV float quad_ref(float dX, float dY, float m11, float m12, float m22) {
+  const float r0 = dX * m11 + dY * m12, r1 = dX * m12 + dY * m22;
+  return r0 * dX + r1 * dY;
+}
+GD_DEV bool offset_not_finite(float dX, float dY) { return !(fabsf(dX) + fabsf(dY) < __builtin_inff()); }
+
+// ------------------------------------------------------------------ kld3d core (ref :109-137)
+// kl(q, r) = kld3d_loss(pred = q, target = r) before sqrt / postprocess = KL(N_r || N_q), with
+//   (u, v) = R_q^T (C_q - C_r)           centre offset in q's frame
+//   xyz    = (u^2/Aq + v^2/Bq + dZ^2/Eq) / 2
+//   whlr   = f(ar/aq) + f(br/bq) + f(er/eq) + sin^2(d) (Ar-Br)(Aq-Bq) / (2 Aq Bq)
+// (tr(Sq^-1 Sr) = Ar/Aq + Br/Bq + sin^2 d (Ar-Br)(1/Bq - 1/Aq); the -1.5 and the six logs of ref :126-136 are inside f.)
+struct KlI {
+  float iaq, ibq, ieq;  // 1 / half extents of q
+  float u, v;
+  float U, V, W;        // u/aq, v/bq, dZ/eq
+  float da, db, de;     // rho - 1 of the three extent ratios r/q
+  float dAr, dAq;       // Ar - Br, Aq - Bq
+  float iAB2;           // 1 / (Aq Bq)
+};
+
+// dX,dY,dZ = C_q - C_r; (cq, sq) = cos / sin of yaw_q; s = sin(yaw_q - yaw_r)
+GD_DEV float kl_fwd(const Box& q, const Box& r, float dX, float dY, float dZ, float cq, float sq, float s, float ia2,
+                    KlI& k) {
+  k.iaq = frcp(q.a);
+  k.ibq = frcp(q.b);
+  k.ieq = frcp(q.e);
+  k.u = fmaf(cq, dX, sq * dY);
+  k.v = fmaf(cq, dY, -sq * dX);
+  k.U = k.u * k.iaq;
+  k.V = k.v * k.ibq;
+  k.W = dZ * k.ieq;
+  float xyz2 = fmaf(k.U, k.U, fmaf(k.V, k.V, k.W * k.W));
+  if (__builtin_expect(offset_not_finite(dX, dY), 0)) {
+    const float iA = k.iaq * k.iaq, iB = k.ibq * k.ibq;
+    const float qr = quad_ref(dX, dY, fmaf(iA, cq * cq, iB * sq * sq), (iA - iB) * (sq * cq), fmaf(iA, sq * sq, iB * cq * cq));
+    if (qr != qr) xyz2 = qr;
   }
-  if (GT) {
-    gt.gX -= g_dX;
-    gt.gY -= g_dY;
-    gt.gZ -= g_dZ;
-    sigma_bwd(t, 0.5f * g_w * k.P11, g_w * k.P12, 0.5f * g_w * k.P22, gt);
-    gt.ga -= g_w * frcp(t.a);
-    gt.gb -= g_w * frcp(t.b);
-    gt.ge += g_w * fmaf(k.iE, t.e, -frcp(t.e));
+  const float fa = ratio_term(r.a, q.a, k.iaq, k.da);
+  const float fb = ratio_term(r.b, q.b, k.ibq, k.db);
+  const float fe = ratio_term(r.e, q.e, k.ieq, k.de);
+  k.dAr = (r.a - r.b) * (r.a + r.b);
+  k.dAq = (q.a - q.b) * (q.a + q.b);
+  const float iAB = k.iaq * k.ibq;
+  k.iAB2 = iAB * iAB;
+  const float T = 0.5f * (s * s) * (k.dAr * k.dAq) * k.iAB2;
+  return fmaf(0.5f * ia2, xyz2, (fa + fb) + (fe + T));
+}
+
+// accumulates into gq (if GQ) and gr (if GR) with upstream g; c = cos(yaw_q - yaw_r)
+template <bool GQ, bool GR>
+GD_DEV void kl_bwd(const Box& q, const Box& r, float cq, float sq, float s, float c, float ia2, const KlI& k, float g,
+                   Adj& gq, Adj& gr) {
+  const float gx = g * ia2;
+  const float gu = gx * k.U * k.iaq, gv = gx * k.V * k.ibq;      // d/du, d/dv
+  const float gDX = fmaf(cq, gu, -sq * gv), gDY = fmaf(sq, gu, cq * gv), gDZ = gx * k.W * k.ieq;
+  const float s2 = s * s;
+  const float gsc = g * (s * c) * (k.dAr * k.dAq) * k.iAB2;       // d/d yaw_q of the sin^2 term (= - d/d yaw_r)
+  if (GQ) {
+    gq.gX += gDX;
+    gq.gY += gDY;
+    gq.gZ += gDZ;
+    gq.gr += fmaf(gu, k.v, fmaf(-gv, k.u, gsc));                  // u' = v, v' = -u under a turn of q
+    const float t2 = g * s2 * k.dAr;                              // d T / d aq = s^2 (Ar-Br) / (Aq aq), d T / d bq = -(...)/(Bq bq)
+    gq.ga += k.iaq * (fmaf(t2, k.iaq * k.iaq, -g * k.da * (2.0f + k.da)) - gx * k.U * k.U);
+    gq.gb += k.ibq * (fmaf(-t2, k.ibq * k.ibq, -g * k.db * (2.0f + k.db)) - gx * k.V * k.V);
+    gq.ge += k.ieq * (-g * k.de * (2.0f + k.de) - gx * k.W * k.W);
+  }
+  if (GR) {
+    gr.gX -= gDX;
+    gr.gY -= gDY;
+    gr.gZ -= gDZ;
+    gr.gr -= gsc;
+    const float t3 = g * s2 * k.dAq * k.iAB2;                     // d T / d ar = s^2 ar (Aq-Bq)/(Aq Bq)
+    gr.ga += fmaf(g * k.da * (2.0f + k.da), frcp(r.a), t3 * r.a);  // d f / d ar = (rho^2 - 1) / ar
+    gr.gb += fmaf(g * k.db * (2.0f + k.db), frcp(r.b), -t3 * r.b);
+    gr.ge += g * k.de * (2.0f + k.de) * frcp(r.e);
   }
 }
 
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float kld(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
-  KldI k;
+GD_DEV float kld(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+  KlI k;
   const float ia2 = frcp(alpha * alpha);
-  float d = kld_fwd(p, t, ia2, k), ds = 1.0f;
+  float d = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k), ds = 1.0f;
   if (SQRT) d = sqrt0(d, ds);
   float dpost;
   const float out = post<FUN>(d, tau, dpost);
   adj_zero(gp);
   adj_zero(gt);
-  kld_bwd<true, GT>(p, t, ia2, k, dpost * ds, gp, gt);
+  kl_bwd<true, GT>(p, t, G.cp, G.sp, G.sd, G.cd, ia2, k, dpost * ds, gp, gt);
   return out;
 }
 
 // ------------------------------------------------------------------ jd3d (ref :189-198)
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float jd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
-  KldI k1, k2;
+GD_DEV float jd(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+  KlI k1, k2;
+  GeoT S;
+  geo_swap(G, S);
   const float ia2 = frcp(alpha * alpha);
-  float v = kld_fwd(p, t, ia2, k1);
-  v = v + kld_fwd(t, p, ia2, k2);
+  float v = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k1);
+  v = v + kl_fwd(t, p, -G.dX, -G.dY, -G.dZ, S.ct, S.st, -G.sd, ia2, k2);
   v = v * 0.5f;
   float ds = 1.0f;
   if (SQRT) v = sqrt0(v, ds);
@@ -345,17 +427,20 @@ GD_DEV float jd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj
   const float g = dpost * ds * 0.5f;
   adj_zero(gp);
   adj_zero(gt);
-  kld_bwd<true, GT>(p, t, ia2, k1, g, gp, gt);
-  kld_bwd<GT, true>(t, p, ia2, k2, g, gt, gp);
+  kl_bwd<true, GT>(p, t, G.cp, G.sp, G.sd, G.cd, ia2, k1, g, gp, gt);
+  kl_bwd<GT, true>(t, p, S.ct, S.st, -G.sd, G.cd, ia2, k2, g, gt, gp);
   return out;
 }
 
 // ------------------------------------------------------------------ symmax / symmin (ref :201-224)
 template <int FUN, bool SQRT, bool GT, bool WANT_MAX>
-GD_DEV float sym(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
-  KldI k1, k2;
+GD_DEV float sym(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+  KlI k1, k2;
+  GeoT S;
+  geo_swap(G, S);
   const float ia2 = frcp(alpha * alpha);
-  float v1 = kld_fwd(p, t, ia2, k1), v2 = kld_fwd(t, p, ia2, k2);
+  float v1 = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k1);
+  float v2 = kl_fwd(t, p, -G.dX, -G.dY, -G.dZ, S.ct, S.st, -G.sd, ia2, k2);
   float ds1 = 1.0f, ds2 = 1.0f;
   if (SQRT) {
     v1 = sqrt0(v1, ds1);
@@ -393,64 +478,104 @@ GD_DEV float sym(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Ad
   adj_zero(gp);
   adj_zero(gt);
   // a zero factor must contribute exactly 0 (not 0 * inf): branch instead of multiply
-  if (f1 != 0.0f) kld_bwd<true, GT>(p, t, ia2, k1, dpost * f1 * ds1, gp, gt);
-  if (f2 != 0.0f) kld_bwd<GT, true>(t, p, ia2, k2, dpost * f2 * ds2, gt, gp);
+  if (f1 != 0.0f) kl_bwd<true, GT>(p, t, G.cp, G.sp, G.sd, G.cd, ia2, k1, dpost * f1 * ds1, gp, gt);
+  if (f2 != 0.0f) kl_bwd<GT, true>(t, p, S.ct, S.st, -G.sd, G.cd, ia2, k2, dpost * f2 * ds2, gt, gp);
   return out;
 }
 
 // ------------------------------------------------------------------ bd3d (ref :144-186)
+// In p's frame, with m = Sigma_p + Sigma_t there (twice the reference's Sigma), Ks = (At-Bt) sin^2 d:
+//   m11 = Ap + At - Ks,  m22 = Bp + Bt + Ks,  m12 = -(At-Bt) sin d cos d
+//   det4 = det m = (Ap+At)(Bp+Bt) + sin^2 d (Ap-Bp)(At-Bt)                  (= 4 det Sigma; sum of products, no cancellation)
+//   xyz  = ( [u v] adj(m) [u v]^T / det4 + dZ^2 / (Ep+Et) ) / 4
+//   whlr = ln( (1+qa)(1+qb)(1+qe)(1+qs) ) / 2,   qa = (ap-at)^2 / (2 ap at), ..., (1+qa)(1+qb) qs = sin^2 d (Ap-Bp)(At-Bt) / (4 ap at bp bt)
+// (ref :174-180's five logs of O(1) quantities cancel to O(delta^2) on similar boxes; here the logarithm's argument is 1 + a sum
+// of squares of differences.)  The reference clamps det Sigma at 1e-7 (:158): lanes that hit the clamp take its expression.
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float bd(const Box& p, const Box& t, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
   const float ia2 = frcp(alpha * alpha);
-  const float S11 = 0.5f * (p.S11 + t.S11), S12 = 0.5f * (p.S12 + t.S12), S22 = 0.5f * (p.S22 + t.S22);
-  const float Ep = p.e * p.e, Et = t.e * t.e, Sl = 0.5f * (Ep + Et);
-  const float det_raw = fmaf(S11, S22, -S12 * S12);
-  // clamp(min=1e-7): a NaN det_raw can only come from NaN inputs, which already poison dX/dY/dZ -> v_max is enough
-  const float mdet = det_raw >= 1e-7f ? 1.0f : 0.0f;
-  const float det = __builtin_fmaxf(det_raw, 1e-7f);
-  const float idet = frcp(det);
-  const float I11 = S22 * idet, I12 = -S12 * idet, I22 = S11 * idet;
-  const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
-  const float quad = fmaf(dX * dX, I11, fmaf(2.0f * dX * dY, I12, dY * dY * I22));
-  const float iSl = frcp(Sl);
-  const float xyz = 0.125f * fmaf(dZ * dZ, iSl, quad);
-  // 0.5(ln det + ln Sl) - 0.25(ln Ap + ln Bp + ln Ep) - 0.25(ln At + ln Bt + ln Et)
-  //   = 0.5 (ln det + ln Sl) - 0.5 (ln(ap bp ep) + ln(at bt et))
-  const float whlr = (0.5f * LN2) * ((flog2(det) + flog2(Sl)) - (flog2(p.a * p.b * p.e) + flog2(t.a * t.b * t.e)));
+  const float u = fmaf(G.cp, G.dX, G.sp * G.dY), v = fmaf(G.cp, G.dY, -G.sp * G.dX);
+  const float s = G.sd, c = G.cd, s2 = s * s, sc = s * c;
+  const float Ep = p.e * p.e, Et = t.e * t.e;
+  const float SA = p.A + t.A, SB = p.B + t.B, SE = Ep + Et;
+  const float dAp = (p.a - p.b) * (p.a + p.b), dAt = (t.a - t.b) * (t.a + t.b);
+  const float Ks = dAt * s2;
+  const float m11 = SA - Ks, m22 = SB + Ks, m12 = -dAt * sc;
+  const float KK = dAp * dAt;
+  const float det4_raw = fmaf(SA, SB, s2 * KK);
+  const bool clamped = !(det4_raw >= 4e-7f);          // det Sigma < 1e-7 (a NaN det can only come from NaN extents: impossible)
+  const float det4 = __builtin_fmaxf(det4_raw, 4e-7f);
+  const float idet4 = frcp(det4);
+  const float N = fmaf(m22 * u, u, fmaf(-2.0f * m12 * u, v, m11 * v * v));
+  const float iSE = frcp(SE);
+  float Nid = N * idet4;
+  if (__builtin_expect(offset_not_finite(G.dX, G.dY), 0)) {
+    GeoT S;
+    geo_swap(G, S);
+    float p11, p12, p22, t11, t12, t22;
+    rotdiag(p.A, p.B, G.cp, G.sp, p11, p12, p22);
+    rotdiag(t.A, t.B, S.ct, S.st, t11, t12, t22);
+    const float qr = quad_ref(G.dX, G.dY, (p22 + t22) * idet4, -(p12 + t12) * idet4, (p11 + t11) * idet4);
+    if (qr != qr) Nid = qr;
+  }
+  const float xyz = 0.25f * fmaf(G.dZ * G.dZ, iSE, Nid);
+  const float da = p.a - t.a, db = p.b - t.b, de = p.e - t.e;
+  const float iPa = frcp(p.a * t.a), iPb = frcp(p.b * t.b), iPe = frcp(p.e * t.e);
+  float whlr;
+  {
+    const float qa = 0.5f * da * da * iPa, qb = 0.5f * db * db * iPb, qe = 0.5f * de * de * iPe;
+    const float Q1 = fmaf(qa, qb, qa + qb);
+    const float Q2 = fmaf(0.25f * s2 * KK, iPa * iPb, Q1);
+    const float Q = fmaf(Q2, qe, Q2 + qe);
+    float unused;
+    whlr = 0.5f * log1p_f(Q, unused);
+  }
+  if (__builtin_expect(clamped, 0))   // ref :158: det := 1e-7
+    whlr = (0.5f * LN2) * ((flog2(1e-7f) + flog2(0.5f * SE)) - (flog2(p.a * p.b * p.e) + flog2(t.a * t.b * t.e)));
   float d = fmaf(xyz, ia2, whlr), ds = 1.0f;
   if (SQRT) d = sqrt0(d, ds);
   float dpost;
   const float out = post<FUN>(d, tau, dpost);
 
-  const float g = dpost * ds, g_xyz = g * ia2, g_w = g;
-  const float g_quad = 0.125f * g_xyz;
-  const float g_Sl = fmaf(-0.125f * g_xyz * dZ * dZ, iSl * iSl, 0.5f * g_w * iSl);
-  const float g_dX = 2.0f * g_quad * fmaf(dX, I11, dY * I12);
-  const float g_dY = 2.0f * g_quad * fmaf(dX, I12, dY * I22);
-  const float g_dZ = 0.25f * g_xyz * dZ * iSl;
-  const float gI11 = g_quad * dX * dX, gI12 = 2.0f * g_quad * dX * dY, gI22 = g_quad * dY * dY;
-  const float g_idet = fmaf(gI11, S22, fmaf(-gI12, S12, gI22 * S11));
-  const float g_det = fmaf(-g_idet * idet, idet, 0.5f * g_w * idet) * mdet;
-  const float gS11 = 0.5f * fmaf(gI22, idet, g_det * S22);
-  const float gS22 = 0.5f * fmaf(gI11, idet, g_det * S11);
-  const float gS12 = 0.5f * fmaf(-gI12, idet, -2.0f * g_det * S12);
-  gp.gX = g_dX;
-  gp.gY = g_dY;
-  gp.gZ = g_dZ;
-  gp.ga = -0.5f * g_w * frcp(p.a);
-  gp.gb = -0.5f * g_w * frcp(p.b);
-  gp.ge = fmaf(g_Sl, p.e, -0.5f * g_w * frcp(p.e));
-  gp.gr = 0.0f;
-  sigma_bwd(p, gS11, gS12, gS22, gp);
+  // Reverse mode.  The upstream factor is multiplied into u and v BEFORE anything is squared: with a centre 1e20 m away the
+  // forward value overflows to its saturated 1.0 and g is exactly 0; 0 x (finite input) stays 0 as in the reference's autograd
+  // graph, 0 x (overflowed intermediate) would be NaN.
+  const float g = dpost * ds, h = 0.25f * g * ia2;
+  const float mdet = clamped ? 0.0f : 1.0f;
+  const float r = h * idet4;                                        // d xyz / d N
+  const float ru = r * u, rv = r * v;
+  const float gu = 2.0f * fmaf(m22, ru, -m12 * rv), gv = 2.0f * fmaf(m11, rv, -m12 * ru);
+  const float rN = 0.5f * fmaf(gu, u, gv * v) * idet4 * mdet;       // r N / det4 = - d xyz / d det4
+  const float gDZ = 2.0f * h * G.dZ * iSE;
+  const float gDX = fmaf(G.cp, gu, -G.sp * gv), gDY = fmaf(G.sp, gu, G.cp * gv);
+  const float gw = 0.5f * g * idet4 * mdet;                         // g / (2 det4): weight of the whlr numerators below
+  // d/dd of N / det4 (u, v fixed): dN/dd = (At-Bt) (2 s c (u^2 - v^2) + 2 u v (c^2 - s^2)), d det4/dd = 2 s c (Ap-Bp)(At-Bt);
+  // d whlr / dd = s c (Ap-Bp)(At-Bt) / det4
+  const float gd = fmaf(2.0f * dAt, fmaf(sc, fmaf(ru, u, -rv * v), ru * v * ((c - s) * (c + s))), 2.0f * sc * KK * (gw - rN));
+  const float gEz = -gDZ * G.dZ * iSE;                              // d xyz / d Ep = d xyz / d Et (before the factor e)
+  const float sApBp = p.A + p.B, sAtBt = t.A + t.B;
+  gp.gX = gDX;
+  gp.gY = gDY;
+  gp.gZ = gDZ;
+  gp.gr = fmaf(gu, v, -gv * u) + gd;
+  // d whlr / d ap = [(Ap-At)(Bp+Bt) + s^2 (At-Bt)(Ap+Bp)] / (2 ap det4)   (clamped: - 1 / (2 ap)), 1 / ap = at / (ap at)
+  gp.ga = fmaf(2.0f * p.a, fmaf(rv, v, -rN * m22),
+               (clamped ? -0.5f * g : gw * fmaf(da * (p.a + t.a), SB, s2 * dAt * sApBp)) * (iPa * t.a));
+  gp.gb = fmaf(2.0f * p.b, fmaf(ru, u, -rN * m11),
+               (clamped ? -0.5f * g : gw * fmaf(db * (p.b + t.b), SA, -s2 * dAt * sApBp)) * (iPb * t.b));
+  gp.ge = fmaf(gEz, p.e, 0.5f * g * de * (p.e + t.e) * iSE * (iPe * t.e));
   if (GT) {
-    gt.gX = -g_dX;
-    gt.gY = -g_dY;
-    gt.gZ = -g_dZ;
-    gt.ga = -0.5f * g_w * frcp(t.a);
-    gt.gb = -0.5f * g_w * frcp(t.b);
-    gt.ge = fmaf(g_Sl, t.e, -0.5f * g_w * frcp(t.e));
-    gt.gr = 0.0f;
-    sigma_bwd(t, gS11, gS12, gS22, gt);
+    const float su = fmaf(s, u, c * v), cu = fmaf(c, u, -s * v);
+    const float rsu = fmaf(s, ru, c * rv), rcu = fmaf(c, ru, -s * rv);
+    gt.gX = -gDX;
+    gt.gY = -gDY;
+    gt.gZ = -gDZ;
+    gt.gr = -gd;
+    gt.ga = fmaf(2.0f * t.a, fmaf(rsu, su, -rN * fmaf(s2, dAp, SB)),
+                 (clamped ? -0.5f * g : gw * fmaf(-da * (p.a + t.a), SB, s2 * dAp * sAtBt)) * (iPa * p.a));
+    gt.gb = fmaf(2.0f * t.b, fmaf(rcu, cu, -rN * fmaf(-s2, dAp, SA)),
+                 (clamped ? -0.5f * g : gw * fmaf(-db * (p.b + t.b), SA, -s2 * dAp * sAtBt)) * (iPb * p.b));
+    gt.ge = fmaf(gEz, t.e, -0.5f * g * de * (p.e + t.e) * iSE * (iPe * p.e));
   }
   return out;
 }
@@ -513,15 +638,18 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
                        float tau, float f, float (&gpred)[7], float (&gtgt)[7]) {
   Box p, t;
   Adj gp, gt;
-  box_make<LOSS != GD3D_GWD3D>(pv, c, p);
-  box_make<LOSS != GD3D_GWD3D>(tv, c, t);
+  constexpr bool SIGMA = LOSS == GD3D_KFIOU3D;   // the only loss left that wants the covariance entries themselves
+  box_make<SIGMA>(pv, c, p);
+  box_make<SIGMA>(tv, c, t);
+  Geo G;
+  if (LOSS != GD3D_GWD3D && LOSS != GD3D_KFIOU3D) geo_make(p, t, pv[6], tv[6], G);
   float out;
   if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6], tv[6], alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, G, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, G, alpha, tau, gp, gt);
   else {
     const bool dim_nan = (pv[3] != pv[3]) || (pv[4] != pv[4]) || (pv[5] != pv[5]) || (tv[3] != tv[3]) ||
                          (tv[4] != tv[4]) || (tv[5] != tv[5]);
