@@ -26,6 +26,14 @@ GD_DEV float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f3
 // sin & cos.  Cody-Waite reduction by pi/2 with FMAs + Cephes minimax polynomials on
 // [-pi/4, pi/4] (abs error < 1.5e-7 for |x| <= 8192).  Beyond that (never in practice for a
 // yaw) fall back to the full-range library routine.
+// quadrant n: sin takes the sign of bit 1 of n, cos that of bit 1 of n + 1 = bit 1 ^ bit 0 — applied as sign-bit XORs
+// (two shifts and two three-input bit operations instead of two compares and two negating selects)
+GD_DEV void quadrant_signs(int n, float sv, float cv, float& s, float& c) {
+  const unsigned t30 = (unsigned)n << 30, t31 = (unsigned)n << 31;
+  s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sv) ^ (t30 & 0x80000000u));
+  c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cv) ^ ((t30 ^ t31) & 0x80000000u));
+}
+
 GD_DEV void sincos_poly(float x, float& s, float& c);
 GD_DEV void sincos_f(float x, float& s, float& c) {
   if (__builtin_expect(!(fabsf(x) <= 8192.0f), 0)) {
@@ -48,12 +56,37 @@ GD_DEV void sincos_poly(float x, float& s, float& c) {
   pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
   const float sv = (n & 1) ? pc : ps;
   const float cv = (n & 1) ? ps : pc;
-  s = (n & 2) ? -sv : sv;
-  c = ((n + 1) & 2) ? -cv : cv;
+  quadrant_signs(n, sv, cv, s, c);
+}
+
+// The same for TWO angles (|x| <= 8192 each): range reduction and both polynomials run as packed fp32 (v_pk_mul_f32 /
+// v_pk_fma_f32 on two-element vectors: one issue slot for both angles); only rounding, the integer quadrant and the final
+// selects are per angle.  Bit-identical to two sincos_poly calls.
+typedef float v2f __attribute__((ext_vector_type(2)));
+GD_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+GD_DEV v2f splat2(float v) { return v2f{v, v}; }
+GD_DEV void sincos_poly2(float x0, float x1, float& s0, float& c0, float& s1, float& c1) {
+  const v2f x = {x0, x1};
+  const v2f xq = x * splat2(0.63661977236758134f);
+  const v2f q = {rintf(xq.x), rintf(xq.y)};
+  v2f r = fma2(q, splat2(-1.5703125f), x);
+  r = fma2(q, splat2(-4.837512969970703125e-4f), r);
+  r = fma2(q, splat2(-7.54978995489188216e-8f), r);
+  const v2f z = r * r;
+  v2f ps = fma2(fma2(splat2(-1.9515295891e-4f), z, splat2(8.3321608736e-3f)), z, splat2(-1.6666654611e-1f));
+  ps = fma2(ps * z, r, r);
+  v2f pc = fma2(fma2(splat2(2.443315711809948e-5f), z, splat2(-1.388731625493765e-3f)), z, splat2(4.166664568298827e-2f));
+  pc = fma2(pc * z, z, fma2(splat2(-0.5f), z, splat2(1.0f)));
+  const int n0 = (int)q.x, n1 = (int)q.y;
+  const float sv0 = (n0 & 1) ? pc.x : ps.x, cv0 = (n0 & 1) ? ps.x : pc.x;
+  const float sv1 = (n1 & 1) ? pc.y : ps.y, cv1 = (n1 & 1) ? ps.y : pc.y;
+  quadrant_signs(n0, sv0, cv0, s0, c0);
+  quadrant_signs(n1, sv1, cv1, s1, c1);
 }
 
 GD_DEV float flog2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (base 2), 1 ulp
 constexpr float LN2 = 0.6931471805599453f;
+static inline float gd3d_inv_alpha2(float alpha) { return 1.0f / (alpha * alpha); }   // host side, once per launch
 
 // log1p with the (1+d) rounding error folded back in; *inv_u returns 1/(1+d) (= d log1p / dd) from the same v_rcp
 GD_DEV float log1p_f(float d, float& inv_u) {
@@ -278,8 +311,7 @@ GD_DEV void geo_make(const Box& p, const Box& t, float yaw_p, float yaw_t, Geo& 
     g.sd = fmaf(g.sp, ct, -g.cp * st);
     g.cd = fmaf(g.cp, ct, g.sp * st);
   } else {
-    sincos_poly(yaw_p - yaw_t, g.sd, g.cd);   // exact difference when the yaws are close (Sterbenz)
-    sincos_poly(yaw_p, g.sp, g.cp);
+    sincos_poly2(yaw_p - yaw_t, yaw_p, g.sd, g.cd, g.sp, g.cp);   // (the difference is exact when the yaws are close: Sterbenz)
   }
 }
 
@@ -322,6 +354,24 @@ GD_DEV float quad_ref(float dX, float dY, float m11, float m12, float m22) {
 }
 GD_DEV bool offset_not_finite(float dX, float dY) { return !(fabsf(dX) + fabsf(dY) < __builtin_inff()); }
 
+// two ratios at once (the a and the b extents), packed fp32; bit-identical to two ratio_term calls
+GD_DEV v2f ratio_term2(v2f num, v2f den, v2f iden, v2f& delta) {
+  const v2f d = num - den, sum = num + den;
+  delta = d * iden;
+  const v2f z = d * v2f{frcp(sum.x), frcp(sum.y)};
+  const v2f w = z * z;
+  v2f P = fma2(w, splat2(1.0f / 11.0f), splat2(1.0f / 9.0f));
+  P = fma2(w, P, splat2(1.0f / 7.0f));
+  P = fma2(w, P, splat2(1.0f / 5.0f));
+  P = fma2(w, P, splat2(1.0f / 3.0f));
+  v2f f = fma2(delta, fma2(splat2(0.5f), delta, z), splat2(-2.0f) * (z * w) * P);
+  if (__builtin_expect(!(3.0f * fabsf(d.x) <= sum.x) || !(3.0f * fabsf(d.y) <= sum.y), 0)) {
+    if (!(3.0f * fabsf(d.x) <= sum.x)) f.x = fmaf(delta.x, fmaf(0.5f, delta.x, 1.0f), -LN2 * flog2(num.x * iden.x));
+    if (!(3.0f * fabsf(d.y) <= sum.y)) f.y = fmaf(delta.y, fmaf(0.5f, delta.y, 1.0f), -LN2 * flog2(num.y * iden.y));
+  }
+  return f;
+}
+
 // ------------------------------------------------------------------ kld3d core (ref :109-137)
 // kl(q, r) = kld3d_loss(pred = q, target = r) before sqrt / postprocess = KL(N_r || N_q), with
 //   (u, v) = R_q^T (C_q - C_r)           centre offset in q's frame
@@ -354,8 +404,11 @@ GD_DEV float kl_fwd(const Box& q, const Box& r, float dX, float dY, float dZ, fl
     const float qr = quad_ref(dX, dY, fmaf(iA, cq * cq, iB * sq * sq), (iA - iB) * (sq * cq), fmaf(iA, sq * sq, iB * cq * cq));
     if (qr != qr) xyz2 = qr;
   }
-  const float fa = ratio_term(r.a, q.a, k.iaq, k.da);
-  const float fb = ratio_term(r.b, q.b, k.ibq, k.db);
+  v2f dab;
+  const v2f fab = ratio_term2(v2f{r.a, r.b}, v2f{q.a, q.b}, v2f{k.iaq, k.ibq}, dab);
+  const float fa = fab.x, fb = fab.y;
+  k.da = dab.x;
+  k.db = dab.y;
   const float fe = ratio_term(r.e, q.e, k.ieq, k.de);
   k.dAr = (r.a - r.b) * (r.a + r.b);
   k.dAq = (q.a - q.b) * (q.a + q.b);
@@ -397,9 +450,8 @@ GD_DEV void kl_bwd(const Box& q, const Box& r, float cq, float sq, float s, floa
 }
 
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float kld(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float kld(const Box& p, const Box& t, const Geo& G, float ia2, float tau, Adj& gp, Adj& gt) {
   KlI k;
-  const float ia2 = frcp(alpha * alpha);
   float d = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k), ds = 1.0f;
   if (SQRT) d = sqrt0(d, ds);
   float dpost;
@@ -412,11 +464,10 @@ GD_DEV float kld(const Box& p, const Box& t, const Geo& G, float alpha, float ta
 
 // ------------------------------------------------------------------ jd3d (ref :189-198)
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float jd(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float jd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, Adj& gp, Adj& gt) {
   KlI k1, k2;
   GeoT S;
   geo_swap(G, S);
-  const float ia2 = frcp(alpha * alpha);
   float v = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k1);
   v = v + kl_fwd(t, p, -G.dX, -G.dY, -G.dZ, S.ct, S.st, -G.sd, ia2, k2);
   v = v * 0.5f;
@@ -434,11 +485,10 @@ GD_DEV float jd(const Box& p, const Box& t, const Geo& G, float alpha, float tau
 
 // ------------------------------------------------------------------ symmax / symmin (ref :201-224)
 template <int FUN, bool SQRT, bool GT, bool WANT_MAX>
-GD_DEV float sym(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
+GD_DEV float sym(const Box& p, const Box& t, const Geo& G, float ia2, float tau, Adj& gp, Adj& gt) {
   KlI k1, k2;
   GeoT S;
   geo_swap(G, S);
-  const float ia2 = frcp(alpha * alpha);
   float v1 = kl_fwd(p, t, G.dX, G.dY, G.dZ, G.cp, G.sp, G.sd, ia2, k1);
   float v2 = kl_fwd(t, p, -G.dX, -G.dY, -G.dZ, S.ct, S.st, -G.sd, ia2, k2);
   float ds1 = 1.0f, ds2 = 1.0f;
@@ -492,8 +542,7 @@ GD_DEV float sym(const Box& p, const Box& t, const Geo& G, float alpha, float ta
 // (ref :174-180's five logs of O(1) quantities cancel to O(delta^2) on similar boxes; here the logarithm's argument is 1 + a sum
 // of squares of differences.)  The reference clamps det Sigma at 1e-7 (:158): lanes that hit the clamp take its expression.
 template <int FUN, bool SQRT, bool GT>
-GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float alpha, float tau, Adj& gp, Adj& gt) {
-  const float ia2 = frcp(alpha * alpha);
+GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, Adj& gp, Adj& gt) {
   const float u = fmaf(G.cp, G.dX, G.sp * G.dY), v = fmaf(G.cp, G.dY, -G.sp * G.dX);
   const float s = G.sd, c = G.cd, s2 = s * s, sc = s * c;
   const float Ep = p.e * p.e, Et = t.e * t.e;
@@ -632,9 +681,10 @@ GD_DEV float kfiou(const Box& p, const Box& t, float nanp, Adj& gp, Adj& gt) {
 }
 
 // ------------------------------------------------------------------ one pair
-// Returns L_i; fills gpred[7] (and gtgt[7] if GT) with f * dL_i/d(row).
+// Returns L_i; fills gpred[7] (and gtgt[7] if GT) with f * dL_i/d(row).  ia2 = 1 / alpha^2 (uniform: formed once on the
+// host, gd3d_inv_alpha2, instead of a v_mul + v_rcp in every lane).
 template <int LOSS, int FUN, bool FLAG, bool GT>
-GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (&c)[3], float alpha,
+GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (&c)[3], float alpha, float ia2,
                        float tau, float f, float (&gpred)[7], float (&gtgt)[7]) {
   Box p, t;
   Adj gp, gt;
@@ -645,11 +695,11 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
   if (LOSS != GD3D_GWD3D && LOSS != GD3D_KFIOU3D) geo_make(p, t, pv[6], tv[6], G);
   float out;
   if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6], tv[6], alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, G, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, G, alpha, tau, gp, gt);
-  else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, G, alpha, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
+  else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
+  else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMAX) out = sym<FUN, FLAG, GT, true>(p, t, G, ia2, tau, gp, gt);
+  else if (LOSS == GD3D_KLD3D_SYMMIN) out = sym<FUN, FLAG, GT, false>(p, t, G, ia2, tau, gp, gt);
   else {
     const bool dim_nan = (pv[3] != pv[3]) || (pv[4] != pv[4]) || (pv[5] != pv[5]) || (tv[3] != tv[3]) ||
                          (tv[4] != tv[4]) || (tv[5] != tv[5]);

@@ -77,6 +77,9 @@ typedef const __attribute__((address_space(1))) void gbl_cptr_t;
 #ifndef GD_MIN_LDS_BD
 #define GD_MIN_LDS_BD GD_MIN_LDS
 #endif
+#ifndef GD_PLAIN_ALL
+#define GD_PLAIN_ALL 0   // 1: the option-free instantiation for every loss type (gwd3d has it regardless), see launch_one
+#endif
 #ifndef GD_NT_STORE
 #define GD_NT_STORE 1  // nontemporal 16-B gradient stores: written once, never re-read by this kernel
 #endif
@@ -139,7 +142,7 @@ struct LossArgs {
   float* fin_out;
   int* fin_any;
   long long n;
-  float scale, alpha, tau;
+  float scale, alpha, ia2, tau;
   float c0, c1, c2;
   int vec_ok;        // all (N,7) pointers 16-byte aligned
   // bbox-coder decode fused into the prologue (include/gd3d.h gd3d_prologue)
@@ -311,7 +314,17 @@ __global__ __launch_bounds__(TILE) void fused_kernel(const LossArgs a_in) {
       alt = fmaf(pv[k], wk, alt);
     }
   }
-  const float L = pair_loss<LOSS, FUN, FLAG, GT>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
+#ifdef GD_FAKE_MATH   // experiment builds only: the tile mechanics without the closed forms (what is the floor of this kernel shape?)
+  float L = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    g1[k] = f * (pv[k] - tv[k]);
+    g2[k] = -g1[k];
+    L = fmaf(g1[k], g1[k], L);
+  }
+#else
+  const float L = pair_loss<LOSS, FUN, FLAG, GT>(pv, tv, c, a.alpha, a.ia2, a.tau, f, g1, g2);
+#endif
   const float fl = valid ? f * L : 0.0f;
   if (a.pro != GD3D_PRO_NONE) {
     encode_grad(g1, Jp, a.pro == GD3D_PRO_ANCHOR_DELTA);
@@ -436,7 +449,7 @@ struct HeadArgs {
   long long P;
   int A, H, W;
   float dw[7];                 // train_cfg['decode_weight'] (all 1 when weights are given without it)
-  float scale, alpha, tau, c0, c1, c2;
+  float scale, alpha, ia2, tau, c0, c1, c2;
   // encoded-box SmoothL1 term of loss_single (gd_anchor3d_head.py:152-159), added to the same sum / gradient
   int dw_on;                   // GD term weighted by mean_k(bbox_weights * dw); else unweighted
   int sl1;                     // 0: off
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
     const float c[3] = {a.c0, a.c1, a.c2};
     const float f = a.scale * wi;
     float g1[7], g2[7];
-    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.tau, f, g1, g2);
+    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.ia2, a.tau, f, g1, g2);
     fl = f * L;
     float gs[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (a.sl1) {  // uniform.  mmdet smooth_l1_loss on the ENCODED rows, weight (P,7), sum / avg_factor
@@ -578,7 +591,7 @@ struct CenterArgs {
   CenterTask t[CENTER_MAX_TASKS];
   int num_tasks, n_l1, norm_bbox;
   float osf, vs0, vs1, pc0, pc1;
-  float alpha, tau, c0, c1, c2;
+  float alpha, ia2, tau, c0, c1, c2;
   float cw[4];
   float* partials;
   long long pstride;
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
     jac[0] = a.osf * a.vs0; jac[1] = a.osf * a.vs1; jac[2] = 1.0f; jac[6] = 1.0f;
     const float c[3] = {a.c0, a.c1, a.c2};
     float g1[7], g2[7];
-    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.tau, T.gd_scale, g1, g2);
+    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.ia2, a.tau, T.gd_scale, g1, g2);
     fgd = T.gd_scale * L;
     // L1 on the remaining channels: dir (sin, cos) and velocity
     float sy, cy;
@@ -990,14 +1003,15 @@ static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
   // as well (483 -> 415, 519 -> 433): with less to issue they keep more bytes in flight, which is what the cap exists to
   // limit, and at 5 per CU they lose more than they gain on a fast box (133.0 vs 130.3 us).  gwd3d is the slowest of
   // the three on fast boxes, i.e. the kernel roofline.frac is computed from.
-  const bool plain = LOSS == GD3D_GWD3D && !GT && a.w == nullptr && a.w7 == nullptr && !a.wsel && a.pro == GD3D_PRO_NONE &&
+  constexpr bool HAS_PLAIN = LOSS == GD3D_GWD3D || (GD_PLAIN_ALL && (LOSS == GD3D_KLD3D || LOSS == GD3D_BD3D));
+  const bool plain = HAS_PLAIN && !GT && a.w == nullptr && a.w7 == nullptr && !a.wsel && a.pro == GD3D_PRO_NONE &&
                      a.loss == nullptr && a.fin == nullptr;
   if (g.ev_start != nullptr || g.ev_stop != nullptr) {
     // hipExtLaunchKernel binds the two events to the begin / end timestamps of this dispatch packet itself: no marker
     // packets enter the stream, and hipEventElapsedTime(start, stop) is the kernel's execution time as rocprofv3 reports
     // it (events recorded AROUND a launch add the ~3 us of two barrier packets to every bracket).
     if (plain)
-      hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, LOSS == GD3D_GWD3D>), dim3(g.tgrid), dim3(TILE),
+      hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, HAS_PLAIN>), dim3(g.tgrid), dim3(TILE),
                             (std::uint32_t)lds, s, g.ev_start, g.ev_stop, 0u, a);
     else
       hipExtLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), (std::uint32_t)lds, s,
@@ -1005,7 +1019,7 @@ static void launch_one(const Geometry& g, hipStream_t s, const LossArgs& a) {
     return;
   }
   if (plain)
-    hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, LOSS == GD3D_GWD3D>), dim3(g.tgrid), dim3(TILE), lds, s, a);
+    hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, false, HAS_PLAIN>), dim3(g.tgrid), dim3(TILE), lds, s, a);
   else
     hipLaunchKernelGGL((fused_kernel<LOSS, FUN, FLAG, GT>), dim3(g.tgrid), dim3(TILE), lds, s, a);
 }
@@ -1159,6 +1173,7 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
   a.n = n;
   a.scale = scale;
   a.alpha = p->alpha;
+  a.ia2 = gd3d_inv_alpha2(p->alpha);
   a.tau = p->tau;
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];
@@ -1308,6 +1323,7 @@ static int anchor_head_impl(const gd3d_params* p, const gd3d_smooth_l1* sl1, con
   }
   a.scale = scale;
   a.alpha = p->alpha;
+  a.ia2 = gd3d_inv_alpha2(p->alpha);
   a.tau = p->tau;
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];
@@ -1389,6 +1405,7 @@ static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const g
   a.pc0 = coder->pc_range[0];
   a.pc1 = coder->pc_range[1];
   a.alpha = p->alpha;
+  a.ia2 = gd3d_inv_alpha2(p->alpha);
   a.tau = p->tau;
   a.c0 = p->center_offset[0];
   a.c1 = p->center_offset[1];

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE: csrc/gd3d_device.h compiled for the host (see hip/hip_runtime.h beside this file).
-//   g++ -O1 -std=c++17 -shared -fPIC -I tests/hostmath -I <repo> tests/hostmath/pair_math.cpp -o libpairmath.so
+//   /opt/rocm/lib/llvm/bin/clang++ -O1 -std=c++17 -shared -fPIC -I tests/hostmath -I <repo> tests/hostmath/pair_math.cpp -o libpairmath.so
 #include "mmdet3d-gaussian_amd/csrc/gd3d_device.h"
 
 using namespace gd3d;
@@ -14,7 +14,7 @@ static void run(const float* pred, const float* target, long n, const float* c, 
       pv[k] = pred[i * 7 + k];
       tv[k] = target[i * 7 + k];
     }
-    const float L = pair_loss<LOSS, FUN, FLAG, true>(pv, tv, cc, alpha, tau, scale, g1, g2);
+    const float L = pair_loss<LOSS, FUN, FLAG, true>(pv, tv, cc, alpha, gd3d_inv_alpha2(alpha), tau, scale, g1, g2);
     loss[i] = scale * L;
     for (int k = 0; k < 7; ++k) {
       gp[i * 7 + k] = g1[k];

@@ -20,9 +20,10 @@ ROOT = os.path.dirname(HERE)
 
 @pytest.fixture(scope='module')
 def hostmath():
-    cxx = shutil.which('g++')
+    # clang (the ROCm toolchain's own host compiler): gd3d_device.h uses clang's vector extensions for packed fp32 math
+    cxx = next((c for c in ('/opt/rocm/lib/llvm/bin/clang++', shutil.which('clang++') or '') if c and os.path.exists(c)), None)
     if cxx is None:
-        pytest.skip('g++ not available')
+        pytest.skip('clang++ not available')
     out_dir = os.path.join(HERE, 'hostmath', '_build')
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, f'libpairmath.{os.getpid()}.so')
@@ -110,9 +111,10 @@ def test_device_math_large_yaws_keep_the_reference_accuracy(hostmath):
 # ------------------------------------------------------------------------------------------------ rotated-box geometry
 @pytest.fixture(scope='module')
 def rboxmath():
-    cxx = shutil.which('g++')
+    # clang (the ROCm toolchain's own host compiler): gd3d_device.h uses clang's vector extensions for packed fp32 math
+    cxx = next((c for c in ('/opt/rocm/lib/llvm/bin/clang++', shutil.which('clang++') or '') if c and os.path.exists(c)), None)
     if cxx is None:
-        pytest.skip('g++ not available')
+        pytest.skip('clang++ not available')
     out_dir = os.path.join(HERE, 'hostmath', '_build')
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, f'librboxmath.{os.getpid()}.so')

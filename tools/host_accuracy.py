@@ -20,7 +20,7 @@ from gd_golden import _relerr, families, index, pair_case_names, pairs  # noqa: 
 
 def build():
     so = os.path.join(tempfile.mkdtemp(prefix='hostmath'), 'libpairmath.so')
-    cmd = ['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'tests', 'hostmath'), '-I', ROOT,
+    cmd = ['/opt/rocm/lib/llvm/bin/clang++', '-O1', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'tests', 'hostmath'), '-I', ROOT,
            os.path.join(ROOT, 'tests', 'hostmath', 'pair_math.cpp'), '-o', so]
     subprocess.run(cmd, check=True)
     lib = ctypes.CDLL(so)
