@@ -184,6 +184,34 @@ def nms_bev(boxes_sorted, thresh, normal=False):
     return keep[:k].copy()
 
 
+def set_trig_nudge(mode=0, seed=0):
+    """Sensitivity knob of the NMS restatement: move every box's sin / cos by one ulp (1: up, 2: down, 3: pseudo-random
+    per box in {-1, 0, +1}); 0 switches it off.  Process-global: always reset to 0 (see tests/test_nms_margin.py)."""
+    lib().rbox_oracle_set_trig_nudge(int(mode), ctypes.c_uint32(int(seed) & 0xffffffff))
+
+
+MARGIN_EDGES = (1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1)
+
+
+def nms_margin(boxes, scores, thresh, pre_max_size=None):
+    """Decision margins |IoU - thresh| over the pairs the greedy scan evaluates (kept box vs later box still alive).
+    Returns dict(kept, pairs, overlapping, min_margin, iou_at_min, within={edge: count})."""
+    scores = np.asarray(scores, dtype=np.float32)
+    order = np.argsort(-scores, kind='stable')
+    if pre_max_size is not None:
+        order = order[:pre_max_size]
+    b = _boxes(np.asarray(boxes, np.float32)[order], 5)
+    edges = np.asarray(MARGIN_EDGES, np.float64)
+    counts = np.zeros(len(edges), np.int64)
+    stats = np.zeros(4, np.float64)
+    fn = lib().rbox_oracle_nms_margin
+    fn.restype = ctypes.c_int64
+    kept = fn(_ptr(b), ctypes.c_int64(b.shape[0]), ctypes.c_float(float(thresh)), _ptr(edges), len(edges), _ptr(counts),
+              _ptr(stats))
+    return dict(kept=int(kept), pairs=int(stats[0]), overlapping=int(stats[1]), min_margin=float(stats[2]),
+                iou_at_min=float(stats[3]), within={e: int(c) for e, c in zip(MARGIN_EDGES, counts)})
+
+
 def nms_mask(boxes_sorted, thresh):
     b = _boxes(boxes_sorted, 5)
     n = b.shape[0]

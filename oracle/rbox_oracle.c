@@ -115,11 +115,41 @@ static int seg_intersection(pt p1, pt p0, pt q1, pt q0, pt *ans) {
 
 typedef struct { float x1, y1, x2, y2, cx, cy, co, si; pt c[5]; } obox;
 
-static void obox_make(const float *b, obox *o) {
+/* Sensitivity knob (tests/test_nms_margin.py): the upstream CUDA op takes sin/cos from libdevice, this restatement and the HIP
+ * kernels from the fixed polynomials above; the two can differ by an ulp.  mode 0: off; 1 / 2: every box's sin AND cos moved
+ * one ulp up / down; 3: per box and per function a pseudo-random move in {-1, 0, +1} ulp (hash of seed and box index). */
+static int g_nudge_mode = 0;
+static uint32_t g_nudge_seed = 0;
+void rbox_oracle_set_trig_nudge(int mode, uint32_t seed) { g_nudge_mode = mode; g_nudge_seed = seed; }
+static uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+static float nudge_ulps(float v, int k) {
+  if (k > 0) return nextafterf(v, INFINITY);
+  if (k < 0) return nextafterf(v, -INFINITY);
+  return v;
+}
+static void nudge_trig(int64_t idx, float *s, float *c) {
+  if (g_nudge_mode == 0) return;
+  int ks, kc;
+  if (g_nudge_mode == 1) ks = kc = 1;
+  else if (g_nudge_mode == 2) ks = kc = -1;
+  else {
+    uint32_t h = mix32(g_nudge_seed ^ mix32((uint32_t)idx * 2654435761U + 12345U));
+    ks = (int)(h % 3U) - 1;
+    kc = (int)((h >> 8) % 3U) - 1;
+  }
+  *s = nudge_ulps(*s, ks);
+  *c = nudge_ulps(*c, kc);
+}
+
+static void obox_make_i(const float *b, obox *o, int64_t idx);
+static void obox_make(const float *b, obox *o) { obox_make_i(b, o, 0); }
+
+static void obox_make_i(const float *b, obox *o, int64_t idx) {
   o->x1 = b[0]; o->y1 = b[1]; o->x2 = b[2]; o->y2 = b[3];
   o->cx = (b[0] + b[2]) / 2.0f;
   o->cy = (b[1] + b[3]) / 2.0f;
   fx_sincosf(b[4], &o->si, &o->co);
+  nudge_trig(idx, &o->si, &o->co);
   const float xs[4] = {b[0], b[2], b[2], b[0]}, ys[4] = {b[1], b[1], b[3], b[3]};
   for (int k = 0; k < 4; ++k) { /* rotate_around_center */
     float dx = xs[k] - o->cx, dy = ys[k] - o->cy;
@@ -195,13 +225,43 @@ int64_t rbox_oracle_nms_bev(const float *boxes_sorted, int64_t n, float thresh, 
   if (n <= 0) return 0;
   obox *ob = (obox *)malloc((size_t)n * sizeof(obox));
   unsigned char *dead = (unsigned char *)calloc((size_t)n, 1);
-  for (int64_t i = 0; i < n; ++i) obox_make(boxes_sorted + 5 * i, &ob[i]);
+  for (int64_t i = 0; i < n; ++i) obox_make_i(boxes_sorted + 5 * i, &ob[i], i);
   int64_t nk = 0;
   for (int64_t i = 0; i < n; ++i) {
     if (dead[i]) continue;
     keep[nk++] = i;
     for (int64_t j = i + 1; j < n; ++j)
       if (!dead[j] && iou_bev_ob(&ob[i], &ob[j]) > thresh) dead[j] = 1;
+  }
+  free(ob); free(dead);
+  return nk;
+}
+
+/* Decision margins of the greedy scan: for every pair the scan EVALUATES (kept box i, a later box j still alive when i is
+ * reached) the distance |iou(i,j) - thresh|.  counts[k] = number of such pairs with |margin| < edges[k] (cumulative), and
+ * stats = {pairs evaluated, pairs with iou > 0, smallest |margin|, its iou}.  Same arithmetic as rbox_oracle_nms_bev. */
+int64_t rbox_oracle_nms_margin(const float *boxes_sorted, int64_t n, float thresh, const double *edges, int n_edges,
+                               int64_t *counts, double *stats) {
+  for (int k = 0; k < n_edges; ++k) counts[k] = 0;
+  stats[0] = stats[1] = 0.0; stats[2] = 1e30; stats[3] = 0.0;
+  if (n <= 0) return 0;
+  obox *ob = (obox *)malloc((size_t)n * sizeof(obox));
+  unsigned char *dead = (unsigned char *)calloc((size_t)n, 1);
+  for (int64_t i = 0; i < n; ++i) obox_make_i(boxes_sorted + 5 * i, &ob[i], i);
+  int64_t nk = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (dead[i]) continue;
+    ++nk;
+    for (int64_t j = i + 1; j < n; ++j) {
+      if (dead[j]) continue;
+      float iou = iou_bev_ob(&ob[i], &ob[j]);
+      double m = fabs((double)iou - (double)thresh);
+      stats[0] += 1.0;
+      if (iou > 0.0f) stats[1] += 1.0;
+      if (m < stats[2]) { stats[2] = m; stats[3] = (double)iou; }
+      for (int k = 0; k < n_edges; ++k) if (m < edges[k]) counts[k] += 1;
+      if (iou > thresh) dead[j] = 1;
+    }
   }
   free(ob); free(dead);
   return nk;

@@ -571,3 +571,28 @@ def test_nms_nan_and_infinite_scores_order_as_torch_sort(amd, n):
     want = order[oracle.nms_bev(b[order], 0.3)]
     got = amd.nms_gpu(bt, st, 0.3).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('n,seed,extent,thr', [(4096, 200, 74.88, 0.25), (4096, 202, 74.88, 0.25), (1000, 77, 51.2, 0.2)])
+def test_nms_keep_list_survives_an_ulp_of_yaw_on_the_gpu(amd, n, seed, extent, thr):
+    """VERDICT r02 item 5, product side: every box's yaw moved to the next / previous fp32 value (sin and cos then move by
+    up to an ulp, differently per box) on the BASELINE workloads — the GPU keep list equals the oracle's on the SAME nudged
+    input bit for bit, and equals the un-nudged keep list (profiles/r03_nms_margin.txt: the closest decision of these
+    workloads sits 9e-7 from the threshold, an ulp of sin / cos moves an IoU by ~1e-7)."""
+    boxes, scores = nms_boxes(n, seed=seed, extent=extent)
+    s = torch.from_numpy(scores).cuda()
+    base = amd.nms_gpu(torch.from_numpy(boxes).cuda(), s, thr, pre_max_size=n)
+    assert np.array_equal(base.cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, thr, pre_max_size=n))
+    rng = np.random.default_rng(seed)
+    for direction in (np.float32(np.inf), np.float32(-np.inf), None):
+        b = boxes.copy()
+        if direction is None:   # a random third up, a third down, a third untouched
+            pick = rng.integers(0, 3, n)
+            b[:, 4] = np.where(pick == 0, np.nextafter(b[:, 4], np.float32(np.inf)),
+                               np.where(pick == 1, np.nextafter(b[:, 4], np.float32(-np.inf)), b[:, 4]))
+        else:
+            b[:, 4] = np.nextafter(b[:, 4], direction)
+        assert (b[:, 4] != boxes[:, 4]).sum() >= n // 2
+        got = amd.nms_gpu(torch.from_numpy(b).cuda(), s, thr, pre_max_size=n)
+        assert np.array_equal(got.cpu().numpy(), oracle.nms_gpu_oracle(b, scores, thr, pre_max_size=n))
+        assert torch.equal(got, base)
