@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD3D_ABI_VERSION 2
+#define GD3D_ABI_VERSION 3
 
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
@@ -236,6 +236,26 @@ int gd3d_center_head_loss(const gd3d_params* params, const gd3d_prologue* coder,
 
 int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks,
                            const float* grad_losses, void* stream);
+
+/* The same call in its two steps, for callers that can sort (ABI 3).  gd3d_center_head_loss adds the objects of a shared
+ * cell by letting the cell's lowest-index object scan the task's keys: O(shared objects x n / 64) wave steps — nothing at
+ * detection sizes (n = 4000, a handful of shared cells), quadratic when tens of thousands of objects fall into few cells.
+ *   gd3d_center_head_stage : first step only (losses per object, staged gradient rows, per-object cell keys: one int32 row
+ *                            of max_n entries per task inside the workspace, -1 = not live);
+ *   gd3d_center_head_keys  : where those rows are: task t's row starts byte_offset + t * byte_stride into the workspace;
+ *   gd3d_center_head_finish: second step with the SAME arguments plus `order` (num_tasks, max_n) int64: per task the
+ *                            positions 0..max_n-1 of its key row sorted by key, STABLE (so that objects of one cell stay in
+ *                            ascending index; e.g. torch.sort(rows, dim=1, stable=True).indices).  One thread per run of equal
+ *                            keys adds the run in that order: O(n).  order == NULL: the scanning form.
+ * stage + finish(order = NULL) == gd3d_center_head_loss; every form is deterministic, none uses float atomics. */
+int gd3d_center_head_stage(const gd3d_params* params, const gd3d_prologue* coder,
+                           const gd3d_center_task* tasks, int32_t num_tasks, const float* code_weights,
+                           int32_t n_l1, float* losses, void* workspace, void* stream);
+int gd3d_center_head_keys(int32_t num_tasks, int64_t max_n, int64_t* byte_offset, int64_t* byte_stride);
+int gd3d_center_head_finish(const gd3d_params* params, const gd3d_prologue* coder,
+                            const gd3d_center_task* tasks, int32_t num_tasks, const float* code_weights,
+                            int32_t n_l1, float* losses, void* workspace, const int64_t* order,
+                            void* stream);
 
 /* GDLoss.forward with an (n,7) weight and a reduced result, INCLUDING its early-out, without a host sync.  The reference
  * begins with `if not torch.any(weight > 0): return (pred * weight).sum()` (gaussian_distance_loss.py:290-292) — a full

@@ -74,6 +74,11 @@ SYMBOLS = {
     'gd3d_center_head_loss': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
                                      ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp]),
     'gd3d_center_head_scale': (_int, [ctypes.POINTER(CenterTask), ctypes.c_int32, _vp, _vp]),
+    'gd3d_center_head_stage': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
+                                      ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp]),
+    'gd3d_center_head_keys': (_int, [ctypes.c_int32, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    'gd3d_center_head_finish': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
+                                       ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp, _vp]),
     'coder_center_decode': (_int, [ctypes.POINTER(Prologue), _vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
     'coder_center_decode_backward': (_int, [ctypes.POINTER(Prologue), _vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp]),
     'coder_center_encode': (_int, [_vp, _i64, ctypes.c_int32, _vp, _vp]),
@@ -109,7 +114,7 @@ def lib_path():
     return _build.LIB_PATH
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _bind(path):

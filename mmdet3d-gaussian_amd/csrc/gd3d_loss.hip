@@ -595,6 +595,7 @@ struct CenterArgs {
   float cw[4];
   float* partials;
   long long pstride;
+  long long max_n;       // keys rows are max_n long: entries past a task's own n are set to -1 (not live)
 };
 
 template <int LOSS, int FUN, bool FLAG>
@@ -605,7 +606,10 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
   const int ti = blockIdx.y;
   const CenterTask& T = a.t[ti];
   const long long i = (long long)blockIdx.x * HEAD_T + tid;
-  if ((long long)blockIdx.x * HEAD_T >= T.n) return;  // uniform: this task has fewer positives than the largest one
+  if ((long long)blockIdx.x * HEAD_T >= T.n) {  // uniform: this task has fewer positives than the largest one
+    if (T.count != nullptr && i < a.max_n) T.keys[i] = -1;   // the rest of its key row: not live (the sorted finish reads whole rows)
+    return;
+  }
   float fgd = 0.0f, fl1 = 0.0f;
   bool live = i < T.n;
   int key = -1;
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
       atomicAdd(&T.count[key], 1);
     }
   }
-  if (T.count != nullptr && i < T.n) T.keys[i] = key;
+  if (T.count != nullptr && i < a.max_n) T.keys[i] = key;   // -1 for rows that are not live and past the task's n
   const float w0 = wave_sum(fl1), w1 = wave_sum(fgd);
   if (lane == 0) {
     swave[0][wave] = w0;
@@ -703,6 +707,26 @@ GD_DEV float* center_slot(const CenterTask& T, int k, long long b, long long off
   if (k == 6) return T.grads[3] != nullptr ? T.grads[3] + b * plane + off : nullptr;
   if (k < 9) return (T.grads[4] != nullptr && n_l1 >= 2) ? T.grads[4] + (b * 2 + (k - 7)) * plane + off : nullptr;
   return (T.grads[5] != nullptr && n_l1 > 2) ? T.grads[5] + (b * 2 + (k - 9)) * plane + off : nullptr;
+}
+
+// block (0, task): fixed-order fp64 sum of the task's loss partials -> losses[task * 2 + {l1, gd}]
+GD_DEV void center_loss_sums(const CenterArgs& a, int ti, long long n, double* sd, float* __restrict__ losses) {
+  const int tid = threadIdx.x;
+  const long long nb = (n + HEAD_T - 1) / HEAD_T;
+  for (int term = 0; term < 2; ++term) {
+    const float* p = a.partials + ((long long)ti * 2 + term) * a.pstride;
+    double acc = 0.0;
+    for (long long k = tid; k < nb; k += HEAD_T) acc += (double)p[k];
+    __syncthreads();
+    sd[tid] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s2 = HEAD_T / 2; s2 > 0; s2 >>= 1) {
+      if (tid < s2) sd[tid] += sd[tid + s2];
+      __syncthreads();
+    }
+    if (tid == 0) losses[ti * 2 + term] = (float)sd[0];
+  }
 }
 
 __global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a, float* __restrict__ losses) {
@@ -755,21 +779,49 @@ __global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a
     }
   }
   if (blockIdx.x != 0) return;
-  const long long nb = (T.n + HEAD_T - 1) / HEAD_T;
-  for (int term = 0; term < 2; ++term) {
-    const float* p = a.partials + ((long long)ti * 2 + term) * a.pstride;
-    double acc = 0.0;
-    for (long long k = tid; k < nb; k += HEAD_T) acc += (double)p[k];
-    __syncthreads();
-    sd[tid] = acc;
-    __syncthreads();
+  center_loss_sums(a, ti, T.n, sd, losses);
+}
+
+// The same second step when the caller hands in, per task, the positions of the key row sorted by key (STABLE: objects of
+// one cell stay in ascending index; order is (tasks, max_n) int64 — torch.sort(keys, dim=1, stable=True) on the rows that
+// head_center_kernel left).  Thread s owns sorted position s: the first entry of a run of equal keys adds the run's staged
+// rows in that order and writes the cell.  O(n) whatever the number of objects per cell: the scan form above costs
+// O(shared-cell objects x n / 64) wave steps, fine for a detection batch (n = 4000, a few shared cells) and quadratic when
+// tens of thousands of objects fall into few cells.
+__global__ __launch_bounds__(HEAD_T) void center_accum_sorted_kernel(const CenterArgs a, float* __restrict__ losses,
+                                                                     const long long* __restrict__ order) {
+  __shared__ double sd[HEAD_T];
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.y;
+  const CenterTask& T = a.t[ti];
+  const long long plane = (long long)T.H * T.W;
+  const long long s = (long long)blockIdx.x * HEAD_T + tid;
+  if (T.count != nullptr && s < a.max_n) {
+    const long long* ord = order + (long long)ti * a.max_n;
+    const long long i = ord[s];
+    const int key = (i >= 0 && i < a.max_n) ? T.keys[i] : -1;
+    const long long ip = s > 0 ? ord[s - 1] : -1;
+    const int prev = (ip >= 0 && ip < a.max_n) ? T.keys[ip] : -2;   // (a malformed order must not read outside the row)
+    if (key >= 0 && key != prev) {  // run start: this thread owns the cell
+      float acc[11];
 #pragma unroll
-    for (int s2 = HEAD_T / 2; s2 > 0; s2 >>= 1) {
-      if (tid < s2) sd[tid] += sd[tid + s2];
-      __syncthreads();
+      for (int k = 0; k < 11; ++k) acc[k] = T.og[i * 11 + k];
+      for (long long e = s + 1; e < a.max_n; ++e) {
+        const long long j = ord[e];
+        if (j < 0 || j >= a.max_n || T.keys[j] != key) break;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc[k] += T.og[j * 11 + k];
+      }
+      const long long b = key / plane, off = key - b * plane;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        float* dst = center_slot(T, k, b, off, plane, a.n_l1);
+        if (dst != nullptr) *dst = acc[k];
+      }
     }
-    if (tid == 0) losses[ti * 2 + term] = (float)sd[0];
   }
+  if (blockIdx.x != 0) return;
+  center_loss_sums(a, ti, T.n, sd, losses);
 }
 
 // backward of the same call when the upstream gradient is not all ones: grads of task t are scaled by
@@ -1446,6 +1498,7 @@ static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const g
   }
   a.partials = (float*)workspace;
   a.pstride = (max_n + HEAD_T - 1) / HEAD_T;
+  a.max_n = max_n;
   // workspace: partials (2 * tasks * pstride floats, padded to 16 B) | per task: keys (max_n int32) | og (max_n * 11 fp32)
   if (workspace != nullptr) {
     char* base = (char*)workspace + center_partial_bytes(num_tasks, max_n);
@@ -1462,10 +1515,9 @@ size_t gd3d_center_head_workspace_bytes(int32_t num_tasks, int64_t max_n) {
   return center_partial_bytes(num_tasks, max_n) + (size_t)num_tasks * 48 * (size_t)max_n;
 }
 
-int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
-                          const float* code_weights, int32_t n_l1, float* losses, void* workspace, void* stream) {
-  CenterArgs a;
-  long long max_n = 0;
+static int center_stage(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                        const float* code_weights, int32_t n_l1, float* losses, void* workspace, void* stream, CenterArgs& a,
+                        long long& max_n, bool launch) {
   const int rc = center_fill(p, coder, tasks, num_tasks, code_weights, n_l1, workspace, a, max_n);
   if (rc != 0) return rc;
   if (losses == nullptr) return GD3D_E_BADARG;
@@ -1476,9 +1528,10 @@ int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, cons
     return GD3D_E_BADARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (max_n == 0) return (int)hipMemsetAsync(losses, 0, sizeof(float) * 2 * (size_t)num_tasks, s);
+  if (max_n == 0) return launch ? (int)hipMemsetAsync(losses, 0, sizeof(float) * 2 * (size_t)num_tasks, s) : 0;
   if (workspace == nullptr) return GD3D_E_BADARG;
   if (a.pstride > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  if (!launch) return 0;
   const dim3 grid((unsigned)a.pstride, (unsigned)num_tasks);
   const bool flag = p->flag != 0;
 #define GD3D_CENTER_LAUNCH(LT, FN, FL) hipLaunchKernelGGL((head_center_kernel<LT, FN, FL>), grid, dim3(HEAD_T), 0, s, a)
@@ -1505,12 +1558,53 @@ int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, cons
   }
 #undef GD3D_CENTER_FUN
 #undef GD3D_CENTER_LAUNCH
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
+  return (int)hipGetLastError();
+}
+
+static int center_finish(const CenterArgs& a, int32_t num_tasks, long long max_n, float* losses, const int64_t* order,
+                         void* stream) {
+  if (max_n == 0) return 0;   // the stage call already zeroed the losses
+  const dim3 grid((unsigned)a.pstride, (unsigned)num_tasks);
   // second step: gradient accumulation (deterministic) + the loss sums.  Tasks without positives: their partial slices
   // are never written; the sum reads nb = 0 entries -> 0
-  hipLaunchKernelGGL(center_accum_kernel, grid, dim3(HEAD_T), 0, s, a, losses);
+  if (order != nullptr)
+    hipLaunchKernelGGL(center_accum_sorted_kernel, grid, dim3(HEAD_T), 0, (hipStream_t)stream, a, losses, (const long long*)order);
+  else
+    hipLaunchKernelGGL(center_accum_kernel, grid, dim3(HEAD_T), 0, (hipStream_t)stream, a, losses);
   return (int)hipGetLastError();
+}
+
+int gd3d_center_head_loss(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                          const float* code_weights, int32_t n_l1, float* losses, void* workspace, void* stream) {
+  CenterArgs a;
+  long long max_n = 0;
+  const int rc = center_stage(p, coder, tasks, num_tasks, code_weights, n_l1, losses, workspace, stream, a, max_n, true);
+  if (rc != 0) return rc;
+  return center_finish(a, num_tasks, max_n, losses, nullptr, stream);
+}
+
+int gd3d_center_head_stage(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                           const float* code_weights, int32_t n_l1, float* losses, void* workspace, void* stream) {
+  CenterArgs a;
+  long long max_n = 0;
+  return center_stage(p, coder, tasks, num_tasks, code_weights, n_l1, losses, workspace, stream, a, max_n, true);
+}
+
+int gd3d_center_head_finish(const gd3d_params* p, const gd3d_prologue* coder, const gd3d_center_task* tasks, int32_t num_tasks,
+                            const float* code_weights, int32_t n_l1, float* losses, void* workspace, const int64_t* order,
+                            void* stream) {
+  CenterArgs a;
+  long long max_n = 0;
+  const int rc = center_stage(p, coder, tasks, num_tasks, code_weights, n_l1, losses, workspace, stream, a, max_n, false);
+  if (rc != 0) return rc;
+  return center_finish(a, num_tasks, max_n, losses, order, stream);
+}
+
+int gd3d_center_head_keys(int32_t num_tasks, int64_t max_n, int64_t* byte_offset, int64_t* byte_stride) {
+  if (num_tasks <= 0 || max_n < 0 || byte_offset == nullptr || byte_stride == nullptr) return GD3D_E_BADARG;
+  *byte_offset = (int64_t)center_partial_bytes(num_tasks, max_n);
+  *byte_stride = 48 * max_n;
+  return 0;
 }
 
 int gd3d_center_head_scale(const gd3d_center_task* tasks, int32_t num_tasks, const float* grad_losses, void* stream) {

@@ -258,6 +258,9 @@ def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
 
 
 _CENTER_HEADS = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
+# objects per task above which center_head_losses sorts the cell keys between its two launches (gd3d_center_head_finish);
+# below it the scanning form's two launches are cheaper than the sort's (tests/perf/config4_head.py)
+CENTER_SORT_MIN_N = 8192
 _CENTER_CH = (2, 1, 3, 1, 2, 2)
 
 
@@ -302,8 +305,20 @@ def _center_head_launch(meta, maps, need):
     ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
     cwp = (ctypes.c_float * max(n_l1, 1))(*[float(x) for x in cw[:n_l1]])
     with torch.cuda.device(dev):
-        rc = lib.gd3d_center_head_loss(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+        stream = torch.cuda.current_stream().cuda_stream
+        if any(need) and max_n > CENTER_SORT_MIN_N:
+            # many objects: the per-cell accumulation walks the keys in SORTED order (one stable batched sort of the
+            # tasks' key rows between the two launches) instead of scanning them once per shared-cell object
+            _lib.check(lib.gd3d_center_head_stage(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(), stream),
+                       'gd3d_center_head_stage')
+            off, stride = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(lib.gd3d_center_head_keys(T, max_n, ctypes.byref(off), ctypes.byref(stride)), 'gd3d_center_head_keys')
+            rows = torch.as_strided(ws.view(torch.int32), (T, max_n), (stride.value // 4, 1), off.value // 4)
+            order = torch.sort(rows, dim=1, stable=True).indices.contiguous()
+            rc = lib.gd3d_center_head_finish(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(),
+                                             order.data_ptr(), stream)
+        else:
+            rc = lib.gd3d_center_head_loss(params, pro, tasks, T, cwp, n_l1, losses.data_ptr(), ws.data_ptr(), stream)
     _lib.check(rc, 'gd3d_center_head_loss')
     return losses, grads, tasks
 

@@ -241,6 +241,90 @@ def test_config4_gradient_is_bitwise_reproducible(amd):
         assert (d[k].grad - runs[0][k]).abs().max().item() <= 1e-5 * (1 + sc), k
 
 
+def test_config4_batch64_objects_in_few_cells_sorted_accumulate(amd):
+    """32 000 objects of ONE task in 64 cells (batch-64 sizes; the scanning accumulate is quadratic
+    there).  Above head_loss.CENTER_SORT_MIN_N objects the finish step walks the cell keys in sorted order
+    (gd3d_center_head_stage -> one stable batched sort -> gd3d_center_head_finish): every head-map gradient and both
+    losses against the fp64 torch restatement, bit-identical run to run, and — on a size both forms handle quickly —
+    bit-identical to the scanning form (same accumulation order: ascending object index per cell)."""
+    from oracle import head_torch
+    from mmdet3d_gaussian_amd import head_loss
+    g = torch.Generator().manual_seed(6)
+    Bs, HW = 64, 128
+    cfg = dict(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+    coder = amd.CenterPointBBoxYawCoder(pc_range=cfg['pc_range'], out_size_factor=4, voxel_size=cfg['voxel_size'], norm_bbox=True)
+    gd = dict(loss_type='bd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    mod = amd.GDLoss('bd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    cw = [1.0, 1.0, 0.2, 0.2]
+    l1 = dict(type='L1Loss', loss_weight=0.25)
+
+    def problem(P):
+        maps = {k: torch.randn(Bs, c, HW, HW, generator=g) * 0.3
+                for k, c in (('reg', 2), ('height', 1), ('dim', 3), ('yaw', 1), ('dir', 2), ('vel', 2))}
+        pos = torch.stack([torch.randint(3, 5, (P,), generator=g), torch.randint(10, 14, (P,), generator=g),
+                           torch.randint(20, 28, (P,), generator=g)], -1)           # 2 x 4 x 8 = 64 cells
+        xy = (pos[:, 1:].float() + torch.rand(P, 2, generator=g)) * 0.8 - 51.2
+        anno = torch.cat([xy, torch.rand(P, 1, generator=g) * 4 - 3, torch.rand(P, 3, generator=g) * 2 + 0.5,
+                          torch.rand(P, 1, generator=g) * 6 - 3, torch.randn(P, 2, generator=g)], -1)
+        return maps, pos, anno
+
+    def run(maps, pos, anno, P):
+        d = {k: v.cuda().requires_grad_(True) for k, v in maps.items()}
+        out = amd.center_head_losses(mod, l1, coder, [d], [pos.cuda()], [anno.cuda()], [P], cw)
+        (out[0][0] + out[0][1]).backward()
+        torch.cuda.synchronize()
+        return out[0][0].item(), out[0][1].item(), {k: v.grad.clone() for k, v in d.items()}
+
+    P = 32_000
+    assert P > head_loss.CENTER_SORT_MIN_N
+    maps, pos, anno = problem(P)
+    a = run(maps, pos, anno, P)
+    b = run(maps, pos, anno, P)
+    assert a[0] == b[0] and a[1] == b[1] and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    res = {}
+    for dtype in (torch.float64, torch.float32):
+        dd = {k: v.to(dtype).requires_grad_(True) for k, v in maps.items()}
+        r1, rg = head_torch.center_head_task_losses(dd, pos, anno.to(dtype), P, cfg, gd, 0.25, cw)
+        (r1 + rg).backward()
+        res[dtype] = (r1.item(), rg.item(), {k: v.grad for k, v in dd.items()})
+    r64, r32 = res[torch.float64], res[torch.float32]
+    for j in range(2):
+        tol = 1e-5 + 3 * abs(r32[j] - r64[j]) / (1 + abs(r64[j]))
+        assert abs(a[j] - r64[j]) <= tol * (1 + abs(r64[j])), (j, a[j], r64[j])
+    for k in maps:
+        g64 = r64[2][k]
+        sc = g64.abs().max().item()
+        tol = 1e-5 + 3 * (r32[2][k].double() - g64).abs().max().item() / (1 + sc)
+        err = (a[2][k].cpu().double() - g64).abs().max().item()
+        assert err <= tol * (1 + sc), (k, err, tol)
+        assert int((a[2][k] != 0).sum()) <= 64 * maps[k].shape[1]     # nothing outside the 64 cells
+    # sorted form == scanning form, bit for bit (6000 objects, 64 cells + a task without shared cells + an empty task)
+    P2 = 6000
+    m2, p2, a2 = problem(P2)
+    m3, p3, a3 = problem(300)
+    p3 = torch.stack([torch.zeros(300, dtype=torch.long), torch.arange(300) % HW, torch.arange(300) // HW], -1)    # all cells distinct
+
+    def run3(min_n):
+        keep = head_loss.CENTER_SORT_MIN_N
+        head_loss.CENTER_SORT_MIN_N = min_n
+        try:
+            ds = [{k: v.cuda().requires_grad_(True) for k, v in m.items()} for m in (m2, m3, m3)]
+            out = amd.center_head_losses(mod, l1, coder, ds, [p2.cuda(), p3.cuda(), p3[:0].cuda()],
+                                         [a2.cuda(), a3.cuda(), a3[:0].cuda()], [P2, 300, 0], cw)
+            sum(x + y for x, y in out).backward()
+            torch.cuda.synchronize()
+            return [(x.item(), y.item()) for x, y in out], [{k: v.grad.clone() for k, v in d.items()} for d in ds]
+        finally:
+            head_loss.CENTER_SORT_MIN_N = keep
+    ls, gs = run3(0)            # sorted
+    lq, gq = run3(10 ** 9)      # scanning
+    assert ls == lq
+    for x, y in zip(gs, gq):
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    assert ls[2] == (0.0, 0.0) and all(float(v.abs().max()) == 0.0 for v in gs[2].values())
+
+
 WAYMO_RANGES = [[-74.88, -74.88, -0.0345, 74.88, 74.88, -0.0345], [-74.88, -74.88, -0.1188, 74.88, 74.88, -0.1188],
                 [-74.88, -74.88, 0, 74.88, 74.88, 0]]
 WAYMO_SIZES = [[2.08, 4.73, 1.77], [0.84, 1.81, 1.77], [0.84, 0.91, 1.74]]

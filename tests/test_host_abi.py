@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_queries_without_gpu():
     lib = amd.load_library()
     arch = ctypes.c_char_p()
-    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 2
+    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 3
     assert arch.value == b'gfx950'
     assert lib.gd3d_loss_workspace_bytes(0) >= 16
     assert lib.gd3d_loss_workspace_bytes(10_000_000) >= 4 * ((10_000_000 + 255) // 256)
