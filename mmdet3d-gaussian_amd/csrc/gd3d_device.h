@@ -330,7 +330,11 @@ GD_DEV void geo_swap(const Geo& G, GeoT& o) {
 //     f = delta^2/2 + delta z - 2 z^3 (1/3 + z^2/5 + z^4/7 + z^6/9 + z^8/11)
 // every term a product of differences.  Five series terms are good to 1.2e-7 of f for |z| <= 1/3 (rho in [1/2, 2]); lanes
 // outside take the direct expression (no cancellation there: |ln rho| > 0.69).  *delta returns rho - 1.
-GD_DEV float ratio_term(float num, float den, float iden, float& delta) {
+GD_DEV bool ratio_far(float d, float sum) { return !(3.0f * fabsf(d) <= sum); }   // |z| > 1/3; also true for NaN
+GD_DEV float ratio_direct(float num, float iden, float delta) {
+  return fmaf(delta, fmaf(0.5f, delta, 1.0f), -LN2 * flog2(num * iden));
+}
+GD_DEV float ratio_series(float num, float den, float iden, float& delta) {
   const float d = num - den, sum = num + den;
   delta = d * iden;
   const float z = d * frcp(sum);
@@ -339,10 +343,19 @@ GD_DEV float ratio_term(float num, float den, float iden, float& delta) {
   P = fmaf(w, P, 1.0f / 7.0f);
   P = fmaf(w, P, 1.0f / 5.0f);
   P = fmaf(w, P, 1.0f / 3.0f);
-  float f = fmaf(delta, fmaf(0.5f, delta, z), -2.0f * (z * w) * P);
-  if (__builtin_expect(!(3.0f * fabsf(d) <= sum), 0))   // also taken by NaN
-    f = fmaf(delta, fmaf(0.5f, delta, 1.0f), -LN2 * flog2(num * iden));
-  return f;
+  return fmaf(delta, fmaf(0.5f, delta, z), -2.0f * (z * w) * P);
+}
+// two ratios at once (the a and the b extents), packed fp32; bit-identical to two ratio_series calls
+GD_DEV v2f ratio_series2(v2f num, v2f den, v2f iden, v2f& delta) {
+  const v2f d = num - den, sum = num + den;
+  delta = d * iden;
+  const v2f z = d * v2f{frcp(sum.x), frcp(sum.y)};
+  const v2f w = z * z;
+  v2f P = fma2(w, splat2(1.0f / 11.0f), splat2(1.0f / 9.0f));
+  P = fma2(w, P, splat2(1.0f / 7.0f));
+  P = fma2(w, P, splat2(1.0f / 5.0f));
+  P = fma2(w, P, splat2(1.0f / 3.0f));
+  return fma2(delta, fma2(splat2(0.5f), delta, z), splat2(-2.0f) * (z * w) * P);
 }
 
 // The reference's own evaluation of [dX dY] M [dX dY]^T (two bmm's, ref :119-121, :168-170).  Used only when a centre offset
@@ -353,24 +366,6 @@ GD_DEV float quad_ref(float dX, float dY, float m11, float m12, float m22) {
   return r0 * dX + r1 * dY;
 }
 GD_DEV bool offset_not_finite(float dX, float dY) { return !(fabsf(dX) + fabsf(dY) < __builtin_inff()); }
-
-// two ratios at once (the a and the b extents), packed fp32; bit-identical to two ratio_term calls
-GD_DEV v2f ratio_term2(v2f num, v2f den, v2f iden, v2f& delta) {
-  const v2f d = num - den, sum = num + den;
-  delta = d * iden;
-  const v2f z = d * v2f{frcp(sum.x), frcp(sum.y)};
-  const v2f w = z * z;
-  v2f P = fma2(w, splat2(1.0f / 11.0f), splat2(1.0f / 9.0f));
-  P = fma2(w, P, splat2(1.0f / 7.0f));
-  P = fma2(w, P, splat2(1.0f / 5.0f));
-  P = fma2(w, P, splat2(1.0f / 3.0f));
-  v2f f = fma2(delta, fma2(splat2(0.5f), delta, z), splat2(-2.0f) * (z * w) * P);
-  if (__builtin_expect(!(3.0f * fabsf(d.x) <= sum.x) || !(3.0f * fabsf(d.y) <= sum.y), 0)) {
-    if (!(3.0f * fabsf(d.x) <= sum.x)) f.x = fmaf(delta.x, fmaf(0.5f, delta.x, 1.0f), -LN2 * flog2(num.x * iden.x));
-    if (!(3.0f * fabsf(d.y) <= sum.y)) f.y = fmaf(delta.y, fmaf(0.5f, delta.y, 1.0f), -LN2 * flog2(num.y * iden.y));
-  }
-  return f;
-}
 
 // ------------------------------------------------------------------ kld3d core (ref :109-137)
 // kl(q, r) = kld3d_loss(pred = q, target = r) before sqrt / postprocess = KL(N_r || N_q), with
@@ -399,17 +394,26 @@ GD_DEV float kl_fwd(const Box& q, const Box& r, float dX, float dY, float dZ, fl
   k.V = k.v * k.ibq;
   k.W = dZ * k.ieq;
   float xyz2 = fmaf(k.U, k.U, fmaf(k.V, k.V, k.W * k.W));
-  if (__builtin_expect(offset_not_finite(dX, dY), 0)) {
-    const float iA = k.iaq * k.iaq, iB = k.ibq * k.ibq;
-    const float qr = quad_ref(dX, dY, fmaf(iA, cq * cq, iB * sq * sq), (iA - iB) * (sq * cq), fmaf(iA, sq * sq, iB * cq * cq));
-    if (qr != qr) xyz2 = qr;
-  }
   v2f dab;
-  const v2f fab = ratio_term2(v2f{r.a, r.b}, v2f{q.a, q.b}, v2f{k.iaq, k.ibq}, dab);
-  const float fa = fab.x, fb = fab.y;
+  v2f fab = ratio_series2(v2f{r.a, r.b}, v2f{q.a, q.b}, v2f{k.iaq, k.ibq}, dab);
+  float fe = ratio_series(r.e, q.e, k.ieq, k.de);
   k.da = dab.x;
   k.db = dab.y;
-  const float fe = ratio_term(r.e, q.e, k.ieq, k.de);
+  // ONE rare branch for everything the fast forms do not cover: an extent ratio outside [1/2, 2] (direct expression) and a
+  // centre offset that is not finite (NaN decision of the reference's own quadratic form)
+  const bool far_a = ratio_far(r.a - q.a, r.a + q.a), far_b = ratio_far(r.b - q.b, r.b + q.b), far_e = ratio_far(r.e - q.e, r.e + q.e);
+  const bool bad_off = offset_not_finite(dX, dY);
+  if (__builtin_expect(far_a || far_b || far_e || bad_off, 0)) {
+    if (far_a) fab.x = ratio_direct(r.a, k.iaq, k.da);
+    if (far_b) fab.y = ratio_direct(r.b, k.ibq, k.db);
+    if (far_e) fe = ratio_direct(r.e, k.ieq, k.de);
+    if (bad_off) {
+      const float iA = k.iaq * k.iaq, iB = k.ibq * k.ibq;
+      const float qr = quad_ref(dX, dY, fmaf(iA, cq * cq, iB * sq * sq), (iA - iB) * (sq * cq), fmaf(iA, sq * sq, iB * cq * cq));
+      if (qr != qr) xyz2 = qr;
+    }
+  }
+  const float fa = fab.x, fb = fab.y;
   k.dAr = (r.a - r.b) * (r.a + r.b);
   k.dAq = (q.a - q.b) * (q.a + q.b);
   const float iAB = k.iaq * k.ibq;
@@ -557,17 +561,9 @@ GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, 
   const float idet4 = frcp(det4);
   const float N = fmaf(m22 * u, u, fmaf(-2.0f * m12 * u, v, m11 * v * v));
   const float iSE = frcp(SE);
-  float Nid = N * idet4;
-  if (__builtin_expect(offset_not_finite(G.dX, G.dY), 0)) {
-    GeoT S;
-    geo_swap(G, S);
-    float p11, p12, p22, t11, t12, t22;
-    rotdiag(p.A, p.B, G.cp, G.sp, p11, p12, p22);
-    rotdiag(t.A, t.B, S.ct, S.st, t11, t12, t22);
-    const float qr = quad_ref(G.dX, G.dY, (p22 + t22) * idet4, -(p12 + t12) * idet4, (p11 + t11) * idet4);
-    if (qr != qr) Nid = qr;
-  }
-  const float xyz = 0.25f * fmaf(G.dZ * G.dZ, iSE, Nid);
+  const float Nid = N * idet4;
+  const bool bad_off = offset_not_finite(G.dX, G.dY);
+  float xyz = 0.25f * fmaf(G.dZ * G.dZ, iSE, Nid);
   const float da = p.a - t.a, db = p.b - t.b, de = p.e - t.e;
   const float iPa = frcp(p.a * t.a), iPb = frcp(p.b * t.b), iPe = frcp(p.e * t.e);
   float whlr;
@@ -579,8 +575,19 @@ GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, 
     float unused;
     whlr = 0.5f * log1p_f(Q, unused);
   }
-  if (__builtin_expect(clamped, 0))   // ref :158: det := 1e-7
-    whlr = (0.5f * LN2) * ((flog2(1e-7f) + flog2(0.5f * SE)) - (flog2(p.a * p.b * p.e) + flog2(t.a * t.b * t.e)));
+  if (__builtin_expect(clamped || bad_off, 0)) {   // ONE rare branch
+    if (clamped)   // ref :158: det := 1e-7
+      whlr = (0.5f * LN2) * ((flog2(1e-7f) + flog2(0.5f * SE)) - (flog2(p.a * p.b * p.e) + flog2(t.a * t.b * t.e)));
+    if (bad_off) {
+      GeoT S;
+      geo_swap(G, S);
+      float p11, p12, p22, t11, t12, t22;
+      rotdiag(p.A, p.B, G.cp, G.sp, p11, p12, p22);
+      rotdiag(t.A, t.B, S.ct, S.st, t11, t12, t22);
+      const float qr = quad_ref(G.dX, G.dY, (p22 + t22) * idet4, -(p12 + t12) * idet4, (p11 + t11) * idet4);
+      if (qr != qr) xyz = qr;   // the reference's quadratic form is NaN: so is the loss
+    }
+  }
   float d = fmaf(xyz, ia2, whlr), ds = 1.0f;
   if (SQRT) d = sqrt0(d, ds);
   float dpost;
@@ -608,10 +615,10 @@ GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, 
   gp.gZ = gDZ;
   gp.gr = fmaf(gu, v, -gv * u) + gd;
   // d whlr / d ap = [(Ap-At)(Bp+Bt) + s^2 (At-Bt)(Ap+Bp)] / (2 ap det4)   (clamped: - 1 / (2 ap)), 1 / ap = at / (ap at)
-  gp.ga = fmaf(2.0f * p.a, fmaf(rv, v, -rN * m22),
-               (clamped ? -0.5f * g : gw * fmaf(da * (p.a + t.a), SB, s2 * dAt * sApBp)) * (iPa * t.a));
-  gp.gb = fmaf(2.0f * p.b, fmaf(ru, u, -rN * m11),
-               (clamped ? -0.5f * g : gw * fmaf(db * (p.b + t.b), SA, -s2 * dAt * sApBp)) * (iPb * t.b));
+  // (gw carries the clamp mask: with the determinant clamped the bracket drops out and cl = -g/2 is what is left)
+  const float cl = clamped ? -0.5f * g : 0.0f;
+  gp.ga = fmaf(2.0f * p.a, fmaf(rv, v, -rN * m22), fmaf(gw, fmaf(da * (p.a + t.a), SB, s2 * dAt * sApBp), cl) * (iPa * t.a));
+  gp.gb = fmaf(2.0f * p.b, fmaf(ru, u, -rN * m11), fmaf(gw, fmaf(db * (p.b + t.b), SA, -s2 * dAt * sApBp), cl) * (iPb * t.b));
   gp.ge = fmaf(gEz, p.e, 0.5f * g * de * (p.e + t.e) * iSE * (iPe * t.e));
   if (GT) {
     const float su = fmaf(s, u, c * v), cu = fmaf(c, u, -s * v);
@@ -621,9 +628,9 @@ GD_DEV float bd(const Box& p, const Box& t, const Geo& G, float ia2, float tau, 
     gt.gZ = -gDZ;
     gt.gr = -gd;
     gt.ga = fmaf(2.0f * t.a, fmaf(rsu, su, -rN * fmaf(s2, dAp, SB)),
-                 (clamped ? -0.5f * g : gw * fmaf(-da * (p.a + t.a), SB, s2 * dAp * sAtBt)) * (iPa * p.a));
+                 fmaf(gw, fmaf(-da * (p.a + t.a), SB, s2 * dAp * sAtBt), cl) * (iPa * p.a));
     gt.gb = fmaf(2.0f * t.b, fmaf(rcu, cu, -rN * fmaf(-s2, dAp, SA)),
-                 (clamped ? -0.5f * g : gw * fmaf(-db * (p.b + t.b), SA, -s2 * dAp * sAtBt)) * (iPb * p.b));
+                 fmaf(gw, fmaf(-db * (p.b + t.b), SA, -s2 * dAp * sAtBt), cl) * (iPb * p.b));
     gt.ge = fmaf(gEz, t.e, -0.5f * g * de * (p.e + t.e) * iSE * (iPe * p.e));
   }
   return out;

@@ -8,8 +8,8 @@ R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-sample 0"
-SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0"
+BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-traffic"
+SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-traffic"
 # the plain bench line first, on the fresh box (the driver's round-end bench also runs on a fresh one)
 python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_kernel_trace.log 2>&1
@@ -25,8 +25,8 @@ python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm
 [ -x tools/hbm_probe2 ] && ./tools/hbm_probe2 > $OUT/${R}_hbm_probe2.txt 2>&1
 # multi-GPU rehearsal with ONE rank under torch.distributed.run (RCCL backend, hipGraph replay + per-step all_gather): the
 # N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --graph > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --strong --graph > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --strong --graph > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
 python3 tests/perf/multi_nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_multi_nms_time.jsonl
 GD3D_HOST_WEIGHT_CHECK=1 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_hostcheck.jsonl
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
@@ -35,6 +35,13 @@ python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_la
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
 cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
 python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config_standins.jsonl
+# config 4 as a model sees it (head maps = conv outputs) + the per-kernel table of that step
+python3 tests/perf/config4_head.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config4_head.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c4 -- python3 tests/perf/config4_head.py > /dev/null 2>&1
+cp $OUT/kt_c4/*/*kernel_stats.csv $OUT/${R}_config4_kernel_stats.csv 2>/dev/null
+# how the step is enqueued (eager / hipGraph, summed / unit-gradient backward), one process, same buffers
+python3 tools/step_variants.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_step_variants.jsonl
+tools/pmc_issue_mix.sh $OUT/${R}_pmc_issue_mix.txt > /dev/null 2>&1
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
 python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt

@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc_issue_mix.txt}
 [ -n "${2:-}" ] && export GD3D_LIB=$2
 D=gpurun_out/_pmc_issue
 rm -rf $D; mkdir -p $D
-SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-graph --prewarm 0"
+SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-graph --prewarm 0 --no-traffic"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $D/a -- $SHORT > $D/a.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $D/b -- $SHORT > $D/b.log 2>&1
 python3 - $D $OUT <<'PY'
