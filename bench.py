@@ -16,16 +16,20 @@ data-path collective; once per step the three per-shard loss values are all-gath
 asynchronously (the next step's kernels overlap it).  Weak scaling: every rank keeps 10 M pairs
 (`--strong`: 10 M pairs in TOTAL, contiguous row ranges per rank — SURVEY.md §8e asks for both).
 
-Launch mode.  N = 1 launches eagerly: every fused launch INSIDE the timed region then carries its own HIP event pair
-(gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no marker packets), and on
-one MI355X the eager step is the FASTER one: same process, same buffers, round 3 (profiles/r03_step_variants.jsonl):
-eager 423-427 us per step, hipGraph replay 430 us around 411 us of fused kernels; the host needs ~95 us per step.
-(Round 2's eager step cost 434-445 us: its backward added a ones-fill, two adds and three early-exit launches.)
-N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~20 us/step) so that the per-step collective call
-cannot make the host the limit with eight ranks sharing the host's cores; HIP events cannot be bound to a dispatch inside a
-captured graph on ROCm, so there the per-kernel durations come from an eager pass run right after the timed region, same
-stream, same process (`roofline.timing` says which), followed by a bracketed run of bare replays
-(`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph` override.
+Launch mode.  N = 1 launches eagerly, and on one MI355X the eager step is the FASTER one: same process, same buffers, round 3
+(profiles/r03_step_variants.jsonl): eager 423-427 us per step, hipGraph replay 430 us around 411 us of fused kernels; the
+host needs ~100 us per step.  (Round 2's eager step cost 434-445 us: its backward added a ones-fill, two adds and three
+early-exit launches.)  Every `--event-every`-th step of the timed region (default 5) carries a HIP event pair on each of
+its fused launches (gd3d_loss_fused_timed: hipExtLaunchKernel binds them to the dispatch's begin/end timestamps; no
+marker packets): the kernel durations behind `roofline` are measured INSIDE the region, but not on every launch, because a
+dispatch with events bound to it costs ~5 us of GPU time more than a plain one (profiles/r03_event_every_ab.txt: the step
+runs 28.7 us over the sum of its three fused kernels with events on every launch, 14-16 us over it with every fifth step or
+none timed; round 2 timed every launch and so taxed its own `value` by 3.5 %).
+N > 1 launches the same eager step on every rank (the per-step collective adds ~50 us of host work to ~100 us: still 3x
+inside the GPU's 425 us).  `--graph` replays a hipGraph of the step instead (torch.cuda.CUDAGraph; host ~20 us/step; round
+2's default for N > 1): HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the per-kernel
+durations come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says
+which), followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).
 The step: three GDLoss forwards, then ONE torch.autograd.backward over the three losses whose upstream gradients are the
 library's unit-gradient constant (gd_loss.unit_grad): backward then launches nothing, because the fused forward launch
 already wrote the final gradients (a plain `loss.backward()` costs a ones-fill plus one early-exit launch per loss).
@@ -314,10 +318,14 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
-    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly, a HIP event pair bound to every fused dispatch in-region (default for N = 1)')
+    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (5 us per step slower than eager launches on one MI355X)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (the default)')
     ap.add_argument('--sum-backward', action='store_true',
                     help="round 2's step: (l0 + l1 + l2).backward() instead of one autograd.backward with unit gradients")
+    ap.add_argument('--event-every', type=int, default=5,
+                    help='eager launches: bind a HIP event pair to the fused dispatches of every N-th step of the timed region '
+                         '(1 = every step as in round 2, which costs ~5 us of GPU time per timed launch; 0 = none in the '
+                         'region, the kernel durations then come from an eager pass right after it)')
     ap.add_argument('--no-traffic', action='store_true',
                     help='skip the two rocprofv3 --pmc passes that count HBM bytes per launch (roofline.traffic; N = 1 only, ~40 s)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
@@ -342,7 +350,7 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    use_graph = (args.graph or world > 1) and not args.no_graph
+    use_graph = args.graph and not args.no_graph
 
     import mmdet3d_gaussian_amd as amd
     from mmdet3d_gaussian_amd import gd_loss as gdl
@@ -431,22 +439,34 @@ def main():
     # The pre-warm steps are launched exactly like the timed ones (event pairs recorded when the timed region records
     # them, then dropped): the first event pairs created after a few thousand event-free launches cost the host ~100 us
     # each on this ROCm (tools/step_drift.py), which would make the timed region host-bound.
+    # Which steps carry event pairs: every `--event-every`-th one.  A dispatch with events bound to it costs ~5 us of GPU time
+    # more than a plain one on this ROCm (round 3: the same eager step ran 13.7 us over the sum of its three fused kernels
+    # without events, tools/step_variants.py, and 28.7 us over it with events on every launch), so timing EVERY launch in
+    # the region taxes `value` by 3.5 %; every fifth step keeps the durations in-region and the tax under 1 %.
+    every = max(args.event_every, 0)
+    tick = [0]
+
+    def sampled():
+        tick[0] += 1
+        return every > 0 and tick[0] % every == 0
+
     if args.prewarm > 0:
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm:
             for _ in range(20):
-                step(True)
+                step(sampled())
             torch.cuda.synchronize(dev)
             for lt in LOSSES:
                 events[lt].clear()
     for _ in range(args.warmup):
-        step(True)
+        step(sampled())
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
+    tick[0] = -1 if every > 0 else 0   # the first timed step is a sampled one
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(sampled())
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU-bound iff this < elapsed)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -456,9 +476,19 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = tt.item()
-    timing = ('HIP event pair bound to every fused dispatch inside the timed region (hipExtLaunchKernel start/stop events: '
-              'begin/end timestamps of the dispatch itself, no marker packets)')
+    timing = (f'HIP event pair bound to the fused dispatches of every {every}-th step inside the timed region '
+              '(hipExtLaunchKernel start/stop events: begin/end timestamps of the dispatch itself, no marker packets)')
     replay_ms = None
+    if graph is None and not any(events[lt] for lt in LOSSES):   # --event-every 0: an eager pass right after the region
+        for it in range(25):
+            compute(True)
+            if it == 4:
+                torch.cuda.synchronize(dev)
+                for lt in LOSSES:
+                    events[lt].clear()
+        torch.cuda.synchronize(dev)
+        timing = ('HIP event pair bound to every fused dispatch (hipExtLaunchKernel start/stop events), eager pass of 20 steps run '
+                  'right after the timed region (which carried no events)')
     if graph is not None:  # events cannot be bound inside a captured graph on ROCm: eager pass right after
         for it in range(25):
             compute(True)

@@ -19,7 +19,7 @@ from .iou3d import (boxes_iou_bev, circle_nms, iou_3d, iou_bev, multi_class_nms,
 from .registry import LOSSES, Registry, build_loss
 from . import sharded
 from .coders import CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
-from .evaluation import (LidarCenterTransBEV, LidarIOU3D, LidarIOUBEV, MatcherCoCo, match_coco, trans_bev)
+from .evaluation import match_coco, trans_bev
 from .scatter import Scatter, scatter_index, scatter_reduce
 from .head_loss import (anchor_decoded_gd_loss, anchor_head_bbox_loss, anchor_head_decoded_loss,
                         anchor_head_decoded_loss_fused, center_head_gd_loss, center_head_losses)
@@ -34,4 +34,4 @@ __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
-           'trans_bev', 'match_coco', 'MatcherCoCo', 'LidarCenterTransBEV', 'LidarIOU3D', 'LidarIOUBEV']
+           'trans_bev', 'match_coco']

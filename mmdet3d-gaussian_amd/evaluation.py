@@ -1,10 +1,13 @@
-"""Device-side mirror of the reference's evaluation helpers:
+"""Device-side counterparts of the reference's compiled evaluation helpers, and nothing above them:
 
-* ``trans_bev`` / ``iou_3d`` / ``iou_bev``  — /root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:8-105 as bound in
-  ops/eval/eval_utils.cpp:26-36; the affinity callables ``LidarCenterTransBEV`` / ``LidarIOU3D`` / ``LidarIOUBEV``
-  restate core/evaluation/affinity.py:5-32 (same names, ``LARGER_CLOSER``, argument meaning, crowd assertion).
-* ``match_coco`` and ``MatcherCoCo`` — ops/eval/matcher.cpp:8-74 behind core/evaluation/matcher.py:6-37 (negated
-  affinities and thresholds when ``affinity_cost_negate``).
+* ``trans_bev`` (and ``iou_3d`` / ``iou_bev`` in iou3d.py) — /root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:8-105
+  as bound in ops/eval/eval_utils.cpp:26-36;
+* ``match_coco`` — ops/eval/matcher.cpp:8-74.
+
+The Python glue the reference wraps around them (core/evaluation/affinity.py:5-32, matcher.py:6-37: four-line callables
+that forward to these functions, negating affinities and thresholds for IoU-like scores) is mAP-accumulation code, out of
+this build's scope, and is not restated here: a caller negates where its matcher does
+(``match_coco(-iou, -thrs, ...)``, tests/test_gpu_rbox.py).
 
 The reference computes all of this on the CPU from numpy arrays.  Here the affinity matrix is produced and consumed in
 HBM; numpy inputs are accepted and moved to the current device, results are returned as tensors on that device.
@@ -62,62 +65,3 @@ def match_coco(cost_mat, cost_thrs, is_ignore, is_crowd):
                                                out.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    'eval_match_coco')
     return out
-
-
-class LidarCenterTransBEV:
-    LARGER_CLOSER = False
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        return trans_bev(det_bboxes, gt_bboxes)
-
-
-class LidarIOU3D:
-    LARGER_CLOSER = True
-
-    def __init__(self, z_offset=0.5):
-        self.z_offset = z_offset
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOU3D')
-        return iou_3d(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOU3D').to(d.device), self.z_offset)
-
-
-class LidarIOUBEV:
-    LARGER_CLOSER = True
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOUBEV')
-        return iou_bev(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOUBEV').to(d.device))
-
-
-class BaseMatcher:
-    def __init__(self, match_thrs, affinity_cost_negate=True):
-        self._match_thrs = match_thrs
-        self.negate = affinity_cost_negate
-
-    @property
-    def match_thrs(self):
-        return self._match_thrs
-
-    def __call__(self, affinity, gt_isignore=None, gt_iscrowd=None):
-        affinity = _dev_tensor(affinity, torch.float32, 'matcher')
-        G = affinity.shape[1]
-        if gt_iscrowd is None:
-            gt_iscrowd = torch.zeros(G, dtype=torch.bool, device=affinity.device)
-        if gt_isignore is None:
-            gt_isignore = torch.zeros(G, dtype=torch.bool, device=affinity.device)
-        thrs = np.array(self.match_thrs, np.float32)
-        if self.negate:
-            return self.match(-affinity, -thrs, gt_isignore, gt_iscrowd)
-        return self.match(affinity, thrs, gt_isignore, gt_iscrowd)
-
-    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
-        raise NotImplementedError
-
-
-class MatcherCoCo(BaseMatcher):
-    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
-        return match_coco(affinity, match_thrs, gt_isignore, gt_iscrowd)

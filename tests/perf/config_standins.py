@@ -136,3 +136,4 @@ us_nmsb = timeit(nms5b, 20)
 print(json.dumps(dict(config=5, what='GWD loss fwd+bwd at 4096 positives + nms_gpu(4096, thr .25, max 500) x 3 classes',
                       loss_us=round(us_loss, 1), nms_us_3_classes=round(us_nms, 1),
                       nms_us_3_classes_one_batched_call=round(us_nmsb, 1), keep_bit_exact=ok)), flush=True)
+assert ok, 'config 5: NMS keep indices differ from the oracle'

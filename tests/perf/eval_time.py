@@ -23,10 +23,10 @@ for D, G in ((300, 40), (3000, 60), (20000, 200)):
     ign = np.zeros(G, bool); ign[::5] = True; crowd = np.zeros(G, bool)
     d, g = torch.from_numpy(det).cuda(), torch.from_numpy(gt).cuda()
     ig, cr = torch.from_numpy(ign).cuda(), torch.from_numpy(crowd).cuda()
-    matcher = amd.MatcherCoCo(thrs)
+    nthr = -torch.tensor(thrs, dtype=torch.float32, device='cuda')
 
     def gpu():
-        return matcher(amd.iou_3d(d, g, 0.5), ig, cr)
+        return amd.match_coco(-amd.iou_3d(d, g, 0.5), nthr, ig, cr)
     for _ in range(5):
         gpu()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -44,3 +44,4 @@ for D, G in ((300, 40), (3000, 60), (20000, 200)):
         a = ev.iou_3d(det, gt, 0.5); ev.match_coco(-a, -np.array(thrs, np.float32), ign, crowd)
         row['cpu_reference_us'] = round((time.perf_counter() - t0) * 1e6, 1)
     print(json.dumps(row), flush=True)
+    assert row['matches_equal'], 'GPU matches differ from the CPU oracle'

@@ -30,6 +30,8 @@ for lt in ('gwd3d', 'kld3d', 'bd3d', 'jd3d', 'kld3d_symmax', 'kfiou3d'):
     print(f'{lt:13s} loss finite: ref {fin_ref.sum()} got {fin_got.sum()} pattern-mismatch rows {np.nonzero(fin_ref != fin_got)[0].tolist()} '
           f'max rel err on common-finite {rel.max() if rel.size else 0:.2e}; grad finite rows: ref {gfin_ref.sum()} got {gfin_got.sum()} '
           f'mismatch {np.nonzero(gfin_ref != gfin_got)[0].tolist()}')
+    # what IS a requirement (tests/golden/gd_nonfinite.npz pins it against the real reference): a NaN input row gives a NaN loss
+    assert np.isnan(got[np.isnan(p).any(-1) | np.isnan(t).any(-1)]).all() or lt == 'kfiou3d', lt
     bad = np.nonzero(both)[0][rel > 1e-4]
     for r in bad[:6]:
         print('    row', r, 'pred', p[r], 'got', got[r], 'ref32', ref['loss'][r])

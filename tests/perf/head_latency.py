@@ -36,6 +36,11 @@ for lt in ('kld3d', 'gwd3d', 'bd3d'):
         def eager():
             pe.grad = None
             gd_torch.gd_loss(coder.decode(an, pe), coder.decode(an, te), lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).backward()
+        # the three forms are the same loss: fused decode vs torch decode + plain fused loss (1e-6), vs the eager op chain (1e-4)
+        lf = amd.anchor_decoded_gd_loss(mod, an, pe, te, w, avg_factor=P).item()
+        lu = mod(coder.decode(an, pe), coder.decode(an, te), w, avg_factor=P).item()
+        le = gd_torch.gd_loss(coder.decode(an, pe), coder.decode(an, te), lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).item()
+        assert abs(lf - lu) <= 1e-5 * (1 + abs(lu)) and abs(lf - le) <= 1e-4 * (1 + abs(le)), (lt, P, lf, lu, le)
         a, b, c = timeit(fused, 200), timeit(unfused, 100), timeit(eager, 50)
         print(json.dumps(dict(loss=lt, P=P, fused_us=round(a, 1), unfused_us=round(b, 1), eager_torch_us=round(c, 1),
                               speedup_vs_eager=round(c / a, 1))), flush=True)

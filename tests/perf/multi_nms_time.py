@@ -23,3 +23,4 @@ for G in (6, 24, 48):
         torch.cuda.synchronize(); res[f.__name__] = (time.perf_counter() - t0) / 30 * 1e6
     print(json.dumps(dict(entries=G, boxes_per_entry=500, per_entry_loop_us=round(res['loop'], 1),
                           one_segmented_call_us=round(res['multi'], 1), identical=same)), flush=True)
+    assert same, 'segmented call and per-entry loop disagree'

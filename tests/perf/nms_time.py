@@ -31,3 +31,4 @@ for n, thr, clutter in ((1000, 0.2, True), (4096, 0.25, True), (4096, 0.25, Fals
     ok = np.array_equal(k.cpu().numpy(), want)
     print(f'n={n:5d} thr={thr} clutter={clutter}: kept {len(want):5d}  GPU kernels {k_us:8.1f} us ({n / k_us:7.2f} Mboxes/s)  '
           f'nms_gpu e2e {e2e_us:8.1f} us  CPU oracle(1 thread) {cpu_us:10.0f} us  keep bit-exact={ok}', flush=True)
+    assert ok, 'keep indices differ from the oracle'

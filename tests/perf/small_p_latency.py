@@ -83,6 +83,9 @@ for weighted, sizes in ((True, (64, 512, 4096, 100_000, 1_000_000, 10_000_000)),
         def ref():
             p.grad = None; gd_torch.gd_loss(p, t, lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).backward()
         iters = 300 if P <= 100_000 else 20
+        # the timed call and the eager op chain are the same loss
+        v_ours, v_ref = mod(p, t, w, avg_factor=P).item(), gd_torch.gd_loss(p, t, lt, weight=w, avg_factor=P, loss_weight=5.0, fun='log1p', tau=0.0).item()
+        assert abs(v_ours - v_ref) <= 1e-4 * (1 + abs(v_ref)), (P, weighted, v_ours, v_ref)
         row = dict(mode=mode, weight='(P,7)' if weighted else None, P=P, isolated_us=round(timeit(iso, iters), 1),
                    forward_us=round(timeit(fwd, iters), 1))
         if len(sets) == 8:

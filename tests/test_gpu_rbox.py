@@ -483,20 +483,21 @@ def test_match_coco_large_vs_oracle(amd, D, G, T):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-def test_matcher_class_pipeline_iou_to_matches(amd):
-    """core/evaluation flow on the device: LidarIOU3D affinity -> MatcherCoCo (negated costs) vs the same flow on the
-    CPU oracle (iou_3d oracle is pinned to the compiled reference; the matcher too)."""
+def test_iou_to_matches_pipeline_on_the_device(amd):
+    """The evaluation flow on the device: iou_3d affinity -> match_coco on negated costs (what the reference's matcher does for
+    IoU-like scores, core/evaluation/matcher.py:20-24) vs the same flow on the CPU oracle (both pinned to the compiled
+    reference); numpy inputs are accepted and the affinity stays in HBM between the two calls."""
     det = eval_boxes(300, seed=1, spread=25.0); gt = eval_boxes(40, seed=2, spread=25.0)
     gt[:20, :] = det[:20, :] + np.float32(0.05)
-    aff = amd.LidarIOU3D(z_offset=0.5)(det, gt)
-    m = amd.MatcherCoCo([0.3, 0.5, 0.7])
+    aff = amd.iou_3d(torch.from_numpy(det).cuda(), torch.from_numpy(gt).cuda(), 0.5)
+    thrs = np.array([0.3, 0.5, 0.7], np.float32)
     ign = np.zeros(40, bool); ign[::4] = True
-    got = m(aff, gt_isignore=ign)
+    got = amd.match_coco(-aff, -thrs, ign, np.zeros(40, bool))
     aff_o = oracle.eval_iou_3d(det, gt, 0.5)
     assert np.array_equal(aff.cpu().numpy(), aff_o)
-    want = oracle.match_coco(-aff_o, -np.array([0.3, 0.5, 0.7], np.float32), ign, np.zeros(40, bool))
-    assert np.array_equal(got.cpu().numpy(), want)
-    assert amd.LidarCenterTransBEV.LARGER_CLOSER is False and amd.LidarIOUBEV.LARGER_CLOSER is True
+    want = oracle.match_coco(-aff_o, -thrs, ign, np.zeros(40, bool))
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(amd.trans_bev(det, gt).cpu().numpy(), oracle.eval_trans_bev(det, gt))
 
 
 def test_pairwise_matrix_offsets_beyond_2_31(amd):
