@@ -98,8 +98,21 @@ GD_DEV float log1p_f(float d, float& inv_u) {
 }
 
 // ------------------------------------------------------------------ box -> Gaussian
+// Offset of the gravity centres, C_p - C_t with C = xyz + c * dims (UNCLAMPED dims, ref :12), taken as
+// (xyz_p - xyz_t) + c * (dims_p - dims_t): the differences first.  The reference rounds each centre (x up to 70 m: half an
+// ulp is 4e-6 m) and subtracts; for boxes that are close the two inner differences here are exact (Sterbenz), so the offset
+// keeps the inputs' full precision — with a non-zero c on x or y this is what limited the reference's own fp32 (and round
+// 2's kernel) to 1e-5 on the KITTI family.  NaN / inf dims still reach the loss through it (0 * NaN, 0 * inf are NaN).
+struct Offs {
+  float dX, dY, dZ;
+};
+GD_DEV void center_delta(const float (&pv)[7], const float (&tv)[7], const float (&c)[3], Offs& o) {
+  o.dX = fmaf(c[0], pv[3] - tv[3], pv[0] - tv[0]);
+  o.dY = fmaf(c[1], pv[4] - tv[4], pv[1] - tv[1]);
+  o.dZ = fmaf(c[2], pv[5] - tv[5], pv[2] - tv[2]);
+}
+
 struct Box {
-  float X, Y, Z;     // gravity centre (UNCLAMPED dims, ref :12)
   float a, b, e;     // half extents of clamped dims (ref :13-14, :19-20)
   float mw, mh, ml;  // 0.5 * clamp pass-through mask
   float co, si;
@@ -138,9 +151,6 @@ GD_DEV void rotdiag_bwd(float dA, float dB, float co, float si, float m12, float
 // SIGMA = false skips sin/cos and the covariance entries (gwd3d only needs the yaw DIFFERENCE, see gwd<>)
 template <bool SIGMA>
 GD_DEV void box_make(const float (&v)[7], const float (&c)[3], Box& o) {
-  o.X = fmaf(c[0], v[3], v[0]);
-  o.Y = fmaf(c[1], v[4], v[1]);
-  o.Z = fmaf(c[2], v[5], v[2]);
   o.a = half_clamp(v[3], o.mw);
   o.b = half_clamp(v[4], o.mh);
   o.e = half_clamp(v[5], o.ml);
@@ -221,8 +231,8 @@ GD_DEV float sqrt0(float u, float& dsu) {
 //     d/d ap = 2 [(ap-at) + at m + ap (At-Bt) sin^2 d / sqrt q],  m = 1 - r0/sqrt q = -K sin^2 d / ((r0 + sqrt q) sqrt q)
 //     d/d bp = 2 [(bp-bt) + bt m - bp (At-Bt) sin^2 d / sqrt q],  d/d r_p = 2 K sin d cos d / sqrt q = - d/d r_t
 template <int FUN, bool NORMALIZE, bool GT>
-GD_DEV float gwd(const Box& p, const Box& t, float yaw_p, float yaw_t, float alpha, float tau, Adj& gp, Adj& gt) {
-  const float dX = p.X - t.X, dY = p.Y - t.Y, dZ = p.Z - t.Z;
+GD_DEV float gwd(const Box& p, const Box& t, const Offs& o, float yaw_p, float yaw_t, float alpha, float tau, Adj& gp, Adj& gt) {
+  const float dX = o.dX, dY = o.dY, dZ = o.dZ;
   const float dxyz = fmaf(dX, dX, fmaf(dY, dY, dZ * dZ));
   float sd, cd;
   if (__builtin_expect(!(fabsf(yaw_p) <= 16.0f && fabsf(yaw_t) <= 16.0f), 0)) {
@@ -298,10 +308,10 @@ struct Geo {
   float sp, cp;      // sin / cos of yaw_p
 };
 
-GD_DEV void geo_make(const Box& p, const Box& t, float yaw_p, float yaw_t, Geo& g) {
-  g.dX = p.X - t.X;
-  g.dY = p.Y - t.Y;
-  g.dZ = p.Z - t.Z;
+GD_DEV void geo_make(const Offs& o, float yaw_p, float yaw_t, Geo& g) {
+  g.dX = o.dX;
+  g.dY = o.dY;
+  g.dZ = o.dZ;
   if (__builtin_expect(!(fabsf(yaw_p) <= 16.0f && fabsf(yaw_t) <= 16.0f), 0)) {
     // fl(yaw_p - yaw_t) is off by up to ulp(yaw)/2 (1e-6 rad at 16, 0.03 rad at 1e6): out there take the difference's sine
     // and cosine from the two angles themselves, as the reference's per-box rotations do (cf. gwd<>)
@@ -698,10 +708,12 @@ GD_DEV float pair_loss(const float (&pv)[7], const float (&tv)[7], const float (
   constexpr bool SIGMA = LOSS == GD3D_KFIOU3D;   // the only loss left that wants the covariance entries themselves
   box_make<SIGMA>(pv, c, p);
   box_make<SIGMA>(tv, c, t);
+  Offs o;
   Geo G;
-  if (LOSS != GD3D_GWD3D && LOSS != GD3D_KFIOU3D) geo_make(p, t, pv[6], tv[6], G);
+  if (LOSS != GD3D_KFIOU3D) center_delta(pv, tv, c, o);
+  if (LOSS != GD3D_GWD3D && LOSS != GD3D_KFIOU3D) geo_make(o, pv[6], tv[6], G);
   float out;
-  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, pv[6], tv[6], alpha, tau, gp, gt);
+  if (LOSS == GD3D_GWD3D) out = gwd<FUN, FLAG, GT>(p, t, o, pv[6], tv[6], alpha, tau, gp, gt);
   else if (LOSS == GD3D_KLD3D) out = kld<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
   else if (LOSS == GD3D_BD3D) out = bd<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
   else if (LOSS == GD3D_JD3D) out = jd<FUN, FLAG, GT>(p, t, G, ia2, tau, gp, gt);
