@@ -25,11 +25,12 @@ marker packets): the kernel durations behind `roofline` are measured INSIDE the 
 dispatch with events bound to it costs ~5 us of GPU time more than a plain one (profiles/r03_event_every_ab.txt: the step
 runs 28.7 us over the sum of its three fused kernels with events on every launch, 14-16 us over it with every fifth step or
 none timed; round 2 timed every launch and so taxed its own `value` by 3.5 %).
-N > 1 launches the same eager step on every rank (the per-step collective adds ~50 us of host work to ~100 us: still 3x
-inside the GPU's 425 us).  `--graph` replays a hipGraph of the step instead (torch.cuda.CUDAGraph; host ~20 us/step; round
-2's default for N > 1): HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the per-kernel
-durations come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says
-which), followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).
+N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~40 us/step with the collective call): with the per-step
+collective in the loop the replayed step is the faster one (one rank under torch.distributed.run, RCCL all_gather per step,
+profiles/r03_rccl_rehearsal_*.json: 425 us per step replayed, 432 us eager, against 406 us for the N = 1 step without a
+collective).  HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the per-kernel durations
+come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says which),
+followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph` override.
 The step: three GDLoss forwards, then ONE torch.autograd.backward over the three losses whose upstream gradients are the
 library's unit-gradient constant (gd_loss.unit_grad): backward then launches nothing, because the fused forward launch
 already wrote the final gradients (a plain `loss.backward()` costs a ones-fill plus one early-exit launch per loss).
@@ -318,8 +319,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
-    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (5 us per step slower than eager launches on one MI355X)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (the default)')
+    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1; at N = 1 it is 5 us per step slower than eager launches)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
     ap.add_argument('--sum-backward', action='store_true',
                     help="round 2's step: (l0 + l1 + l2).backward() instead of one autograd.backward with unit gradients")
     ap.add_argument('--event-every', type=int, default=5,
@@ -350,7 +351,7 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    use_graph = args.graph and not args.no_graph
+    use_graph = (args.graph or world > 1) and not args.no_graph
 
     import mmdet3d_gaussian_amd as amd
     from mmdet3d_gaussian_amd import gd_loss as gdl

@@ -25,8 +25,12 @@ python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm
 [ -x tools/hbm_probe2 ] && ./tools/hbm_probe2 > $OUT/${R}_hbm_probe2.txt 2>&1
 # multi-GPU rehearsal with ONE rank under torch.distributed.run (RCCL backend, hipGraph replay + per-step all_gather): the
 # N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --strong --graph > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
+RUN1="python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
+$RUN1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
+$RUN1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
+$RUN1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph > $OUT/${R}_rccl_rehearsal_weak_graph.json 2> $OUT/rehearsal_weak_graph.err
+# the driver's own N = 1 command
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${R}_bench_driver_form.json 2> $OUT/bench_driver_form.err
 python3 tests/perf/multi_nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_multi_nms_time.jsonl
 GD3D_HOST_WEIGHT_CHECK=1 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_hostcheck.jsonl
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
