@@ -201,7 +201,7 @@ def pmc_child(pairs):
     torch.cuda.synchronize(dev)
 
 
-def measure_traffic(pairs, timeout_s=240):
+def measure_traffic(pairs, timeout_s=120):
     """HBM bytes per launch of every fused kernel, counted in THIS run: two `rocprofv3 --pmc` passes (FETCH_SIZE and
     WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over a child process that launches the
     kernels at the benchmark size.  Corrections as that guide's HBM section prescribes: both counters are in units of
