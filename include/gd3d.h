@@ -479,6 +479,21 @@ int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_
                          const int32_t* argmax, int64_t n, int32_t c, int64_t v, int reduce,
                          float* grad_feats, void* stream);
 
+/* From point coordinates to the index structures above, in one stream-ordered call (ABI 3; replaces ~20 framework launches:
+ * per-column extents, one mixed-radix int64 key per point, a stable radix sort of (key, point id), run heads -> voxel ids).
+ *   coors (n, ndim) int32, ndim <= 8; a point with ANY negative coordinate is dropped (scatter_points_cuda.cu:236-246).
+ * Outputs, caller-allocated at their UPPER bounds (every point a voxel of its own):
+ *   point2voxel_map (n) int32 (-1 = dropped);  order (n) int32: point ids grouped by voxel, ascending inside a voxel, the
+ *   dropped points first;  seg (n + 1) int32: seg[v] .. seg[v+1] = voxel v's run in `order` (seg[0] = dropped points);
+ *   counts (n) int32;  voxel_coors (n, ndim) int32: the sorted unique rows (lexicographic = the reference's unique_dim order,
+ *   samples in batch order);  num (2) int64 on the DEVICE: [number of voxels V, number of dropped points] — the one thing
+ *   the host has to read back before it can cut voxel_coors / counts / seg to V rows.
+ *   workspace: vox_index_workspace_bytes(n, ndim) bytes, 256-byte aligned (0 is returned if the query itself fails). */
+size_t vox_index_workspace_bytes(int64_t n, int32_t ndim);
+int vox_index_build(const int32_t* coors, int64_t n, int32_t ndim, void* workspace,
+                    int32_t* point2voxel_map, int32_t* order, int32_t* seg, int32_t* counts,
+                    int32_t* voxel_coors, int64_t* num, void* stream);
+
 /* Same gradient, produced in VOXEL order from the forward's grouping (order, seg as in vox_scatter_reduce): each voxel's
  * gradient row is read once and streamed to its points, instead of being re-gathered once per point — about half the
  * HBM traffic of the map-ordered form.  Points in no voxel (the prefix order[0 .. seg[0])) receive zeros.

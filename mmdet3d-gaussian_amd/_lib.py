@@ -105,6 +105,8 @@ SYMBOLS = {
     'eval_match_coco': (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     'vox_scatter_reduce': (_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp, _vp]),
     'vox_scatter_backward': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
+    'vox_index_workspace_bytes': (_sz, [_i64, ctypes.c_int32]),
+    'vox_index_build': (_int, [_vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vox_scatter_backward_grouped': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }

@@ -22,6 +22,7 @@ SOURCES = {
     'gd3d_loss.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],
     'rbox.hip': ['-ffp-contract=off'],
     'voxel_scatter.hip': [],
+    'voxel_index.hip': [],                     # rocPRIM radix sort + scan between hand-written kernels
     'eval_match.hip': ['-ffp-contract=off'],
     'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
 }

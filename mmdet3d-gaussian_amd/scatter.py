@@ -37,6 +37,43 @@ class _on_device:
 
 
 def _index_and_grouping(coors):
+    """From point coordinates to everything the scatter ops need, batched or not: ONE library call (vox_index_build:
+    per-column extents, a mixed-radix int64 key per point, a stable radix sort of (key, point id), run heads -> voxel ids
+    -> map / segments / counts / decoded voxel rows, csrc/voxel_index.hip) and ONE host read of two integers — the
+    number of voxels is data dependent, as in the reference's unique_dim.  Round 2 did the same with ~20 ATen launches
+    (`_index_and_grouping_torch` below, kept as the statement the tests compare against)."""
+    n, ndim = coors.shape
+    if not coors.is_cuda:
+        raise RuntimeError('scatter_index: the MI355X implementation has no CPU path (neither has the reference: '
+                           'voxelization.h:46)')
+    if ndim > 8 or n >= 2 ** 31:
+        return _index_and_grouping_torch(coors)     # beyond the kernels' limits: the same result from device-side ATen ops
+    dev = coors.device
+    lib = _lib.load()
+    c32 = coors if coors.dtype == torch.int32 else coors.to(torch.int32)
+    c32 = c32.contiguous()
+    pmap = torch.empty(n, dtype=torch.int32, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    vcoors = torch.empty((n, ndim), dtype=torch.int32, device=dev)
+    num = torch.empty(2, dtype=torch.int64, device=dev)
+    nbytes = lib.vox_index_workspace_bytes(n, ndim)
+    if nbytes == 0:
+        raise RuntimeError('vox_index_workspace_bytes failed (no usable device for the sort-size query)')
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with _on_device(dev) as stream:
+        rc = lib.vox_index_build(c32.data_ptr(), n, ndim, ws.data_ptr(), pmap.data_ptr(), order.data_ptr(), seg.data_ptr(),
+                                 counts.data_ptr(), vcoors.data_ptr(), num.data_ptr(), stream)
+    _lib.check(rc, 'vox_index_build')
+    v = int(num[0].item())                                                     # the one wait: V sizes every output
+    voxel_coors = vcoors[:v]
+    if coors.dtype != torch.int32:
+        voxel_coors = voxel_coors.to(coors.dtype)
+    return voxel_coors, pmap, counts[:v], (order, seg[:v + 1])
+
+
+def _index_and_grouping_torch(coors):
     """One pass from point coordinates to everything the scatter ops need, batched or not, without a per-sample loop
     and without a host read of any VALUE (the only wait is the one inside torch.unique_consecutive: the number of
     voxels is data dependent).

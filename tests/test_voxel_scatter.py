@@ -48,9 +48,13 @@ def test_oracle_index_and_reduce_properties():
 
 
 def test_host_scatter_index_matches_oracle_cpu():
-    from mmdet3d_gaussian_amd.scatter import group_points, scatter_index
+    """The ATen statement of the index (what the product runs on the DEVICE beyond the kernels' limits, and what the GPU
+    test compares vox_index_build with) against the numpy oracle, on CPU tensors; the public entry has no CPU path."""
+    from mmdet3d_gaussian_amd.scatter import _index_and_grouping_torch, group_points, scatter_index
     coors, _ = _cloud(2000, 3)
-    u, m, c = scatter_index(torch.from_numpy(coors))
+    with pytest.raises(RuntimeError):
+        scatter_index(torch.from_numpy(coors))
+    u, m, c = _index_and_grouping_torch(torch.from_numpy(coors))[:3]
     uo, mo, co = vo.scatter_index(coors)
     np.testing.assert_array_equal(u.numpy(), uo); np.testing.assert_array_equal(m.numpy(), mo); np.testing.assert_array_equal(c.numpy(), co)
     assert m.dtype == torch.int32 and c.dtype == torch.int32
@@ -62,6 +66,41 @@ def test_host_scatter_index_matches_oracle_cpu():
         assert (mo[pts] == v).all() and (np.diff(pts) > 0).all()          # grouped, ascending point id
     e = scatter_index(torch.zeros(0, 3, dtype=torch.int32))
     assert e[0].shape == (0, 3) and e[1].numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,ndim,dtype', [(1, 3, torch.int32), (255, 3, torch.int32), (70_001, 4, torch.int32), (2_000_000, 4, torch.int32),
+                                          (5000, 4, torch.int64), (3000, 2, torch.int32), (4096, 8, torch.int32)])
+def test_gpu_index_build_equals_the_aten_statement_and_the_oracle(n, ndim, dtype):
+    """vox_index_build (round 3: one library call instead of ~20 ATen launches) against the ATen statement on the same
+    device tensors — every output, bit for bit, incl. the grouping — and against the numpy oracle; dropped points
+    (negative coordinates), an all-dropped batch, a single voxel and a batch column."""
+    from mmdet3d_gaussian_amd.scatter import _index_and_grouping, _index_and_grouping_torch, scatter_index
+    rng = np.random.default_rng(n + ndim)
+    hi = [4, 6, 60, 70, 3, 3, 3, 3][:ndim] if ndim >= 4 else [40, 50, 30][:ndim]
+    coors = np.stack([rng.integers(-1 if d == ndim - 1 else 0, h, n) for d, h in enumerate(hi)], -1)
+    cases = [coors]
+    if n >= 255:
+        allneg = coors.copy(); allneg[:, 0] = -1
+        one = np.zeros_like(coors); one[:, -1] = 7
+        cases += [allneg, one]
+    for cc in cases:
+        t = torch.from_numpy(cc).to(dtype).cuda()
+        got = _index_and_grouping(t)
+        want = _index_and_grouping_torch(t)
+        assert got[0].dtype == t.dtype and got[1].dtype == torch.int32 and got[2].dtype == torch.int32
+        for a, b in zip(got[:3], want[:3]):
+            assert torch.equal(a, b)
+        assert torch.equal(got[3][0], want[3][0]) and torch.equal(got[3][1], want[3][1])
+        if n <= 70_001:
+            uo, mo, co = vo.scatter_index(cc)
+            np.testing.assert_array_equal(got[0].cpu().numpy(), uo)
+            np.testing.assert_array_equal(got[1].cpu().numpy(), mo)
+            np.testing.assert_array_equal(got[2].cpu().numpy(), co)
+    t0 = torch.from_numpy(coors).to(dtype).cuda()
+    u, m, c = scatter_index(t0)
+    w0 = _index_and_grouping_torch(t0)
+    assert torch.equal(u, w0[0]) and torch.equal(m, w0[1]) and torch.equal(c, w0[2])
 
 
 @pytest.mark.gpu

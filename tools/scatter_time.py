@@ -34,3 +34,15 @@ for n, c, grid in ((120_000, 64, (432, 496, 1)), (2_000_000, 64, (432, 496, 1)),
         a, b = timeit(ours, 30), timeit(ref, 10)
         fwd_bytes = n * c * 4 + n * 4 + v * c * 4
         print(json.dumps(dict(n=n, c=c, v=v, reduce=red, fused_fwd_bwd_us=round(a, 1), torch_fwd_bwd_us=round(b, 1), speedup=round(b / a, 2))), flush=True)
+
+# the index build itself: one vox_index_build call (round 3) vs the ~20 ATen launches it replaced, batched (b, z, y, x) rows
+from mmdet3d_gaussian_amd.scatter import _index_and_grouping, _index_and_grouping_torch
+for n, grid in ((120_000, (4, 1, 496, 432)), (960_000, (8, 1, 496, 432)), (2_000_000, (8, 40, 200, 176))):
+    g = torch.Generator(device=dev).manual_seed(1)
+    coors = torch.stack([torch.randint(0, s, (n,), generator=g, device=dev) for s in grid], -1).int()
+    a, b = timeit(lambda: _index_and_grouping(coors), 30), timeit(lambda: _index_and_grouping_torch(coors), 10)
+    x, y = _index_and_grouping(coors), _index_and_grouping_torch(coors)
+    same = all(torch.equal(p, q) for p, q in zip(x[:3], y[:3])) and torch.equal(x[3][0], y[3][0]) and torch.equal(x[3][1], y[3][1])
+    assert same, 'index build differs from its ATen statement'
+    print(json.dumps(dict(what='scatter index build (incl. the one host read)', n=n, grid=list(grid), voxels=int(x[0].shape[0]),
+                          vox_index_build_us=round(a, 1), aten_statement_us=round(b, 1), speedup=round(b / a, 2), identical=same)), flush=True)
