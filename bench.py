@@ -359,10 +359,10 @@ def main():
 
     _, n = shard_rows(args.pairs, rank, world, args.strong)
     pred0, tgt = synthetic_pairs(n, seed=rank, device=dev)
-    # one leaf per loss (same values): the step calls backward() ONCE on the sum of the three losses, as a training
-    # step does with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations
-    # that are not part of the metric.  (One backward per loss costs ~60 us of autograd-engine thread hand-off each:
-    # 3 x that made the eager step host-bound on boxes with a slow host, see tools/host_profile.py.)
+    # one leaf per loss (same values): the step runs ONE autograd backward over the three losses, as a training step does
+    # with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations that are not
+    # part of the metric.  (One backward per loss costs ~60 us of autograd-engine thread hand-off each: 3 x that made
+    # the eager step host-bound on boxes with a slow host, see tools/host_profile.py.)
     preds = {lt: pred0.clone().requires_grad_(True) for lt in LOSSES}
     del pred0
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
