@@ -52,6 +52,20 @@ for k in range(sets):
         for nm in names:
             for lt in lts:
                 res[(nm, lt)].append(run(libs[nm], lt, p, t, gp, 10))
+    if k == 0:   # every variant must produce the shipped library's bits (sum and gradient)
+        for lt in lts:
+            want_out = torch.zeros(4, device=dev); want_gp = torch.empty_like(p)
+            rc = base.gd3d_loss_fused_decoded(prm[lt], None, p.data_ptr(), t.data_ptr(), None, None, n, 5.0 / n, None,
+                                              want_out.data_ptr(), want_gp.data_ptr(), None, ws.data_ptr(), stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            for nm in names:
+                out.zero_(); gp.zero_()
+                run(libs[nm], lt, p, t, gp, 1)
+                same = bool(torch.equal(out[:1], want_out[:1])) and bool(torch.equal(gp, want_gp))
+                if not same:
+                    print(f'  !! {nm} {lt}: result differs from the shipped library (sum {out[0].item()!r} vs {want_out[0].item()!r}, '
+                          f'{int((gp != want_gp).sum())} gradient entries)', flush=True)
     print(f'buffer set {k}   ' + '   '.join(f'{lt:>7s}' for lt in lts))
     for nm in names:
         print(f'  {nm:<10s}  ' + '   '.join(f'{sum(res[(nm, lt)]) / len(res[(nm, lt)]):7.1f}' for lt in lts), flush=True)
