@@ -12,11 +12,11 @@ bit-identical to it, tests/test_gpu_rbox.py) for
   * the nuScenes CenterPoint setting: 1000 boxes, thr 0.2                    (gd_centerpoint_head.py:340-345)
   * a sparse scene of 4096 boxes (every box almost alone), thr 0.25
 
-usage: python3 tools/nms_margin_report.py > profiles/r03_nms_margin.txt        (CPU only, ~10 s)"""
+usage: python3 tests/perf/nms_margin_report.py > profiles/r03_nms_margin.txt        (CPU only, ~10 s)"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np  # noqa: E402

@@ -1,7 +1,7 @@
 """Decision margins of the rotated NMS and its sensitivity to an ulp of sin / cos, on the CPU
 restatement of the upstream op (parity unpinned: mmdet3d is absent; oracle/rbox_oracle.c part 1).  The GPU kernels are
 bit-identical to that restatement (tests/test_gpu_rbox.py), so what holds here holds for them.  The report these
-numbers go into is tools/nms_margin_report.py -> profiles/r03_nms_margin.txt."""
+numbers go into is tests/perf/nms_margin_report.py -> profiles/r03_nms_margin.txt."""
 import os
 import sys
 
@@ -11,7 +11,6 @@ import pytest
 import oracle
 from rbox_inputs import nms_boxes
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
 
 
 @pytest.fixture(autouse=True)
