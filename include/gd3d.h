@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD3D_ABI_VERSION 3
+#define GD3D_ABI_VERSION 4
 
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
@@ -307,7 +307,9 @@ int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats
  *   coder : kind GD3D_PRO_CENTER fields (norm_bbox, out_size_factor, voxel_size, pc_range; aux ignored)
  *   locs (n,2) fp32 grid coordinates, preds (n,c) fp32 rows [dx, dy, z, dim x3, yaw, sin, cos, others...], c >= 7
  *   (c >= 9 when correct_yaw);  out (n, 7 + max(c-9, 0)) = [x, y, z, dim x3, yaw, others...].
- *   correct_yaw != 0: k = floor((atan2(sin, cos) - yaw) / (pi/2) + 0.5), yaw += k pi/2, w <-> l swapped when k is odd.
+ *   correct_yaw == 1: k = floor((atan2(sin, cos) - yaw) / (pi/2) + 0.5), yaw += k pi/2, w <-> l swapped when k is odd.
+ *   correct_yaw == 2: CenterPointBBoxCoderRev.decode instead (centerpoint_bbox_coders.py:87-112): preds rows
+ *   [dx, dy, z, dim x3, sin, cos, others...], c >= 8, rot = atan2(sin, cos), out (n, c - 1); no backward.
  *   num_rot_parity (n) int32, nullable: receives k & 1 (what the backward needs).
  * coder_center_decode_backward: grad_preds (n,c) from grad_out (n, out cols), `out` of the forward and the parity
  *   flags (NULL = no swap); the sin / cos columns receive 0 (k is computed under no_grad in the reference).
@@ -502,6 +504,91 @@ int vox_index_build(const int32_t* coors, int64_t n, int32_t ndim, void* workspa
 int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, const int32_t* seg,
                                  const int32_t* argmax, int64_t n, int32_t c, int64_t v, int reduce,
                                  float* grad_feats, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * CenterPoint inference slice: from the head maps of all tasks to the detections of every sample, stream-ordered, no
+ * host round trip inside (ABI 4).  Replaces, per task,
+ *   heatmap.sigmoid() -> _reconstruct_bbox (a cat of the head maps) -> bbox_coder.select_best (two torch.topk, gathers, a
+ *   per-sample Python loop) -> bbox_coder.decode -> score / centre-range mask -> boolean indexing per sample ->
+ *   per sample xywhr2xyxyr + nms_gpu (or circle_nms on the host) -> the merge of all tasks per sample
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_centerpoint_head.py:218-303 (get_bboxes), :305-361
+ *   (get_task_detections), :202-216 and :372-387 (_reconstruct_bbox),
+ *   /root/reference/mmdet3d_gaussian/core/bbox/coders/centerpoint_bbox_coders.py:23-58 (select_best / _topk), :87-112
+ *   (decode), centerpoint_bbox_yaw_coders.py:18-56 (decode with correct_yaw)
+ * by: one selection kernel (one workgroup per task x sample: the max_per_img best cells over all classes straight from the
+ * logits — sampled threshold + one filtering pass, exact radix select when that pass cannot prove itself —, LDS bitonic
+ * sort, gather of the head channels at those cells from the SEPARATE maps, decode, mask, ordered compaction), the batched
+ * NMS of rnms_batched over all task x sample groups, one merge kernel.
+ *
+ * Selection rule: descending score; equal scores in ascending flat index (class * H*W + y * W + x).  The reference's
+ * per-class-then-global torch.topk picks the same set whenever the scores are distinct; the order among EQUAL scores is
+ * unspecified there.  With heat_is_logit the selection runs on the logits (sigmoid is monotonic) and only the selected
+ * scores are passed through 1 / (1 + exp(-x)).  NaN scores rank first (torch.topk) and fail the score threshold.
+ * The centre-range test is the reference's expression `x.ge(lo).le(hi)`: the BOOLEAN (x >= lo), as 0 / 1, is compared with
+ * hi (:248-250) — kept as written.
+ *
+ * center_infer_task (HOST array of num_tasks entries):
+ *   heatmap       (batch, classes, H, W) fp32, contiguous;
+ *   channel[j]    plane of gathered channel j of sample 0 ((H, W) fp32, contiguous); NULL = the constant 0.5 (head without
+ *                 'reg', :206-208).  Channel order = _reconstruct_bbox: reg x2, height, dim x3, then rot(sin, cos) [decode 1]
+ *                 or yaw, dir(sin, cos) [decode 2], then vel x2 if present;  sample_stride[j] floats from sample b to b+1;
+ *   label_offset  added to the class index in the merged labels (:293-297);  nms_thresh: nms_thr, or min_radius[task] for
+ *                 circle NMS.
+ * center_infer_desc:
+ *   decode 0: none (center_infer_select only), 1: CenterPointBBoxCoderRev.decode, 2: CenterPointBBoxYawCoder.decode with
+ *   correct_yaw;  max_per_img <= center_infer_max_k() and <= H*W (torch.topk's own limit);  num_channels <= 16;
+ *   H*W*classes < 2^31;  nms_type 0 rotate / 2 circle;  pre_max_size, post_max_size < 0: none.
+ * center_infer_select: the selection alone (the coder's select_best): sel_scores (G, K) fp32, sel_cls (G, K) int64,
+ *   sel_xy (G, K, 2) int64 (x, y), sel_preds (G, K, num_channels) fp32 raw channels; group G = task * batch + sample.
+ * center_infer_bboxes: out_boxes (batch, num_tasks * P, co) fp32 with z moved to the box bottom (:289), out_scores
+ *   (batch, num_tasks * P), out_labels (batch, num_tasks * P) int32, out_count (batch) int64 on the DEVICE — the one thing the
+ *   host reads back;  P = center_infer_rows_per_task(desc) = min(max_per_img, pre_max_size, post_max_size);  co = num_channels
+ *   - 1 (decode 1) or - 2 (decode 2).  workspace: center_infer_workspace_bytes(desc), 256-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+#define CENTER_INFER_MAX_CHANNELS 16
+#define CENTER_INFER_MAX_TASKS 10
+
+typedef struct center_infer_task {
+  const float* heatmap;
+  const float* channel[CENTER_INFER_MAX_CHANNELS];
+  int64_t sample_stride[CENTER_INFER_MAX_CHANNELS];
+  int32_t classes;
+  int32_t label_offset;
+  float nms_thresh;
+  int32_t reserved;
+} center_infer_task;
+
+typedef struct center_infer_desc {
+  int32_t num_tasks, batch, height, width;
+  int32_t max_per_img, num_channels, decode, heat_is_logit;
+  int32_t norm_bbox, use_score_threshold, use_limit_range, nms_type;
+  int32_t pre_max_size, post_max_size;
+  float out_size_factor;
+  float voxel_size[2];
+  float pc_range[2];
+  float score_threshold;
+  float limit_range[6];
+  const center_infer_task* tasks;
+} center_infer_desc;
+
+int center_infer_max_k(void);
+int64_t center_infer_rows_per_task(const center_infer_desc* desc);
+size_t center_infer_workspace_bytes(const center_infer_desc* desc);
+/* Where center_infer_bboxes leaves the candidates of the NMS in `workspace` (for inspection and stage-wise tests): byte offsets
+ * of boxes (G, max_per_img, co) fp32, scores (G, max_per_img) fp32, class indices (G, max_per_img) int32 and counts (G) int32 —
+ * per group the survivors of the score / range mask, compacted, in score order. */
+int center_infer_candidates(const center_infer_desc* desc, int64_t* byte_offsets);
+/* Profiling aid: while device_buffer != NULL every later selection launch records, per group, 8 int64: s_memrealtime stamps
+ * (100 MHz) at kernel start / after the threshold sample / after the filtering pass / after the exact radix select (when it
+ * had to run) / after the ordering / at the end, then the number of candidates, then 0.  (groups, 8) int64 on the device. */
+int center_infer_debug_clocks(int64_t* device_buffer);
+/* Clock probe: `iters` dependent FMAs per thread in `blocks` workgroups of 256; device_out[0] = wall time of workgroup 0 in
+ * 10 ns ticks (device_out: 2 int64).  One workgroup vs a chip-filling launch shows the clock an almost idle chip is granted. */
+int center_infer_debug_clock_probe(int64_t* device_out, int32_t blocks, int32_t iters, void* stream);
+int center_infer_select(const center_infer_desc* desc, float* sel_scores, int64_t* sel_cls, int64_t* sel_xy,
+                        float* sel_preds, void* stream);
+int center_infer_bboxes(const center_infer_desc* desc, void* workspace, float* out_boxes, float* out_scores,
+                        int32_t* out_labels, int64_t* out_count, void* stream);
 
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */

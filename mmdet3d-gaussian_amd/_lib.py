@@ -40,6 +40,24 @@ class CenterTask(ctypes.Structure):
                 ('l1_scale', ctypes.c_float)]
 
 
+class CenterInferTask(ctypes.Structure):
+    """center_infer_task (include/gd3d.h)."""
+    _fields_ = [('heatmap', ctypes.c_void_p), ('channel', ctypes.c_void_p * 16), ('sample_stride', ctypes.c_int64 * 16),
+                ('classes', ctypes.c_int32), ('label_offset', ctypes.c_int32), ('nms_thresh', ctypes.c_float),
+                ('reserved', ctypes.c_int32)]
+
+
+class CenterInferDesc(ctypes.Structure):
+    """center_infer_desc (include/gd3d.h)."""
+    _fields_ = [('num_tasks', ctypes.c_int32), ('batch', ctypes.c_int32), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('max_per_img', ctypes.c_int32), ('num_channels', ctypes.c_int32), ('decode', ctypes.c_int32),
+                ('heat_is_logit', ctypes.c_int32), ('norm_bbox', ctypes.c_int32), ('use_score_threshold', ctypes.c_int32),
+                ('use_limit_range', ctypes.c_int32), ('nms_type', ctypes.c_int32), ('pre_max_size', ctypes.c_int32),
+                ('post_max_size', ctypes.c_int32), ('out_size_factor', ctypes.c_float), ('voxel_size', ctypes.c_float * 2),
+                ('pc_range', ctypes.c_float * 2), ('score_threshold', ctypes.c_float), ('limit_range', ctypes.c_float * 6),
+                ('tasks', ctypes.POINTER(CenterInferTask))]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -108,6 +126,14 @@ SYMBOLS = {
     'vox_index_workspace_bytes': (_sz, [_i64, ctypes.c_int32]),
     'vox_index_build': (_int, [_vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vox_scatter_backward_grouped': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
+    'center_infer_max_k': (_int, []),
+    'center_infer_rows_per_task': (_i64, [ctypes.POINTER(CenterInferDesc)]),
+    'center_infer_workspace_bytes': (_sz, [ctypes.POINTER(CenterInferDesc)]),
+    'center_infer_candidates': (_int, [ctypes.POINTER(CenterInferDesc), ctypes.POINTER(_i64)]),
+    'center_infer_debug_clocks': (_int, [_vp]),
+    'center_infer_debug_clock_probe': (_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
+    'center_infer_select': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp]),
+    'center_infer_bboxes': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 
@@ -116,7 +142,7 @@ def lib_path():
     return _build.LIB_PATH
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _bind(path):

@@ -1,5 +1,7 @@
 """The bbox coders on either side of the loss.
 
+* ``CenterPointBBoxCoderRev`` — centerpoint_bbox_coders.py:7-112: ``select_best`` (one selection launch, csrc/center_infer.hip),
+  ``decode`` (rot = atan2(sin, cos); csrc/coders.hip), ``encode`` (target generation, a handful of torch ops).
 * ``CenterPointBBoxYawCoder`` — the call surface of
   /root/reference/mmdet3d_gaussian/core/bbox/coders/centerpoint_bbox_yaw_coders.py:8-56 (``encode``, ``decode(locs, preds,
   correct_yaw=True)``; constructor of centerpoint_bbox_coders.py:7-21) on top of the device kernels of csrc/coders.hip:
@@ -76,8 +78,9 @@ class _CenterDecode(torch.autograd.Function):
         return (gp if dtype == torch.float32 else gp.to(dtype)), None, None, None
 
 
-class CenterPointBBoxYawCoder:
-    """Constructor arguments as the reference's CenterPointBBoxCoderRev (centerpoint_bbox_coders.py:9-21)."""
+class CenterPointBBoxCoderRev:
+    """centerpoint_bbox_coders.py:7-112 (`CenterPointBBoxCoderRev`): constructor, `select_best`, `encode`, `decode`."""
+    infer_kind = 'rev'
 
     def __init__(self, pc_range, out_size_factor, voxel_size, code_size=9, norm_bbox=True):
         self.pc_range = pc_range
@@ -85,6 +88,41 @@ class CenterPointBBoxYawCoder:
         self.voxel_size = voxel_size
         self.code_size = code_size
         self.norm_bbox = norm_bbox
+
+    def select_best(self, scores, preds, topk):
+        """scores (B,C,H,W) after the sigmoid, preds (B,N,H,W) -> scores (B,K), classes, locs (x, y), preds (B,K,N)."""
+        from .center_infer import select_best
+        return select_best(scores, preds, topk)
+
+    def encode(self, target_boxes):
+        """(..., 7+k) metric boxes -> (..., 8+k) regression targets: cell-relative xy, z, (log) dims, sin, cos, others.
+        Target generation (get_targets), off the hot path: plain tensor ops on whatever device the boxes live on."""
+        cell = [(target_boxes[..., k] - self.pc_range[k]) / self.voxel_size[k] / self.out_size_factor for k in (0, 1)]
+        frac = [c - c.floor() for c in cell]
+        dims = target_boxes[..., 3:6].log() if self.norm_bbox else target_boxes[..., 3:6]
+        yaw = target_boxes[..., 6]
+        head = torch.stack((frac[0], frac[1], target_boxes[..., 2]), dim=-1)
+        return torch.cat((head, dims, torch.stack((yaw.sin(), yaw.cos()), dim=-1), target_boxes[..., 7:]), dim=-1)
+
+    def decode(self, locs, preds):
+        """locs (..., 2) cells, preds (..., N) raw [dx, dy, z, dims x3, sin, cos, others] -> (..., N-1) metric boxes."""
+        if not preds.is_cuda:
+            raise RuntimeError('CenterPointBBoxCoderRev: the MI355X implementation has no CPU path')
+        lib = _lib.load()
+        lead, c = preds.shape[:-1], preds.shape[-1]
+        p2, l2 = _rows32(preds.detach(), c), _rows32(locs.to(preds.device), 2)
+        out = torch.empty((p2.shape[0], c - 1), dtype=torch.float32, device=p2.device)
+        with torch.cuda.device(p2.device):
+            rc = lib.coder_center_decode(_coder_struct(self), l2.data_ptr(), p2.data_ptr(), p2.shape[0], c, 2, out.data_ptr(), None,
+                                         torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'coder_center_decode')
+        out = out.reshape(lead + (c - 1,))
+        return out if preds.dtype == torch.float32 else out.to(preds.dtype)
+
+
+class CenterPointBBoxYawCoder(CenterPointBBoxCoderRev):
+    """centerpoint_bbox_yaw_coders.py:8-56; constructor and `select_best` of the base class."""
+    infer_kind = 'yaw'
 
     def encode(self, target_boxes):
         """(..., 7+k) boxes [x,y,z,w,l,h,yaw, others] -> (..., 9+k): the first 7 as they are, sin yaw, cos yaw, others."""

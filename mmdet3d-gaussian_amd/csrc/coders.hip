@@ -13,20 +13,20 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/gd3d.h"
+#include "coder_device.h"
 
 namespace gdcoder {
 
 constexpr int T = 256;
-constexpr float HALF_PI = 1.57079632679489661923f;
 
 struct DecArgs {
   const float* locs;   // (n,2)
   const float* preds;  // (n,c)
-  float* out;          // (n,co) co = 7 + max(c - 9, 0)
+  float* out;          // (n,co)
   int* swapk;          // (n) nullable: num_rot90 of the forward, for the backward
   long long n;
-  int c, co, norm_bbox, correct_yaw;
-  float osf, vs0, vs1, pc0, pc1;
+  int c, co, mode;     // mode 0: yaw as it is, 1: correct_yaw, 2: CenterPointBBoxCoderRev (rot = atan2(p6, p7))
+  Geom g;
 };
 
 __global__ __launch_bounds__(T) void center_decode_kernel(const DecArgs a) {
@@ -34,36 +34,19 @@ __global__ __launch_bounds__(T) void center_decode_kernel(const DecArgs a) {
   if (i >= a.n) return;
   const float* p = a.preds + i * a.c;
   float* o = a.out + i * a.co;
-  o[0] = (p[0] + a.locs[i * 2]) * a.osf * a.vs0 + a.pc0;
-  o[1] = (p[1] + a.locs[i * 2 + 1]) * a.osf * a.vs1 + a.pc1;
+  const bool rev = a.mode == 2;
+  const Core c = decode_core(p[0], p[1], p[3], p[4], p[5], rev ? 0.f : p[6], a.mode == 1 ? p[7] : 0.f, a.mode == 1 ? p[8] : 0.f,
+                             a.locs[i * 2], a.locs[i * 2 + 1], a.g, a.mode == 1);
+  o[0] = c.x;
+  o[1] = c.y;
   o[2] = p[2];
-  float d0 = p[3], d1 = p[4], d2 = p[5];
-  if (a.norm_bbox) {
-    d0 = expf(d0);
-    d1 = expf(d1);
-    d2 = expf(d2);
-  }
-  float yaw = p[6];
-  int k = 0;
-  if (a.correct_yaw) {
-    const float dir = atan2f(p[7], p[8]);
-    const float nr = floorf((dir - yaw) / HALF_PI + 0.5f);
-    // `num_rot90.long() % 2 == 0`: parity of the truncated integer (Python % on tensors follows the divisor's sign: -1 % 2 = 1)
-    const long long kl = (long long)nr;
-    k = (int)(kl & 1);
-    yaw = yaw + nr * HALF_PI;
-    if (k) {
-      const float t = d0;
-      d0 = d1;
-      d1 = t;
-    }
-  }
-  o[3] = d0;
-  o[4] = d1;
-  o[5] = d2;
-  o[6] = yaw;
-  for (int j = 9; j < a.c; ++j) o[7 + (j - 9)] = p[j];
-  if (a.swapk != nullptr) a.swapk[i] = k;
+  o[3] = c.d0;
+  o[4] = c.d1;
+  o[5] = c.d2;
+  o[6] = rev ? atan2f(p[6], p[7]) : c.yaw;
+  const int first = rev ? 8 : 9;             // the columns after the rotation channels pass through
+  for (int j = first; j < a.c; ++j) o[7 + (j - first)] = p[j];
+  if (a.swapk != nullptr) a.swapk[i] = c.k;
 }
 
 // backward of decode wrt preds: gp (n,c) from go (n,co), the decoded output and the swap flags
@@ -122,8 +105,9 @@ extern "C" {
 
 int coder_center_decode(const gd3d_prologue* coder, const float* locs, const float* preds, int64_t n, int32_t c,
                         int32_t correct_yaw, float* out, int32_t* num_rot_parity, void* stream) {
-  if (coder == nullptr || n < 0 || c < 7) return GD3D_E_BADARG;
-  if (correct_yaw && c < 9) return GD3D_E_BADARG;
+  if (coder == nullptr || n < 0 || c < 7 || correct_yaw < 0 || correct_yaw > 2) return GD3D_E_BADARG;
+  if (correct_yaw == 1 && c < 9) return GD3D_E_BADARG;
+  if (correct_yaw == 2 && c < 8) return GD3D_E_BADARG;
   if (n == 0) return 0;
   if (locs == nullptr || preds == nullptr || out == nullptr) return GD3D_E_BADARG;
   DecArgs a;
@@ -133,14 +117,14 @@ int coder_center_decode(const gd3d_prologue* coder, const float* locs, const flo
   a.swapk = (int*)num_rot_parity;
   a.n = n;
   a.c = c;
-  a.co = 7 + (c > 9 ? c - 9 : 0);
-  a.norm_bbox = coder->norm_bbox;
-  a.correct_yaw = correct_yaw;
-  a.osf = coder->out_size_factor;
-  a.vs0 = coder->voxel_size[0];
-  a.vs1 = coder->voxel_size[1];
-  a.pc0 = coder->pc_range[0];
-  a.pc1 = coder->pc_range[1];
+  a.co = correct_yaw == 2 ? c - 1 : 7 + (c > 9 ? c - 9 : 0);
+  a.mode = correct_yaw;
+  a.g.norm_bbox = coder->norm_bbox;
+  a.g.osf = coder->out_size_factor;
+  a.g.vs0 = coder->voxel_size[0];
+  a.g.vs1 = coder->voxel_size[1];
+  a.g.pc0 = coder->pc_range[0];
+  a.g.pc1 = coder->pc_range[1];
   const long long nb = (n + T - 1) / T;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   hipLaunchKernelGGL(center_decode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);

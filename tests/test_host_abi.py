@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder)_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer)_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_queries_without_gpu():
     lib = amd.load_library()
     arch = ctypes.c_char_p()
-    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 3
+    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 4
     assert arch.value == b'gfx950'
     assert lib.gd3d_loss_workspace_bytes(0) >= 16
     assert lib.gd3d_loss_workspace_bytes(10_000_000) >= 4 * ((10_000_000 + 255) // 256)
@@ -158,3 +158,55 @@ def test_bench_core_count_respects_the_cgroup_quota():
             assert n <= max(1, int(int(quota) / int(period) + 0.5))
     except OSError:
         pass
+
+
+def test_center_infer_struct_layouts_match_the_header():
+    """sizeof / offsetof of center_infer_task and center_infer_desc as gcc sees include/gd3d.h against the ctypes mirrors."""
+    import subprocess
+    import tempfile
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(center_infer_task), offsetof(center_infer_task, sample_stride), offsetof(center_infer_task, classes),'
+           'offsetof(center_infer_task, nms_thresh), sizeof(center_infer_desc), offsetof(center_infer_desc, out_size_factor),'
+           'offsetof(center_infer_desc, score_threshold), offsetof(center_infer_desc, limit_range), offsetof(center_infer_desc, tasks));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(c, 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
+        got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    T, D = _lib.CenterInferTask, _lib.CenterInferDesc
+    want = [ctypes.sizeof(T), T.sample_stride.offset, T.classes.offset, T.nms_thresh.offset, ctypes.sizeof(D),
+            D.out_size_factor.offset, D.score_threshold.offset, D.limit_range.offset, D.tasks.offset]
+    assert got == want, (got, want)
+
+
+def test_center_infer_queries_and_argument_checks_without_gpu():
+    lib = amd.load_library()
+    assert lib.center_infer_max_k() == 4096
+    task = _lib.CenterInferTask()
+    task.heatmap = 4096          # never dereferenced: the checks below fail (or only size things) before any launch
+    task.classes = 2
+    d = _lib.CenterInferDesc()
+    d.num_tasks, d.batch, d.height, d.width = 1, 2, 128, 128
+    d.max_per_img, d.num_channels, d.decode, d.nms_type = 500, 11, 2, 0
+    d.pre_max_size, d.post_max_size = 1000, 83
+    d.tasks = ctypes.pointer(task)
+    assert lib.center_infer_rows_per_task(ctypes.byref(d)) == 83
+    ws = lib.center_infer_workspace_bytes(ctypes.byref(d))
+    assert ws >= 2 * 500 * (9 + 1 + 1 + 5) * 4 and ws % 256 == 0
+    d.post_max_size = -1
+    assert lib.center_infer_rows_per_task(ctypes.byref(d)) == 500
+    d.pre_max_size = 40
+    assert lib.center_infer_rows_per_task(ctypes.byref(d)) == 40
+    d.max_per_img = 5000
+    assert lib.center_infer_bboxes(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10002   # GD3D_E_TOOLARGE
+    d.max_per_img, d.height, d.width = 500, 16, 16
+    assert lib.center_infer_bboxes(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10001   # GD3D_E_BADARG: K > H*W: torch.topk raises in the reference
+    d.height = d.width = 128
+    d.num_channels = 8
+    assert lib.center_infer_bboxes(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10001   # yaw decode needs 9 channels
+    d.num_channels = 17
+    assert lib.center_infer_select(ctypes.byref(d), 256, 256, 256, 256, None) == 10001
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.select_best(torch.zeros(1, 1, 8, 8), torch.zeros(1, 4, 8, 8), 4)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.CenterPointBBoxCoderRev([0, 0], 4, [0.2, 0.2]).decode(torch.zeros(1, 4, 2), torch.zeros(1, 4, 10))

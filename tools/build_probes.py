@@ -3,6 +3,7 @@
    hbm_probe   measured HBM ceilings for the fused kernel's access mix
    clip_probe  cycle accounting of one polygon-clipping pass of the rotated-NMS predicate
    mask_probe  cycle stamps of one wave of the NMS mask kernel inside a real call
+   sort_probe  LDS bitonic sort of (key, ~index) entries in one 1024-thread workgroup: passes, barriers, idle-chip effects
 The binaries are built in-tree (git-ignored; they travel to the GPU box with the snapshot)."""
 import os
 import subprocess
@@ -14,6 +15,7 @@ PROBES = {
     'hbm_probe2': ['-O3'],
     'clip_probe': ['-O3', '-ffp-contract=off'],
     'mask_probe': ['-O3', '-ffp-contract=off', '-Wno-unused-value'],
+    'sort_probe': ['-O3', '-Wno-unused-result'],
 }
 
 

@@ -47,6 +47,13 @@ cp $OUT/kt_c4/*/*kernel_stats.csv $OUT/${R}_config4_kernel_stats.csv 2>/dev/null
 python3 tools/step_variants.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_step_variants.jsonl
 tools/pmc_issue_mix.sh $OUT/${R}_pmc_issue_mix.txt > /dev/null 2>&1
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
+# CenterPoint inference slice (head maps -> detections): end to end vs the reference's op sequence, per-kernel table, the
+# phases inside the selection kernel, the stand-alone sort probe.  The trace goes to /tmp: its raw csv exceeds gpurun's 64 MiB.
+python3 tests/perf/center_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_time.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ci -o ci -- python3 tests/perf/center_infer_time.py > /dev/null 2>&1
+cp /tmp/kt_ci/ci_kernel_stats.csv $OUT/${R}_center_infer_kernel_stats.csv 2>/dev/null
+python3 tools/center_infer_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_phases.txt
+[ -x tools/sort_probe ] && ./tools/sort_probe > $OUT/${R}_sort_probe.txt 2>&1
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
 python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
 # accuracy report of THIS build: the test module deletes any older file of that name before it runs and writes it only from
