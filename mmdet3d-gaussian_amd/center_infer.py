@@ -18,6 +18,7 @@ from . import _lib
 _REV_ORDER = ('reg', 'height', 'dim', 'rot', 'vel')
 _YAW_ORDER = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
 _WIDTH = dict(reg=2, height=1, dim=3, rot=2, yaw=1, dir=2, vel=2)
+_DESC_CACHE = {}
 
 
 def _task_dict(entry):
@@ -91,7 +92,8 @@ def _coder_kind(coder, first):
     return kind, [k for k in need if k in first or k == 'reg']
 
 
-def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_metas=None, return_candidates=False):
+def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_metas=None, return_candidates=False,
+                           padded=False):
     """`CenterHeadRev.get_bboxes(preds_dicts, img_metas)` (gd_centerpoint_head.py:218-303) for heads with rotate or circle NMS.
 
     preds_dicts : per task a dict (or the reference's one-element list of it) with 'heatmap' (B,C,H,W) LOGITS and the head
@@ -102,6 +104,9 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
     test_cfg    : the head's test_cfg (dict-like);  num_classes: classes per task (label offsets, :293-297).
     Returns, per sample, [bboxes (n, 7 + vel) with z at the box bottom, scores (n,), labels (n,) int32]; with `img_metas`
     given the boxes are wrapped by img_metas[i]['box_type_3d'](bboxes, bbox_coder.code_size) as the reference does.
+    padded=True: no read-back at all — returns dict(bboxes (B, R, co), scores (B, R), labels (B, R) int32, counts (B,) int64) on
+    the device, rows beyond counts[b] undefined: the whole slice is then stream-ordered and can sit inside a captured hipGraph
+    (tests/test_gpu_center_infer.py::test_get_bboxes_replays_as_a_hipgraph) or feed a tracker without a host round trip.
     return_candidates: also return what went INTO the NMS, per task a dict(boxes (B,K,co), scores (B,K), labels (B,K) int32,
     counts (B,) int32): the survivors of the score / range mask in score order (rows beyond counts[b] are undefined)."""
     tasks = [_task_dict(e) for e in preds_dicts]
@@ -126,64 +131,84 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
         raise RuntimeError('selected index k out of range')
     if K > lib.center_infer_max_k():
         raise RuntimeError(f'max_per_img {K} > {lib.center_infer_max_k()} (the selection kernel sorts in LDS)')
-    keep_alive = []
-    arr = (_lib.CenterInferTask * len(tasks))()
-    flag = 0
-    for t, (pd, nc) in enumerate(zip(tasks, num_classes)):
+    # first pass: validate, make the maps fp32-contiguous, collect their addresses.  The descriptor (some 150 ctypes fields) is
+    # rebuilt only when an address, a shape or a setting changed: an inference loop whose head writes into the same buffers
+    # (the caching allocator hands them back step after step) pays for it once.
+    keep_alive, ptrs, ncls = [], [], []
+    for t, pd in enumerate(tasks):
         heat = _f32c(pd['heatmap'])
-        if tuple(heat.shape) != (B, heat.shape[1], H, W):
+        if heat.dim() != 4 or heat.shape[0] != B or tuple(heat.shape[2:]) != (H, W):
             raise RuntimeError(f'task {t}: heatmap {tuple(heat.shape)} vs (B={B}, C, {H}, {W})')
         keep_alive.append(heat)
-        arr[t].heatmap = heat.data_ptr()
-        arr[t].classes = heat.shape[1]
-        j = 0
+        ptrs.append(heat.data_ptr())
+        ncls.append(heat.shape[1])
         for k in names:
-            w = _WIDTH[k]
             m = pd.get(k) if hasattr(pd, 'get') else (pd[k] if k in pd else None)
             if m is None:
                 if k != 'reg':
                     raise RuntimeError(f'task {t}: head map {k!r} is missing')
-                for q in range(w):           # no 'reg' head: the constant 0.5 (:206-208)
-                    arr[t].channel[j + q] = None
-                    arr[t].sample_stride[j + q] = 0
-            else:
-                m = _f32c(m)
-                if tuple(m.shape) != (B, w, H, W):
-                    raise RuntimeError(f'task {t}: {k} is {tuple(m.shape)}, expected {(B, w, H, W)}')
-                keep_alive.append(m)
-                for q in range(w):
-                    arr[t].channel[j + q] = m.data_ptr() + 4 * q * H * W
-                    arr[t].sample_stride[j + q] = w * H * W
-            j += w
-        arr[t].label_offset = flag
-        flag += int(nc)
-        arr[t].nms_thresh = float(test_cfg['min_radius'][t] if nms_type == 'circle' else test_cfg['nms_thr'])
-    desc = _lib.CenterInferDesc()
-    desc.num_tasks, desc.batch, desc.height, desc.width = len(tasks), B, H, W
-    desc.max_per_img, desc.num_channels = K, nchan
-    desc.decode = 2 if kind == 'yaw' else 1
-    desc.heat_is_logit = 1
-    _fill_geometry(desc, bbox_coder)
-    desc.use_score_threshold = 1
-    desc.score_threshold = float(test_cfg.get('score_threshold', 0.1))
+                ptrs.append(0)               # no 'reg' head: the constant 0.5 (:206-208)
+                continue
+            m = _f32c(m)
+            if tuple(m.shape) != (B, _WIDTH[k], H, W):
+                raise RuntimeError(f'task {t}: {k} is {tuple(m.shape)}, expected {(B, _WIDTH[k], H, W)}')
+            keep_alive.append(m)
+            ptrs.append(m.data_ptr())
     rng = test_cfg.get('post_center_limit_range', None)
-    desc.use_limit_range = int(rng is not None)
-    if rng is not None:
-        desc.limit_range = (ctypes.c_float * 6)(*[float(v) for v in rng])
-    desc.nms_type = 2 if nms_type == 'circle' else 0
     pre = None if nms_type == 'circle' else test_cfg.get('pre_max_size', None)
     post = test_cfg.get('post_max_size', None)
     if (pre is not None and pre < 0) or (post is not None and post < 0):
         raise RuntimeError('center_head_get_bboxes: negative pre_max_size / post_max_size (a slice bound in the reference) is not supported')
-    # `if pre_max_size is not None` / `if post_max_size is not None` in nms_gpu; circle_nms always cuts to post_max_size
-    desc.pre_max_size = -1 if pre is None else int(pre)
-    desc.post_max_size = -1 if post is None else int(post)
-    desc.tasks = arr
-    rows = int(lib.center_infer_rows_per_task(ctypes.byref(desc)))
+    thr = [float(test_cfg['min_radius'][t] if nms_type == 'circle' else test_cfg['nms_thr']) for t in range(len(tasks))]
+    key = (dev.index, tuple(ptrs), tuple(ncls), tuple(names), B, H, W, K, kind, nms_type, tuple(thr), tuple(int(c) for c in num_classes),
+           float(test_cfg.get('score_threshold', 0.1)), None if rng is None else tuple(float(v) for v in rng), pre, post,
+           bool(bbox_coder.norm_bbox), float(bbox_coder.out_size_factor), tuple(float(v) for v in bbox_coder.voxel_size[:2]),
+           tuple(float(v) for v in bbox_coder.pc_range[:2]))
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        arr = (_lib.CenterInferTask * len(tasks))()
+        flag, pi = 0, 0
+        for t, nc in enumerate(num_classes):
+            arr[t].heatmap = ptrs[pi]
+            pi += 1
+            arr[t].classes = ncls[t]
+            j = 0
+            for k in names:
+                w = _WIDTH[k]
+                base = ptrs[pi]
+                pi += 1
+                for q in range(w):
+                    arr[t].channel[j + q] = (base + 4 * q * H * W) if base else None
+                    arr[t].sample_stride[j + q] = w * H * W if base else 0
+                j += w
+            arr[t].label_offset = flag
+            flag += int(nc)
+            arr[t].nms_thresh = thr[t]
+        desc = _lib.CenterInferDesc()
+        desc.num_tasks, desc.batch, desc.height, desc.width = len(tasks), B, H, W
+        desc.max_per_img, desc.num_channels = K, nchan
+        desc.decode = 2 if kind == 'yaw' else 1
+        desc.heat_is_logit = 1
+        _fill_geometry(desc, bbox_coder)
+        desc.use_score_threshold = 1
+        desc.score_threshold = float(test_cfg.get('score_threshold', 0.1))
+        desc.use_limit_range = int(rng is not None)
+        if rng is not None:
+            desc.limit_range = (ctypes.c_float * 6)(*[float(v) for v in rng])
+        desc.nms_type = 2 if nms_type == 'circle' else 0
+        # `if pre_max_size is not None` / `if post_max_size is not None` in nms_gpu; circle_nms always cuts to post_max_size
+        desc.pre_max_size = -1 if pre is None else int(pre)
+        desc.post_max_size = -1 if post is None else int(post)
+        desc.tasks = arr
+        if len(_DESC_CACHE) >= 16:
+            _DESC_CACHE.clear()
+        hit = _DESC_CACHE[key] = (desc, arr, int(lib.center_infer_rows_per_task(ctypes.byref(desc))),
+                                  int(lib.center_infer_workspace_bytes(ctypes.byref(desc))))
+    desc, _, rows, ws_bytes = hit
     co = nchan - (2 if kind == 'yaw' else 1)
     T = len(tasks)
     with torch.cuda.device(dev):
-        ws = torch.empty(lib.center_infer_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         boxes = torch.empty((B, T * rows, co), dtype=torch.float32, device=dev)
         scores = torch.empty((B, T * rows), dtype=torch.float32, device=dev)
         labels = torch.empty((B, T * rows), dtype=torch.int32, device=dev)
@@ -191,6 +216,8 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
         _lib.check(lib.center_infer_bboxes(ctypes.byref(desc), ws.data_ptr(), boxes.data_ptr(), scores.data_ptr(),
                                            labels.data_ptr(), count.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    'center_infer_bboxes')
+    if padded:
+        return dict(bboxes=boxes, scores=scores, labels=labels, counts=count)
     ns = count.tolist()          # the one sync: B data-dependent detection counts
     out = []
     for i in range(B):

@@ -280,3 +280,32 @@ def test_errors():
     del gpu[0]['dir']
     with pytest.raises(RuntimeError, match='dir'):
         amd.center_head_get_bboxes(gpu, coder, dict(NUS_TEST, max_per_img=50), [1])
+
+
+def test_get_bboxes_replays_as_a_hipgraph():
+    """padded=True: nothing is read back, so the slice can be captured once and replayed on new head outputs in the same
+    buffers; the replayed detections equal the eager call's"""
+    g = torch.Generator().manual_seed(27)
+    classes = [1, 2, 2, 1, 2, 2]
+    coder = amd.CenterPointBBoxYawCoder(**NUS)
+    first = make_tasks(g, 2, 128, 128, classes, 'yaw')
+    second = make_tasks(g, 2, 128, 128, classes, 'yaw')
+    static = [{k: v.to(dev()).clone() for k, v in pd.items()} for pd in first]
+    cfg = dict(NUS_TEST, score_threshold=midgap(first + second, 500, 0.4))
+    amd.center_head_get_bboxes(static, coder, cfg, classes, padded=True)          # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = amd.center_head_get_bboxes(static, coder, cfg, classes, padded=True)
+    for src in (second, first):
+        for pd_s, pd_n in zip(static, src):
+            for k in pd_s:
+                pd_s[k].copy_(pd_n[k])
+        graph.replay()
+        torch.cuda.synchronize()
+        want = amd.center_head_get_bboxes([{k: v.to(dev()) for k, v in pd.items()} for pd in src], coder, cfg, classes)
+        n = out['counts'].tolist()
+        for b in range(2):
+            assert n[b] == want[b][0].shape[0] > 0
+            assert torch.equal(out['bboxes'][b, :n[b]], want[b][0]) and torch.equal(out['scores'][b, :n[b]], want[b][1])
+            assert torch.equal(out['labels'][b, :n[b]], want[b][2])
