@@ -539,7 +539,9 @@ int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, co
  *   correct_yaw;  max_per_img <= center_infer_max_k() and <= H*W (torch.topk's own limit);  num_channels <= 16;
  *   H*W*classes < 2^31;  nms_type 0 rotate / 2 circle;  pre_max_size, post_max_size < 0: none.
  * center_infer_select: the selection alone (the coder's select_best): sel_scores (G, K) fp32, sel_cls (G, K) int64,
- *   sel_xy (G, K, 2) int64 (x, y), sel_preds (G, K, num_channels) fp32 raw channels; group G = task * batch + sample.
+ *   sel_xy (G, K, 2) int64 (x, y), sel_preds (G, K, num_channels) fp32 raw channels; group G = task * batch + sample;
+ *   workspace: center_infer_select_workspace_bytes(desc), 256-byte aligned (only maps above 131072 cells per group use it:
+ *   their threshold and filtering pass run as chip-wide launches of their own and hand the candidates over in it).
  * center_infer_bboxes: out_boxes (batch, num_tasks * P, co) fp32 with z moved to the box bottom (:289), out_scores
  *   (batch, num_tasks * P), out_labels (batch, num_tasks * P) int32, out_count (batch) int64 on the DEVICE — the one thing the
  *   host reads back;  P = center_infer_rows_per_task(desc) = min(max_per_img, pre_max_size, post_max_size);  co = num_channels
@@ -585,8 +587,9 @@ int center_infer_debug_clocks(int64_t* device_buffer);
 /* Clock probe: `iters` dependent FMAs per thread in `blocks` workgroups of 256; device_out[0] = wall time of workgroup 0 in
  * 10 ns ticks (device_out: 2 int64).  One workgroup vs a chip-filling launch shows the clock an almost idle chip is granted. */
 int center_infer_debug_clock_probe(int64_t* device_out, int32_t blocks, int32_t iters, void* stream);
-int center_infer_select(const center_infer_desc* desc, float* sel_scores, int64_t* sel_cls, int64_t* sel_xy,
-                        float* sel_preds, void* stream);
+size_t center_infer_select_workspace_bytes(const center_infer_desc* desc);
+int center_infer_select(const center_infer_desc* desc, void* workspace, float* sel_scores, int64_t* sel_cls,
+                        int64_t* sel_xy, float* sel_preds, void* stream);
 int center_infer_bboxes(const center_infer_desc* desc, void* workspace, float* out_boxes, float* out_scores,
                         int32_t* out_labels, int64_t* out_count, void* stream);
 

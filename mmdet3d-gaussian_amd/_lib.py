@@ -132,7 +132,8 @@ SYMBOLS = {
     'center_infer_candidates': (_int, [ctypes.POINTER(CenterInferDesc), ctypes.POINTER(_i64)]),
     'center_infer_debug_clocks': (_int, [_vp]),
     'center_infer_debug_clock_probe': (_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
-    'center_infer_select': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp]),
+    'center_infer_select_workspace_bytes': (_sz, [ctypes.POINTER(CenterInferDesc)]),
+    'center_infer_select': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'center_infer_bboxes': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }

@@ -72,7 +72,8 @@ def select_best(scores, preds, topk):
     out_xy = torch.empty((B, K, 2), dtype=torch.int64, device=dev)
     out_p = torch.empty((B, K, N), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.center_infer_select(ctypes.byref(desc), out_s.data_ptr(), out_c.data_ptr(), out_xy.data_ptr(),
+        ws = torch.empty(lib.center_infer_select_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.center_infer_select(ctypes.byref(desc), ws.data_ptr(), out_s.data_ptr(), out_c.data_ptr(), out_xy.data_ptr(),
                                            out_p.data_ptr(), torch.cuda.current_stream().cuda_stream), 'center_infer_select')
     if scores.dtype != torch.float32:
         out_s = out_s.to(scores.dtype)

@@ -23,8 +23,11 @@
 //      maps (no concatenated copy of the maps exists), decode, score and centre-range mask, ORDERED compaction of the
 //      survivors (they stay in score order: the NMS needs no second sort), NMS boxes [x1, y1, x2, y2, yaw] / circle centres.
 // One workgroup per group is the right grain for the reference's geometry (128 x 128 cells x 1-2 classes, K = 500: 34-47 us,
-// tools/center_infer_phases.py); a 468 x 468 x 3 map with K = 4096 takes ~0.9 ms this way (the exact select streams the
-// map through one CU four times) — correct, tested, and slower than torch.topk there.
+// tools/center_infer_phases.py).  Maps above 131072 cells per group (468 x 468 x 3 with K = 4096 took 0.9 ms that way: one CU
+// streaming the map) take the WIDE form: wide_sample_kernel (the threshold, one workgroup per group), wide_filter_kernel (the
+// filtering pass by slices of 32768 cells over the whole chip, candidates appended to a list in global memory), then
+// select_kernel starts from that list — thinned by a second threshold, sampled from the candidates themselves, when it exceeds
+// the LDS buffer — and falls back to the exact select over the map when the list proves nothing (fewer than K entries, overflow).
 // merge_kernel, one thread per output row: the kept rows of every task, in task order, z moved to the box bottom, labels
 // shifted by the task's class offset, and the number of detections of the sample.
 #include <hip/hip_runtime.h>
@@ -42,6 +45,8 @@ constexpr int MAXT = CENTER_INFER_MAX_TASKS;
 constexpr int BINS = 4096;
 constexpr int SORT_CAP = 8192;
 constexpr int MAX_K = 4096;
+constexpr int WIDE_N = 131072;       // above this many cells per group the map is filtered by many workgroups
+constexpr int WIDE_SLICE = 32768;    // cells per workgroup of that pass
 // the candidate list is stored with one pad entry after every 8 (PH below): a thread of the sort that owns 8 consecutive
 // entries (64 bytes) would otherwise share its two LDS banks with 31 other lanes of its wave
 constexpr size_t LDS_BYTES = sizeof(int) * BINS + sizeof(unsigned long long) * (SORT_CAP + SORT_CAP / 8);
@@ -76,6 +81,11 @@ struct SelArgs {
   long long* order;
   float* thresh;
   long long* clocks;   // nullable: (groups, 8) s_memrealtime stamps of the kernel's phases (center_infer_debug_clocks)
+  // wide form (maps above WIDE_N cells): the threshold and the filtering pass ran in their own chip-wide launches
+  int wide, wcap;
+  unsigned* wtau;               // (G) threshold keys
+  int* wcount;                  // (G) candidates found (may exceed wcap: overflow)
+  unsigned long long* wlist;    // (G, wcap) candidates, unordered
 };
 
 __device__ __forceinline__ unsigned key_of(float v) {
@@ -261,14 +271,25 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {
   return x - v;
 }
 
-__device__ __forceinline__ void emit(float v, int i, bool take, int& pos, unsigned long long* list) {
+// the float whose key is `k` (0: -inf, keeps everything; the NaN key gives a NaN, and `!(v < NaN)` keeps everything as well: the
+// pass then overflows unless the map is small, and the exact select takes over)
+__device__ __forceinline__ float key_to_float(unsigned k) {
+  return k == 0u ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// LDS_LIST: the padded LDS list of one workgroup (capacity SORT_CAP); otherwise a plain list in global memory (capacity
+// `cap`) that many workgroups append to, `i0` = flat index of heat[0] in the group's map
+template <bool LDS_LIST>
+__device__ __forceinline__ void emit(float v, int i, bool take, int& pos, unsigned long long* list, int cap) {
   if (take) {
-    if (pos < SORT_CAP) list[PH(pos)] = pack(key_of(v), (unsigned)i);
+    if (pos < cap) list[LDS_LIST ? PH(pos) : pos] = pack(key_of(v), (unsigned)i);
     ++pos;
   }
 }
 
-__device__ __forceinline__ void filter_pass(const float* __restrict__ heat, int N, float tau, unsigned long long* list, int* counter) {
+template <bool LDS_LIST>
+__device__ __forceinline__ void filter_pass(const float* __restrict__ heat, int N, float tau, unsigned long long* list, int* counter,
+                                            int cap = SORT_CAP, int i0 = 0) {
   const int tid = threadIdx.x, lane = tid & 63;
   int head = (int)((4u - (unsigned)(((uintptr_t)heat >> 2) & 3u)) & 3u);
   head = head < N ? head : N;
@@ -286,7 +307,7 @@ __device__ __forceinline__ void filter_pass(const float* __restrict__ heat, int 
       int base = 0;
       if (lane == 0) base = atomicAdd(counter, tot);
       int pos = __builtin_amdgcn_readfirstlane(base) + ex;
-      emit(v, i, take, pos, list);
+      emit<LDS_LIST>(v, i0 + i, take, pos, list, cap);
     }
   }
   const float4* __restrict__ hv = (const float4*)(heat + head);
@@ -314,11 +335,11 @@ __device__ __forceinline__ void filter_pass(const float* __restrict__ heat, int 
     if (cnt > 0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = head + 4 * (b0 + u * T + tid);
-        emit(x[u].x, i, ok[u] && !(x[u].x < tau), pos, list);
-        emit(x[u].y, i + 1, ok[u] && !(x[u].y < tau), pos, list);
-        emit(x[u].z, i + 2, ok[u] && !(x[u].z < tau), pos, list);
-        emit(x[u].w, i + 3, ok[u] && !(x[u].w < tau), pos, list);
+        const int i = i0 + head + 4 * (b0 + u * T + tid);
+        emit<LDS_LIST>(x[u].x, i, ok[u] && !(x[u].x < tau), pos, list, cap);
+        emit<LDS_LIST>(x[u].y, i + 1, ok[u] && !(x[u].y < tau), pos, list, cap);
+        emit<LDS_LIST>(x[u].z, i + 2, ok[u] && !(x[u].z < tau), pos, list, cap);
+        emit<LDS_LIST>(x[u].w, i + 3, ok[u] && !(x[u].w < tau), pos, list, cap);
       }
     }
   }
@@ -426,43 +447,71 @@ __global__ __launch_bounds__(T) void select_kernel(const SelArgs a) {
   // the rank the K-th best is expected at), then ONE pass over the map that keeps the keys >= threshold.  The pass proves
   // itself: with K <= M <= SORT_CAP survivors the K best are among them, whatever the sample looked like; otherwise (sample
   // not representative, masses of equal keys) the exact radix select below runs instead.
+  // Wide form: threshold and pass already ran chip-wide (wide_sample_kernel, wide_filter_kernel) and left M candidates in
+  // global memory; more than fit the LDS buffer are thinned by a second threshold, sampled from the candidates themselves.
   if (tid == 0) {
     s_nsel = 0;
     s_tau = 0u;
   }
-  bool fast = N <= SORT_CAP;                // tau = 0 keeps everything
-  if (N > 2048) {
-    const float rho = (float)K * (float)T / (float)N;
-    const int R = (int)ceilf(rho + 4.0f * sqrtf(rho) + 8.0f);
-    if (R < T) {
+  unsigned long long* samp = (unsigned long long*)hist;      // 1152 x 8 bytes of the histogram's 16 KB
+  bool fast = false;
+  int M = 0;
+  if (a.wide) {
+    STAMP(7);
+    STAMP(1);
+    const int G = a.group0 + g;
+    const int Mw = a.wcount[G];
+    const unsigned long long* wl = a.wlist + (size_t)G * (size_t)a.wcap;
+    if (Mw >= K && Mw <= a.wcap) {
       fast = true;
-      unsigned long long* samp = (unsigned long long*)hist;      // 1152 x 8 bytes of the histogram's 16 KB
-      const unsigned si = (unsigned)(((unsigned long long)tid * (unsigned long long)N) / (unsigned long long)T);
-      const unsigned long long mine = pack(key_of(heat[si]), si);
-      samp[PH(tid)] = mine;
+      if (Mw > SORT_CAP) {
+        const float rho = (float)K * (float)T / (float)Mw;
+        const int R = (int)ceilf(rho + 4.0f * sqrtf(rho) + 8.0f);
+        if (R < T) {
+          samp[PH(tid)] = wl[(unsigned)(((unsigned long long)tid * (unsigned long long)Mw) / (unsigned long long)T)];
+          __syncthreads();
+          bitonic_desc(samp, T);
+          if (tid == 0) s_tau = (unsigned)(samp[PH(R - 1)] >> 32);
+        }
+      }
       __syncthreads();
-      STAMP(7);
-      bitonic_desc(samp, T);
-      if (tid == 0) s_tau = (unsigned)(samp[PH(R - 1)] >> 32);
+      const unsigned tk = s_tau;
+      for (int base = 0; base < Mw; base += T) {
+        const int i = base + tid;
+        const unsigned long long e = i < Mw ? wl[i] : 0ull;
+        append(i < Mw && (unsigned)(e >> 32) >= tk, e, cand, &s_nsel);
+      }
+      __syncthreads();
+      M = s_nsel;
+    }
+  } else {
+    fast = N <= SORT_CAP;                   // tau = 0 keeps everything
+    if (N > 2048) {
+      const float rho = (float)K * (float)T / (float)N;
+      const int R = (int)ceilf(rho + 4.0f * sqrtf(rho) + 8.0f);
+      if (R < T) {
+        fast = true;
+        const unsigned si = (unsigned)(((unsigned long long)tid * (unsigned long long)N) / (unsigned long long)T);
+        samp[PH(tid)] = pack(key_of(heat[si]), si);
+        __syncthreads();
+        STAMP(7);
+        bitonic_desc(samp, T);
+        if (tid == 0) s_tau = (unsigned)(samp[PH(R - 1)] >> 32);
+      }
+    }
+    __syncthreads();
+    STAMP(1);
+    if (fast) {
+      filter_pass<true>(heat, N, key_to_float(s_tau), cand, &s_nsel);
+      __syncthreads();
+      M = s_nsel;
     }
   }
-  __syncthreads();
-  STAMP(1);
-  int M = 0;
-  if (fast) {
-    // the float whose key is the threshold (0: keep everything; a NaN threshold keeps everything as well: the pass then overflows
-    // unless the map is small, and the exact select takes over)
-    const unsigned tk = s_tau;
-    const float tau = tk == 0u ? -__builtin_inff() : __uint_as_float((tk & 0x80000000u) ? (tk ^ 0x80000000u) : ~tk);
-    filter_pass(heat, N, tau, cand, &s_nsel);
+  if (fast && (M < K || M > SORT_CAP)) {
+    fast = false;
     __syncthreads();
-    M = s_nsel;
-    if (M < K || M > SORT_CAP) {
-      fast = false;
-      __syncthreads();
-      if (tid == 0) s_nsel = 0;
-      __syncthreads();
-    }
+    if (tid == 0) s_nsel = 0;
+    __syncthreads();
   }
   STAMP(2);
   if (!fast) {
@@ -568,6 +617,54 @@ __global__ __launch_bounds__(T) void select_kernel(const SelArgs a) {
 #undef STAMP
 }
 
+// ---- wide form: maps above WIDE_N cells per group -------------------------------------------------------------------------
+// wide_sample_kernel (one workgroup per group): the threshold from 1024 strided cells, as above.
+// wide_filter_kernel (grid: slices of WIDE_SLICE cells x groups): the filtering pass, appending to the group's list in global
+// memory (one global atomic per wave and batch).  select_kernel then starts from that list.
+struct WideArgs {
+  Task task[MAXT];
+  int B, H, W, K, group0, wcap;
+  unsigned* wtau;
+  int* wcount;
+  unsigned long long* wlist;
+};
+
+__global__ __launch_bounds__(T) void wide_sample_kernel(const WideArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned long long samp[T + T / 8];
+  const int tid = threadIdx.x, g = blockIdx.x;
+  const int t = g / a.B, b = g - t * a.B;
+  const Task& tk = a.task[t];
+  const int N = tk.classes * a.H * a.W;
+  const float* heat = tk.heat + (size_t)b * (size_t)N;
+  const float rho = (float)a.K * (float)T / (float)N;
+  const int R = (int)ceilf(rho + 4.0f * sqrtf(rho) + 8.0f);
+  unsigned tau = 0u;                        // R >= T: keep everything (the list then overflows and the exact select runs)
+  if (R < T) {
+    const unsigned si = (unsigned)(((unsigned long long)tid * (unsigned long long)N) / (unsigned long long)T);
+    samp[PH(tid)] = pack(key_of(heat[si]), si);
+    __syncthreads();
+    bitonic_desc(samp, T);
+    tau = (unsigned)(samp[PH(R - 1)] >> 32);
+  }
+  if (tid == 0) {
+    a.wtau[a.group0 + g] = tau;
+    a.wcount[a.group0 + g] = 0;
+  }
+}
+
+__global__ __launch_bounds__(T) void wide_filter_kernel(const WideArgs a) {
+  const int g = blockIdx.y;
+  const int t = g / a.B, b = g - t * a.B;
+  const Task& tk = a.task[t];
+  const int N = tk.classes * a.H * a.W;
+  const int i0 = blockIdx.x * WIDE_SLICE;
+  if (i0 >= N) return;
+  const int n = N - i0 < WIDE_SLICE ? N - i0 : WIDE_SLICE;
+  const int G = a.group0 + g;
+  filter_pass<false>(tk.heat + (size_t)b * (size_t)N + i0, n, key_to_float(a.wtau[G]), a.wlist + (size_t)G * (size_t)a.wcap,
+                     a.wcount + G, a.wcap, i0);
+}
+
 struct MergeArgs {
   const float* boxes;        // (G,K,co)
   const float* scores;       // (G,K)
@@ -630,6 +727,29 @@ struct Layout {
   int co;
 };
 
+// the wide form's buffers: (G) threshold keys, (G) counters, (G, wcap) candidate lists; all zero-sized below WIDE_N cells
+struct WideLayout {
+  size_t tau, count, list, total;
+  int wcap;
+  bool wide;
+};
+
+static void wide_layout(const center_infer_desc* d, WideLayout& W) {
+  int64_t nmax = 0;
+  for (int t = 0; t < d->num_tasks; ++t) {
+    const int64_t n = (int64_t)d->tasks[t].classes * d->height * d->width;
+    nmax = n > nmax ? n : nmax;
+  }
+  W.wide = nmax > WIDE_N;
+  W.wcap = 8 * d->max_per_img + 32768;
+  const size_t G = (size_t)d->num_tasks * (size_t)d->batch;
+  size_t o = 0;
+  W.tau = o; o += W.wide ? up256(sizeof(unsigned) * G) : 0;
+  W.count = o; o += W.wide ? up256(sizeof(int) * G) : 0;
+  W.list = o; o += W.wide ? up256(sizeof(unsigned long long) * G * (size_t)W.wcap) : 0;
+  W.total = o;
+}
+
 static int check(const center_infer_desc* d, bool need_decode) {
   if (d == nullptr || d->tasks == nullptr) return GD3D_E_BADARG;
   if (d->num_tasks < 1 || d->batch < 1 || d->height < 1 || d->width < 1) return GD3D_E_BADARG;
@@ -689,7 +809,22 @@ static void fill_common(const center_infer_desc* d, SelArgs& a) {
 }
 
 // the tasks go through the kernel arguments, MAXT per launch
-static int launch_select(const center_infer_desc* d, SelArgs& a, hipStream_t s) {
+static int launch_select(const center_infer_desc* d, SelArgs& a, void* wide_ws, hipStream_t s) {
+  WideLayout WL;
+  wide_layout(d, WL);
+  if (WL.wide && wide_ws == nullptr) return GD3D_E_BADARG;
+  WideArgs w = {};
+  a.wide = WL.wide ? 1 : 0;
+  if (WL.wide) {
+    a.wcap = w.wcap = WL.wcap;
+    a.wtau = w.wtau = (unsigned*)((char*)wide_ws + WL.tau);
+    a.wcount = w.wcount = (int*)((char*)wide_ws + WL.count);
+    a.wlist = w.wlist = (unsigned long long*)((char*)wide_ws + WL.list);
+    w.B = d->batch;
+    w.H = d->height;
+    w.W = d->width;
+    w.K = d->max_per_img;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
@@ -712,6 +847,17 @@ static int launch_select(const center_infer_desc* d, SelArgs& a, hipStream_t s) 
       dst.pad = 0;
     }
     a.group0 = t0 * d->batch;
+    if (WL.wide) {
+      int64_t nmax = 0;
+      for (int t = 0; t < nt; ++t) {
+        w.task[t] = a.task[t];
+        const int64_t n = (int64_t)a.task[t].classes * d->height * d->width;
+        nmax = n > nmax ? n : nmax;
+      }
+      w.group0 = a.group0;
+      hipLaunchKernelGGL(wide_sample_kernel, dim3((unsigned)(nt * d->batch)), dim3(T), 0, s, w);
+      hipLaunchKernelGGL(wide_filter_kernel, dim3((unsigned)((nmax + WIDE_SLICE - 1) / WIDE_SLICE), (unsigned)(nt * d->batch)), dim3(T), 0, s, w);
+    }
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)(nt * d->batch)), dim3(T), LDS_BYTES, s, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -738,7 +884,16 @@ size_t center_infer_workspace_bytes(const center_infer_desc* desc) {
   if (check(desc, true) != 0) return 256;
   Layout L;
   layout(desc, L);
-  return L.total;
+  WideLayout W;
+  wide_layout(desc, W);
+  return L.total + W.total;
+}
+
+size_t center_infer_select_workspace_bytes(const center_infer_desc* desc) {
+  if (check(desc, false) != 0) return 256;
+  WideLayout W;
+  wide_layout(desc, W);
+  return W.total > 0 ? W.total : 256;
 }
 
 int center_infer_debug_clock_probe(int64_t* device_out, int32_t blocks, int32_t iters, void* stream) {
@@ -765,8 +920,8 @@ int center_infer_candidates(const center_infer_desc* desc, int64_t* byte_offsets
   return 0;
 }
 
-int center_infer_select(const center_infer_desc* d, float* sel_scores, int64_t* sel_cls, int64_t* sel_xy, float* sel_preds,
-                        void* stream) {
+int center_infer_select(const center_infer_desc* d, void* workspace, float* sel_scores, int64_t* sel_cls, int64_t* sel_xy,
+                        float* sel_preds, void* stream) {
   const int rc = check(d, false);
   if (rc != 0) return rc;
   if (sel_scores == nullptr || sel_cls == nullptr || sel_xy == nullptr || (d->num_channels > 0 && sel_preds == nullptr))
@@ -778,7 +933,8 @@ int center_infer_select(const center_infer_desc* d, float* sel_scores, int64_t* 
   a.sel_cls = (long long*)sel_cls;
   a.sel_xy = (long long*)sel_xy;
   a.sel_preds = sel_preds;
-  return launch_select(d, a, (hipStream_t)stream);
+  if (workspace != nullptr && ((uintptr_t)workspace & 255) != 0) return GD3D_E_BADARG;
+  return launch_select(d, a, workspace, (hipStream_t)stream);
 }
 
 int center_infer_bboxes(const center_infer_desc* d, void* workspace, float* out_boxes, float* out_scores, int32_t* out_labels,
@@ -813,7 +969,7 @@ int center_infer_bboxes(const center_infer_desc* d, void* workspace, float* out_
   a.counts = (int*)(w + L.counts);
   a.order = (long long*)(w + L.order);
   a.thresh = (float*)(w + L.thresh);
-  rc = launch_select(d, a, s);
+  rc = launch_select(d, a, w + L.total, s);
   if (rc != 0) return rc;
   rc = rnms_batched(a.circle ? 2 : 0, a.nmsbox, (const int64_t*)a.order, a.counts, (int32_t)L.G, L.cap, a.thresh,
                     (int64_t*)(w + L.keep), (int64_t*)(w + L.num_keep), w + L.nms, stream);

@@ -103,6 +103,25 @@ def test_select_best_degenerate_maps(shape, K):
         assert torch.equal(s.cpu().nan_to_num(nan=7.0), want.nan_to_num(nan=7.0))
 
 
+@pytest.mark.parametrize('shape,K', [((2, 3, 468, 468), 500), ((1, 2, 320, 320), 2000), ((1, 3, 468, 468), 4096), ((3, 1, 400, 330), 64)])
+def test_select_best_wide_maps(shape, K):
+    """above 131072 cells per group the threshold and the filtering pass are chip-wide launches of their own; candidates that
+    fit the LDS buffer directly, candidates thinned by a second threshold, and (equal keys everywhere) the exact fallback"""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    pred = torch.randn(B, 3, H, W, generator=g)
+    for kind in ('normal', 'uniform', 'quantised'):
+        m = torch.randn(shape, generator=g) if kind == 'normal' else torch.rand(shape, generator=g)
+        if kind == 'quantised':
+            m = (m * 16).floor() / 16
+        s, c, xy, p = amd.select_best(m.to(dev()), pred.to(dev()), K)
+        idx = torch.from_numpy(lex_topk(m, K))
+        cell = idx % (H * W)
+        assert torch.equal(c.cpu(), idx // (H * W)), kind
+        assert torch.equal(xy.cpu(), torch.stack((cell % W, cell // W), -1)), kind
+        assert torch.equal(s.cpu(), torch.stack([m.view(B, -1)[b][idx[b]] for b in range(B)])), kind
+
+
 def distinct_heat(shape, g, lo=0.002, hi=0.7):
     """Logits whose sigmoid scores are pairwise distinct per sample and stay so through fp32 rounding (a shuffled regular grid,
     spacing >= 1e-6): torch.topk then has ONE answer and the kernel's tie rule cannot show.  (Scores of a trained head that

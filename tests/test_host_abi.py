@@ -205,7 +205,7 @@ def test_center_infer_queries_and_argument_checks_without_gpu():
     d.num_channels = 8
     assert lib.center_infer_bboxes(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10001   # yaw decode needs 9 channels
     d.num_channels = 17
-    assert lib.center_infer_select(ctypes.byref(d), 256, 256, 256, 256, None) == 10001
+    assert lib.center_infer_select(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10001
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.select_best(torch.zeros(1, 1, 8, 8), torch.zeros(1, 4, 8, 8), 4)
     with pytest.raises(RuntimeError, match='no CPU path'):

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Phase times inside the selection kernel of the CenterPoint inference slice (center_infer_debug_clocks): per map shape the
+"""Phase times inside the selection kernel (select_kernel only: for maps above 131072 cells the threshold sample and the filtering
+pass are launches of their own and "filter pass" below is the thinning of their candidate list)
+Phase times inside the selection kernel of the CenterPoint inference slice (center_infer_debug_clocks): per map shape the
 us spent in threshold sample / filtering pass / exact radix select (when it ran) / ordering / gather + decode, and the number
 of candidates the pass left.  usage: tools/center_infer_phases.py"""
 import os
