@@ -40,17 +40,20 @@ us = timeit(step2, 100)
 print(json.dumps(dict(config=2, what='anchor-head decoded-box loss slice fwd+bwd from NCHW, KITTI geometry', batch=B,
                       anchors=B * n_per, positives=60 * B, us_per_step=round(us, 1))), flush=True)
 
-# the same step captured once and replayed as a hipGraph (the dense form has static shapes and no host sync)
-side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(3): step2()
-torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
-g2 = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g2):
-    step2()
-usg = timeit(g2.replay, 200)
-print(json.dumps(dict(config=2, what='the same step replayed as a hipGraph (static shapes, no sync)', us_per_step=round(usg, 1),
-                      eager_us_per_step=round(us, 1))), flush=True)
+# the same step captured once and replayed as a hipGraph (the dense form has static shapes and no host sync): the package's
+# GraphedStep; `replay only` = new values written straight into the graph's input buffers, `with input copies` = through its
+# call interface (one device copy of the 108 MB head output per step)
+gstep = amd.GraphedStep(lambda bp, lb: amd.anchor_head_decoded_loss_fused(mod, bp, bbox_targets, bbox_weights, lb, anchors, C, 360.0, [1.0] * 7),
+                        (bbox_pred, labels))
+sbp, slb = gstep.static_inputs()
+usg = timeit(lambda: gstep(sbp, slb), 200)
+usc = timeit(lambda: gstep(bbox_pred, labels), 100)
+lg, gg = gstep(bbox_pred, labels)
+step2()
+torch.cuda.synchronize()
+assert torch.equal(gg[0], bbox_pred.grad), 'graph replay and eager step disagree'
+print(json.dumps(dict(config=2, what='the same step replayed as a hipGraph (GraphedStep: static shapes, no sync)', us_per_step=round(usg, 1),
+                      us_per_step_with_input_copies=round(usc, 1), eager_us_per_step=round(us, 1))), flush=True)
 
 # ---- config 4
 coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
@@ -100,6 +103,16 @@ def step4_eager():
         tot = tot + l1 + gd
     tot.backward()
 us_m, us_e = timeit(step4_maps, 50), timeit(step4_eager, 10)
+names4 = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
+flat4 = [d[k] for d in maps4 for k in names4]
+def fn4(*flat):
+    ds = [dict(zip(names4, flat[6 * i:6 * i + 6])) for i in range(tasks)]
+    return amd.center_head_losses(modb, l1cfg, coder, ds, [p for p, _, _ in data], [a for _, _, a in data], [Bs * K] * tasks, cw4)
+g4 = amd.GraphedStep(fn4, flat4)
+s4 = g4.static_inputs()
+us_g4 = timeit(lambda: g4(*s4), 100)
+print(json.dumps(dict(config=4, what='the same 6-task head-loss step replayed as a hipGraph (GraphedStep)', us_per_step=round(us_g4, 1),
+                      eager_one_launch_us=round(us_m, 1))), flush=True)
 print(json.dumps(dict(config=4, what='all regression losses (loss_l1 + loss_gd) of 6 CenterPoint tasks from the raw head maps (8 x 128 x 128), fwd+bwd',
                       positives_per_task=Bs * K, one_launch_us=round(us_m, 1), eager_torch_us=round(us_e, 1),
                       speedup=round(us_e / us_m, 1))), flush=True)

@@ -575,3 +575,37 @@ def test_anchor_head_num_total_samples_none_is_the_batch_size(amd):
     z = amd.center_head_gd_loss(mod, coder, torch.zeros(2, 0, 3, dtype=torch.long, device='cuda'), pred,
                                 torch.zeros(2, 0, 9, device='cuda'), num_pos=0)
     assert tuple(z.shape) == (1,) and z.item() == 0.0 and z.requires_grad
+
+
+def test_graphed_step_replays_head_losses_bit_for_bit(amd):
+    """GraphedStep: the anchor head's regression losses (dense form) and a plain GDLoss, forward + backward, captured once and
+    replayed on new values: losses and gradients equal the eager calls bit for bit; structure of the outputs is kept"""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(3)
+    lt, kw, sl1, cw, dw, sin = SL1_CASES[0]
+    mod = amd.GDLoss(lt, loss_weight=5.0, **kw)
+    plain = amd.GDLoss('bd3d', fun='log1p', tau=1.0, loss_weight=2.0)
+    bt, bw, an = bbox_targets.cuda(), bbox_weights.cuda(), anchors.cuda()
+    g = torch.Generator().manual_seed(5)
+    pairs = torch.rand(512, 7, generator=g).cuda() + 0.5
+
+    def fn(bp, lb, pr):
+        head = amd.anchor_head_bbox_loss(mod, sl1, bp, bt, bw, lb, an, C, 37.0, code_weight=cw, decode_weight=dw,
+                                         diff_rad_by_sin=sin, dense=True)
+        return dict(loss_bbox=head, extra=(plain(pr, pairs),))
+    bp0 = bbox_pred.cuda().requires_grad_(True)
+    pr0 = (pairs + 0.1).requires_grad_(True)
+    step = amd.GraphedStep(fn, (bp0, labels.cuda(), pr0))
+    for it in range(3):
+        bp = (bbox_pred.cuda() + 0.03 * it).requires_grad_(True)
+        lb = labels.cuda().roll(5 * it, dims=-1)
+        pr = (pairs + 0.1 + 0.01 * it).requires_grad_(True)
+        losses, grads = step(bp, lb, pr)
+        got = (losses['loss_bbox'].clone(), losses['extra'][0].clone(), grads[0].clone(), grads[2].clone())
+        assert grads[1] is None and isinstance(losses['extra'], tuple)
+        want = fn(bp, lb, pr)
+        (want['loss_bbox'] + want['extra'][0]).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want['loss_bbox'].detach()) and torch.equal(got[1], want['extra'][0].detach())
+        assert torch.equal(got[2], bp.grad) and torch.equal(got[3], pr.grad)
+    with pytest.raises(RuntimeError, match='was captured'):
+        step(bp0[:, :7], labels.cuda(), pr0)
