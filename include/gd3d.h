@@ -396,6 +396,14 @@ int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const i
                  int32_t groups, int64_t cap, const float* thresh, int64_t* keep, int64_t* num_keep,
                  void* workspace, void* stream);
 
+/* rnms_batched (mode 0) for a caller INSIDE the library that has already written the oriented boxes: the first counts[g]
+ * entries of row g of a (groups, cap) array of 64-byte records (csrc/rbox_device.h `OBox`, made by `obox_make` from the
+ * [x1,y1,x2,y2,ry] rows in score order) at the start of `workspace`.  Saves the preparation launch; center_infer.hip's
+ * selection kernel writes the records while it compacts its survivors. */
+int rnms_batched_prepared(const float* boxes, const int64_t* order, const int32_t* counts, int32_t groups,
+                          int64_t cap, const float* thresh, int64_t* keep, int64_t* num_keep,
+                          void* workspace, void* stream);
+
 /* rnms_batched with the score order taken inside the library (rank by counting, as rnms_scored), so the caller needs no
  * masked_fill / sum / sort passes:
  *   scores (groups, n) fp32;  valid (groups, n) bytes, nullable — which boxes take part in group g;  pre_max < 0: none.

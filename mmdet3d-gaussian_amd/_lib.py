@@ -112,6 +112,7 @@ SYMBOLS = {
     'rnms_scored': (_int, [ctypes.c_int32, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     'rnms_batched_workspace_bytes': (_sz, [ctypes.c_int32, _i64]),
     'rnms_batched': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'rnms_batched_prepared': (_int, [_vp, _vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_batched_scored_workspace_bytes': (_sz, [ctypes.c_int32, _i64, _i64]),
     'rnms_batched_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_segmented_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -35,6 +35,7 @@
 
 #include "../../include/gd3d.h"
 #include "coder_device.h"
+#include "rbox_device.h"
 
 namespace cinfer {
 
@@ -80,6 +81,7 @@ struct SelArgs {
   int* counts;
   long long* order;
   float* thresh;
+  rbox::OBox* obox;    // nullable: (G, cap) oriented boxes of the survivors for rnms_batched_prepared (rotate NMS)
   long long* clocks;   // nullable: (groups, 8) s_memrealtime stamps of the kernel's phases (center_infer_debug_clocks)
   // wide form (maps above WIDE_N cells): the threshold and the filtering pass ran in their own chip-wide launches
   int wide, wcap;
@@ -601,6 +603,13 @@ __global__ __launch_bounds__(T) void select_kernel(const SelArgs a) {
           a.nmsbox[o * 5 + 2] = box[0] + hw;
           a.nmsbox[o * 5 + 3] = box[1] + hh;
           a.nmsbox[o * 5 + 4] = box[6];
+          const int pcomp = kept + inc - 1;
+          if (a.obox != nullptr && pcomp < a.cap) {   // what obox_prep_kernel would compute from that row in a launch of its own
+            const float nb[5] = {box[0] - hw, box[1] - hh, box[0] + hw, box[1] + hh, box[6]};
+            rbox::OBox ob;
+            rbox::obox_make(nb, ob);
+            a.obox[(size_t)G * a.cap + pcomp] = ob;
+          }
         }
       }
       kept += tot;
@@ -969,10 +978,15 @@ int center_infer_bboxes(const center_infer_desc* d, void* workspace, float* out_
   a.counts = (int*)(w + L.counts);
   a.order = (long long*)(w + L.order);
   a.thresh = (float*)(w + L.thresh);
+  a.obox = a.circle ? nullptr : (rbox::OBox*)(w + L.nms);      // the NMS workspace starts with its (G, cap) oriented boxes
   rc = launch_select(d, a, w + L.total, s);
   if (rc != 0) return rc;
-  rc = rnms_batched(a.circle ? 2 : 0, a.nmsbox, (const int64_t*)a.order, a.counts, (int32_t)L.G, L.cap, a.thresh,
-                    (int64_t*)(w + L.keep), (int64_t*)(w + L.num_keep), w + L.nms, stream);
+  if (a.circle)
+    rc = rnms_batched(2, a.nmsbox, (const int64_t*)a.order, a.counts, (int32_t)L.G, L.cap, a.thresh, (int64_t*)(w + L.keep),
+                      (int64_t*)(w + L.num_keep), w + L.nms, stream);
+  else
+    rc = rnms_batched_prepared(a.nmsbox, (const int64_t*)a.order, a.counts, (int32_t)L.G, L.cap, a.thresh,
+                               (int64_t*)(w + L.keep), (int64_t*)(w + L.num_keep), w + L.nms, stream);
   if (rc != 0) return rc;
   MergeArgs m = {};
   m.boxes = a.boxes;

@@ -892,6 +892,19 @@ int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const i
   return rnms_launch(mode, boxes, order, counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep, workspace, stream);
 }
 
+int rnms_batched_prepared(const float* boxes, const int64_t* order, const int32_t* counts, int32_t groups, int64_t cap,
+                          const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
+  if (groups < 0 || cap < 0) return GD3D_E_BADARG;
+  if (groups == 0) return 0;
+  if (num_keep == nullptr) return GD3D_E_BADARG;
+  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, (hipStream_t)stream);
+  if (boxes == nullptr || order == nullptr || counts == nullptr || thresh == nullptr || keep == nullptr ||
+      workspace == nullptr)
+    return GD3D_E_BADARG;
+  return rnms_launch(MODE_ROT, boxes, order, counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep, workspace, stream,
+                     /*prepped=*/true);
+}
+
 int rnms_circle_ordered(const float* xy, const int64_t* order, int64_t n, double thresh, int64_t* keep, int64_t* num_keep,
                         void* workspace, void* stream) {
   return rnms_impl(MODE_CIRCLE, xy, order, n, (float)thresh, thresh, keep, num_keep, workspace, stream);
