@@ -601,6 +601,45 @@ int center_infer_select(const center_infer_desc* desc, void* workspace, float* s
 int center_infer_bboxes(const center_infer_desc* desc, void* workspace, float* out_boxes, float* out_scores,
                         int32_t* out_labels, int64_t* out_count, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * CenterPoint target assignment on the device (ABI 4): heat maps, anno_boxes and pos_inds of ALL samples and tasks in two
+ * launches — what produces the inputs of gd3d_center_head_loss.  Replaces the per-sample / per-task / per-box Python loops of
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_centerpoint_head.py:65-81 (get_targets), :83-156
+ *   (get_targets_single) with mmdet3d's gaussian_radius / draw_heatmap_gaussian inside them (third party, absent: restated).
+ *   boxes (total, box_cols) fp32: the samples' ground-truth rows one after the other, sample b = rows
+ *   [sample_start[b], sample_start[b+1]); columns x, y, z, w, l, h, yaw, ... ; bottom_center != 0: z is the box bottom
+ *   (LiDARInstance3DBoxes.tensor) and the gravity centre z + h/2 is written to anno_boxes (:85-87), else rows are copied;
+ *   labels (total) int64: task t owns the labels [sum classes[<t], + classes[t]); others (e.g. -1) are ignored;
+ *   height / width = feature_map_size[0] / [1] as the reference uses them (rows, columns of a heat-map plane, :115-126).
+ * Outputs: heatmaps = ONE flat fp32 buffer, ZEROED BY THE CALLER, task t's (batch, classes[t], height, width) block after the
+ *   blocks of the tasks before it;  anno_boxes (total, box_cols) and pos_inds (total, 3) int64 [batch, x, y]: the valid boxes in
+ *   the reference's order (tasks; samples in batch order; the task's classes in turn; index order), task t = rows
+ *   [task_start[t], task_start[t+1]);  task_start (num_tasks + 1) int64 on the DEVICE (the one thing the host reads back).
+ *   A box is valid iff w, l > 0 and its cell lies on the map; cell = trunc((x - pc_range[0]) / voxel_size[0] / out_size_factor)
+ *   (`.long()` truncates toward zero).  total <= center_targets_max_boxes() (8192).
+ *   workspace: center_targets_workspace_bytes(total), 256-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+#define CENTER_TARGETS_MAX_TASKS 40
+#define CENTER_TARGETS_MAX_BATCH 64
+
+typedef struct center_targets_desc {
+  int32_t num_tasks, batch, height, width;
+  int32_t total, box_cols, bottom_center, min_radius;
+  int32_t classes[CENTER_TARGETS_MAX_TASKS];
+  int32_t sample_start[CENTER_TARGETS_MAX_BATCH + 1];
+  int32_t reserved;
+  float pc_range[2];
+  float voxel_size[2];
+  float out_size_factor;
+  float reserved2;
+  double gaussian_overlap;
+} center_targets_desc;
+
+int center_targets_max_boxes(void);
+size_t center_targets_workspace_bytes(int64_t total);
+int center_targets_build(const center_targets_desc* desc, const float* boxes, const int64_t* labels, void* workspace,
+                         float* heatmaps, float* anno_boxes, int64_t* pos_inds, int64_t* task_start, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

@@ -58,6 +58,15 @@ class CenterInferDesc(ctypes.Structure):
                 ('tasks', ctypes.POINTER(CenterInferTask))]
 
 
+class CenterTargetsDesc(ctypes.Structure):
+    """center_targets_desc (include/gd3d.h)."""
+    _fields_ = [('num_tasks', ctypes.c_int32), ('batch', ctypes.c_int32), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('total', ctypes.c_int32), ('box_cols', ctypes.c_int32), ('bottom_center', ctypes.c_int32),
+                ('min_radius', ctypes.c_int32), ('classes', ctypes.c_int32 * 40), ('sample_start', ctypes.c_int32 * 65),
+                ('reserved', ctypes.c_int32), ('pc_range', ctypes.c_float * 2), ('voxel_size', ctypes.c_float * 2),
+                ('out_size_factor', ctypes.c_float), ('reserved2', ctypes.c_float), ('gaussian_overlap', ctypes.c_double)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -136,6 +145,9 @@ SYMBOLS = {
     'center_infer_select_workspace_bytes': (_sz, [ctypes.POINTER(CenterInferDesc)]),
     'center_infer_select': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'center_infer_bboxes': (_int, [ctypes.POINTER(CenterInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'center_targets_max_boxes': (_int, []),
+    'center_targets_workspace_bytes': (_sz, [_i64]),
+    'center_targets_build': (_int, [ctypes.POINTER(CenterTargetsDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

@@ -25,7 +25,8 @@ SOURCES = {
     'voxel_index.hip': [],                     # rocPRIM radix sort + scan between hand-written kernels
     'eval_match.hip': ['-ffp-contract=off'],
     'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
-    'center_infer.hip': ['-ffp-contract=off'],  # decode as coders.hip; the NMS boxes feed bit-exact keep decisions
+    'center_infer.hip': ['-ffp-contract=off'],    # decode as coders.hip; the NMS boxes feed bit-exact keep decisions
+    'center_targets.hip': ['-ffp-contract=off'],  # gaussian_radius in the reference's fp32 operation order
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

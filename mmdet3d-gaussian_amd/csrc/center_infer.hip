@@ -834,11 +834,14 @@ static int launch_select(const center_infer_desc* d, SelArgs& a, void* wide_ws, 
     w.W = d->width;
     w.K = d->max_per_img;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  // more than 64 KB of dynamic LDS has to be allowed per function AND per device (one process may drive several)
+  static bool attr_set[64] = {};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess) return GD3D_E_BADARG;
+  if (devid < 0 || devid >= 64 || !attr_set[devid]) {
     const hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    if (devid >= 0 && devid < 64) attr_set[devid] = true;
   }
   for (int t0 = 0; t0 < d->num_tasks; t0 += MAXT) {
     const int nt = d->num_tasks - t0 < MAXT ? d->num_tasks - t0 : MAXT;

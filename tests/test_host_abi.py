@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer)_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets)_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -210,3 +210,31 @@ def test_center_infer_queries_and_argument_checks_without_gpu():
         amd.select_best(torch.zeros(1, 1, 8, 8), torch.zeros(1, 4, 8, 8), 4)
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.CenterPointBBoxCoderRev([0, 0], 4, [0.2, 0.2]).decode(torch.zeros(1, 4, 2), torch.zeros(1, 4, 10))
+
+
+def test_center_targets_struct_layout_and_argument_checks():
+    import subprocess
+    import tempfile
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(center_targets_desc), offsetof(center_targets_desc, classes), offsetof(center_targets_desc, sample_start),'
+           'offsetof(center_targets_desc, pc_range), offsetof(center_targets_desc, out_size_factor),'
+           'offsetof(center_targets_desc, gaussian_overlap));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(c, 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
+        got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    D = _lib.CenterTargetsDesc
+    assert got == [ctypes.sizeof(D), D.classes.offset, D.sample_start.offset, D.pc_range.offset, D.out_size_factor.offset,
+                   D.gaussian_overlap.offset], got
+    lib = amd.load_library()
+    assert lib.center_targets_max_boxes() == 8192 and lib.center_targets_workspace_bytes(100) % 256 == 0
+    d = D()
+    d.num_tasks, d.batch, d.height, d.width, d.total, d.box_cols = 1, 1, 8, 8, 9000, 9
+    d.classes[0] = 1
+    assert lib.center_targets_build(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, None) == 10002      # too many boxes
+    d.total = 4
+    d.sample_start[1] = 3                                                                                       # does not cover the rows
+    assert lib.center_targets_build(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, None) == 10001
+    d.sample_start[1], d.classes[0] = 4, 0
+    assert lib.center_targets_build(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, None) == 10001
