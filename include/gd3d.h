@@ -640,6 +640,36 @@ size_t center_targets_workspace_bytes(int64_t total);
 int center_targets_build(const center_targets_desc* desc, const float* boxes, const int64_t* labels, void* workspace,
                          float* heatmaps, float* anno_boxes, int64_t* pos_inds, int64_t* task_start, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Heat-map classification loss of the CenterPoint heads for all tasks (ABI 4): clip_sigmoid + GaussianFocalLoss + the
+ * num_pos normaliser, forward and gradient in one pass over the maps (12 bytes per cell), no host sync.  Replaces, per task,
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_centerpoint_head.py:403-411
+ *   (mmdet3d `clip_sigmoid`, mmdet `GaussianFocalLoss`: third party, absent, restated from the published text):
+ *     p = clamp(sigmoid(x), clip_eps, 1 - clip_eps);  pos = -log(p + log_eps) (1 - p)^alpha [t == 1];
+ *     neg = -log(1 - p + log_eps) p^alpha (1 - t)^gamma;  num_pos = #(t == 1);
+ *     loss = loss_weight * sum(pos + neg) / max(num_pos, 1).
+ * gd3d_heat_focal_task (HOST array): logits, target (n) fp32; grad (n) fp32 or NULL: receives d sum(pos + neg) / d logit (the
+ *   raw gradient; gd3d_heat_focal_scale turns it into the gradient of the caller's scalar in place).
+ * gd3d_heat_focal_loss: losses, factor = loss_weight / max(num_pos, 1), num_pos: (num_tasks) fp32 each, on the device;
+ *   workspace: gd3d_heat_focal_workspace_bytes(tasks, num_tasks).  Sums are taken in a fixed order in fp64: deterministic.
+ * gd3d_heat_focal_scale: grad[i] *= factor[t] * upstream[t] for every task (upstream (num_tasks) fp32 on the device).
+ * ---------------------------------------------------------------------------------- */
+#define GD3D_HEAT_FOCAL_MAX_TASKS 16
+
+typedef struct gd3d_heat_focal_task {
+  const float* logits;
+  const float* target;
+  float* grad;
+  int64_t n;
+} gd3d_heat_focal_task;
+
+size_t gd3d_heat_focal_workspace_bytes(const gd3d_heat_focal_task* tasks, int32_t num_tasks);
+int gd3d_heat_focal_loss(const gd3d_heat_focal_task* tasks, int32_t num_tasks, float alpha, float gamma,
+                         float clip_eps, float log_eps, float loss_weight, float* losses, float* factor,
+                         float* num_pos, void* workspace, void* stream);
+int gd3d_heat_focal_scale(const gd3d_heat_focal_task* tasks, int32_t num_tasks, const float* factor,
+                          const float* upstream, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

@@ -67,6 +67,11 @@ class CenterTargetsDesc(ctypes.Structure):
                 ('out_size_factor', ctypes.c_float), ('reserved2', ctypes.c_float), ('gaussian_overlap', ctypes.c_double)]
 
 
+class HeatFocalTask(ctypes.Structure):
+    """gd3d_heat_focal_task (include/gd3d.h)."""
+    _fields_ = [('logits', ctypes.c_void_p), ('target', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('n', ctypes.c_int64)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -148,6 +153,9 @@ SYMBOLS = {
     'center_targets_max_boxes': (_int, []),
     'center_targets_workspace_bytes': (_sz, [_i64]),
     'center_targets_build': (_int, [ctypes.POINTER(CenterTargetsDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_heat_focal_workspace_bytes': (_sz, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32]),
+    'gd3d_heat_focal_loss': (_int, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_heat_focal_scale': (_int, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

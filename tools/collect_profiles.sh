@@ -52,6 +52,7 @@ python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.
 python3 tests/perf/center_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_time.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ci -o ci -- python3 tests/perf/center_infer_time.py > /dev/null 2>&1
 cp /tmp/kt_ci/ci_kernel_stats.csv $OUT/${R}_center_infer_kernel_stats.csv 2>/dev/null
+python3 tests/perf/center_head_loss_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_head_loss_time.jsonl
 python3 tests/perf/center_targets_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_targets_time.jsonl
 python3 tools/center_infer_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_phases.txt
 [ -x tools/sort_probe ] && ./tools/sort_probe > $OUT/${R}_sort_probe.txt 2>&1
