@@ -328,3 +328,17 @@ def test_get_bboxes_replays_as_a_hipgraph():
             assert n[b] == want[b][0].shape[0] > 0
             assert torch.equal(out['bboxes'][b, :n[b]], want[b][0]) and torch.equal(out['scores'][b, :n[b]], want[b][1])
             assert torch.equal(out['labels'][b, :n[b]], want[b][2])
+
+
+def test_get_bboxes_kitti_centerpoint_geometry():
+    """configs/_base_/models/pillarmvf_centerpoint_016pillar_second_secfpn_kitti.py: maps of 248 rows x 216 columns, tasks with
+    1 / 1 / 2 heat-map classes, CenterPointBBoxCoderRev (rot = atan2(sin, cos)), its test_cfg"""
+    g = torch.Generator().manual_seed(28)
+    classes = [1, 1, 2]
+    tasks = make_tasks(g, 2, 248, 216, classes, 'rev')
+    cfg = dict(pc_range=[0, -39.68], out_size_factor=2, voxel_size=[0.16, 0.16], norm_bbox=True)
+    test_cfg = dict(post_center_limit_range=[-10, -49.68, -10, 79.12, 49.68, 10], max_per_img=500, score_threshold=midgap(tasks, 500, 0.3),
+                    nms_type='rotate', nms_thr=0.2, pre_max_size=1000, post_max_size=83, min_radius=[0.85, 0.175, 4])
+    out = run_and_check(tasks, 'rev', cfg, test_cfg, classes)
+    assert all(o[0].shape[1] == 9 and o[0].shape[0] > 0 for o in out)
+    run_and_check(tasks, 'rev', cfg, dict(test_cfg, nms_type='circle'), classes)

@@ -84,6 +84,18 @@ def test_targets_edge_cases():
     for d in data:
         d[1].clamp_(max=2)
     check([d[0] for d in data], [d[1] for d in data], [['a', 'b', 'c']], cfg)
+    # the reference's KITTI CenterPoint geometry (configs/_base_/models/pillarmvf_centerpoint_016pillar_second_secfpn_kitti.py):
+    # grid_size = [496, 432, 1] -> maps of 248 rows x 216 columns, tasks Pedestrian | Cyclist | Car
+    kitti = dict(grid_size=[496, 432, 1], point_cloud_range=[0, -39.68, -3, 69.12, 39.68, 1], voxel_size=[0.16, 0.16, 4],
+                 out_size_factor=2, gaussian_overlap=0.1, min_radius=2)
+    data = []
+    for n in (40, 25):
+        b, l = scene(g, n)
+        b[:, 0] = torch.rand(n, generator=g) * 75 - 3           # x in [-3, 72): a few outside [0, 69.12)
+        b[:, 1] = torch.rand(n, generator=g) * 84 - 42
+        data.append((b, l.clamp(min=-1, max=2)))
+    hm, an, pi = check([d[0] for d in data], [d[1] for d in data], [['Pedestrian'], ['Cyclist'], ['Car']], kitti)
+    assert hm[0].shape == (2, 1, 248, 216) and int(torch.cat(pi)[:, 1].max()) < 216 and int(torch.cat(pi)[:, 2].max()) > 216
 
 
 def test_targets_feed_the_head_losses():
