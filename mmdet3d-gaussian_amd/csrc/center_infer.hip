@@ -35,9 +35,13 @@
 
 #include "../../include/gd3d.h"
 #include "coder_device.h"
+#include "lds_sort.h"
 #include "rbox_device.h"
 
 namespace cinfer {
+
+using ldssort::PH;
+using ldssort::bitonic_desc;
 
 constexpr int T = 1024;
 constexpr int WAVES = T / 64;
@@ -52,7 +56,6 @@ constexpr int WIDE_SLICE = 32768;    // cells per workgroup of that pass
 // entries (64 bytes) would otherwise share its two LDS banks with 31 other lanes of its wave
 constexpr size_t LDS_BYTES = sizeof(int) * BINS + sizeof(unsigned long long) * (SORT_CAP + SORT_CAP / 8);
 
-__device__ __forceinline__ int PH(int i) { return i + (i >> 3); }
 
 struct Task {
   const float* heat;
@@ -192,70 +195,6 @@ __device__ __forceinline__ void scan_keys(const float* __restrict__ heat, int N,
 
 __device__ __forceinline__ unsigned long long pack(unsigned key, unsigned idx) {
   return ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - idx);
-}
-
-// Descending bitonic sort of list[0 .. M) in LDS (padded with zeros, which lie below every real entry), register blocked:
-// the compare-exchange steps j = k/2 .. 1 of a merge are taken three at a time — a thread loads the 8 entries that differ
-// in those three index bits, runs the three steps in registers and stores them back, so the list crosses the LDS once per
-// three steps instead of once per step (one entry pair per thread and step moved 4 LDS instructions per compare-exchange:
-// 36 us for 1024 entries).
-template <int C>
-__device__ __forceinline__ void bitonic_chunk(unsigned long long* list, int P, int k, int b) {
-  constexpr int E = 1 << C;
-  const unsigned low = (1u << b) - 1u;
-  for (int t = threadIdx.x; t < (P >> C); t += T) {
-    const int base = (int)((((unsigned)t & ~low) << C) | ((unsigned)t & low));
-    const bool desc = (base & k) == 0;
-    // entries as (high, low) words: a 64-bit compare is a quarter-rate instruction here, three 32-bit compares are not.
-    // Entries are distinct (the index is part of them), so "a > b" is "not a < b": one comparison serves both directions
-    // (equal entries exist only as zero padding, where a swap changes nothing).
-    unsigned xh[E], xl[E];
-#pragma unroll
-    for (int m = 0; m < E; ++m) {
-      const unsigned long long v = list[PH(base + (m << b))];
-      xh[m] = (unsigned)(v >> 32);
-      xl[m] = (unsigned)v;
-    }
-#pragma unroll
-    for (int s2 = C - 1; s2 >= 0; --s2) {
-#pragma unroll
-      for (int m = 0; m < E; ++m) {
-        if ((m & (1 << s2)) == 0) {
-          const int n = m | (1 << s2);
-          const bool lt = (xh[m] < xh[n]) | ((xh[m] == xh[n]) & (xl[m] < xl[n]));
-          const bool sw = lt == desc;
-          const unsigned h0 = xh[m], l0 = xl[m];
-          xh[m] = sw ? xh[n] : h0;
-          xl[m] = sw ? xl[n] : l0;
-          xh[n] = sw ? h0 : xh[n];
-          xl[n] = sw ? l0 : xl[n];
-        }
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < E; ++m) list[PH(base + (m << b))] = ((unsigned long long)xh[m] << 32) | (unsigned long long)xl[m];
-  }
-}
-
-__device__ __forceinline__ void bitonic_desc(unsigned long long* list, int M) {
-  const int tid = threadIdx.x;
-  int P = 8;
-  while (P < M) P <<= 1;
-  for (int i = M + tid; i < P; i += T) list[PH(i)] = 0ull;
-  __syncthreads();
-  int bitsk = 1;
-  for (int k = 2; k <= P; k <<= 1, ++bitsk) {
-    int top = bitsk;                         // index bits [0, top) still to be merged for this k
-    while (top > 0) {
-      const int c = top >= 3 ? 3 : top;
-      const int b = top - c;
-      if (c == 3) bitonic_chunk<3>(list, P, k, b);
-      else if (c == 2) bitonic_chunk<2>(list, P, k, b);
-      else bitonic_chunk<1>(list, P, k, b);
-      __syncthreads();
-      top = b;
-    }
-  }
 }
 
 // One pass over the map that keeps the cells with value >= tau (NaN counts as greater than everything): per thread and

@@ -20,8 +20,11 @@
 #include <stdint.h>
 
 #include "../../include/gd3d.h"
+#include "lds_sort.h"
 
 namespace ctargets {
+
+using ldssort::PH;
 
 constexpr int T = 1024;
 constexpr int MAX_BOXES = 8192;
@@ -50,8 +53,6 @@ struct Args {
   float* heat;
 };
 
-__device__ __forceinline__ int PH(int i) { return i + (i >> 3); }
-
 // gaussian_radius((height, width) = (length, width), min_overlap) on float32 scalars, operation by operation (python numbers
 // enter as float32 scalars after their own float64 arithmetic); this file is compiled with -ffp-contract=off
 __device__ __forceinline__ float gaussian_radius(float height, float width, double mo) {
@@ -72,51 +73,6 @@ __device__ __forceinline__ float gaussian_radius(float height, float width, doub
   if (r2 < m) m = r2;
   if (r3 < m) m = r3;
   return m;
-}
-
-// descending bitonic sort of list[0 .. P) (P a power of two, padded by the caller), three steps per LDS round trip, as in
-// center_infer.hip (kept local: the two files share no translation unit)
-template <int C>
-__device__ __forceinline__ void chunk(unsigned long long* list, int P, int k, int b) {
-  constexpr int E = 1 << C;
-  const unsigned low = (1u << b) - 1u;
-  for (int t = threadIdx.x; t < (P >> C); t += T) {
-    const int base = (int)((((unsigned)t & ~low) << C) | ((unsigned)t & low));
-    const bool desc = (base & k) == 0;
-    unsigned long long x[E];
-#pragma unroll
-    for (int m = 0; m < E; ++m) x[m] = list[PH(base + (m << b))];
-#pragma unroll
-    for (int s2 = C - 1; s2 >= 0; --s2) {
-#pragma unroll
-      for (int m = 0; m < E; ++m) {
-        if ((m & (1 << s2)) == 0) {
-          const unsigned long long lo = x[m], hi = x[m | (1 << s2)];
-          const bool sw = (lo < hi) == desc;
-          x[m] = sw ? hi : lo;
-          x[m | (1 << s2)] = sw ? lo : hi;
-        }
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < E; ++m) list[PH(base + (m << b))] = x[m];
-  }
-}
-
-__device__ __forceinline__ void sort_desc(unsigned long long* list, int P) {
-  int bitsk = 1;
-  for (int k = 2; k <= P; k <<= 1, ++bitsk) {
-    int top = bitsk;
-    while (top > 0) {
-      const int c = top >= 3 ? 3 : top;
-      const int b = top - c;
-      if (c == 3) chunk<3>(list, P, k, b);
-      else if (c == 2) chunk<2>(list, P, k, b);
-      else chunk<1>(list, P, k, b);
-      __syncthreads();
-      top = b;
-    }
-  }
 }
 
 struct Cell {
@@ -182,7 +138,7 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
   }
   if (nv) atomicAdd(&s_nvalid, nv);
   __syncthreads();
-  sort_desc(keys, P);
+  ldssort::bitonic_desc(keys, P);          // the list is already padded to P entries
   const int nvalid = s_nvalid;
   // heads of the tasks' runs
   for (int r = tid; r < nvalid; r += T) {
