@@ -18,36 +18,31 @@ from . import coder_torch
 
 
 def topk(scores, K):
-    """_topk (:23-49): per-class top K, then top K over the classes' candidates."""
-    batch, cat, height, width = scores.size()
-    topk_scores, topk_inds = torch.topk(scores.view(batch, cat, -1), K)
-    topk_inds = topk_inds % (height * width)
-    topk_ys = (topk_inds.float() // width).long()
-    topk_xs = (topk_inds % width).long()
-    topk_score, topk_ind = torch.topk(topk_scores.view(batch, -1), K)
-    topk_clses = (topk_ind // K).long()
-    topk_ys = topk_ys.view(batch, -1).gather(1, topk_ind)
-    topk_xs = topk_xs.view(batch, -1).gather(1, topk_ind)
-    return topk_score, topk_clses, topk_ys, topk_xs
+    """_topk (:23-49): the K best cells of every class, then the K best of those candidates over all classes.
+    -> scores (B,K), class (B,K), y (B,K), x (B,K)"""
+    B, C, H, W = scores.shape
+    per_class_val, per_class_cell = scores.reshape(B, C, H * W).topk(K)            # (B, C, K)
+    per_class_cell = per_class_cell % (H * W)
+    rows = (per_class_cell.float() // W).long()                                   # float floor-division, as the reference does
+    cols = (per_class_cell % W).long()
+    best_val, pick = per_class_val.reshape(B, C * K).topk(K)                      # pick indexes the (class, rank) candidates
+    return best_val, (pick // K).long(), rows.reshape(B, -1).gather(1, pick), cols.reshape(B, -1).gather(1, pick)
 
 
 def select_best(scores, preds, K):
     """select_best (:51-58): scores (B,C,H,W) after the sigmoid, preds (B,N,H,W) -> scores, classes, (x, y) cells, (B,K,N)."""
-    batch = scores.shape[0]
-    sc, clses, ys, xs = topk(scores, K)
-    locs = torch.stack((xs, ys), dim=-1)
-    p = preds.permute(0, 2, 3, 1)
-    p = torch.stack([p[b, ys[b], xs[b]] for b in range(batch)], dim=0)
-    return sc, clses, locs, p
+    val, cls, ys, xs = topk(scores, K)
+    channels_last = preds.permute(0, 2, 3, 1)
+    picked = torch.stack([channels_last[b, ys[b], xs[b]] for b in range(scores.shape[0])], dim=0)
+    return val, cls, torch.stack((xs, ys), dim=-1), picked
 
 
 def decode_rev(locs, preds, pc_range, out_size_factor, voxel_size, norm_bbox=True):
-    """CenterPointBBoxCoderRev.decode (:87-112)."""
-    x = (preds[..., 0] + locs[..., 0]) * out_size_factor * voxel_size[0] + pc_range[0]
-    y = (preds[..., 1] + locs[..., 1]) * out_size_factor * voxel_size[1] + pc_range[1]
-    dim = preds[..., 3:6].exp() if norm_bbox else preds[..., 3:6]
-    rot = torch.atan2(preds[..., 6], preds[..., 7])
-    return torch.cat((x.unsqueeze(-1), y.unsqueeze(-1), preds[..., 2:3], dim, rot.unsqueeze(-1), preds[..., 8:]), dim=-1)
+    """CenterPointBBoxCoderRev.decode (:87-112): cell + offset -> metres, exp of the log dims, rot = atan2(sin, cos)."""
+    centre = [((preds[..., k] + locs[..., k]) * out_size_factor * voxel_size[k] + pc_range[k]).unsqueeze(-1) for k in (0, 1)]
+    dims = preds[..., 3:6].exp() if norm_bbox else preds[..., 3:6]
+    rot = torch.atan2(preds[..., 6], preds[..., 7]).unsqueeze(-1)
+    return torch.cat(centre + [preds[..., 2:3], dims, rot, preds[..., 8:]], dim=-1)
 
 
 def reconstruct(preds_dict, kind):

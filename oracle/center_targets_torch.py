@@ -9,7 +9,7 @@ published mmdet3d 0.x `core/utils/gaussian.py` — PARITY UNPINNED):
   gaussian_radius(det_size, min_overlap)     the CornerNet three-case radius, evaluated on 0-dim float32 tensors
   gaussian_2d / draw_heatmap_gaussian        float64 numpy Gaussian of sigma = diameter / 6, values below eps * max zeroed,
                                              cast to float32, element-wise max into the heat map window
-The head class needs mmdet3d / mmcv to import, so this follows the text of :83-156 statement by statement (boxes arrive as the
+The head class needs mmdet3d / mmcv to import, so this restates :83-156 step by step in the same fp32 operation order (boxes arrive as the
 (N, 9) rows `cat(gravity_center, tensor[:, 3:])` of :85-87; a task's classes are the label range [flag, flag + len(class_names))).
 Never imported by the product package."""
 import numpy as np
@@ -59,50 +59,44 @@ def draw_heatmap_gaussian(heatmap, center, radius, k=1):
 
 
 def get_targets_single(gt9, gt_labels, class_counts, train_cfg):
-    """:83-156 for one sample.  gt9 (N, 9) = cat(gravity_center, tensor[:, 3:]); class_counts[t] = len(class_names[t])."""
-    grid_size = torch.tensor(train_cfg['grid_size'])
+    """:83-156 for one sample.  gt9 (N, 9) = cat(gravity_center, tensor[:, 3:]); class_counts[t] = len(class_names[t]).
+    Per task: boxes are regrouped class by class (index order inside a class, :97-113), mapped to cells by float division and
+    truncation (:118-126), filtered, and every survivor stamps a Gaussian of its radius into its class plane (:131-141)."""
     pc_range = torch.tensor(train_cfg['point_cloud_range'])
-    voxel_size = torch.tensor(train_cfg['voxel_size'])
+    voxel = torch.tensor(train_cfg['voxel_size'])
     osf = train_cfg['out_size_factor']
-    feature_map_size = grid_size[:2] // osf
-    task_masks, flag = [], 0
-    for n in class_counts:
-        task_masks.append([torch.where(gt_labels == i + flag) for i in range(n)])
-        flag += n
-    task_boxes, task_classes, flag2 = [], [], 0
-    for mask in task_masks:
-        task_boxes.append(torch.cat([gt9[m] for m in mask], dim=0))
-        task_classes.append(torch.cat([gt_labels[m] + 1 - flag2 for m in mask]).long())
-        flag2 += len(mask)
-    heatmaps, anno_boxes, pos_inds = [], [], []
-    for idx, n in enumerate(class_counts):
-        heatmap = gt9.new_zeros((n, int(feature_map_size[0]), int(feature_map_size[1])))
-        width = task_boxes[idx][:, 3] / voxel_size[0] / osf
-        length = task_boxes[idx][:, 4] / voxel_size[1] / osf
-        x_ind = ((task_boxes[idx][:, 0] - pc_range[0]) / voxel_size[0] / osf).long()
-        y_ind = ((task_boxes[idx][:, 1] - pc_range[1]) / voxel_size[1] / osf).long()
-        valid = width.gt(0) * length.gt(0)
-        valid = valid * (x_ind.ge(0) * x_ind.lt(feature_map_size[1]))
-        valid = valid * (y_ind.ge(0) * y_ind.lt(feature_map_size[0]))
-        center_xy_int = torch.stack((x_ind, y_ind), dim=-1)
-        for k in valid.nonzero(as_tuple=True)[0]:
-            cls_id = task_classes[idx][k] - 1
-            radius = gaussian_radius((length[k], width[k]), min_overlap=train_cfg['gaussian_overlap'])
-            radius = max(train_cfg['min_radius'], int(radius))
-            draw_heatmap_gaussian(heatmap[cls_id], center_xy_int[k], radius)
-        heatmaps.append(heatmap)
-        anno_boxes.append(task_boxes[idx][valid])
-        pos_inds.append(center_xy_int[valid])
-    return heatmaps, anno_boxes, pos_inds
+    fmap = torch.tensor(train_cfg['grid_size'])[:2] // osf              # rows, columns of a plane as the reference uses them
+    out_heat, out_boxes, out_cells = [], [], []
+    first_label = 0
+    for n_cls in class_counts:
+        members = [torch.where(gt_labels == first_label + c)[0] for c in range(n_cls)]
+        boxes = torch.cat([gt9[m] for m in members], dim=0)
+        cls_of = torch.cat([torch.full((m.numel(),), c, dtype=torch.long) for c, m in enumerate(members)])
+        first_label += n_cls
+        plane = gt9.new_zeros((n_cls, int(fmap[0]), int(fmap[1])))
+        wide = boxes[:, 3] / voxel[0] / osf
+        long_ = boxes[:, 4] / voxel[1] / osf
+        col = ((boxes[:, 0] - pc_range[0]) / voxel[0] / osf).long()
+        row = ((boxes[:, 1] - pc_range[1]) / voxel[1] / osf).long()
+        keep = wide.gt(0) & long_.gt(0) & col.ge(0) & col.lt(fmap[1]) & row.ge(0) & row.lt(fmap[0])
+        cells = torch.stack((col, row), dim=-1)
+        for k in keep.nonzero(as_tuple=True)[0]:
+            r = gaussian_radius((long_[k], wide[k]), min_overlap=train_cfg['gaussian_overlap'])
+            draw_heatmap_gaussian(plane[cls_of[k]], cells[k], max(train_cfg['min_radius'], int(r)))
+        out_heat.append(plane)
+        out_boxes.append(boxes[keep])
+        out_cells.append(cells[keep])
+    return out_heat, out_boxes, out_cells
 
 
 def get_targets(gt9_list, gt_labels_list, class_counts, train_cfg):
     """:65-81: per task the stacked heat maps (B, C_t, H, W), the concatenated boxes and [batch, x, y] positions."""
     per_sample = [get_targets_single(b, l, class_counts, train_cfg) for b, l in zip(gt9_list, gt_labels_list)]
-    heatmaps = [torch.stack(h) for h in zip(*[p[0] for p in per_sample])]
-    anno_boxes = [torch.cat(a, dim=0) for a in zip(*[p[1] for p in per_sample])]
-    batch_pos_inds = []
-    for pos_ind in zip(*[p[2] for p in per_sample]):
-        prefix = torch.cat([ind.new_full((ind.size(0), 1), b) for b, ind in enumerate(pos_ind)], dim=0)
-        batch_pos_inds.append(torch.cat((prefix, torch.cat(pos_ind, dim=0)), dim=-1))
-    return heatmaps, anno_boxes, batch_pos_inds
+    T = len(class_counts)
+    heatmaps = [torch.stack([s[0][t] for s in per_sample]) for t in range(T)]
+    anno_boxes = [torch.cat([s[1][t] for s in per_sample], dim=0) for t in range(T)]
+    pos_inds = []
+    for t in range(T):
+        rows = [torch.cat((torch.full((s[2][t].shape[0], 1), b, dtype=s[2][t].dtype), s[2][t]), dim=-1) for b, s in enumerate(per_sample)]
+        pos_inds.append(torch.cat(rows, dim=0))
+    return heatmaps, anno_boxes, pos_inds
