@@ -72,6 +72,23 @@ def main():
     print(json.dumps(dict(what='heatmap_loss fwd+bwd, 6 tasks, batch 8, 128x128', cells=cells, ours_us=round(us_a, 1),
                           eager_torch_us=round(us_b, 1))), flush=True)
 
+    # the same kernel at batch 64 (12.6 M cells, 151 MB moved per call): the device time of the pass, forward only
+    big_x = [torch.randn(64, len(names), 128, 128, generator=g).to(dev).requires_grad_(True) for names in TASKS]
+    big_t = [torch.rand(64, len(names), 128, 128, generator=g).to(dev) ** 6 for names in TASKS]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        amd.center_head_heatmap_loss(cls, big_x, big_t)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        amd.center_head_heatmap_loss(cls, big_x, big_t)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    cells_big = sum(x.numel() for x in big_x)
+    print(json.dumps(dict(what='heatmap_loss forward call at batch 64 (logit + target read, raw gradient written: 12 B per cell)', cells=cells_big,
+                          us_per_call=round(ms * 1e3, 1), GBps_of_12B_per_cell=round(cells_big * 12 / (ms * 1e-3) / 1e9, 1))), flush=True)
+
     def full_ours():
         zero()
         out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds)

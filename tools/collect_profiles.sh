@@ -53,6 +53,8 @@ python3 tests/perf/center_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_ce
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ci -o ci -- python3 tests/perf/center_infer_time.py > /dev/null 2>&1
 cp /tmp/kt_ci/ci_kernel_stats.csv $OUT/${R}_center_infer_kernel_stats.csv 2>/dev/null
 python3 tests/perf/center_head_loss_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_head_loss_time.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_hl -o hl -- python3 tests/perf/center_head_loss_time.py > /dev/null 2>&1
+grep -E "Name|hfocal|ctargets|head_center|center_accum|center_scale" /tmp/kt_hl/hl_kernel_stats.csv > $OUT/${R}_center_head_loss_kernel_stats.csv
 python3 tests/perf/center_targets_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_targets_time.jsonl
 python3 tools/center_infer_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_phases.txt
 [ -x tools/sort_probe ] && ./tools/sort_probe > $OUT/${R}_sort_probe.txt 2>&1
