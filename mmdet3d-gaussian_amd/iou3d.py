@@ -280,6 +280,34 @@ def multi_class_nms(box_probs, boxes_for_nms, score_thr, nms_thr, use_rotate_nms
     return torch.cat(sel, dim=0) if sel else []
 
 
+def multi_class_nms_batch(box_probs, boxes_for_nms, roi_batch_id, batch_size, score_thr, nms_thr, use_rotate_nms=True):
+    """The per-sample loop of PVRCNNBboxHead.get_bboxes around multi_class_nms (pvrcnn_bbox_head.py:393-405) in ONE batched
+    NMS and one host sync for the whole batch: group (sample b, class k) takes the rois of sample b with probability
+    >= score_thr[k].
+    box_probs (R, C) / boxes_for_nms (R, 5) [x1,y1,x2,y2,ry] for ALL rois of the batch; roi_batch_id (R,) sample of every roi
+    (`rois[..., 0]`); batch_size: number of samples (a host value: the reference reads it back with `.item()`, :378).
+    Returns per sample what `multi_class_nms(class_pred[b], boxes[roi_batch_id == b], ...)` returns: indices LOCAL to the
+    sample's own rois (its rois in their original order), classes in turn; `[]` when a sample keeps nothing."""
+    R, C = box_probs.shape
+    st = score_thr if isinstance(score_thr, (list, tuple)) else [score_thr] * C
+    nt = list(nms_thr) if isinstance(nms_thr, (list, tuple)) else [nms_thr] * C
+    dev = box_probs.device
+    bid = roi_batch_id.to(device=dev, dtype=torch.int64).reshape(-1)
+    sc = box_probs.t().contiguous().to(torch.float32)                                   # (C, R)
+    above = sc >= _thresh_tensor(st, C, dev).unsqueeze(1)                              # (C, R)
+    member = bid.unsqueeze(0) == torch.arange(batch_size, device=dev).unsqueeze(1)      # (B, R)
+    valid = (member.unsqueeze(1) & above.unsqueeze(0)).reshape(batch_size * C, R)       # group b * C + k
+    scores = sc.unsqueeze(0).expand(batch_size, C, R).reshape(batch_size * C, R)
+    kept = nms_gpu_batched(boxes_for_nms, scores.contiguous(), nt * batch_size, valid, normal=not use_rotate_nms)
+    # position of every roi among the rois of its own sample
+    local = (torch.cumsum(member.to(torch.int64), dim=1) - 1).gather(0, bid.unsqueeze(0)).reshape(-1)
+    out = []
+    for b in range(batch_size):
+        sel = [local[k] for k in kept[b * C:(b + 1) * C] if k.shape[0] > 0]
+        out.append(torch.cat(sel, dim=0) if sel else [])
+    return out
+
+
 def circle_nms(dets, thresh, post_max_size=83):
     """mmdet3d `circle_nms` on the device (the reference copies the detections to the host for the numba version,
     gd_centerpoint_head.py:256-272).  dets (N,3) [x, y, score]; a detection is suppressed by a kept, higher-scored one

@@ -443,6 +443,31 @@ def test_multi_class_nms_matches_reference_loop(amd):
     assert isinstance(none, list) and none == []
 
 
+def test_multi_class_nms_batch_equals_the_per_sample_loop(amd):
+    """pvrcnn_bbox_head.py:393-405: `multi_class_nms(class_pred[b], boxes[roi_batch_id == b], ...)` per sample, against the one
+    batched call over all (sample, class) groups; rois of the samples interleaved, one sample with nothing above threshold"""
+    B, C = 4, 3
+    n = 600
+    boxes, _ = nms_boxes(n, seed=18)
+    rng = np.random.default_rng(19)
+    probs = rng.uniform(0, 1, (n, C)).astype(np.float32)
+    bid = rng.integers(0, B, n)
+    probs[bid == 2] *= 0.05                                        # sample 2: nothing reaches the thresholds
+    score_thr, nms_thr = [0.5, 0.2, 0.8], [0.1, 0.3, 0.5]
+    gp, gb, gi = torch.from_numpy(probs).cuda(), torch.from_numpy(boxes).cuda(), torch.from_numpy(bid).cuda()
+    got = amd.multi_class_nms_batch(gp, gb, gi, B, score_thr, nms_thr)
+    assert len(got) == B
+    for b in range(B):
+        m = gi == b
+        want = amd.multi_class_nms(gp[m], gb[m], score_thr, nms_thr)
+        if isinstance(want, list):
+            assert isinstance(got[b], list) and got[b] == [] and b == 2
+        else:
+            assert torch.equal(got[b], want), b
+    one = amd.multi_class_nms_batch(gp, gb, torch.zeros_like(gi), 1, 0.3, 0.2, use_rotate_nms=False)
+    assert torch.equal(one[0], amd.multi_class_nms(gp, gb, 0.3, 0.2, use_rotate_nms=False))
+
+
 @pytest.mark.parametrize('n,thr', [(1, 1.0), (500, 4.0), (3000, 0.85), (3000, 0.175), (5000, 12.0)])
 def test_circle_nms_bit_exact(amd, n, thr):
     """mmdet3d circle_nms restated (oracle) vs the device version: same kept indices, same order, post_max_size cut."""
