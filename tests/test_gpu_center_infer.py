@@ -342,3 +342,52 @@ def test_get_bboxes_kitti_centerpoint_geometry():
     out = run_and_check(tasks, 'rev', cfg, test_cfg, classes)
     assert all(o[0].shape[1] == 9 and o[0].shape[0] > 0 for o in out)
     run_and_check(tasks, 'rev', cfg, dict(test_cfg, nms_type='circle'), classes)
+
+
+def test_select_best_random_shapes_and_k():
+    """40 random (B, C, H, W, K) with heat maps of different value distributions (dense ties, heavy tails, plateaus, a few cells):
+    the kernel's rule (score descending, equal scores by ascending class, y, x) against numpy"""
+    g = torch.Generator().manual_seed(77)
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        B, C = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        K = int(rng.integers(1, min(H * W, 1200) + 1))
+        kind = it % 5
+        m = torch.randn(B, C, H, W, generator=g)
+        if kind == 1:
+            m = (m * 3).round() / 3                       # a few dozen distinct values
+        elif kind == 2:
+            m = torch.where(m > 1.5, m * 50, torch.full_like(m, -7.0))   # a plateau with a sparse heavy tail
+        elif kind == 3:
+            m = m.exp() * 1e-3                            # everything squeezed into two exponent bins
+        elif kind == 4:
+            m = -m.abs() - 100.0                          # all negative
+        pred = torch.randn(B, 2, H, W, generator=g)
+        s, c, xy, p = amd.select_best(m.to(dev()), pred.to(dev()), K)
+        idx = torch.from_numpy(lex_topk(m, K))
+        cell = idx % (H * W)
+        assert torch.equal(c.cpu(), idx // (H * W)), (it, B, C, H, W, K, kind)
+        assert torch.equal(xy.cpu(), torch.stack((cell % W, cell // W), -1)), (it, B, C, H, W, K, kind)
+        assert torch.equal(s.cpu(), torch.stack([m.view(B, -1)[b][idx[b]] for b in range(B)])), (it, B, C, H, W, K, kind)
+
+
+def test_get_bboxes_random_configurations():
+    """10 random heads (tasks, classes, map shapes, batch, K, coder, cuts, NMS kind, with / without reg and vel): stage-wise check"""
+    g = torch.Generator().manual_seed(99)
+    rng = np.random.default_rng(99)
+    for it in range(10):
+        B = int(rng.integers(1, 4))
+        classes = [int(rng.integers(1, 4)) for _ in range(int(rng.integers(1, 5)))]
+        H, W = int(rng.integers(12, 90)), int(rng.integers(12, 90))
+        K = int(rng.integers(8, min(H * W, 400)))
+        kind = 'rev' if it % 2 else 'yaw'
+        tasks = make_tasks(g, B, H, W, classes, kind, with_reg=bool(rng.integers(0, 2)), with_vel=bool(rng.integers(0, 2)))
+        osf, vs = int(rng.choice([2, 4])), float(rng.choice([0.16, 0.2]))
+        cfg = dict(pc_range=[-W * osf * vs / 2, -H * osf * vs / 2], out_size_factor=osf, voxel_size=[vs, vs], norm_bbox=True)
+        circle = bool(it % 3 == 2)
+        test_cfg = dict(post_center_limit_range=None if it % 4 == 3 else [-100.0, -100.0, -10.0, 100.0, 100.0, 10.0], max_per_img=K,
+                        score_threshold=midgap(tasks, K, float(rng.uniform(0.05, 0.8))), nms_type='circle' if circle else 'rotate',
+                        nms_thr=float(rng.choice([0.1, 0.2, 0.5])), pre_max_size=None if circle else int(rng.integers(4, 2 * K)),
+                        post_max_size=int(rng.integers(1, K + 10)), min_radius=[float(rng.uniform(0.2, 6.0)) for _ in classes])
+        run_and_check(tasks, kind, cfg, test_cfg, classes, wrap=bool(it % 2))

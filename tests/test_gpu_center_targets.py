@@ -123,3 +123,28 @@ def test_targets_errors():
     big = scene(g, 9000)
     with pytest.raises(RuntimeError, match='sorts at most'):
         amd.center_head_get_targets([big[0].cuda()], [big[1].cuda()], TASKS, NUS)
+
+
+def test_targets_random_batches():
+    """25 random batches (sample counts, box counts incl. empty samples, task layouts, geometries, overlaps): everything bit for bit"""
+    g = torch.Generator().manual_seed(88)
+    rng = np.random.default_rng(88)
+    for it in range(25):
+        B = int(rng.integers(1, 6))
+        layout = [['c'] * int(rng.integers(1, 4)) for _ in range(int(rng.integers(1, 7)))]
+        ncls = sum(len(t) for t in layout)
+        osf = int(rng.choice([1, 2, 4, 8]))
+        vs = float(rng.choice([0.1, 0.16, 0.2, 0.32]))
+        nx, ny = int(rng.integers(4, 40)) * osf * 4, int(rng.integers(4, 40)) * osf * 4
+        cfg = dict(grid_size=[ny, nx, 1], point_cloud_range=[-nx * vs / 2, -ny * vs / 3, -5.0, nx * vs / 2, ny * vs * 2 / 3, 3.0],
+                   voxel_size=[vs, vs, 8], out_size_factor=osf, gaussian_overlap=float(rng.choice([0.1, 0.3, 0.5])),
+                   min_radius=int(rng.integers(0, 4)))
+        boxes, labels = [], []
+        for b in range(B):
+            n = int(rng.integers(0, 120))
+            bx, _ = scene(g, n)
+            bx[:, 0] = (torch.rand(n, generator=g) * 1.2 - 0.1) * nx * vs - nx * vs / 2
+            bx[:, 1] = (torch.rand(n, generator=g) * 1.2 - 0.1) * ny * vs - ny * vs / 3
+            boxes.append(bx)
+            labels.append(torch.randint(-1, ncls + 1, (n,), generator=g))     # -1 and ncls belong to no task
+        check(boxes, labels, layout, cfg, objects=bool(it % 2))
