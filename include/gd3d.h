@@ -225,6 +225,15 @@ typedef struct gd3d_center_task {
   int64_t n;
   int32_t B, H, W, anno_cols;
   float gd_scale, l1_scale;
+  /* device-resident form (ABI 4), both nullable: rows_dev -> two int64 on the device, the task's rows are
+   * [rows_dev[0], rows_dev[1]) of pos_ind / anno (shared arrays; `n` is then the CAPACITY the launch is sized for, rows
+   * beyond it are ignored);  avg_dev -> one fp32 on the device, the scales become gd_weight / max(*avg_dev, 1) and
+   * l1_weight / max(*avg_dev, 1) (gd_scale / l1_scale ignored).  With them neither the task's size nor its normaliser
+   * passes through the host: center_targets_build's task_start and gd3d_heat_focal_loss's num_pos plug in directly and
+   * the whole CenterGDHead.loss becomes one stream-ordered, graph-capturable sequence. */
+  const int64_t* rows_dev;
+  const float* avg_dev;
+  double gd_weight, l1_weight;
 } gd3d_center_task;
 
 size_t gd3d_center_head_workspace_bytes(int32_t num_tasks, int64_t max_n);

@@ -37,7 +37,8 @@ class CenterTask(ctypes.Structure):
                 ('anno', ctypes.c_void_p), ('cell_count', ctypes.c_void_p), ('n', ctypes.c_int64), ('B', ctypes.c_int32),
                 ('H', ctypes.c_int32),
                 ('W', ctypes.c_int32), ('anno_cols', ctypes.c_int32), ('gd_scale', ctypes.c_float),
-                ('l1_scale', ctypes.c_float)]
+                ('l1_scale', ctypes.c_float), ('rows_dev', ctypes.c_void_p), ('avg_dev', ctypes.c_void_p),
+                ('gd_weight', ctypes.c_double), ('l1_weight', ctypes.c_double)]
 
 
 class CenterInferTask(ctypes.Structure):

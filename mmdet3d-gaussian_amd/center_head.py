@@ -10,7 +10,8 @@ from .head_loss import center_head_losses
 from .heat_loss import center_head_heatmap_loss
 
 
-def center_gd_head_loss(loss_cls, loss_bbox, loss_gd, bbox_coder, class_names, train_cfg, gt_bboxes_3d, gt_labels_3d, preds_dicts):
+def center_gd_head_loss(loss_cls, loss_bbox, loss_gd, bbox_coder, class_names, train_cfg, gt_bboxes_3d, gt_labels_3d, preds_dicts,
+                        static=False):
     """loss_cls / loss_bbox / loss_gd : the head's loss modules (or config dicts for the first two): GaussianFocalLoss, L1Loss,
                                       this package's GDLoss;
     bbox_coder  : CenterPointBBoxYawCoder;  class_names: per task its class names;  train_cfg: the head's train_cfg
@@ -18,13 +19,21 @@ def center_gd_head_loss(loss_cls, loss_bbox, loss_gd, bbox_coder, class_names, t
     gt_bboxes_3d, gt_labels_3d : the batch's ground truth (see center_head_get_targets);
     preds_dicts : per task the head outputs (a dict, or the reference's one-element list of it) with 'heatmap' LOGITS and the
                   regression maps.  Unlike the reference (:405) the heat maps are NOT replaced by their clipped sigmoid.
+    static=True : NO read-back at all — the targets' row offsets and num_pos stay on the device and the regression kernels read
+                  them there; with ground truth padded to a fixed number of rows (label -1 for the padding) the whole method is
+                  one stream-ordered sequence that `GraphedStep` can capture (forward and backward) and replay.
     Returns the reference's loss_dict: 'task{t}.loss_heatmap', 'task{t}.loss_l1', 'task{t}.loss_gd'."""
     pds = [p[0] if isinstance(p, (list, tuple)) else p for p in preds_dicts]
-    heatmaps, anno_boxes, pos_inds = center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg)
-    hm_losses, num_pos = center_head_heatmap_loss(loss_cls, [p['heatmap'] for p in pds], heatmaps)
-    npos = num_pos.tolist()                      # avg_factor of the regression losses (:408, :431-434)
-    # code_weights as configured: one weight per L1 column (sin, cos(, vx, vy)), :426-428
-    reg = center_head_losses(loss_gd, loss_bbox, bbox_coder, pds, pos_inds, anno_boxes, npos, train_cfg['code_weights'])
+    if static:
+        heatmaps, anno, pos, rows = center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg, padded=True)
+        hm_losses, num_pos = center_head_heatmap_loss(loss_cls, [p['heatmap'] for p in pds], heatmaps)
+        reg = center_head_losses(loss_gd, loss_bbox, bbox_coder, pds, pos, anno, num_pos, train_cfg['code_weights'], rows=rows)
+    else:
+        heatmaps, anno_boxes, pos_inds = center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg)
+        hm_losses, num_pos = center_head_heatmap_loss(loss_cls, [p['heatmap'] for p in pds], heatmaps)
+        npos = num_pos.tolist()                      # avg_factor of the regression losses (:408, :431-434)
+        # code_weights as configured: one weight per L1 column (sin, cos(, vx, vy)), :426-428
+        reg = center_head_losses(loss_gd, loss_bbox, bbox_coder, pds, pos_inds, anno_boxes, npos, train_cfg['code_weights'])
     hm = hm_losses.unbind(0)
     loss_dict = {}
     for t, (l1, gd) in enumerate(reg):

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 
-def center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg):
+def center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg, padded=False):
     """gt_bboxes_3d : per sample either a box object with `.tensor` (N, 7+) in bottom-centre form (LiDARInstance3DBoxes: the
                    gravity centre z + h/2 is taken here, as `.gravity_center` does, :85-87) or a plain (N, 7+) tensor whose rows
                    already are `cat(gravity_center, tensor[:, 3:])`;
@@ -22,7 +22,10 @@ def center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg):
                    any other value, e.g. -1, is ignored);
     class_names  : per task the list of its class names (only the lengths are used), or the lengths themselves;
     train_cfg    : 'grid_size', 'point_cloud_range', 'voxel_size', 'out_size_factor', 'gaussian_overlap', 'min_radius'.
-    Returns (heatmaps, anno_boxes, batch_pos_inds), lists over tasks."""
+    Returns (heatmaps, anno_boxes, batch_pos_inds), lists over tasks.
+    padded=True: no read-back — returns (heatmaps, anno (N, C), pos (N, 3) int64, task_start (T+1,) int64 on the device): task t
+    owns the rows [task_start[t], task_start[t+1]) of the two shared arrays, N = all boxes of the batch (rows past
+    task_start[T] are undefined).  `center_head_losses(..., rows=task_start)` consumes exactly that."""
     B = len(gt_bboxes_3d)
     if B == 0 or len(gt_labels_3d) != B:
         raise RuntimeError(f'center_head_get_targets: {B} box sets and {len(gt_labels_3d)} label sets')
@@ -77,6 +80,12 @@ def center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg):
         _lib.check(lib.center_targets_build(ctypes.byref(d), boxes.data_ptr(), labels.data_ptr(), ws.data_ptr(), heat.data_ptr(),
                                             anno.data_ptr(), pos.data_ptr(), start.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream), 'center_targets_build')
+    if padded:
+        heatmaps, ho = [], 0
+        for c in counts:
+            heatmaps.append(heat[ho:ho + B * c * H * W].view(B, c, H, W))
+            ho += B * c * H * W
+        return heatmaps, anno, pos, start
     st = start.tolist()          # the one sync: T + 1 data-dependent row offsets
     heatmaps, anno_boxes, pos_inds, ho = [], [], [], 0
     for t, c in enumerate(counts):

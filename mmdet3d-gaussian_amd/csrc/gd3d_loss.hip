@@ -586,7 +586,36 @@ struct CenterTask {
   long long n;
   int B, H, W, anno_cols;
   float gd_scale, l1_scale;
+  // device-resident form (nullable): the task's rows are [rows_dev[0], rows_dev[1]) of pos_ind / anno (n is then the
+  // capacity the grid was sized for) and the scales are weight / max(*avg_dev, 1): nothing about the task's size or its
+  // normaliser has to pass through the host
+  const long long* rows_dev;
+  const float* avg_dev;
+  double gd_weight, l1_weight;
 };
+struct CenterDyn {
+  long long row0, n;
+  float gd_scale, l1_scale;
+};
+GD_DEV CenterDyn center_dyn(const CenterTask& T) {
+  CenterDyn d;
+  d.row0 = 0;
+  d.n = T.n;
+  d.gd_scale = T.gd_scale;
+  d.l1_scale = T.l1_scale;
+  if (T.rows_dev != nullptr) {
+    d.row0 = T.rows_dev[0];
+    long long m = T.rows_dev[1] - d.row0;
+    m = m < 0 ? 0 : m;
+    d.n = m < T.n ? m : T.n;
+  }
+  if (T.avg_dev != nullptr) {     // the host form divides two Python floats and rounds once: the same here
+    const double avg = (double)fmaxf(*T.avg_dev, 1.0f);
+    d.gd_scale = (float)(T.gd_weight / avg);
+    d.l1_scale = (float)(T.l1_weight / avg);
+  }
+  return d;
+}
 struct CenterArgs {
   CenterTask t[CENTER_MAX_TASKS];
   int num_tasks, n_l1, norm_bbox;
@@ -605,19 +634,21 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ti = blockIdx.y;
   const CenterTask& T = a.t[ti];
+  const CenterDyn D = center_dyn(T);
   const long long i = (long long)blockIdx.x * HEAD_T + tid;
-  if ((long long)blockIdx.x * HEAD_T >= T.n) {  // uniform: this task has fewer positives than the largest one
+  if ((long long)blockIdx.x * HEAD_T >= D.n) {  // uniform: this task has fewer positives than the largest one
     if (T.count != nullptr && i < a.max_n) T.keys[i] = -1;   // the rest of its key row: not live (the sorted finish reads whole rows)
     return;
   }
   float fgd = 0.0f, fl1 = 0.0f;
-  bool live = i < T.n;
+  bool live = i < D.n;
   int key = -1;
   long long b = 0, x = 0, y = 0;
+  const long long row = D.row0 + i;
   if (live) {
-    b = T.pos_ind[i * 3];
-    x = T.pos_ind[i * 3 + 1];
-    y = T.pos_ind[i * 3 + 2];
+    b = T.pos_ind[row * 3];
+    x = T.pos_ind[row * 3 + 1];
+    y = T.pos_ind[row * 3 + 2];
     if (b < 0 || b >= T.B || x < 0 || x >= T.W || y < 0 || y >= T.H) {
       // an index outside the head map (the reference would fault in its gather): no memory is touched for it and both
       // losses of the task come out NaN, so the error is loud without a host-side range check (= a sync per task)
@@ -638,7 +669,7 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
     enc[6] = T.maps[3][b * plane + off];
     float tv[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) tv[k] = T.anno[i * T.anno_cols + k];
+    for (int k = 0; k < 7; ++k) tv[k] = T.anno[row * T.anno_cols + k];
     // decode (centerpoint_bbox_yaw_coders.py:18-31, correct_yaw=False)
     float pv[7], jac[7];
     pv[0] = (enc[0] + (float)x) * a.osf * a.vs0 + a.pc0;
@@ -653,8 +684,8 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
     jac[0] = a.osf * a.vs0; jac[1] = a.osf * a.vs1; jac[2] = 1.0f; jac[6] = 1.0f;
     const float c[3] = {a.c0, a.c1, a.c2};
     float g1[7], g2[7];
-    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.ia2, a.tau, T.gd_scale, g1, g2);
-    fgd = T.gd_scale * L;
+    const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.ia2, a.tau, D.gd_scale, g1, g2);
+    fgd = D.gd_scale * L;
     // L1 on the remaining channels: dir (sin, cos) and velocity
     float sy, cy;
     sincos_f(tv[6], sy, cy);
@@ -663,13 +694,13 @@ __global__ __launch_bounds__(HEAD_T) void head_center_kernel(const CenterArgs a)
     for (int k = 0; k < 4; ++k) {
       if (k < a.n_l1) {
         const float p = k < 2 ? T.maps[4][(b * 2 + k) * plane + off] : T.maps[5][(b * 2 + (k - 2)) * plane + off];
-        const float t = k == 0 ? sy : (k == 1 ? cy : T.anno[i * T.anno_cols + 7 + (k - 2)]);
+        const float t = k == 0 ? sy : (k == 1 ? cy : T.anno[row * T.anno_cols + 7 + (k - 2)]);
         const float d = p - t;
         fl1 += fabsf(d) * a.cw[k];
-        gl1[k] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * a.cw[k] * T.l1_scale;  // torch abs'(0) = 0
+        gl1[k] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * a.cw[k] * D.l1_scale;  // torch abs'(0) = 0
       }
     }
-    fl1 *= T.l1_scale;
+    fl1 *= D.l1_scale;
     // stage: GD gradient -> reg / height / dim / yaw slots, L1 gradient -> dir / vel slots
     if (T.count != nullptr) {
       float* o = T.og + i * 11;
@@ -734,10 +765,11 @@ __global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a
   const int tid = threadIdx.x, lane = tid & 63;
   const int ti = blockIdx.y;
   const CenterTask& T = a.t[ti];
+  const long long Tn = center_dyn(T).n;
   const long long plane = (long long)T.H * T.W;
-  if (T.count != nullptr && (long long)blockIdx.x * HEAD_T < T.n) {  // uniform
+  if (T.count != nullptr && (long long)blockIdx.x * HEAD_T < Tn) {  // uniform
     const long long i = (long long)blockIdx.x * HEAD_T + tid;
-    const int key = i < T.n ? T.keys[i] : -1;
+    const int key = i < Tn ? T.keys[i] : -1;
     const int c = key >= 0 ? T.count[key] : 0;
     if (c == 1) {
       const long long b = key / plane, off = key - b * plane;
@@ -755,9 +787,9 @@ __global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a
       const long long iL = i - lane + L;
       float acc = 0.0f;
       bool owner = true, first = true;
-      for (long long j0 = 0; j0 < T.n && owner; j0 += 64) {
+      for (long long j0 = 0; j0 < Tn && owner; j0 += 64) {
         const long long j = j0 + lane;
-        unsigned long long m = __builtin_amdgcn_ballot_w64(j < T.n && T.keys[j] == kL);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(j < Tn && T.keys[j] == kL);
         while (m != 0ull) {
           const long long jj = j0 + __builtin_ctzll(m);
           m &= m - 1;
@@ -779,7 +811,7 @@ __global__ __launch_bounds__(HEAD_T) void center_accum_kernel(const CenterArgs a
     }
   }
   if (blockIdx.x != 0) return;
-  center_loss_sums(a, ti, T.n, sd, losses);
+  center_loss_sums(a, ti, Tn, sd, losses);
 }
 
 // The same second step when the caller hands in, per task, the positions of the key row sorted by key (STABLE: objects of
@@ -821,7 +853,7 @@ __global__ __launch_bounds__(HEAD_T) void center_accum_sorted_kernel(const Cente
     }
   }
   if (blockIdx.x != 0) return;
-  center_loss_sums(a, ti, T.n, sd, losses);
+  center_loss_sums(a, ti, center_dyn(T).n, sd, losses);
 }
 
 // backward of the same call when the upstream gradient is not all ones: grads of task t are scaled by
@@ -1494,6 +1526,10 @@ static int center_fill(const gd3d_params* p, const gd3d_prologue* coder, const g
     d.anno_cols = s.anno_cols;
     d.gd_scale = s.gd_scale;
     d.l1_scale = s.l1_scale;
+    d.rows_dev = (const long long*)s.rows_dev;
+    d.avg_dev = s.avg_dev;
+    d.gd_weight = s.gd_weight;
+    d.l1_weight = s.l1_weight;
     if (s.n > max_n) max_n = s.n;
   }
   a.partials = (float*)workspace;

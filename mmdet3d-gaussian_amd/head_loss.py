@@ -267,7 +267,7 @@ _CENTER_CH = (2, 1, 3, 1, 2, 2)
 def _center_head_launch(meta, maps, need):
     """gd3d_center_head_loss on all tasks -> (losses (T,2), per-map gradient views | None, task table)."""
     lib = _lib.load()
-    params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta
+    params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta[:8]     # meta[8:] only keeps device operands alive
     T = len(layout)
     dev = maps[0].device
     tasks = (_lib.CenterTask * T)()
@@ -299,7 +299,10 @@ def _center_head_launch(meta, maps, need):
         tk.pos_ind = pos_inds[t].data_ptr()
         tk.anno = annos[t].data_ptr()
         tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
-        tk.gd_scale, tk.l1_scale = scales[t]
+        if len(scales[t]) == 4:
+            tk.gd_weight, tk.l1_weight, tk.rows_dev, tk.avg_dev = scales[t]
+        else:
+            tk.gd_scale, tk.l1_scale = scales[t]
         max_n = max(max_n, tk.n)
     losses = torch.empty((T, 2), dtype=torch.float32, device=dev)
     ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
@@ -352,7 +355,7 @@ class _CenterHeadFused(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_boxes, num_pos, code_weights):
+def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_boxes, num_pos, code_weights, rows=None):
     """`loss_l1` and `loss_gd` of EVERY CenterGDHead task (gd_centerpoint_head.py:402-441) in one launch, reading the
     head outputs where they lie: no `_reconstruct_bbox` cat (:372-387), no `_gather_feat` (:59-63), no coder calls, no
     per-task loss modules and none of their autograd nodes.
@@ -363,6 +366,10 @@ def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_bo
     (B, c, H, W) — `preds_dict[0]` of the reference;  pos_inds: per task (n,3) long [batch, x, y] (:72-80);
     anno_boxes: per task (n, 7 | 9);  num_pos: per task the positive count (avg_factor = max(num_pos, 1), :405-408);
     code_weights: train_cfg['code_weights'] for [sin, cos(, vx, vy)].
+    Device-resident form (no host value about the tasks' sizes: the call can sit inside a captured hipGraph):
+    rows = (T+1,) int64 DEVICE tensor, task t = rows [rows[t], rows[t+1]) of ONE shared `pos_inds` (N,3) / `anno_boxes` (N,C)
+    pair (what `center_head_get_targets(..., padded=True)` returns), and num_pos a (T,) float DEVICE tensor (what
+    `center_head_heatmap_loss` returns): the kernels read both where they lie.
     Returns a list of (loss_l1, loss_gd) pairs, one per task (0-dim tensors; the graph reaches the head maps)."""
     from .gd_loss import GDLoss
     assert isinstance(loss_gd, GDLoss)
@@ -375,7 +382,16 @@ def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_bo
     if kind != 'L1Loss' or red != 'mean':
         raise RuntimeError(f'encoded-box loss {kind!r} (reduction {red!r}) is not fused; supported: L1Loss, mean')
     T = len(preds_dicts)
-    if not (len(pos_inds) == len(anno_boxes) == len(num_pos) == T) or T == 0 or T > 8:
+    dyn = rows is not None
+    if dyn:
+        if not (isinstance(pos_inds, torch.Tensor) and isinstance(anno_boxes, torch.Tensor) and isinstance(num_pos, torch.Tensor)):
+            raise RuntimeError('center_head_losses: with `rows`, pos_inds / anno_boxes are the shared (N,3) / (N,C) tensors and '
+                               'num_pos a (T,) device tensor')
+        if rows.dtype != torch.int64 or rows.numel() != T + 1 or not rows.is_cuda or num_pos.numel() != T or not num_pos.is_cuda:
+            raise RuntimeError('center_head_losses: rows must be (T+1,) int64 and num_pos (T,) float32, both on the device')
+        rows, num_pos = rows.contiguous(), num_pos.to(torch.float32).contiguous()
+        pos_inds, anno_boxes = [pos_inds] * T, [anno_boxes] * T
+    if not (len(pos_inds) == len(anno_boxes) == T) or (not dyn and len(num_pos) != T) or T == 0 or T > 8:
         raise RuntimeError('center_head_losses: 1..8 tasks, one entry per task in every list')
     has_vel = all('vel' in d for d in preds_dicts)
     n_l1 = 4 if has_vel else 2
@@ -409,10 +425,13 @@ def center_head_losses(loss_gd, loss_bbox, coder, preds_dicts, pos_inds, anno_bo
         #  losses into NaN — no host-side min/max, i.e. no sync)
         pis.append(pi)
         ans.append(an)
-        avg = max(float(num_pos[t]), 1.0)
-        scales.append((float(loss_gd.loss_weight) / avg, lw / avg))
+        if dyn:    # (gd weight, l1 weight, address of rows[t], address of num_pos[t]): the division happens on the device
+            scales.append((float(loss_gd.loss_weight), lw, rows.data_ptr() + 8 * t, num_pos.data_ptr() + 4 * t))
+        else:
+            avg = max(float(num_pos[t]), 1.0)
+            scales.append((float(loss_gd.loss_weight) / avg, lw / avg))
     pro = _prologue(2, maps[0], norm_bbox=coder.norm_bbox, out_size_factor=coder.out_size_factor,
                     voxel_size=coder.voxel_size, pc_range=coder.pc_range)
-    losses = _CenterHeadFused.apply((loss_gd._params({}), pro, layout, pis, ans, scales, cw, n_l1), *maps)
+    losses = _CenterHeadFused.apply((loss_gd._params({}), pro, layout, pis, ans, scales, cw, n_l1, rows, num_pos if dyn else None), *maps)
     flat = losses.reshape(-1).unbind(0)          # one autograd node for all 2T scalars
     return [(flat[2 * t], flat[2 * t + 1]) for t in range(T)]

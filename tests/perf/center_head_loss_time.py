@@ -107,8 +107,26 @@ def main():
             tot = tot + lh + a + b
         tot.backward()
     us_a, us_b = timeit(full_ours, 30), timeit(full_eager, 3, warm=1)
+
+    # static form: nothing is read back (row offsets and num_pos stay on the device), so the whole method can be captured
+    def full_static():
+        zero()
+        out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds, static=True)
+        sum(out.values()).backward()
+    us_s = timeit(full_static, 30)
+    keys = ('heatmap', 'reg', 'height', 'dim', 'yaw', 'dir', 'vel')
+
+    def fn(*args):
+        bx, lb, flat = args[:B], args[B:2 * B], args[2 * B:]
+        out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, list(bx), list(lb),
+                                      [dict(zip(keys, flat[7 * t:7 * t + 7])) for t in range(len(TASKS))], static=True)
+        return [out[k] for k in sorted(out)]
+    step = amd.GraphedStep(fn, gb + gl + [p[k] for p in pds for k in keys])
+    st = step.static_inputs()
+    us_g = timeit(lambda: step(*st), 100)
     print(json.dumps(dict(what='CenterGDHead.loss end to end (targets + heat-map loss + regression losses) fwd+bwd, 6 tasks, batch 8 x 150 boxes',
-                          ours_us=round(us_a, 1), reference_statement_us=round(us_b, 1))), flush=True)
+                          ours_us=round(us_a, 1), ours_static_no_readback_us=round(us_s, 1), ours_static_as_a_hipgraph_us=round(us_g, 1),
+                          reference_statement_us=round(us_b, 1))), flush=True)
 
 
 if __name__ == '__main__':

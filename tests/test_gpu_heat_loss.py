@@ -139,3 +139,59 @@ def test_full_head_loss_is_the_sum_of_its_pieces():
         assert torch.equal(out[f'task{t}.loss_gd'], reg[t][1])
         for k, _ in chans:
             assert pds[t][k].grad is not None and torch.equal(pds[t][k].grad, ref[t][k].grad), (t, k)
+
+
+def test_static_head_loss_equals_the_dynamic_one_and_replays_as_a_hipgraph():
+    """center_gd_head_loss(static=True): row offsets and num_pos never leave the device — same losses and gradients as the form
+    with two read-backs, bit for bit; with ground truth padded to a fixed row count (label -1) the whole method is captured by
+    GraphedStep and replayed on another batch"""
+    from test_gpu_center_targets import NUS, TASKS, scene
+    cfg = dict(NUS, code_weights=[1.0, 1.0, 0.2, 0.2])
+    coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
+    gd = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    l1 = dict(type='L1Loss', reduction='mean', loss_weight=0.25)
+    cls = dict(type='GaussianFocalLoss', reduction='mean')
+    names = ('heatmap', 'reg', 'height', 'dim', 'yaw', 'dir', 'vel')
+    width = dict(reg=2, height=1, dim=3, yaw=1, dir=2, vel=2)
+    B, ROWS = 2, 128
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        boxes, labels = [], []
+        for n in (70, 100):
+            b, l = scene(g, n, spread=50.0)
+            pad_b = torch.zeros(ROWS, 9)
+            pad_l = torch.full((ROWS,), -1, dtype=torch.int64)
+            pad_b[:n], pad_l[:n] = b, l
+            boxes.append(pad_b.cuda())
+            labels.append(pad_l.cuda())
+        maps = [(torch.randn(B, len(TASKS[t]) if k == 'heatmap' else width[k], 128, 128, generator=g) * 0.5 - (2.0 if k == 'heatmap' else 0.0)).cuda()
+                for t in range(len(TASKS)) for k in names]
+        return boxes, labels, maps
+
+    def loss_fn(static):
+        def fn(b0, b1, l0, l1_, *flat):
+            pds = [dict(zip(names, flat[7 * t:7 * t + 7])) for t in range(len(TASKS))]
+            out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, [b0, b1], [l0, l1_], pds, static=static)
+            return [out[k] for k in sorted(out)]
+        return fn
+    boxes, labels, maps = batch(50)
+    res = {}
+    for static in (False, True):
+        leaves = [m.clone().requires_grad_(True) for m in maps]
+        out = loss_fn(static)(boxes[0], boxes[1], labels[0], labels[1], *leaves)
+        sum(out).backward()
+        res[static] = ([o.detach().clone() for o in out], [x.grad.clone() for x in leaves])
+    assert all(torch.equal(a, b) for a, b in zip(res[False][0], res[True][0]))
+    assert all(torch.equal(a, b) for a, b in zip(res[False][1], res[True][1]))
+    assert all(float(o) != 0.0 for o in res[True][0])
+    step = amd.GraphedStep(loss_fn(True), [boxes[0], boxes[1], labels[0], labels[1]] + [m.clone().requires_grad_(True) for m in maps])
+    for seed in (51, 50):
+        b2, l2, m2 = batch(seed)
+        losses, grads = step(b2[0], b2[1], l2[0], l2[1], *m2)
+        got_l, got_g = [x.clone() for x in losses], [g.clone() for g in grads[4:]]
+        leaves = [m.clone().requires_grad_(True) for m in m2]
+        want = loss_fn(False)(b2[0], b2[1], l2[0], l2[1], *leaves)
+        sum(want).backward()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(got_l, want))
+        assert all(torch.equal(a, x.grad) for a, x in zip(got_g, leaves))

@@ -238,3 +238,19 @@ def test_center_targets_struct_layout_and_argument_checks():
     assert lib.center_targets_build(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, None) == 10001
     d.sample_start[1], d.classes[0] = 4, 0
     assert lib.center_targets_build(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, None) == 10001
+
+
+def test_center_task_struct_layout_matches_header():
+    import subprocess
+    import tempfile
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(gd3d_center_task), offsetof(gd3d_center_task, pos_ind), offsetof(gd3d_center_task, n), offsetof(gd3d_center_task, gd_scale),'
+           'offsetof(gd3d_center_task, rows_dev), offsetof(gd3d_center_task, avg_dev), offsetof(gd3d_center_task, gd_weight));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(c, 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
+        got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    D = _lib.CenterTask
+    assert got == [ctypes.sizeof(D), D.pos_ind.offset, D.n.offset, D.gd_scale.offset, D.rows_dev.offset, D.avg_dev.offset,
+                   D.gd_weight.offset], got
