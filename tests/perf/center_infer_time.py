@@ -100,8 +100,15 @@ def main():
             us_a = timeit(lambda: amd.center_head_get_bboxes(tasks, coder, cfg, classes), 50)
             us_b = timeit(lambda: eager(tasks, NUS, cfg, classes, False), 10, warm=2)
             us_c = timeit(lambda: eager(tasks, NUS, cfg, classes, True), 10, warm=2)
+            # nothing read back (padded=True): the call pipelines, and the slice replays as a hipGraph
+            us_p = timeit(lambda: amd.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True), 100)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                amd.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True)
+            us_g = timeit(graph.replay, 200)
             print(json.dumps(dict(what=f'get_bboxes, 6 tasks x batch {B}, 128x128, K=500; {name}', detections=[int(x[0].shape[0]) for x in a],
-                                  ours_us=round(us_a, 1), eager_us=round(us_b, 1), eager_batched_nms_us=round(us_c, 1))), flush=True)
+                                  ours_us=round(us_a, 1), ours_padded_no_readback_us=round(us_p, 1), ours_padded_as_a_hipgraph_us=round(us_g, 1),
+                                  eager_us=round(us_b, 1), eager_batched_nms_us=round(us_c, 1))), flush=True)
     # the selection alone against two torch.topk + gathers (select_best), one task
     for shape, K in (((4, 2, 128, 128), 500), ((1, 3, 468, 468), 4096)):
         g = torch.Generator().manual_seed(4)
