@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of center_head_get_bboxes (6 tasks, nuScenes geometry) and the per-call time of the padded form.
+usage: tools/center_infer_host_profile.py"""
 import sys, cProfile, pstats
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, mmdet3d_gaussian_amd as amd
 from test_gpu_center_infer import NUS, NUS_TEST, make_tasks
 dev = torch.device('cuda:0')
