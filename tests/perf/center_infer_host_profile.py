@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """cProfile of the host side of center_head_get_bboxes (6 tasks, nuScenes geometry) and the per-call time of the padded form.
-usage: tools/center_infer_host_profile.py"""
+usage: tests/perf/center_infer_host_profile.py   (lives under tests/: its inputs come from the test module, which uses the oracle)"""
 import sys, cProfile, pstats
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, mmdet3d_gaussian_amd as amd
 from test_gpu_center_infer import NUS, NUS_TEST, make_tasks
