@@ -35,7 +35,7 @@ def _check_boxes(boxes, cols, name):
     return boxes.to(torch.float32).contiguous()
 
 
-def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
+def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=False):
     name = 'nms_normal_gpu' if normal else 'nms_gpu'
     boxes = _check_boxes(boxes, 5, name)
     if scores.shape[0] != boxes.shape[0]:
@@ -49,7 +49,8 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
         pre_max_size = max(n_all + pre_max_size, 0)
     n = n_all if pre_max_size is None else min(n_all, pre_max_size)
     if n == 0:
-        return torch.zeros((0,), dtype=torch.int64, device=dev)
+        empty = torch.zeros((0,), dtype=torch.int64, device=dev)
+        return (empty, torch.zeros(1, dtype=torch.int64, device=dev)) if padded else empty
     # up to 16384 candidates (the heads cut to nms_pre first) the library orders the scores itself (rank by counting, prep
     # scattered to the rank: no torch.sort); float64 scores keep torch.sort (their order may differ after rounding to fp32)
     fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
@@ -72,6 +73,10 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal):
             fn = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
             _lib.check(fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
                           ws.data_ptr(), stream), name)
+    if padded:   # nothing read back: (kept indices padded to n rows, count on the device); the post_max_size cut applies to both
+        if post_max_size is not None:
+            keep, num = keep[:post_max_size], num.clamp(max=max(int(post_max_size), 0))
+        return keep, num
     k = int(num.item())  # the one unavoidable sync: the result length is data dependent
     keep = keep[:k]
     if post_max_size is not None:
@@ -89,12 +94,15 @@ def _scored_max(lib):
     return _SCORED_MAX
 
 
-def nms_gpu(boxes, scores, thresh, pre_max_size=None, post_max_size=None, pre_maxsize=None):
+def nms_gpu(boxes, scores, thresh, pre_max_size=None, post_max_size=None, pre_maxsize=None, padded=False):
     """Rotated BEV NMS.  boxes (N,5) [x1,y1,x2,y2,ry]; returns kept indices (LongTensor).
-    `pre_maxsize` is the spelling of older mmdet3d releases and is accepted as an alias."""
+    `pre_maxsize` is the spelling of older mmdet3d releases and is accepted as an alias.
+    padded=True (not in mmdet3d): no host sync — returns (keep, num): keep (min(N, pre_max_size[, post_max_size]),) int64 whose
+    first num[0] entries are the kept indices (the rest undefined) and num (1,) int64 on the device; the call can then sit
+    inside a captured hipGraph."""
     if pre_max_size is None:
         pre_max_size = pre_maxsize
-    return _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal=False)
+    return _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal=False, padded=padded)
 
 
 def nms_normal_gpu(boxes, scores, thresh):

@@ -443,6 +443,31 @@ def test_multi_class_nms_matches_reference_loop(amd):
     assert isinstance(none, list) and none == []
 
 
+def test_nms_gpu_padded_is_sync_free_and_replays_as_a_hipgraph(amd):
+    """nms_gpu(..., padded=True): kept indices padded to the candidate count + a device count, no read-back: equal to the plain
+    call, also from inside a captured graph on new boxes in the same buffers"""
+    b0, s0 = nms_boxes(1500, seed=31)
+    b1, s1 = nms_boxes(1500, seed=32)
+    boxes, scores = torch.from_numpy(b0).cuda(), torch.from_numpy(s0).cuda()
+    for pre, post in ((None, None), (1000, 83), (4000, None)):
+        keep, num = amd.nms_gpu(boxes, scores, 0.2, pre_max_size=pre, post_max_size=post, padded=True)
+        want = amd.nms_gpu(boxes, scores, 0.2, pre_max_size=pre, post_max_size=post)
+        assert num.shape == (1,) and int(num) == want.shape[0] and torch.equal(keep[:int(num)], want)
+    amd.nms_gpu(boxes, scores, 0.2, pre_max_size=1000, post_max_size=83, padded=True)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        keep, num = amd.nms_gpu(boxes, scores, 0.2, pre_max_size=1000, post_max_size=83, padded=True)
+    boxes.copy_(torch.from_numpy(b1).cuda())
+    scores.copy_(torch.from_numpy(s1).cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    want = amd.nms_gpu(boxes, scores, 0.2, pre_max_size=1000, post_max_size=83)
+    assert int(num) == want.shape[0] and torch.equal(keep[:int(num)], want)
+    e, n = amd.nms_gpu(boxes[:0], scores[:0], 0.2, padded=True)
+    assert e.shape == (0,) and int(n) == 0
+
+
 def test_multi_class_nms_batch_equals_the_per_sample_loop(amd):
     """pvrcnn_bbox_head.py:393-405: `multi_class_nms(class_pred[b], boxes[roi_batch_id == b], ...)` per sample, against the one
     batched call over all (sample, class) groups; rois of the samples interleaved, one sample with nothing above threshold"""
