@@ -262,6 +262,7 @@ _CENTER_HEADS = ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')
 # below it the scanning form's two launches are cheaper than the sort's (tests/perf/config4_head.py)
 CENTER_SORT_MIN_N = 8192
 _CENTER_CH = (2, 1, 3, 1, 2, 2)
+_CENTER_TASKS = {}
 
 
 def _center_head_launch(meta, maps, need):
@@ -270,7 +271,6 @@ def _center_head_launch(meta, maps, need):
     params, pro, layout, pos_inds, annos, scales, cw, n_l1 = meta[:8]     # meta[8:] only keeps device operands alive
     T = len(layout)
     dev = maps[0].device
-    tasks = (_lib.CenterTask * T)()
     # ONE zero fill covers every gradient map of every task (36 maps at 6 tasks) and the per-task cell counters
     # (B*H*W int32 each, all-zero bits): views into a single flat buffer
     sizes = [m.numel() if nd else 0 for m, nd in zip(maps, need)]
@@ -284,26 +284,39 @@ def _center_head_launch(meta, maps, need):
     for m, nd, sz in zip(maps, need, sizes):
         grads.append(flat[off:off + sz].view_as(m) if nd else None)
         off += sz
-    max_n = 0
-    for t in range(T):
-        tk = tasks[t]
-        for h in range(6):
-            k = layout[t][h]
-            tk.maps[h] = maps[k].data_ptr() if k >= 0 else None
-            tk.grads[h] = grads[k].data_ptr() if (k >= 0 and grads[k] is not None) else None
-        ref = maps[layout[t][1]]
-        tk.B, tk.H, tk.W = ref.shape[0], ref.shape[2], ref.shape[3]
-        tk.cell_count = flat.data_ptr() + 4 * off if wants[t] else None
-        off += cells[t]
-        tk.n = pos_inds[t].shape[0]
-        tk.pos_ind = pos_inds[t].data_ptr()
-        tk.anno = annos[t].data_ptr()
-        tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
-        if len(scales[t]) == 4:
-            tk.gd_weight, tk.l1_weight, tk.rows_dev, tk.avg_dev = scales[t]
-        else:
-            tk.gd_scale, tk.l1_scale = scales[t]
-        max_n = max(max_n, tk.n)
+    # the task table (~30 ctypes fields per task) is rebuilt only when an address, a size or a scale changed: a training loop
+    # whose tensors come back from the caching allocator at the same addresses pays for it once
+    key = (dev.index, tuple(m.data_ptr() for m in maps), tuple(m.shape for m in maps), tuple(need), 0 if flat is None else flat.data_ptr(),
+           tuple(p.data_ptr() for p in pos_inds), tuple(p.shape[0] for p in pos_inds), tuple(a.data_ptr() for a in annos),
+           tuple(a.shape[1] if a.dim() == 2 else 7 for a in annos), tuple(scales), tuple(tuple(r) for r in layout))
+    hit = _CENTER_TASKS.get(key)
+    if hit is not None:
+        tasks, max_n = hit
+    else:
+        tasks = (_lib.CenterTask * T)()
+        max_n = 0
+        for t in range(T):
+            tk = tasks[t]
+            for h in range(6):
+                k = layout[t][h]
+                tk.maps[h] = maps[k].data_ptr() if k >= 0 else None
+                tk.grads[h] = grads[k].data_ptr() if (k >= 0 and grads[k] is not None) else None
+            ref = maps[layout[t][1]]
+            tk.B, tk.H, tk.W = ref.shape[0], ref.shape[2], ref.shape[3]
+            tk.cell_count = flat.data_ptr() + 4 * off if wants[t] else None
+            off += cells[t]
+            tk.n = pos_inds[t].shape[0]
+            tk.pos_ind = pos_inds[t].data_ptr()
+            tk.anno = annos[t].data_ptr()
+            tk.anno_cols = annos[t].shape[1] if annos[t].dim() == 2 else 7
+            if len(scales[t]) == 4:
+                tk.gd_weight, tk.l1_weight, tk.rows_dev, tk.avg_dev = scales[t]
+            else:
+                tk.gd_scale, tk.l1_scale = scales[t]
+            max_n = max(max_n, tk.n)
+        if len(_CENTER_TASKS) >= 16:
+            _CENTER_TASKS.clear()
+        _CENTER_TASKS[key] = (tasks, max_n)
     losses = torch.empty((T, 2), dtype=torch.float32, device=dev)
     ws = torch.empty(lib.gd3d_center_head_workspace_bytes(T, max_n) // 4, dtype=torch.float32, device=dev)
     cwp = (ctypes.c_float * max(n_l1, 1))(*[float(x) for x in cw[:n_l1]])
