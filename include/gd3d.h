@@ -534,8 +534,9 @@ int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, co
  *   (decode), centerpoint_bbox_yaw_coders.py:18-56 (decode with correct_yaw)
  * by: one selection kernel (one workgroup per task x sample: the max_per_img best cells over all classes straight from the
  * logits — sampled threshold + one filtering pass, exact radix select when that pass cannot prove itself —, LDS bitonic
- * sort, gather of the head channels at those cells from the SEPARATE maps, decode, mask, ordered compaction), the batched
- * NMS of rnms_batched over all task x sample groups, one merge kernel.
+ * sort, gather of the head channels at those cells from the SEPARATE maps, decode, mask, ordered compaction, and the
+ * oriented-box records of the survivors), the batched NMS over all task x sample groups (rnms_batched_prepared; circle:
+ * rnms_batched), one merge kernel.  Maps above 131072 cells per group: threshold and filtering pass as two chip-wide launches.
  *
  * Selection rule: descending score; equal scores in ascending flat index (class * H*W + y * W + x).  The reference's
  * per-class-then-global torch.topk picks the same set whenever the scores are distinct; the order among EQUAL scores is
@@ -554,7 +555,8 @@ int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, co
  * center_infer_desc:
  *   decode 0: none (center_infer_select only), 1: CenterPointBBoxCoderRev.decode, 2: CenterPointBBoxYawCoder.decode with
  *   correct_yaw;  max_per_img <= center_infer_max_k() and <= H*W (torch.topk's own limit);  num_channels <= 16;
- *   H*W*classes < 2^31;  nms_type 0 rotate / 2 circle;  pre_max_size, post_max_size < 0: none.
+ *   H*W*classes < 2^31;  nms_type 0 rotate / 2 circle;  pre_max_size, post_max_size < 0: none;  num_tasks: any number for
+ *   center_infer_select (10 tasks travel per launch), at most 40 for center_infer_bboxes.
  * center_infer_select: the selection alone (the coder's select_best): sel_scores (G, K) fp32, sel_cls (G, K) int64,
  *   sel_xy (G, K, 2) int64 (x, y), sel_preds (G, K, num_channels) fp32 raw channels; group G = task * batch + sample;
  *   workspace: center_infer_select_workspace_bytes(desc), 256-byte aligned (only maps above 131072 cells per group use it:
@@ -599,7 +601,8 @@ size_t center_infer_workspace_bytes(const center_infer_desc* desc);
 int center_infer_candidates(const center_infer_desc* desc, int64_t* byte_offsets);
 /* Profiling aid: while device_buffer != NULL every later selection launch records, per group, 8 int64: s_memrealtime stamps
  * (100 MHz) at kernel start / after the threshold sample / after the filtering pass / after the exact radix select (when it
- * had to run) / after the ordering / at the end, then the number of candidates, then 0.  (groups, 8) int64 on the device. */
+ * had to run) / after the ordering / at the end, then the number of candidates, then the stamp taken when the sample had been
+ * loaded.  (groups, 8) int64 on the device. */
 int center_infer_debug_clocks(int64_t* device_buffer);
 /* Clock probe: `iters` dependent FMAs per thread in `blocks` workgroups of 256; device_out[0] = wall time of workgroup 0 in
  * 10 ns ticks (device_out: 2 int64).  One workgroup vs a chip-filling launch shows the clock an almost idle chip is granted. */
