@@ -19,7 +19,7 @@ All arithmetic runs in hand-written HIP kernels reached through the C ABI of inc
 from . import build as _build_mod
 from ._lib import load as load_library, lib_path
 from .gd_loss import GDLoss, make_params
-from .iou3d import (boxes_iou_bev, circle_nms, iou_3d, iou_bev, multi_class_nms, multi_class_nms_batch, nms_gpu, nms_gpu_batched,
+from .iou3d import (box3d_multiclass_nms, boxes_iou_bev, circle_nms, iou_3d, iou_bev, multi_class_nms, multi_class_nms_batch, nms_gpu, nms_gpu_batched,
                     nms_gpu_multi, nms_normal_gpu, xywhr2xyxyr)
 from .registry import LOSSES, Registry, build_loss
 from . import sharded
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
     return _build_mod.build(force=force, verbose=verbose)
 
 
-__all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'circle_nms',
+__all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'box3d_multiclass_nms', 'circle_nms',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'center_head_get_bboxes', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',

@@ -316,6 +316,39 @@ def multi_class_nms_batch(box_probs, boxes_for_nms, roi_batch_id, batch_size, sc
     return out
 
 
+def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None):
+    """mmdet3d `core/post_processing/box3d_nms.py::box3d_multiclass_nms` (third party, absent: restated from the published 0.x
+    text) — what `Anchor3DHead.get_bboxes_single`, which the reference's GDAnchor3DHead inherits, runs on the `nms_pre` best
+    anchors of a sample — with the class loop inside ONE batched NMS and one host sync instead of two per class:
+      per class i < C-1 (the last score column is the padding / background column): candidates = scores[:, i] > score_thr
+      (strictly), `nms_gpu` / `nms_normal_gpu` (cfg.use_rotate_nms) at cfg.nms_thr, kept boxes / scores / labels / direction
+      scores concatenated class after class; more than max_num detections: the max_num best by score.
+    mlvl_bboxes (N, box_dim), mlvl_bboxes_for_nms (N, 5) [x1,y1,x2,y2,ry], mlvl_scores (N, C), cfg: `.use_rotate_nms`, `.nms_thr`
+    (attributes or keys).  Returns (bboxes, scores, labels int64, dir_scores | None)."""
+    get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+    N, C1 = mlvl_scores.shape
+    C = C1 - 1
+    dev = mlvl_scores.device
+    if C <= 0 or N == 0:
+        keep_flat = torch.zeros(0, dtype=torch.int64, device=dev)
+        labels = keep_flat
+    else:
+        sc = mlvl_scores[:, :C].t().contiguous().to(torch.float32)                  # (C, N)
+        valid = sc > float(score_thr)
+        kept = nms_gpu_batched(mlvl_bboxes_for_nms, sc, float(get('nms_thr')), valid, normal=not get('use_rotate_nms'))
+        keep_flat = torch.cat(kept, dim=0)
+        labels = torch.cat([torch.full((k.shape[0],), i, dtype=torch.int64, device=dev) for i, k in enumerate(kept)], dim=0)
+    bboxes = mlvl_bboxes[keep_flat]
+    scores = mlvl_scores[keep_flat, labels] if keep_flat.numel() else mlvl_scores.new_zeros((0,))
+    dir_scores = None if mlvl_dir_scores is None else mlvl_dir_scores[keep_flat]
+    if bboxes.shape[0] > max_num:
+        inds = scores.sort(descending=True, stable=True)[1][:max_num]
+        bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
+        if dir_scores is not None:
+            dir_scores = dir_scores[inds]
+    return bboxes, scores, labels, dir_scores
+
+
 def circle_nms(dets, thresh, post_max_size=83):
     """mmdet3d `circle_nms` on the device (the reference copies the detections to the host for the numba version,
     gd_centerpoint_head.py:256-272).  dets (N,3) [x, y, score]; a detection is suppressed by a kept, higher-scored one

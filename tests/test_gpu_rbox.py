@@ -443,6 +443,39 @@ def test_multi_class_nms_matches_reference_loop(amd):
     assert isinstance(none, list) and none == []
 
 
+def test_box3d_multiclass_nms_matches_the_restated_loop(amd):
+    """mmdet3d's box3d_multiclass_nms (what the inherited Anchor3DHead.get_bboxes_single runs; third party, restated) as the loop it
+    is — strict score threshold, nms per class, concat, max_num cut by score — on the CPU oracle vs the one batched call.
+    BASELINE configs[4]'s shape: 4096 candidates, 3 classes + padding column, thr 0.25 / score_thr 0.1 / max_num 500"""
+    n, C = 4096, 3
+    boxes5, _ = nms_boxes(n, seed=41)
+    rng = np.random.default_rng(42)
+    scores = np.concatenate([rng.uniform(0, 1, (n, C)).astype(np.float32) ** 3, np.zeros((n, 1), np.float32)], 1)
+    box7 = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    dirs = rng.integers(0, 2, n)
+    for score_thr, nms_thr, max_num in ((0.1, 0.25, 500), (0.5, 0.01, 100), (0.999999, 0.25, 500)):
+        wb, ws, wl, wd = [], [], [], []
+        for i in range(C):
+            m = scores[:, i] > np.float32(score_thr)
+            if not m.any():
+                continue
+            idx = np.nonzero(m)[0]
+            sel = idx[oracle.nms_gpu_oracle(boxes5[idx], scores[idx, i], nms_thr)]
+            wb.append(box7[sel]); ws.append(scores[sel, i]); wl.append(np.full(len(sel), i)); wd.append(dirs[sel])
+        if wb:
+            wb, ws, wl, wd = np.concatenate(wb), np.concatenate(ws), np.concatenate(wl), np.concatenate(wd)
+            if wb.shape[0] > max_num:
+                inds = np.argsort(-ws, kind='stable')[:max_num]
+                wb, ws, wl, wd = wb[inds], ws[inds], wl[inds], wd[inds]
+        else:
+            wb, ws, wl, wd = np.zeros((0, 7), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        cfg = dict(use_rotate_nms=True, nms_thr=nms_thr)
+        gb, gs, gl, gd = amd.box3d_multiclass_nms(torch.from_numpy(box7).cuda(), torch.from_numpy(boxes5).cuda(), torch.from_numpy(scores).cuda(),
+                                                  score_thr, max_num, cfg, torch.from_numpy(dirs).cuda())
+        assert np.array_equal(gb.cpu().numpy(), wb) and np.array_equal(gs.cpu().numpy(), ws)
+        assert gl.dtype == torch.int64 and np.array_equal(gl.cpu().numpy(), wl) and np.array_equal(gd.cpu().numpy(), wd)
+
+
 def test_nms_gpu_padded_is_sync_free_and_replays_as_a_hipgraph(amd):
     """nms_gpu(..., padded=True): kept indices padded to the candidate count + a device count, no read-back: equal to the plain
     call, also from inside a captured graph on new boxes in the same buffers"""
