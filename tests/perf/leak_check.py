@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""2000 calls each of the CenterPoint slices with FRESH tensors every time (new addresses defeat the descriptor caches): device
+memory in use and host RSS before / after.  Asserts no growth beyond noise."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import psutil  # noqa: E402
+import torch  # noqa: E402
+
+import mmdet3d_gaussian_amd as amd  # noqa: E402
+from test_gpu_center_infer import NUS, NUS_TEST, make_tasks  # noqa: E402
+from test_gpu_center_targets import NUS as TCFG, TASKS, scene  # noqa: E402
+
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(0)
+classes = [1, 2, 2, 1, 2, 2]
+cpu_tasks = make_tasks(g, 1, 64, 64, classes, 'yaw')
+coder = amd.CenterPointBBoxYawCoder(**NUS)
+cfg = dict(NUS_TEST, max_per_img=200)
+boxes, labels = scene(g, 80)
+tcfg = dict(TCFG, grid_size=[256, 256, 1], code_weights=[1.0, 1.0, 0.2, 0.2])
+gd = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+proc = psutil.Process()
+
+
+def once():
+    tasks = [{k: v.to(dev) + 0.0 for k, v in pd.items()} for pd in cpu_tasks]          # fresh tensors: new addresses
+    amd.center_head_get_bboxes(tasks, coder, cfg, classes)
+    hm, an, pi = amd.center_head_get_targets([boxes.to(dev)], [labels.to(dev)], TASKS, tcfg)
+    pds = [{k: v.requires_grad_(True) for k, v in t.items()} for t in tasks]
+    out = amd.center_gd_head_loss(dict(type='GaussianFocalLoss'), dict(type='L1Loss', loss_weight=0.25), gd, coder, TASKS, tcfg,
+                                  [boxes.to(dev)], [labels.to(dev)], pds, static=True)
+    sum(out.values()).backward()
+
+
+for _ in range(200):
+    once()
+torch.cuda.synchronize()
+m0, r0 = torch.cuda.memory_allocated(), proc.memory_info().rss
+for _ in range(2000):
+    once()
+torch.cuda.synchronize()
+m1, r1 = torch.cuda.memory_allocated(), proc.memory_info().rss
+print(f'device bytes in use {m0} -> {m1}; host RSS {r0 / 1e6:.1f} MB -> {r1 / 1e6:.1f} MB')
+assert m1 - m0 < 8 << 20, 'device memory grows'
+assert r1 - r0 < 64 << 20, 'host memory grows'
