@@ -682,6 +682,47 @@ int gd3d_heat_focal_loss(const gd3d_heat_focal_task* tasks, int32_t num_tasks, f
 int gd3d_heat_focal_scale(const gd3d_heat_focal_task* tasks, int32_t num_tasks, const float* factor,
                           const float* upstream, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Anchor-head inference slice (ABI 4): from the head maps of a batch to its detections, no host sync inside.
+ * The reference's GDAnchor3DHead inherits inference from mmdet3d unchanged (gd_anchor3d_head.py:10): what is replaced is
+ * mmdet3d's Anchor3DHead.get_bboxes_single + box3d_multiclass_nms + DeltaXYZWLHRBBoxCoder.decode + limit_period (third party,
+ * absent: restated from the published 0.x text), i.e. per sample: sigmoid of all class maps, max over classes, topk(nms_pre),
+ * four gathers, ~15 decode ops, and per class a mask, two host syncs and an nms_gpu call, then concat / sort / yaw correction.
+ *   anchor_infer_level (HOST array): cls_score (batch, A*C, H, W), bbox_pred (batch, A*7, H, W), dir_cls_pred (batch, A*2, H, W)
+ *     fp32 contiguous, the head's raw outputs; anchors (H*W*A, 7) in the head's anchor order (h, w, a).
+ *   anchor_infer_desc: nms_pre <= 0: every anchor enters the NMS (then H*W*A must be <= 4096 per level); the candidates of all
+ *     levels together must not exceed rnms_scored_max_n();  score_thr is compared STRICTLY (score > score_thr), as mmdet3d does;
+ *     box code size 7 only.
+ *   out_boxes (batch, max_num, 7) with the direction-bin correction applied, out_scores (batch, max_num), out_labels
+ *   (batch, max_num) int64, out_count (batch) int64 on the DEVICE.  Order: classes in turn, score order inside a class; beyond
+ *   max_num detections the max_num best by score (equal scores keep that order).
+ *   workspace: anchor_infer_workspace_bytes(desc), 256-byte aligned.
+ * anchor_infer_candidates: byte offsets in the workspace of what entered the NMS — boxes (batch, K, 7) fp32, scores
+ *   (batch, C, K) fp32, direction bins (batch, K) int32 — and K (return value; -1 on a bad descriptor), for stage-wise tests.
+ * ---------------------------------------------------------------------------------- */
+#define ANCHOR_INFER_MAX_LEVELS 4
+#define ANCHOR_INFER_MAX_CLASSES 16
+
+typedef struct anchor_infer_level {
+  const float* cls_score;
+  const float* bbox_pred;
+  const float* dir_cls_pred;
+  const float* anchors;
+  int32_t height, width;
+} anchor_infer_level;
+
+typedef struct anchor_infer_desc {
+  int32_t num_levels, batch, num_anchors, num_classes;
+  int32_t nms_pre, max_num, use_rotate_nms, reserved;
+  float score_thr, nms_thr, dir_offset, dir_limit_offset;
+  const anchor_infer_level* levels;
+} anchor_infer_desc;
+
+size_t anchor_infer_workspace_bytes(const anchor_infer_desc* desc);
+int64_t anchor_infer_candidates(const anchor_infer_desc* desc, int64_t* byte_offsets);
+int anchor_infer_bboxes(const anchor_infer_desc* desc, void* workspace, float* out_boxes, float* out_scores,
+                        int64_t* out_labels, int64_t* out_count, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

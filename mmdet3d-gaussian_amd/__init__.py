@@ -12,6 +12,7 @@ Exposes the reference's call surface for the one path this package accelerates:
   * ``center_gd_head_loss``    — CenterGDHead.loss end to end (targets + heat-map loss + regression losses, :390-441)
   * ``center_head_heatmap_loss`` — clip_sigmoid + GaussianFocalLoss of all tasks in one pass (:403-411)
   * ``center_head_get_targets``— CenterPoint target assignment (heat maps, anno_boxes, pos_inds: gd_centerpoint_head.py:65-156)
+  * ``anchor_head_get_bboxes`` — the anchor heads' inference slice (mmdet3d's, inherited by GDAnchor3DHead) around the NMS
   * ``center_head_get_bboxes`` — the CenterPoint inference slice that ends in rotated NMS (gd_centerpoint_head.py:218-361)
 All arithmetic runs in hand-written HIP kernels reached through the C ABI of include/gd3d.h
 (libgd3d.so, built in-tree by ``build.py``).  There is no CPU fallback.
@@ -26,6 +27,7 @@ from . import sharded
 from .coders import CenterPointBBoxCoderRev, CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
 from .center_infer import center_head_get_bboxes, select_best
 from .graphed import GraphedStep
+from .anchor_infer import anchor_head_get_bboxes
 from .center_targets import center_head_get_targets
 from .heat_loss import center_head_heatmap_loss
 from .center_head import center_gd_head_loss
@@ -42,6 +44,6 @@ def build(force=False, verbose=False):
 
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'box3d_multiclass_nms', 'circle_nms',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
-           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'center_head_get_bboxes', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
+           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
            'trans_bev', 'match_coco']

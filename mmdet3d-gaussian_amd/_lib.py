@@ -73,6 +73,20 @@ class HeatFocalTask(ctypes.Structure):
     _fields_ = [('logits', ctypes.c_void_p), ('target', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('n', ctypes.c_int64)]
 
 
+class AnchorInferLevel(ctypes.Structure):
+    """anchor_infer_level (include/gd3d.h)."""
+    _fields_ = [('cls_score', ctypes.c_void_p), ('bbox_pred', ctypes.c_void_p), ('dir_cls_pred', ctypes.c_void_p),
+                ('anchors', ctypes.c_void_p), ('height', ctypes.c_int32), ('width', ctypes.c_int32)]
+
+
+class AnchorInferDesc(ctypes.Structure):
+    """anchor_infer_desc (include/gd3d.h)."""
+    _fields_ = [('num_levels', ctypes.c_int32), ('batch', ctypes.c_int32), ('num_anchors', ctypes.c_int32), ('num_classes', ctypes.c_int32),
+                ('nms_pre', ctypes.c_int32), ('max_num', ctypes.c_int32), ('use_rotate_nms', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('score_thr', ctypes.c_float), ('nms_thr', ctypes.c_float), ('dir_offset', ctypes.c_float),
+                ('dir_limit_offset', ctypes.c_float), ('levels', ctypes.POINTER(AnchorInferLevel))]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -157,6 +171,9 @@ SYMBOLS = {
     'gd3d_heat_focal_workspace_bytes': (_sz, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32]),
     'gd3d_heat_focal_loss': (_int, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_heat_focal_scale': (_int, [ctypes.POINTER(HeatFocalTask), ctypes.c_int32, _vp, _vp, _vp]),
+    'anchor_infer_workspace_bytes': (_sz, [ctypes.POINTER(AnchorInferDesc)]),
+    'anchor_infer_candidates': (_i64, [ctypes.POINTER(AnchorInferDesc), ctypes.POINTER(_i64)]),
+    'anchor_infer_bboxes': (_int, [ctypes.POINTER(AnchorInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

@@ -27,6 +27,7 @@ SOURCES = {
     'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
     'center_infer.hip': ['-ffp-contract=off'],    # decode as coders.hip; the NMS boxes feed bit-exact keep decisions
     'heat_focal.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],   # elementwise loss + gradient, graded at 1e-5
+    'anchor_infer.hip': ['-ffp-contract=off'],    # delta decode in the reference's operation order; boxes feed the NMS
     'center_targets.hip': ['-ffp-contract=off'],  # gaussian_radius in the reference's fp32 operation order
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets)_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets|anchor_infer)_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():

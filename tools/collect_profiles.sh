@@ -52,6 +52,9 @@ python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.
 python3 tests/perf/center_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_time.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ci -o ci -- python3 tests/perf/center_infer_time.py > /dev/null 2>&1
 cp /tmp/kt_ci/ci_kernel_stats.csv $OUT/${R}_center_infer_kernel_stats.csv 2>/dev/null
+python3 tests/perf/anchor_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_anchor_infer_time.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ai -o ai -- python3 tests/perf/anchor_infer_time.py > /dev/null 2>&1
+grep -E "Name|ainfer|cinfer|rbox" /tmp/kt_ai/ai_kernel_stats.csv > $OUT/${R}_anchor_infer_kernel_stats.csv
 python3 tests/perf/center_head_loss_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_head_loss_time.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_hl -o hl -- python3 tests/perf/center_head_loss_time.py > /dev/null 2>&1
 grep -E "Name|hfocal|ctargets|head_center|center_accum|center_scale" /tmp/kt_hl/hl_kernel_stats.csv > $OUT/${R}_center_head_loss_kernel_stats.csv
