@@ -145,3 +145,17 @@ def test_anchor_head_get_bboxes_padded_replays_as_a_hipgraph_and_errors():
         amd.anchor_head_get_bboxes([static[0]], [static[1]], [static[2]], [static[3]], dict(cfg, nms_pre=-1), 3)     # 20 088 anchors into the NMS
     with pytest.raises(RuntimeError, match='do not describe'):
         amd.anchor_head_get_bboxes([static[0]], [static[1][:, :35]], [static[2]], [static[3]], cfg, 3)
+
+
+def test_anchor_head_get_bboxes_random_configurations():
+    g = torch.Generator().manual_seed(64)
+    rng = np.random.default_rng(64)
+    for it in range(8):
+        B, A, C = int(rng.integers(1, 4)), int(rng.choice([2, 4, 6])), int(rng.integers(1, 5))
+        H, W = int(rng.integers(6, 70)), int(rng.integers(6, 70))
+        lv = head_outputs(g, B, A, C, H, W, scene=float(rng.uniform(20, 120)))
+        n = H * W * A
+        nms_pre = int(rng.choice([-1, 50, 400, 5000])) if n <= 4096 else int(rng.choice([60, 700, 4096]))
+        cfg = dict(use_rotate_nms=bool(it % 3), nms_pre=nms_pre, nms_thr=float(rng.choice([0.01, 0.2, 0.5])),
+                   score_thr=midgap_scores([lv[0]], C, float(rng.uniform(0.9, 0.999))), max_num=int(rng.integers(1, 300)))
+        run_and_check([lv], cfg, C, float(rng.choice([0.0, 0.7854])), float(rng.choice([0.0, 0.5, 1.0])))
