@@ -723,6 +723,27 @@ int64_t anchor_infer_candidates(const anchor_infer_desc* desc, int64_t* byte_off
 int anchor_infer_bboxes(const anchor_infer_desc* desc, void* workspace, float* out_boxes, float* out_scores,
                         int64_t* out_labels, int64_t* out_count, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Classification (sigmoid focal) and direction (2-way cross entropy) terms of the anchor heads' loss for a whole batch,
+ * forward + gradient in one pass over the head's NCHW maps (ABI 4).  Replaces, in GDAnchor3DHead.loss_single,
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_anchor3d_head.py:84-92 (permuted copy of the class maps, mmdet FocalLoss)
+ *   and :143-149 (gather of the positives' direction logits, mmdet CrossEntropyLoss) — both loss modules third party, restated:
+ *     t = [label == c], p = sigmoid(x):  BCEwithLogits(x, t) (alpha t + (1-alpha)(1-t)) ((1-p) t + p (1-t))^gamma label_weight;
+ *     direction, positives only (label in [0, num_classes)): (logsumexp(d) - d[dir_target]) dir_weight.
+ *   cls_score (batch, A*C, H, W), dir_cls_preds (batch, A*2, H, W) or NULL: the head's raw outputs;  labels / dir_targets
+ *   (batch, H*W*A) int64 and label_weights / dir_weights (batch, H*W*A) fp32 in the head's anchor order (h, w, a);
+ *   cls_scale = loss_weight / avg_factor of loss_cls, dir_scale likewise (avg_factor = num_total_samples, a host value).
+ * Outputs: losses (2) fp32 on the device [loss_cls, loss_dir]; grad_cls / grad_dir (nullable): d loss / d logit in the maps'
+ *   own layout (every entry written: no zero fill needed).  workspace: gd3d_anchor_cls_dir_workspace_bytes(batch, H, W).
+ *   Sums in a fixed order in fp64: deterministic.  No host sync.  num_anchors <= 32, batch <= 65535 (GD3D_E_TOOLARGE).
+ * ---------------------------------------------------------------------------------- */
+size_t gd3d_anchor_cls_dir_workspace_bytes(int32_t batch, int32_t height, int32_t width);
+int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds, const int64_t* labels,
+                             const float* label_weights, const int64_t* dir_targets, const float* dir_weights,
+                             int32_t batch, int32_t num_anchors, int32_t num_classes, int32_t height, int32_t width,
+                             float gamma, float alpha, float cls_scale, float dir_scale, float* grad_cls,
+                             float* grad_dir, float* losses, void* workspace, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

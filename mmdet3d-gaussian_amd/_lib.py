@@ -174,6 +174,9 @@ SYMBOLS = {
     'anchor_infer_workspace_bytes': (_sz, [ctypes.POINTER(AnchorInferDesc)]),
     'anchor_infer_candidates': (_i64, [ctypes.POINTER(AnchorInferDesc), ctypes.POINTER(_i64)]),
     'anchor_infer_bboxes': (_int, [ctypes.POINTER(AnchorInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_anchor_cls_dir_workspace_bytes': (_sz, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'gd3d_anchor_cls_dir_loss': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import mmdet3d_gaussian_amd as amd
-from mmdet3d_gaussian_amd import graphed, heat_loss
+from mmdet3d_gaussian_amd import anchor_cls, graphed, heat_loss
 
 
 def test_graphed_step_flatten_rebuilds_nested_outputs():
@@ -47,3 +47,38 @@ def test_heatmap_loss_config_parsing():
         heat_loss._cfg(dict(type='FocalLoss'))
     with pytest.raises(RuntimeError, match="'mean'"):
         heat_loss._cfg(dict(type='GaussianFocalLoss', reduction='sum'))
+
+
+def test_anchor_cls_config_parsing_and_cpu_refusal():
+    assert anchor_cls._focal_cfg(dict(type='FocalLoss', use_sigmoid=True)) == (2.0, 0.25, 1.0)
+    assert anchor_cls._focal_cfg(dict(type='FocalLoss', use_sigmoid=True, gamma=1.5, alpha=0.5, loss_weight=3.0)) == (1.5, 0.5, 3.0)
+    assert anchor_cls._ce_cfg(dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.2)) == 0.2
+
+    class FocalLoss:
+        use_sigmoid, gamma, alpha, loss_weight, reduction = True, 2.0, 0.25, 1.0, 'mean'
+    assert anchor_cls._focal_cfg(FocalLoss()) == (2.0, 0.25, 1.0)
+    with pytest.raises(RuntimeError, match='FocalLoss'):
+        anchor_cls._focal_cfg(dict(type='FocalLoss', use_sigmoid=False))
+    with pytest.raises(RuntimeError, match='CrossEntropyLoss'):
+        anchor_cls._ce_cfg(dict(type='CrossEntropyLoss', use_sigmoid=True))
+    with pytest.raises(RuntimeError, match="'mean'"):
+        anchor_cls._focal_cfg(dict(type='FocalLoss', reduction='sum'))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.anchor_head_cls_dir_loss(dict(type='FocalLoss'), dict(type='CrossEntropyLoss'), torch.zeros(1, 2, 3, 3), torch.zeros(1, 4, 3, 3),
+                                     torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), 1, 1.0)
+
+
+def test_anchor_cls_oracle_known_answers():
+    """oracle/anchor_cls_torch.py against hand-computed values of mmdet's formulas: at logit 0 every p = 1/2, so a positive of
+    class 0 among C = 2 costs alpha/4 ln 2 + (1 - alpha)/4 ln 2 and a background anchor 2 (1 - alpha)/4 ln 2; the direction term
+    of equal logits is ln 2 per positive."""
+    import math
+    from oracle import anchor_cls_torch as ORA
+    cls = torch.zeros(1, 2, 1, 2, dtype=torch.float64)            # A = 1, C = 2, two cells
+    dirs = torch.zeros(1, 2, 1, 2, dtype=torch.float64)
+    labels = torch.tensor([[0, 2]])
+    lc, ld = ORA.cls_dir_losses(cls, dirs, labels, torch.ones(1, 2, dtype=torch.float64), torch.tensor([[1, 0]]), torch.tensor([[1.0, 0.0]], dtype=torch.float64),
+                                2, 4.0, cls_weight=1.0, dir_weight=0.2)
+    ln2 = math.log(2.0)
+    assert abs(lc.item() - (0.25 / 4 + 0.75 / 4 + 2 * 0.75 / 4) * ln2 / 4.0) < 1e-12
+    assert abs(ld.item() - 0.2 * ln2 / 4.0) < 1e-12
