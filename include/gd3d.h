@@ -333,6 +333,16 @@ int coder_center_decode_backward(const gd3d_prologue* coder, const float* grad_o
 
 int coder_center_encode(const float* boxes, int64_t n, int32_t c, float* out, void* stream);
 
+/* PointBBoxYawCoder.decode (/root/reference/mmdet3d_gaussian/core/bbox/coders/point_bbox_yaw_coders.py:19-52) and its backward
+ * wrt preds.  priors (n,3) [px, py, scale]; preds (n,c) [dx, dy, z, log dims x3, yaw, sin dir, cos dir, others], c >= 7
+ * (>= 9 with correct_yaw = 1); out (n, 7 + max(c - 9, 0)) = [dx scale + px, dy scale + py, z, exp(dims) (first two x scale),
+ * yaw, others]; correct_yaw = 1: yaw snapped by whole quarter turns towards atan2(sin, cos), w <-> l on odd turns;
+ * num_rot_parity (n) nullable: parity of the turns for the backward.  encode (:12-16) is coder_center_encode. */
+int coder_point_decode(const float* priors, const float* preds, int64_t n, int32_t c, int32_t correct_yaw, float* out,
+                       int32_t* num_rot_parity, void* stream);
+int coder_point_decode_backward(const float* priors, const float* grad_out, const float* out,
+                                const int32_t* num_rot_parity, int64_t n, int32_t c, float* grad_preds, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

@@ -26,7 +26,7 @@ from .iou3d import (box3d_multiclass_nms, boxes_iou_bev, circle_nms, iou_3d, iou
                     nms_gpu_multi, nms_normal_gpu, xywhr2xyxyr)
 from .registry import LOSSES, Registry, build_loss
 from . import sharded
-from .coders import CenterPointBBoxCoderRev, CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder
+from .coders import CenterPointBBoxCoderRev, CenterPointBBoxYawCoder, DeltaXYZWLHRBBoxCoder, PointBBoxYawCoder
 from .center_infer import center_head_get_bboxes, select_best
 from .graphed import GraphedStep
 from .anchor_infer import anchor_head_get_bboxes
@@ -48,6 +48,6 @@ def build(force=False, verbose=False):
 
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'box3d_multiclass_nms', 'circle_nms',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
-           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'anchor_head_cls_dir_loss', 'gd_anchor_head_loss_single', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
+           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'PointBBoxYawCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'anchor_head_cls_dir_loss', 'gd_anchor_head_loss_single', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
            'trans_bev', 'match_coco']

@@ -7,6 +7,9 @@
   correct_yaw=True)``; constructor of centerpoint_bbox_coders.py:7-21) on top of the device kernels of csrc/coders.hip:
   one launch per call instead of ~15 elementwise ops, differentiable wrt ``preds`` (own backward kernel).  GPU tensors
   only; the elementwise torch statement that pins it lives with the test infrastructure, outside this package.
+* ``PointBBoxYawCoder`` — point_bbox_yaw_coders.py:7-52 (priors = point + scale; registered by the reference, used by none of its
+  shipped heads or configs): ``encode`` shares the yaw coder's kernel, ``decode(priors, preds, correct_yaw=True)`` has its own
+  forward and backward kernels.
 * ``DeltaXYZWLHRBBoxCoder`` — mmdet3d (third party, absent, unpinned); restated from its published formulas; the
   reference calls it at models/dense_heads/gd_anchor3d_head.py:133-136.
 
@@ -145,6 +148,64 @@ class CenterPointBBoxYawCoder(CenterPointBBoxCoderRev):
         if not preds.is_cuda:
             raise RuntimeError('CenterPointBBoxYawCoder: the MI355X implementation has no CPU path')
         return _CenterDecode.apply(preds, locs.to(preds.device), _coder_struct(self), bool(correct_yaw))
+
+
+class _PointDecode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, priors, correct_yaw):
+        lib = _lib.load()
+        lead, c = preds.shape[:-1], preds.shape[-1]
+        p2, q2 = _rows32(preds, c), _rows32(priors, 3)
+        n = p2.shape[0]
+        if q2.shape[0] != n:
+            raise RuntimeError(f'priors {tuple(priors.shape)} and preds {tuple(preds.shape)} describe different box counts')
+        co = 7 + max(c - 9, 0)
+        out = torch.empty((n, co), dtype=torch.float32, device=preds.device)
+        need = ctx.needs_input_grad[0]
+        parity = torch.empty(n, dtype=torch.int32, device=preds.device) if (need and correct_yaw) else None
+        with torch.cuda.device(preds.device):
+            rc = lib.coder_point_decode(q2.data_ptr(), p2.data_ptr(), n, c, int(bool(correct_yaw)), out.data_ptr(),
+                                        None if parity is None else parity.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'coder_point_decode')
+        ctx.meta = (n, c, lead, preds.dtype)
+        if need:
+            ctx.save_for_backward(out, parity, q2)
+        res = out.reshape(lead + (co,))
+        return res if preds.dtype == torch.float32 else res.to(preds.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        out, parity, q2 = ctx.saved_tensors
+        n, c, lead, dtype = ctx.meta
+        go = _rows32(grad_out, out.shape[1])
+        gp = torch.empty((n, c), dtype=torch.float32, device=go.device)
+        with torch.cuda.device(go.device):
+            rc = lib.coder_point_decode_backward(q2.data_ptr(), go.data_ptr(), out.data_ptr(), None if parity is None else parity.data_ptr(),
+                                                 n, c, gp.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'coder_point_decode_backward')
+        gp = gp.reshape(lead + (c,))
+        return (gp if dtype == torch.float32 else gp.to(dtype)), None, None
+
+
+class PointBBoxYawCoder:
+    """point_bbox_yaw_coders.py:7-52 (`PointBBoxYawCoder`): `code_size`, `encode`, `decode(priors, preds, correct_yaw=True)`."""
+
+    @property
+    def code_size(self):
+        return 9
+
+    encode = CenterPointBBoxYawCoder.encode          # the same statements (:12-16 == centerpoint_bbox_yaw_coders.py:11-16)
+
+    def decode(self, priors, preds, correct_yaw=True):
+        """priors (..., 3) [x, y, scale] of the points, preds (..., N) raw outputs [dx, dy, z, log dims, yaw, sin, cos, others]
+        -> (..., N-2) boxes [dx scale + x, dy scale + y, z, exp(dims) (w, l times scale), yaw, others]; correct_yaw as in the
+        CenterPoint yaw coder (:38-48).  Differentiable wrt preds (the priors are data: no gradient is produced for them)."""
+        if not preds.is_cuda:
+            raise RuntimeError('PointBBoxYawCoder: the MI355X implementation has no CPU path')
+        if priors.requires_grad:
+            raise RuntimeError('PointBBoxYawCoder.decode: priors that require grad are not supported (gradient flows to preds only)')
+        return _PointDecode.apply(preds, priors.to(preds.device), bool(correct_yaw))
 
 
 class DeltaXYZWLHRBBoxCoder:

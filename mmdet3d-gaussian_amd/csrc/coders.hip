@@ -1,4 +1,4 @@
-// coders.hip — CenterPointBBoxYawCoder on the device.
+// coders.hip — CenterPointBBoxYawCoder, CenterPointBBoxCoderRev and PointBBoxYawCoder on the device.
 //
 // Replaces the ~15 elementwise ATen ops (+ their autograd nodes) of
 //   /root/reference/mmdet3d_gaussian/core/bbox/coders/centerpoint_bbox_yaw_coders.py:11-16 (encode), :18-56 (decode)
@@ -97,6 +97,82 @@ __global__ __launch_bounds__(T) void center_encode_kernel(const float* __restric
   for (int j = 7; j < c; ++j) o[j + 2] = b[j];
 }
 
+
+// PointBBoxYawCoder.decode (/root/reference/mmdet3d_gaussian/core/bbox/coders/point_bbox_yaw_coders.py:19-52): the prior of a
+// box is a point (px, py) and a scale s;  x = p0 * s + px, y = p1 * s + py, z = p2, dims = exp(p3..p5) with the first two
+// times s, yaw = p6 and the same quarter-turn correction from the (sin, cos) channels p7, p8 as the CenterPoint yaw coder.
+struct PointArgs {
+  const float* priors;  // (n,3)
+  const float* preds;   // (n,c)
+  float* out;           // (n,co)
+  int* swapk;           // (n) nullable
+  long long n;
+  int c, co, correct_yaw;
+};
+
+__global__ __launch_bounds__(T) void point_decode_kernel(const PointArgs a) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= a.n) return;
+  const float* p = a.preds + i * a.c;
+  const float* q = a.priors + i * 3;
+  float* o = a.out + i * a.co;
+  const float s = q[2];
+  o[0] = p[0] * s + q[0];
+  o[1] = p[1] * s + q[1];
+  o[2] = p[2];
+  float d0 = expf(p[3]) * s, d1 = expf(p[4]) * s;
+  float yaw = p[6];
+  int k = 0;
+  if (a.correct_yaw) {
+    const float dir = atan2f(p[7], p[8]);
+    const float nr = floorf((dir - yaw) / HALF_PI + 0.5f);
+    k = (int)((long long)nr & 1);           // parity of `num_rot90.long()` (:44)
+    yaw = yaw + nr * HALF_PI;
+    if (k) {
+      const float t = d0;
+      d0 = d1;
+      d1 = t;
+    }
+  }
+  o[3] = d0;
+  o[4] = d1;
+  o[5] = expf(p[5]);
+  o[6] = yaw;
+  for (int j = 9; j < a.c; ++j) o[7 + (j - 9)] = p[j];
+  if (a.swapk != nullptr) a.swapk[i] = k;
+}
+
+struct PointBwdArgs {
+  const float* go;      // (n,co)
+  const float* out;     // (n,co)
+  const float* priors;  // (n,3)
+  const int* swapk;     // (n) nullable
+  float* gp;            // (n,c)
+  long long n;
+  int c, co;
+};
+
+__global__ __launch_bounds__(T) void point_decode_bwd_kernel(const PointBwdArgs a) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= a.n) return;
+  const float* g = a.go + i * a.co;
+  const float* o = a.out + i * a.co;
+  float* gp = a.gp + i * a.c;
+  const float s = a.priors[i * 3 + 2];
+  gp[0] = g[0] * s;
+  gp[1] = g[1] * s;
+  gp[2] = g[2];
+  const bool sw = a.swapk != nullptr && a.swapk[i] != 0;
+  // out[3] = exp(p[sw ? 4 : 3]) s, out[4] = exp(p[sw ? 3 : 4]) s: each is its own derivative
+  gp[3] = sw ? g[4] * o[4] : g[3] * o[3];
+  gp[4] = sw ? g[3] * o[3] : g[4] * o[4];
+  gp[5] = g[5] * o[5];
+  gp[6] = g[6];
+  if (a.c > 7) gp[7] = 0.0f;
+  if (a.c > 8) gp[8] = 0.0f;
+  for (int j = 9; j < a.c; ++j) gp[j] = g[7 + (j - 9)];
+}
+
 }  // namespace gdcoder
 
 using namespace gdcoder;
@@ -162,6 +238,47 @@ int coder_center_encode(const float* boxes, int64_t n, int32_t c, float* out, vo
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   hipLaunchKernelGGL(center_encode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, boxes, out, (long long)n,
                      (int)c);
+  return (int)hipGetLastError();
+}
+
+int coder_point_decode(const float* priors, const float* preds, int64_t n, int32_t c, int32_t correct_yaw, float* out,
+                       int32_t* num_rot_parity, void* stream) {
+  if (n < 0 || c < 7 || correct_yaw < 0 || correct_yaw > 1) return GD3D_E_BADARG;
+  if (correct_yaw == 1 && c < 9) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (priors == nullptr || preds == nullptr || out == nullptr) return GD3D_E_BADARG;
+  PointArgs a;
+  a.priors = priors;
+  a.preds = preds;
+  a.out = out;
+  a.swapk = (int*)num_rot_parity;
+  a.n = n;
+  a.c = c;
+  a.co = 7 + (c > 9 ? c - 9 : 0);
+  a.correct_yaw = correct_yaw;
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(point_decode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int coder_point_decode_backward(const float* priors, const float* grad_out, const float* out, const int32_t* num_rot_parity,
+                                int64_t n, int32_t c, float* grad_preds, void* stream) {
+  if (n < 0 || c < 7) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (priors == nullptr || grad_out == nullptr || out == nullptr || grad_preds == nullptr) return GD3D_E_BADARG;
+  PointBwdArgs a;
+  a.go = grad_out;
+  a.out = out;
+  a.priors = priors;
+  a.swapk = (const int*)num_rot_parity;
+  a.gp = grad_preds;
+  a.n = n;
+  a.c = c;
+  a.co = 7 + (c > 9 ? c - 9 : 0);
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(point_decode_bwd_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -29,3 +29,22 @@ def center_decode(locs, preds, pc_range, out_size_factor, voxel_size, norm_bbox=
         dim = torch.where(odd.unsqueeze(-1), dim[..., [1, 0, 2]], dim)
     cols = [xy[0].unsqueeze(-1), xy[1].unsqueeze(-1), preds[..., 2:3], dim, yaw.unsqueeze(-1), preds[..., 9:]]
     return torch.cat(cols, dim=-1)
+
+
+def point_decode(priors, preds, correct_yaw=True):
+    """PointBBoxYawCoder.decode (/root/reference/mmdet3d_gaussian/core/bbox/coders/point_bbox_yaw_coders.py:19-52), PINNED bit for
+    bit by tests/golden/coder_point.npz (tests/golden/make_golden_coder_point.py, the real class); encode (:12-16) has the
+    statements of center_encode."""
+    scale = priors[..., 2]
+    x = preds[..., 0] * scale + priors[..., 0]
+    y = preds[..., 1] * scale + priors[..., 1]
+    e = preds[..., 3:6].exp()
+    dim = torch.stack((e[..., 0] * scale, e[..., 1] * scale, e[..., 2]), dim=-1)
+    yaw = preds[..., 6]
+    if correct_yaw:
+        with torch.no_grad():
+            quarter_turns = torch.floor((torch.atan2(preds[..., 7], preds[..., 8]) - yaw) / (math.pi / 2) + 0.5)
+            odd = quarter_turns.long() % 2 != 0
+        yaw = yaw + quarter_turns * (math.pi / 2)
+        dim = torch.where(odd.unsqueeze(-1), dim[..., [1, 0, 2]], dim)
+    return torch.cat((x.unsqueeze(-1), y.unsqueeze(-1), preds[..., 2:3], dim, yaw.unsqueeze(-1), preds[..., 9:]), dim=-1)

@@ -71,3 +71,24 @@ def test_anchor_delta_coder_roundtrip_and_oracle_consistency():
         lp = oracle.gd_loss_decoded(pred_enc + d, enc.numpy(), prm, oracle.PRO_ANCHOR_DELTA, anchors)['loss']
         lm = oracle.gd_loss_decoded(pred_enc - d, enc.numpy(), prm, oracle.PRO_ANCHOR_DELTA, anchors)['loss']
         np.testing.assert_allclose((lp - lm) / (2 * eps), r['grad_pred'][:, k], rtol=2e-5, atol=1e-7)
+
+
+POINT_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'coder_point.npz')
+
+
+def test_point_coder_statement_bit_exact_with_reference():
+    """oracle/coder_torch.py point_decode / center_encode vs the REAL PointBBoxYawCoder (tests/golden/coder_point.npz): values bit
+    for bit in fp32 and fp64, autograd gradients wrt preds likewise."""
+    g = np.load(POINT_GOLD)
+    for dtype, t in ((torch.float32, '32'), (torch.float64, '64')):
+        priors = torch.from_numpy(g['priors']).to(dtype)
+        up = torch.from_numpy(g['up']).to(dtype)
+        for cy, tag in ((False, 'noyaw'), (True, 'yaw')):
+            p = torch.from_numpy(g['preds']).to(dtype).requires_grad_(True)
+            d = coder_torch.point_decode(priors, p, correct_yaw=cy)
+            (d * up).sum().backward()
+            np.testing.assert_array_equal(d.detach().numpy(), g[f'decode_{tag}{t}'])
+            np.testing.assert_array_equal(p.grad.numpy(), g[f'gpreds_{tag}{t}'])
+        np.testing.assert_array_equal(coder_torch.center_encode(torch.from_numpy(g['boxes']).to(dtype)).numpy(), g[f'encode{t}'])
+    assert g['decode_yaw32'].shape[-1] == 10 and g['encode32'].shape[-1] == 11
+    assert 0.4 < (g['decode_yaw32'][..., 3] != g['decode_noyaw32'][..., 3]).mean() < 0.7      # odd quarter turns are exercised

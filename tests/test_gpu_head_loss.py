@@ -609,3 +609,36 @@ def test_graphed_step_replays_head_losses_bit_for_bit(amd):
         assert torch.equal(got[2], bp.grad) and torch.equal(got[3], pr.grad)
     with pytest.raises(RuntimeError, match='was captured'):
         step(bp0[:, :7], labels.cuda(), pr0)
+
+
+def test_device_point_coder_vs_reference_golden(amd):
+    """PointBBoxYawCoder on the device (csrc/coders.hip point kernels) against outputs and autograd gradients of the REAL reference
+    class (tests/golden/coder_point.npz; the direction channels sit >= 0.05 rad from a quarter-turn boundary, so the decision
+    must agree everywhere): values and gradients within 2e-6 relative of the fp32 reference (device exp / atan2 differ from the
+    CPU's by ulps) and of the fp64 one."""
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'coder_point.npz'))
+    coder = amd.PointBBoxYawCoder()
+    assert coder.code_size == 9
+    priors, up = torch.from_numpy(g['priors']).cuda(), torch.from_numpy(g['up']).cuda()
+    for cy, tag in ((False, 'noyaw'), (True, 'yaw')):
+        p = torch.from_numpy(g['preds']).cuda().requires_grad_(True)
+        d = coder.decode(priors, p, correct_yaw=cy) if not cy else coder.decode(priors, p)          # correct_yaw=True is the default (:19)
+        (d * up).sum().backward()
+        for t in ('32', '64'):
+            np.testing.assert_allclose(d.detach().cpu().numpy(), g[f'decode_{tag}{t}'], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'gpreds_{tag}{t}'], rtol=2e-6, atol=2e-6)
+    e = coder.encode(torch.from_numpy(g['boxes']).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(e[..., :7], g['encode32'][..., :7])
+    np.testing.assert_allclose(e[..., 7:9], g['encode32'][..., 7:9], atol=2e-7)
+    np.testing.assert_array_equal(e[..., 9:], g['encode32'][..., 9:])
+    # narrow rows (no direction channels, no extras), no-grad path, argument checks
+    p7 = torch.from_numpy(g['preds'][..., :7]).cuda()
+    d7 = coder.decode(priors, p7, correct_yaw=False)
+    np.testing.assert_allclose(d7.cpu().numpy(), g['decode_noyaw32'][..., :7], rtol=2e-6, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        coder.decode(priors, p7, correct_yaw=True)                  # the correction needs the (sin, cos) channels
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        coder.decode(priors.cpu(), p7.cpu())
+    with pytest.raises(RuntimeError, match='different box counts'):
+        coder.decode(priors[:, :-1], p7, correct_yaw=False)
+    assert coder.decode(priors[:0], p7[:0], correct_yaw=False).shape == (0, 200, 7)
