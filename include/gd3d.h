@@ -754,6 +754,44 @@ int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds,
                              float gamma, float alpha, float cls_scale, float dir_scale, float* grad_cls,
                              float* grad_dir, float* losses, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Target assignment of the anchor heads for a whole batch, one feature level (ABI 4).  Replaces what GDAnchor3DHead.loss calls at
+ *   /root/reference/mmdet3d_gaussian/models/dense_heads/gd_anchor3d_head.py:206-214 (`self.anchor_target_3d(...)`), inherited from
+ *   mmdet3d's AnchorTrainMixin with mmdet's MaxIoUAssigner / PseudoSampler, mmdet3d's BboxOverlapsNearest3D,
+ *   DeltaXYZWLHRBBoxCoder.encode and get_direction_target (third party, absent: restated).
+ *   anchors (cells, num_sizes, num_rots, 7) fp32: one level's grid, reshape_out=False order; gt_boxes (gt_start[batch], 7) fp32
+ *   [x, y, z, dx, dy, dz, yaw] and gt_labels int64, sample b owning rows [gt_start[b], gt_start[b+1]) (at most
+ *   anchor_targets_max_gt() each).  num_assigners == num_sizes: assigner q matches the anchors of size q, with assign_per_class
+ *   only against the boxes labelled q; num_assigners == 1: one assigner for all anchors and boxes.  Thresholds per assigner.
+ * Outputs, anchor order (cell, size, rotation) = the (h, w, a) order of the head's maps: labels (batch, N) int64 (num_classes =
+ *   background / ignored), label_weights (0 for the anchors between the thresholds), bbox_targets / bbox_weights (batch, N, 7),
+ *   dir_targets int64 / dir_weights (batch, N); counts (batch, 2) int32 = positives, negatives per sample.  Every entry is
+ *   written.  workspace: anchor_targets_workspace_bytes(num_assigners, gt_start[batch]).  Two launches, integer atomics only.
+ * ---------------------------------------------------------------------------------- */
+#define ANCHOR_TARGETS_MAX_SIZES 16
+#define ANCHOR_TARGETS_MAX_BATCH 64
+#define ANCHOR_TARGETS_MAX_GT 1024
+typedef struct {
+  int32_t batch, cells, num_sizes, num_rots, num_classes;
+  int32_t num_assigners;       /* num_sizes, or 1 */
+  int32_t assign_per_class;
+  int32_t match_low_quality;   /* MaxIoUAssigner: default 1 */
+  int32_t gt_max_assign_all;   /* MaxIoUAssigner: default 1 */
+  int32_t num_dir_bins;        /* get_direction_target: 2 */
+  int32_t gt_start[ANCHOR_TARGETS_MAX_BATCH + 1];
+  float pos_iou_thr[ANCHOR_TARGETS_MAX_SIZES];
+  float neg_iou_thr[ANCHOR_TARGETS_MAX_SIZES];
+  float min_pos_iou[ANCHOR_TARGETS_MAX_SIZES];
+  float pos_weight;            /* train_cfg.pos_weight: <= 0 means 1 */
+  float dir_offset;
+} anchor_targets_desc;
+int32_t anchor_targets_max_gt(void);
+size_t anchor_targets_workspace_bytes(int32_t num_assigners, int32_t gt_total);
+int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, const float* gt_boxes,
+                         const int64_t* gt_labels, void* workspace, int64_t* labels, float* label_weights,
+                         float* bbox_targets, float* bbox_weights, int64_t* dir_targets, float* dir_weights,
+                         int32_t* counts, void* stream);
+
 /* Library identification: returns GD3D_ABI_VERSION; *arch (if non-NULL) receives a static
  * string naming the code-object target, e.g. "gfx950". */
 int gd3d_abi_version(const char** arch);

@@ -87,6 +87,15 @@ class AnchorInferDesc(ctypes.Structure):
                 ('dir_limit_offset', ctypes.c_float), ('levels', ctypes.POINTER(AnchorInferLevel))]
 
 
+class AnchorTargetsDesc(ctypes.Structure):
+    """anchor_targets_desc (include/gd3d.h)."""
+    _fields_ = [('batch', ctypes.c_int32), ('cells', ctypes.c_int32), ('num_sizes', ctypes.c_int32), ('num_rots', ctypes.c_int32),
+                ('num_classes', ctypes.c_int32), ('num_assigners', ctypes.c_int32), ('assign_per_class', ctypes.c_int32),
+                ('match_low_quality', ctypes.c_int32), ('gt_max_assign_all', ctypes.c_int32), ('num_dir_bins', ctypes.c_int32),
+                ('gt_start', ctypes.c_int32 * 65), ('pos_iou_thr', ctypes.c_float * 16), ('neg_iou_thr', ctypes.c_float * 16),
+                ('min_pos_iou', ctypes.c_float * 16), ('pos_weight', ctypes.c_float), ('dir_offset', ctypes.c_float)]
+
+
 # every symbol include/gd3d.h declares: name -> (restype, argtypes)
 _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 SYMBOLS = {
@@ -176,6 +185,9 @@ SYMBOLS = {
     'anchor_infer_workspace_bytes': (_sz, [ctypes.POINTER(AnchorInferDesc)]),
     'anchor_infer_candidates': (_i64, [ctypes.POINTER(AnchorInferDesc), ctypes.POINTER(_i64)]),
     'anchor_infer_bboxes': (_int, [ctypes.POINTER(AnchorInferDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'anchor_targets_max_gt': (ctypes.c_int32, []),
+    'anchor_targets_workspace_bytes': (_sz, [ctypes.c_int32, ctypes.c_int32]),
+    'anchor_targets_build': (_int, [ctypes.POINTER(AnchorTargetsDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_anchor_cls_dir_workspace_bytes': (_sz, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'gd3d_anchor_cls_dir_loss': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

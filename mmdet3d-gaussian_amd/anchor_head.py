@@ -1,4 +1,5 @@
-"""`GDAnchor3DHead.loss_single` end to end on the device: classification, regression and direction terms of one level.
+"""`GDAnchor3DHead.loss` and `loss_single` end to end on the device: target assignment, then the classification, regression and
+direction terms of the level.
 
 The reference's method (/root/reference/mmdet3d_gaussian/models/dense_heads/gd_anchor3d_head.py:62-161) composed from this
 package's two fused slices — `anchor_head_cls_dir_loss` (:84-92, :143-149) and `anchor_head_bbox_loss` (:95-141, :150-161) — in
@@ -6,6 +7,7 @@ four launches forward, with no permuted copies of the head's maps, no `nonzero` 
 twice (`labels.max().item()` at :90, `nonzero` at :101-103).  Static shapes: `GraphedStep` can capture forward and backward.
 """
 from .anchor_cls import anchor_head_cls_dir_loss
+from .anchor_targets import anchor_head_get_targets
 from .head_loss import anchor_head_bbox_loss
 
 
@@ -30,3 +32,48 @@ def gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox,
                                    num_total_samples, code_weight=get('code_weight'), decode_weight=get('decode_weight'),
                                    diff_rad_by_sin=diff_rad_by_sin, dense=True)
     return l_cls, l_bbox, l_dir
+
+
+def _one(x, name):
+    if isinstance(x, (list, tuple)):
+        if len(x) != 1:
+            raise RuntimeError(f'gd_anchor_head_loss: {len(x)} feature levels in {name}; the reference heads have one')
+        return x[0]
+    return x
+
+
+def gd_anchor_head_loss(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_cfg, num_classes, anchors, cls_scores, bbox_preds,
+                        dir_cls_preds, gt_bboxes, gt_labels, assign_per_class=True, dir_offset=0.0, diff_rad_by_sin=True,
+                        use_direction_classifier=True, sampling=False, static=False):
+    """`GDAnchor3DHead.loss` (/root/reference/mmdet3d_gaussian/models/dense_heads/gd_anchor3d_head.py:167-240) for the one feature
+    level the reference's anchor heads have: `anchor_target_3d` (:206-214, mmdet3d's mixin: `anchor_head_get_targets`), the
+    normaliser `num_total_samples = num_total_pos` (:221-222, sampling=False) and `loss_single` (:227-238).
+    anchors       : the level's grid (H, W, S, R, 7) (what `get_anchors` / `grid_anchors` return with reshape_out=False: one grid for
+                    every sample);  cls_scores / bbox_preds / dir_cls_preds: the head's outputs (tensors or one-element lists);
+    gt_bboxes, gt_labels : the batch's ground truth (see anchor_head_get_targets);  train_cfg: 'assigner', 'pos_weight',
+                    'code_weight', 'decode_weight';  the loss modules as in gd_anchor_head_loss_single.
+    ONE read-back for the batch: the per-sample (positives, negatives) counts that make the normaliser.
+    static=True   : none at all — the normaliser stays on the device (the three losses are computed for num_total_samples = 1 and
+                    divided there; equal to the eager form within fp32 rounding), so with ground truth padded to a fixed number
+                    of rows (label -1 for the padding) the whole method is one stream-ordered sequence that `GraphedStep` captures.
+    Returns the reference's dict: loss_cls, loss_bbox, loss_dir, each a one-element list."""
+    cls_score, bbox_pred = _one(cls_scores, 'cls_scores'), _one(bbox_preds, 'bbox_preds')
+    dir_pred = _one(dir_cls_preds, 'dir_cls_preds') if use_direction_classifier else None
+    get = (lambda k, d=None: train_cfg.get(k, d)) if isinstance(train_cfg, dict) else (lambda k, d=None: getattr(train_cfg, k, d))
+    tg = anchor_head_get_targets(anchors, gt_bboxes, gt_labels, get('assigner'), num_classes, assign_per_class=assign_per_class,
+                                 pos_weight=get('pos_weight', -1), dir_offset=dir_offset, sampling=sampling, padded=static)
+    labels, label_weights, bbox_targets, bbox_weights, dir_targets, dir_weights = tg[:6]
+    flat = anchors.reshape(-1, 7)
+    if static:
+        norm = tg[6][:, 0].clamp(min=1).sum().to(cls_score.dtype)                 # sum_b max(positives_b, 1), on the device
+        l_cls, l_bbox, l_dir = gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_cfg, num_classes,
+                                                          cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
+                                                          dir_targets, dir_weights, flat, 1.0, diff_rad_by_sin, use_direction_classifier)
+        l_cls, l_bbox = l_cls / norm, l_bbox / norm
+        l_dir = None if l_dir is None else l_dir / norm
+    else:
+        l_cls, l_bbox, l_dir = gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_cfg, num_classes,
+                                                          cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
+                                                          dir_targets, dir_weights, flat, float(tg[6]), diff_rad_by_sin,
+                                                          use_direction_classifier)
+    return dict(loss_cls=[l_cls], loss_bbox=[l_bbox], loss_dir=[l_dir])

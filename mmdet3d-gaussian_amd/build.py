@@ -26,6 +26,7 @@ SOURCES = {
     'eval_match.hip': ['-ffp-contract=off'],
     'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
     'center_infer.hip': ['-ffp-contract=off'],    # decode as coders.hip; the NMS boxes feed bit-exact keep decisions
+    'anchor_targets.hip': ['-ffp-contract=off'],   # IoU and thresholds decide as the torch elementwise ops do
     'anchor_cls.hip': [],                       # elementwise focal + direction loss with gradient, graded at 1e-5
     'heat_focal.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],   # elementwise loss + gradient, graded at 1e-5
     'anchor_infer.hip': ['-ffp-contract=off'],    # delta decode in the reference's operation order; boxes feed the NMS

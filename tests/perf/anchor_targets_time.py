@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Anchor heads' target assignment and the whole GDAnchor3DHead.loss at the reference's KITTI PointPillars training geometry
+(248 x 216 cells x 3 sizes x 2 rotations = 321 408 anchors per sample, batch 6, 3 classes, the config's three MaxIoUAssigners),
+us per call (synchronised):
+  targets : ours = anchor_head_get_targets (two launches + one read-back of the counts)
+            eager = mmdet3d's anchor_target_3d chain (oracle/anchor_targets_torch.py's statement) on device tensors
+  loss    : ours = gd_anchor_head_loss eager, static, and static as one hipGraph (forward + backward)
+            eager = the restated chain + the reference's loss ops on device tensors (forward + backward)
+Asserts equal labels / counts first."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch  # noqa: E402
+
+import mmdet3d_gaussian_amd as amd  # noqa: E402
+from oracle import anchor_cls_torch, head_torch  # noqa: E402
+from oracle import anchor_targets_torch as ORA  # noqa: E402
+from test_gpu_anchor_targets import CE, FOCAL, KITTI_ASSIGNERS, SL1, TRAIN_CFG, head_outputs, kitti_anchors, random_gt  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, it, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(it):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / it * 1e6
+
+
+def main():
+    B, H, W, G = 6, 248, 216, 24
+    anchors = kitti_anchors(H, W).to(dev)
+    pairs = [random_gt(G, seed=100 + i, with_ignored=False) for i in range(B)]
+    gts, labels = [p[0].to(dev) for p in pairs], [p[1].to(dev) for p in pairs]
+    ours = lambda: amd.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3)          # noqa: E731
+    eager = lambda: ORA.anchor_target_3d(anchors, gts, labels, KITTI_ASSIGNERS, 3)                # noqa: E731
+    a, e = ours(), eager()
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and a[6] == e[6] and a[7] == e[7]
+    t_o, t_e = timeit(ours, 30), timeit(eager, 3, warm=1)
+    t_p = timeit(lambda: amd.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3, padded=True), 30)
+    print(json.dumps(dict(step='anchor_target_3d', geometry='kitti', batch=B, anchors_per_sample=H * W * 6, boxes_per_sample=G, positives=a[6],
+                          ours_us=round(t_o, 1), ours_no_readback_us=round(t_p, 1), reference_ops_on_gpu_us=round(t_e, 1),
+                          speedup=round(t_e / t_o, 1))), flush=True)
+
+    outs = [o.to(dev).requires_grad_(True) for o in head_outputs(B, H, W, seed=1)]
+    mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    gt_t, gl_t = torch.stack(gts), torch.stack(labels)
+
+    def fn(cls, bbox, dirs, gt, gl, static=True):
+        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), static=static)
+        return r['loss_cls'][0], r['loss_bbox'][0], r['loss_dir'][0]
+
+    def run(static):
+        for o in outs:
+            o.grad = None
+        l = fn(outs[0], outs[1], outs[2], gt_t, gl_t, static)
+        (l[0] + l[1] + l[2]).backward()
+
+    def ref():
+        for o in outs:
+            o.grad = None
+        tg = ORA.anchor_target_3d(anchors, gts, labels, KITTI_ASSIGNERS, 3)
+        avg = float(tg[6])
+        lc, ld = anchor_cls_torch.cls_dir_losses(outs[0], outs[2], tg[0], tg[1], tg[4], tg[5], 3, avg)
+        lb = head_torch.loss_single_bbox(outs[1], tg[2], tg[3], tg[0], anchors.reshape(-1, 7), 3, avg,
+                                         gd=dict(loss_type='kld3d', fun='log1p', tau=1.0, loss_weight=5.0),
+                                         sl1=dict(beta=SL1['beta'], loss_weight=SL1['loss_weight']), code_weight=TRAIN_CFG['code_weight'],
+                                         decode_weight=TRAIN_CFG['decode_weight'], diff_rad_by_sin=True)
+        (lc + lb + ld).backward()
+    step = amd.GraphedStep(fn, (outs[0], outs[1], outs[2], gt_t, gl_t))
+    t_eager, t_static = timeit(lambda: run(False), 30), timeit(lambda: run(True), 30)
+    t_graph = timeit(lambda: step(outs[0], outs[1], outs[2], gt_t, gl_t), 30)
+    t_ref = timeit(ref, 3, warm=1)
+    print(json.dumps(dict(step='GDAnchor3DHead.loss fwd+bwd', geometry='kitti', batch=B, ours_eager_us=round(t_eager, 1), ours_static_us=round(t_static, 1),
+                          ours_graph_us=round(t_graph, 1), reference_ops_on_gpu_us=round(t_ref, 1), speedup_eager=round(t_ref / t_eager, 1),
+                          speedup_graph=round(t_ref / t_graph, 1))), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets|anchor_infer)_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|size_t|int64_t|int32_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets|anchor_infer|anchor_targets)_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -254,3 +254,36 @@ def test_center_task_struct_layout_matches_header():
     D = _lib.CenterTask
     assert got == [ctypes.sizeof(D), D.pos_ind.offset, D.n.offset, D.gd_scale.offset, D.rows_dev.offset, D.avg_dev.offset,
                    D.gd_weight.offset], got
+
+
+def test_anchor_targets_struct_layout_and_argument_checks():
+    import subprocess
+    import tempfile
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(anchor_targets_desc), offsetof(anchor_targets_desc, num_dir_bins), offsetof(anchor_targets_desc, gt_start),'
+           'offsetof(anchor_targets_desc, pos_iou_thr), offsetof(anchor_targets_desc, min_pos_iou),'
+           'offsetof(anchor_targets_desc, dir_offset));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(c, 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
+        got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    D = _lib.AnchorTargetsDesc
+    assert got == [ctypes.sizeof(D), D.num_dir_bins.offset, D.gt_start.offset, D.pos_iou_thr.offset, D.min_pos_iou.offset, D.dir_offset.offset], got
+    lib = amd.load_library()
+    assert lib.anchor_targets_max_gt() == 1024 and lib.anchor_targets_workspace_bytes(3, 100) % 256 == 0
+    d = D()
+    d.batch, d.cells, d.num_sizes, d.num_rots, d.num_classes, d.num_assigners, d.num_dir_bins = 1, 16, 3, 2, 3, 2, 2
+    args = [256] * 11
+    assert lib.anchor_targets_build(ctypes.byref(d), *args, None) == 10001          # 2 assigners for 3 sizes
+    d.num_assigners = 3
+    d.gt_start[1] = 2000
+    assert lib.anchor_targets_build(ctypes.byref(d), *args, None) == 10002          # too many boxes in a sample
+    d.gt_start[1] = -1
+    assert lib.anchor_targets_build(ctypes.byref(d), *args, None) == 10001
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
+                                    [dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45)], 1)
+    with pytest.raises(RuntimeError, match='sampling=True'):
+        amd.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
+                                    dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45), 1, sampling=True)
