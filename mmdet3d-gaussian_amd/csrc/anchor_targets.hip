@@ -7,14 +7,16 @@
 // loop over the gts with a full-row compare each), PseudoSampler (two nonzero + unique), DeltaXYZWLHR encode, direction bins and
 // six scatters: ~60 launches and several host syncs per (sample, class), 18 such calls per KITTI batch of 6.
 // Here, two launches for the batch, no sync:
-//   pass 1  iou_max_kernel : thread per anchor of one (sample, assigner); the sample's boxes sit in LDS as nearest-BEV rectangles;
+//   pass 1  iou_max_kernel : a workgroup owns a tile of cells with all their anchors, walked size by size (a wave works for one
+//                            assigner at a time); the sample's boxes sit in LDS as nearest-BEV rectangles;
 //                            per box the best overlap over the assigner's anchors as one 64-bit key (IoU bits, then lowest anchor
 //                            index) — LDS atomicMax per workgroup, one global atomicMax per (workgroup, box) that any anchor touches.
 //   pass 2  assign_kernel  : recomputes the thread's overlaps (same instructions, same bits), applies the assigner's rules in the
 //                            reference's order (negative below neg_iou_thr, positive from pos_iou_thr on, then box after box its
-//                            best anchors when that best reaches min_pos_iou — later boxes overwrite earlier ones), and writes
-//                            labels, weights, encoded regression targets, direction bins in the head's (h, w, size, rotation)
-//                            order; positives / negatives per sample counted with integer atomics.
+//                            best anchors when that best reaches min_pos_iou — later boxes overwrite earlier ones), stages the
+//                            tile's labels, weights, encoded regression targets and direction bins in LDS in the head's
+//                            (h, w, size, rotation) order and writes them out as contiguous ranges; positives / negatives per
+//                            sample counted with integer atomics.
 // Integer atomics only: the result does not depend on scheduling.  Built with -ffp-contract=off: the IoU (+, -, x, /, max, min)
 // carries the rounding of the torch elementwise ops, so thresholds and ties decide as they do there.
 #include <hip/hip_runtime.h>
@@ -63,7 +65,7 @@ struct Args {
   const float* anchors;        // (cells, S, R, 7)
   const float* gt;             // (G_total, 7)
   const long long* gt_labels;  // (G_total)
-  unsigned long long* keys;    // (Q, G_total)
+  unsigned long long* keys;    // (K, G_total), K = 1 or S (see key_rows)
   long long* labels;           // (B, N)
   float* label_w;              // (B, N)
   float* bbox_t;               // (B, N, 7)
@@ -71,96 +73,154 @@ struct Args {
   long long* dir_t;            // (B, N)
   float* dir_w;                // (B, N)
   int* counts;                 // (B, 2)
-  int g_total;
+  int g_total, g_cap;          // all boxes; LDS capacity per sample (the largest sample, rounded up)
+  int tile_cells;              // cells of a workgroup's tile
 };
 
+// A box's best overlap is kept per (assigner, box).  With assign_per_class only assigner `label` ever sees the box, with one
+// assigner there is one row anyway: K = 1 row of keys; a list of assigners that all see every box needs K = S rows.
+__device__ __forceinline__ int key_rows(const anchor_targets_desc& d) { return (d.num_assigners > 1 && !d.assign_per_class) ? d.num_sizes : 1; }
+
+// dynamic LDS: [Rect r[g_cap]] [float area[g_cap]] [int label[g_cap]] then the kernel's own arrays
 struct Staged {
-  Rect r[MAX_GT];
-  float area[MAX_GT];
-  int label[MAX_GT];
+  Rect* r;
+  float* area;
+  int* label;
+  unsigned char* rest;
 };
 
-// the sample's boxes -> LDS; returns how many of them assigner q may match
-__device__ __forceinline__ int stage(const Args& a, int b, int q, Staged& s, int* s_count) {
+__device__ __forceinline__ Staged carve(unsigned char* smem, int g_cap) {
+  Staged s;
+  s.r = (Rect*)smem;
+  s.area = (float*)(smem + (size_t)g_cap * 16);
+  s.label = (int*)(smem + (size_t)g_cap * 20);
+  s.rest = smem + (size_t)g_cap * 24;
+  return s;
+}
+
+// the sample's boxes -> LDS as nearest-BEV rectangles
+__device__ __forceinline__ int stage(const Args& a, int b, const Staged& s) {
   const int g0 = a.d.gt_start[b], G = a.d.gt_start[b + 1] - g0;
-  if (threadIdx.x == 0) *s_count = 0;
-  __syncthreads();
-  int mine = 0;
   for (int g = threadIdx.x; g < G; g += T) {
     const float* row = a.gt + (size_t)(g0 + g) * 7;
     const Rect q4 = nearest_bev(row[0], row[1], row[3], row[4], row[6]);
     s.r[g] = q4;
     s.area[g] = rect_area(q4);
     const long long lab = a.gt_labels[g0 + g];
-    const int li = (lab >= 0 && lab < 0x7fffffffLL) ? (int)lab : -1;
-    s.label[g] = li;
-    mine += (!a.d.assign_per_class || li == q) ? 1 : 0;
+    s.label[g] = (lab >= 0 && lab < 0x7fffffffLL) ? (int)lab : -1;
   }
-  if (mine) atomicAdd(s_count, mine);
-  __syncthreads();
   return G;
 }
 
-// anchor m of assigner q -> its index n in the head's order (cell, size, rotation)
-__device__ __forceinline__ long long anchor_index(const anchor_targets_desc& d, int q, long long m) {
-  if (d.num_assigners == 1) return m;
-  return ((m / d.num_rots) * d.num_sizes + q) * d.num_rots + m % d.num_rots;
+// A workgroup owns tile_cells consecutive cells of one sample with all their S x R anchors: items i = t, t + T, ... in size-major
+// order (size q = i / (cells x R)), so that a wave works for one assigner at a time (tile_cells x R is a multiple of 64 at the
+// reference's geometries) and skips the boxes of the other classes as a whole.  j = the anchor's offset in the tile in the
+// head's order (cell, size, rotation).
+struct Item {
+  int q, j;
+  bool live;
+};
+
+__device__ __forceinline__ Item item_of(const anchor_targets_desc& d, int tile_cells, int ncell, int i) {
+  const int per_q = tile_cells * d.num_rots;
+  Item it;
+  it.q = i / per_q;
+  const int rest = i - it.q * per_q;
+  const int cell = rest / d.num_rots, r = rest - cell * d.num_rots;
+  it.j = (cell * d.num_sizes + it.q) * d.num_rots + r;
+  it.live = cell < ncell;
+  return it;
 }
 
 __global__ __launch_bounds__(T) void iou_max_kernel(const Args a) {
-  __shared__ Staged s;
-  __shared__ unsigned long long s_key[MAX_GT];
-  __shared__ int s_count;
-  const int b = blockIdx.z, q = blockIdx.y;
-  const int G = stage(a, b, q, s, &s_count);
-  if (G == 0 || s_count == 0) return;
-  for (int g = threadIdx.x; g < G; g += T) s_key[g] = 0ull;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Staged s = carve(smem, a.g_cap);
+  unsigned long long* s_key = (unsigned long long*)s.rest;          // (K, g_cap)
+  const int b = blockIdx.y;
+  const int G = stage(a, b, s);
+  if (G == 0) return;
+  const int K = key_rows(a.d);
+  for (int k = threadIdx.x; k < K * a.g_cap; k += T) s_key[k] = 0ull;
   __syncthreads();
-  const long long M = a.d.num_assigners == 1 ? (long long)a.d.cells * a.d.num_sizes * a.d.num_rots : (long long)a.d.cells * a.d.num_rots;
-  const long long m = (long long)blockIdx.x * T + threadIdx.x;
-  if (m < M) {
-    const float* an = a.anchors + anchor_index(a.d, q, m) * 7;
+  const int cell0 = blockIdx.x * a.tile_cells;
+  const int ncell = min(a.tile_cells, a.d.cells - cell0);
+  const int SR = a.d.num_sizes * a.d.num_rots;
+  const float* tile = a.anchors + (size_t)cell0 * SR * 7;
+  const bool one = a.d.num_assigners == 1;
+  for (int i = threadIdx.x; i < a.tile_cells * SR; i += T) {
+    const Item it = item_of(a.d, a.tile_cells, ncell, i);
+    if (!it.live) continue;
+    const float* an = tile + (size_t)it.j * 7;
     const Rect ra = nearest_bev(an[0], an[1], an[3], an[4], an[6]);
     const float aa = rect_area(ra);
-    const unsigned low = 0xffffffffu - (unsigned)m;            // equal overlaps: the lowest anchor index wins (first maximum)
+    // position of the anchor among the anchors its assigner sees (first maximum = lowest position)
+    const long long n = (long long)cell0 * SR + it.j;
+    const long long m = one ? n : ((n / SR) * a.d.num_rots + n % a.d.num_rots);
+    const unsigned low = 0xffffffffu - (unsigned)m;
+    unsigned long long* keys = s_key + (K > 1 ? (size_t)it.q * a.g_cap : 0);
     for (int g = 0; g < G; ++g) {
-      if (a.d.assign_per_class && s.label[g] != q) continue;
+      if (a.d.assign_per_class && s.label[g] != it.q) continue;
       const float v = iou_of(s.r[g], s.area[g], ra, aa);
-      if (v > 0.0f) atomicMax(&s_key[g], ((unsigned long long)__float_as_uint(v) << 32) | low);
+      if (v > 0.0f) atomicMax(&keys[g], ((unsigned long long)__float_as_uint(v) << 32) | low);
     }
   }
   __syncthreads();
   const int g0 = a.d.gt_start[b];
-  for (int g = threadIdx.x; g < G; g += T)
-    if (s_key[g] != 0ull) atomicMax(&a.keys[(size_t)q * a.g_total + g0 + g], s_key[g]);
+  for (int k = threadIdx.x; k < K * G; k += T) {
+    const int row = k / G, g = k - row * G;
+    const unsigned long long v = s_key[(size_t)row * a.g_cap + g];
+    if (v != 0ull) atomicMax(&a.keys[(size_t)row * a.g_total + g0 + g], v);
+  }
 }
 
 __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
-  __shared__ Staged s;
-  __shared__ float s_gmax[MAX_GT];
-  __shared__ unsigned s_garg[MAX_GT];
-  __shared__ int s_count, s_pos[T / 64], s_neg[T / 64];
-  const int b = blockIdx.z, q = blockIdx.y;
-  const int G = stage(a, b, q, s, &s_count);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_pos[T / 64], s_neg[T / 64], s_have[ANCHOR_TARGETS_MAX_SIZES];
+  const Staged s = carve(smem, a.g_cap);
+  const int K = key_rows(a.d);
+  float* s_gmax = (float*)s.rest;                                    // (K, g_cap)
+  unsigned* s_garg = (unsigned*)(s.rest + (size_t)K * a.g_cap * 4);  // (K, g_cap)
+  float* st = (float*)(s.rest + (size_t)K * a.g_cap * 8);            // staged outputs of the tile: (items, 9) words
+  const int b = blockIdx.y;
+  if (threadIdx.x < ANCHOR_TARGETS_MAX_SIZES) s_have[threadIdx.x] = 0;
+  const int G = stage(a, b, s);
   const int g0 = a.d.gt_start[b];
-  for (int g = threadIdx.x; g < G; g += T) {
-    const unsigned long long k = a.keys[(size_t)q * a.g_total + g0 + g];
-    s_gmax[g] = __uint_as_float((unsigned)(k >> 32));                       // 0 when no anchor overlaps the box
-    s_garg[g] = k == 0ull ? 0u : 0xffffffffu - (unsigned)(k & 0xffffffffull);   // argmax of an all-zero row: its first entry
+  for (int k = threadIdx.x; k < K * G; k += T) {
+    const int row = k / G, g = k - row * G;
+    const unsigned long long key = a.keys[(size_t)row * a.g_total + g0 + g];
+    s_gmax[(size_t)row * a.g_cap + g] = __uint_as_float((unsigned)(key >> 32));                    // 0: no anchor overlaps the box
+    s_garg[(size_t)row * a.g_cap + g] = key == 0ull ? 0u : 0xffffffffu - (unsigned)(key & 0xffffffffull);   // argmax of an all-zero row: its first entry
   }
   __syncthreads();
-  const long long M = a.d.num_assigners == 1 ? (long long)a.d.cells * a.d.num_sizes * a.d.num_rots : (long long)a.d.cells * a.d.num_rots;
-  const long long N = (long long)a.d.cells * a.d.num_sizes * a.d.num_rots;
-  const long long m = (long long)blockIdx.x * T + threadIdx.x;
-  int is_pos = 0, is_neg = 0;
-  if (m < M) {
-    const long long n = anchor_index(a.d, q, m);
-    const float* an = a.anchors + n * 7;
+  // does assigner q have a box at all?  (`len(gt_bboxes) > 0` of anchor_target_single_assigner)
+  for (int g = threadIdx.x; g < G; g += T) {
+    if (!a.d.assign_per_class) {
+      s_have[0] = 1;
+    } else if (s.label[g] >= 0 && s.label[g] < a.d.num_sizes) {
+      s_have[s.label[g]] = 1;
+    }
+  }
+  __syncthreads();
+  const int cell0 = blockIdx.x * a.tile_cells;
+  const int ncell = min(a.tile_cells, a.d.cells - cell0);
+  const int SR = a.d.num_sizes * a.d.num_rots;
+  const float* tile = a.anchors + (size_t)cell0 * SR * 7;
+  const bool one = a.d.num_assigners == 1;
+  int n_pos = 0, n_neg = 0;
+  for (int i = threadIdx.x; i < a.tile_cells * SR; i += T) {
+    const Item it = item_of(a.d, a.tile_cells, ncell, i);
+    if (!it.live) continue;
+    const int q = one ? 0 : it.q;                       // the assigner of this anchor
+    const float* an = tile + (size_t)it.j * 7;
     int assigned = 0;                                   // no box for this assigner: every anchor is a negative
-    if (s_count > 0) {
+    if (s_have[a.d.assign_per_class ? q : 0]) {
       const Rect ra = nearest_bev(an[0], an[1], an[3], an[4], an[6]);
       const float aa = rect_area(ra);
       const float pos_thr = a.d.pos_iou_thr[q], neg_thr = a.d.neg_iou_thr[q], min_pos = a.d.min_pos_iou[q];
+      const long long n = (long long)cell0 * SR + it.j;
+      const unsigned m = (unsigned)(one ? n : ((n / SR) * a.d.num_rots + n % a.d.num_rots));
+      const float* gmax = s_gmax + (K > 1 ? (size_t)q * a.g_cap : 0);
+      const unsigned* garg = s_garg + (K > 1 ? (size_t)q * a.g_cap : 0);
       float best = -1.0f;
       int arg = -1, low = -1;
       for (int g = 0; g < G; ++g) {
@@ -170,8 +230,8 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
           best = v;
           arg = g;
         }
-        if (a.d.match_low_quality && s_gmax[g] >= min_pos) {
-          const bool hit = a.d.gt_max_assign_all ? v == s_gmax[g] : (unsigned)m == s_garg[g];
+        if (a.d.match_low_quality && gmax[g] >= min_pos) {
+          const bool hit = a.d.gt_max_assign_all ? v == gmax[g] : m == garg[g];
           if (hit) low = g;                             // the reference's loop runs box after box: the last one stays
         }
       }
@@ -180,10 +240,9 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
       if (best >= pos_thr) assigned = arg + 1;
       if (low >= 0) assigned = low + 1;
     }
-    const size_t o = (size_t)b * N + n;
     float t[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    long long lab = a.d.num_classes, dt = 0;
-    float lw = 0.0f, w = 0.0f;
+    int lab = a.d.num_classes, dt = 0, pos = 0;
+    float lw = 0.0f;
     if (assigned > 0) {
       const int g = assigned - 1;
       const float* gt = a.gt + (size_t)(g0 + g) * 7;
@@ -200,31 +259,49 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
       // get_direction_target(anchor, targets, dir_offset, num_bins)
       const float rot = t[6] + an[6] - a.d.dir_offset;
       const float off = rot - floorf(rot / TWO_PI_F + 0.0f) * TWO_PI_F;
-      long long bin = (long long)floorf(off / (TWO_PI_F / (float)a.d.num_dir_bins));
+      int bin = (int)floorf(off / (TWO_PI_F / (float)a.d.num_dir_bins));
       bin = bin < 0 ? 0 : (bin > a.d.num_dir_bins - 1 ? a.d.num_dir_bins - 1 : bin);
       dt = bin;
       lab = s.label[g];
       lw = a.d.pos_weight <= 0.0f ? 1.0f : a.d.pos_weight;
-      w = 1.0f;
-      is_pos = 1;
+      pos = 1;
+      ++n_pos;
     } else if (assigned == 0) {
       lw = 1.0f;
-      is_neg = 1;
+      ++n_neg;
     }
-    a.labels[o] = lab;
-    a.label_w[o] = lw;
-    a.dir_t[o] = dt;
-    a.dir_w[o] = w;
+    float* o = st + (size_t)it.j * 9;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      a.bbox_t[o * 7 + j] = t[j];
-      a.bbox_w[o * 7 + j] = w;
-    }
+    for (int k = 0; k < 7; ++k) o[k] = t[k];
+    o[7] = lw;
+    ((int*)o)[8] = (lab & 0xffffff) | (dt << 24) | (pos << 31);      // labels < 2^24, direction bins < 128
   }
-  const unsigned long long bp = __ballot(is_pos), bn = __ballot(is_neg);
+  __syncthreads();
+  // the tile's outputs are contiguous ranges of the six arrays: written in whole lines
+  const int items = ncell * SR;
+  const size_t N = (size_t)a.d.cells * SR;
+  const size_t o0 = (size_t)b * N + (size_t)cell0 * SR;
+  for (int j = threadIdx.x; j < items; j += T) {
+    const int packed = ((const int*)st)[(size_t)j * 9 + 8];
+    const float w = packed < 0 ? 1.0f : 0.0f;
+    a.labels[o0 + j] = (long long)(packed & 0xffffff);
+    a.dir_t[o0 + j] = (long long)((packed >> 24) & 0x7f);
+    a.label_w[o0 + j] = st[(size_t)j * 9 + 7];
+    a.dir_w[o0 + j] = w;
+  }
+  for (int k = threadIdx.x; k < items * 7; k += T) {
+    const int j = k / 7, c = k - j * 7;
+    a.bbox_t[o0 * 7 + k] = st[(size_t)j * 9 + c];
+    a.bbox_w[o0 * 7 + k] = ((const int*)st)[(size_t)j * 9 + 8] < 0 ? 1.0f : 0.0f;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    n_pos += __shfl_down(n_pos, off, 64);
+    n_neg += __shfl_down(n_neg, off, 64);
+  }
   if ((threadIdx.x & 63) == 0) {
-    s_pos[threadIdx.x >> 6] = __popcll(bp);
-    s_neg[threadIdx.x >> 6] = __popcll(bn);
+    s_pos[threadIdx.x >> 6] = n_pos;
+    s_neg[threadIdx.x >> 6] = n_neg;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -260,18 +337,30 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   if (d.num_assigners != 1 && d.num_assigners != d.num_sizes) return GD3D_E_BADARG;
   if (d.num_assigners == 1 && d.assign_per_class) return GD3D_E_BADARG;
   if (d.gt_start[0] != 0) return GD3D_E_BADARG;
+  int g_max = 0;
   for (int b = 0; b < d.batch; ++b) {
     const int g = d.gt_start[b + 1] - d.gt_start[b];
     if (g < 0) return GD3D_E_BADARG;
     if (g > MAX_GT) return GD3D_E_TOOLARGE;
+    g_max = g > g_max ? g : g_max;
   }
+  if (d.num_classes >= (1 << 24) || d.num_dir_bins > 127) return GD3D_E_TOOLARGE;
   const int g_total = d.gt_start[d.batch];
   if (g_total > 0 && (gt_boxes == nullptr || gt_labels == nullptr)) return GD3D_E_BADARG;
   const long long N = (long long)d.cells * d.num_sizes * d.num_rots;
   const long long M = d.num_assigners == 1 ? N : (long long)d.cells * d.num_rots;
   if (N * 7 >= 0x7fffffffLL || M >= 0xffffffffLL) return GD3D_E_TOOLARGE;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, anchor_targets_workspace_bytes(d.num_assigners, g_total), s);
+  const int K = (d.num_assigners > 1 && !d.assign_per_class) ? d.num_sizes : 1;
+  // tile: about 768 anchors (3 rounds of the 256 threads), a power of two of cells
+  const int SR = d.num_sizes * d.num_rots;
+  int tile_cells = 1;
+  while (tile_cells * 2 * SR <= 768 && tile_cells < 128) tile_cells *= 2;
+  const int g_cap = (g_max + 3) & ~3;
+  const size_t lds1 = (size_t)g_cap * 24 + (size_t)K * g_cap * 8;
+  const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
+  if (lds2 > 64 * 1024) return GD3D_E_TOOLARGE;
+  hipError_t e = hipMemsetAsync(workspace, 0, anchor_targets_workspace_bytes(K, g_total), s);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * d.batch, s);
   if (e != hipSuccess) return (int)e;
@@ -289,9 +378,11 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   a.dir_w = dir_weights;
   a.counts = counts;
   a.g_total = g_total > 0 ? g_total : 1;
-  const dim3 grid((unsigned)((M + T - 1) / T), (unsigned)d.num_assigners, (unsigned)d.batch);
-  if (g_total > 0) hipLaunchKernelGGL(iou_max_kernel, grid, dim3(T), 0, s, a);
-  hipLaunchKernelGGL(assign_kernel, grid, dim3(T), 0, s, a);
+  a.g_cap = g_cap;
+  a.tile_cells = tile_cells;
+  const dim3 grid((unsigned)((d.cells + tile_cells - 1) / tile_cells), (unsigned)d.batch);
+  if (g_total > 0) hipLaunchKernelGGL(iou_max_kernel, grid, dim3(T), lds1, s, a);
+  hipLaunchKernelGGL(assign_kernel, grid, dim3(T), lds2, s, a);
   return (int)hipGetLastError();
 }
 
