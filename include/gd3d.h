@@ -434,6 +434,15 @@ int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, c
                         int64_t n, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
                         void* workspace, void* stream);
 
+/* rnms_batched_scored over several box sets in one set of launches (ABI 4): `sets` x groups_per_set groups, group g working on the
+ * n boxes of set g / groups_per_set = rows [set n, (set + 1) n) of boxes (sets n, 5) — the per-sample class problems of a whole
+ * batch (box3d_multiclass_nms of every sample at once).  scores / valid (sets groups_per_set, n), thresh (sets groups_per_set) on the
+ * device; keep holds indices into the flat box array (set n + i).  workspace: rnms_batched_scored_workspace_bytes(sets
+ * groups_per_set, n, cap).  Each group's result equals rnms_batched_scored on its own set. */
+int rnms_batched_scored_sets(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t sets,
+                             int32_t groups_per_set, int64_t n, int64_t pre_max, const float* thresh, int64_t* keep,
+                             int64_t* num_keep, void* workspace, void* stream);
+
 /* The same for G problems that each own a CONTIGUOUS run of one flat box / score array (the per-sample x per-task NMS
  * calls of CenterHeadRev.get_bboxes, gd_centerpoint_head.py:233-345, concatenated): group g = boxes [seg[g], seg[g+1]).
  * Every group ranks only its own slice — O(sum n_g^2) key compares and O(G * n_max^2 / 256) workspace, where the dense

@@ -155,6 +155,7 @@ SYMBOLS = {
     'rnms_batched_prepared': (_int, [_vp, _vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_batched_scored_workspace_bytes': (_sz, [ctypes.c_int32, _i64, _i64]),
     'rnms_batched_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'rnms_batched_scored_sets': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_segmented_scored': (_int, [ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'rnms_circle_ordered': (_int, [_vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _vp]),
     'riou_bev_xyxyr': (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),

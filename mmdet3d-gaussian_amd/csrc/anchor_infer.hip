@@ -12,7 +12,7 @@
 //   anchor_gather_kernel  per selected anchor: its C class scores (sigmoid), direction bin, the 7 deltas and its anchor ->
 //                         DeltaXYZWLHR decode in the reference's fp32 operation order, the BEV box for the NMS, and the
 //                         per-class score rows / validity bytes (score > score_thr, strictly) the batched NMS reads;
-//   rnms_batched_scored   (rbox.hip) the C class problems of a sample in one set of launches, no host sync;
+//   rnms_batched_scored_sets (rbox.hip) the C class problems of EVERY sample in one set of launches, no host sync;
 //   anchor_collect_kernel per sample: the classes' kept lists in turn; beyond max_num detections the max_num best by score
 //                         (rank by binary search over the classes' score-ordered lists in LDS: stable, equal scores keep the
 //                         concatenation order); direction-bin correction of the yaw (limit_period); counts.
@@ -63,13 +63,13 @@ struct GatherArgs {
   float* scoresT;         // (B, C, Ktot)
   unsigned char* valid;   // (B, C, Ktot)
   int* dirs;              // (B, Ktot)
-  float* thresh;          // (C)
+  float* thresh;          // (B, C)
 };
 
 __global__ __launch_bounds__(T) void anchor_gather_kernel(const GatherArgs a) {
   const int b = blockIdx.y;
   const int k = blockIdx.x * T + threadIdx.x;
-  if (b == 0 && k < a.C) a.thresh[k] = a.nms_thr;
+  if (k < a.C) a.thresh[(size_t)b * a.C + k] = a.nms_thr;
   if (k >= a.K) return;
   const long long n = a.sel_xy != nullptr ? a.sel_xy[((size_t)b * a.K + k) * 2] : (long long)k;
   const int cell = (int)(n / a.A), an = (int)(n - (long long)cell * a.A);
@@ -113,7 +113,7 @@ struct CollectArgs {
   const float* boxes7;       // (B, Ktot, 7)
   const float* scoresT;      // (B, C, Ktot)
   const int* dirs;           // (B, Ktot)
-  const long long* keep;     // (B, C, Ktot) candidate indices in class-score order
+  const long long* keep;     // (B, C, Ktot) candidate indices in class-score order, into the batch's flat arrays (b Ktot + i)
   const long long* num;      // (B, C)
   int C, Ktot, max_num;
   float dir_offset, dir_limit_offset;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(T) void anchor_collect_kernel(const CollectArgs a) 
   for (int c = 0; c < a.C; ++c) {
     const int m = s_n[c] < a.max_num ? s_n[c] : a.max_num;
     for (int r = tid; r < m; r += T)
-      ssc[c * a.max_num + r] = a.scoresT[((size_t)b * a.C + c) * a.Ktot + a.keep[((size_t)b * a.C + c) * a.Ktot + r]];
+      ssc[c * a.max_num + r] = a.scoresT[((size_t)b * a.C + c) * a.Ktot + (a.keep[((size_t)b * a.C + c) * a.Ktot + r] - (long long)b * a.Ktot)];
   }
   __syncthreads();
   for (int c = 0; c < a.C; ++c) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(T) void anchor_collect_kernel(const CollectArgs a) 
         pos = rank;
         if (pos >= a.max_num) continue;
       }
-      const long long cand = a.keep[((size_t)b * a.C + c) * a.Ktot + r];
+      const long long cand = a.keep[((size_t)b * a.C + c) * a.Ktot + r] - (long long)b * a.Ktot;
       const float* src = a.boxes7 + ((size_t)b * a.Ktot + (size_t)cand) * 7;
       float* dst = a.out_boxes + ((size_t)b * a.max_num + pos) * 7;
 #pragma unroll
@@ -254,10 +254,10 @@ static int layout(const anchor_infer_desc* d, Layout& L) {
   L.scoresT = o; o += up256(sizeof(float) * (size_t)(B * C * L.Ktot));
   L.valid = o; o += up256((size_t)(B * C * L.Ktot));
   L.dirs = o; o += up256(sizeof(int) * (size_t)(B * L.Ktot));
-  L.thresh = o; o += up256(sizeof(float) * (size_t)C);
+  L.thresh = o; o += up256(sizeof(float) * (size_t)(B * C));
   L.keep = o; o += up256(sizeof(long long) * (size_t)(B * C * L.Ktot));
   L.num = o; o += up256(sizeof(long long) * (size_t)(B * C));
-  L.nms = o; o += up256(rnms_batched_scored_workspace_bytes((int32_t)C, L.Ktot, L.Ktot));
+  L.nms = o; o += up256(rnms_batched_scored_workspace_bytes((int32_t)(B * C), L.Ktot, L.Ktot));
   L.total = o;
   return 0;
 }
@@ -339,13 +339,10 @@ int anchor_infer_bboxes(const anchor_infer_desc* d, void* workspace, float* out_
     hipLaunchKernelGGL(anchor_gather_kernel, dim3((unsigned)gx, (unsigned)B), dim3(T), 0, s, g);
     koff += (int)L.K[l];
   }
-  for (int b = 0; b < B; ++b) {
-    rc = rnms_batched_scored(d->use_rotate_nms ? 0 : 1, (const float*)(w + L.bev5) + (size_t)b * L.Ktot * 5,
-                             (const float*)(w + L.scoresT) + (size_t)b * C * L.Ktot, (const uint8_t*)(w + L.valid) + (size_t)b * C * L.Ktot, C, L.Ktot,
-                             -1, (const float*)(w + L.thresh), (int64_t*)(w + L.keep) + (size_t)b * C * L.Ktot,
-                             (int64_t*)(w + L.num) + (size_t)b * C, w + L.nms, stream);
-    if (rc != 0) return rc;
-  }
+  // the C class problems of every sample in one set of launches: sample b's groups work on its own Ktot boxes
+  rc = rnms_batched_scored_sets(d->use_rotate_nms ? 0 : 1, (const float*)(w + L.bev5), (const float*)(w + L.scoresT), (const uint8_t*)(w + L.valid),
+                                B, C, L.Ktot, -1, (const float*)(w + L.thresh), (int64_t*)(w + L.keep), (int64_t*)(w + L.num), w + L.nms, stream);
+  if (rc != 0) return rc;
   CollectArgs c;
   c.boxes7 = (const float*)(w + L.boxes7);
   c.scoresT = (const float*)(w + L.scoresT);

@@ -128,10 +128,11 @@ template <bool PREP>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ valid_,
                                                           const int* __restrict__ seg, const int* __restrict__ prank_, int n,
                                                           int slices, int n_keep, long long* __restrict__ order_,
-                                                          OBox* __restrict__ ob_, int* __restrict__ counts) {
+                                                          OBox* __restrict__ ob_, int* __restrict__ counts, int gps) {
   const int g = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int base = seg != nullptr ? seg[g] : 0;
+  // gps > 0: every gps consecutive groups share one set of n boxes, set k at rows [k n, (k + 1) n) of the flat box array
+  const int base = seg != nullptr ? seg[g] : (gps > 0 ? (g / gps) * n : 0);
   const int ng = seg != nullptr ? seg[g + 1] - base : n;
   const int* prank = prank_ + (size_t)g * slices * n;
   bool placed = false;
@@ -942,10 +943,10 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   const dim3 sg((unsigned)((n_all + 255) / 256));
   if (normal)
     hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0);
   else
     hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr);
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
@@ -962,7 +963,7 @@ size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t ca
 
 static int batched_scored_impl(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, const int32_t* seg,
                                int32_t groups, int64_t n, int64_t pre_max, const float* thresh, int64_t* keep,
-                               int64_t* num_keep, void* workspace, void* stream) {
+                               int64_t* num_keep, void* workspace, void* stream, int gps = 0) {
   if (mode < MODE_ROT || mode > MODE_CIRCLE || groups < 0 || n < 0) return GD3D_E_BADARG;
   if (groups == 0) return 0;
   if (num_keep == nullptr) return GD3D_E_BADARG;
@@ -985,10 +986,10 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   const dim3 sg((unsigned)((n + 255) / 256), (unsigned)groups);
   if (mode == MODE_ROT)
     hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts);
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps);
   else
     hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts);
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
@@ -998,6 +999,14 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
 int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,
                         int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
   return batched_scored_impl(mode, boxes, scores, valid, nullptr, groups, n, pre_max, thresh, keep, num_keep, workspace, stream);
+}
+
+int rnms_batched_scored_sets(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t sets,
+                             int32_t groups_per_set, int64_t n, int64_t pre_max, const float* thresh, int64_t* keep, int64_t* num_keep,
+                             void* workspace, void* stream) {
+  if (sets < 0 || groups_per_set < 1 || (int64_t)sets * groups_per_set > 65535 || (int64_t)sets * n > 0x7fffffffLL) return GD3D_E_BADARG;
+  return batched_scored_impl(mode, boxes, scores, valid, nullptr, sets * groups_per_set, n, pre_max, thresh, keep, num_keep, workspace,
+                             stream, groups_per_set);
 }
 
 int rnms_segmented_scored(int32_t mode, const float* boxes, const float* scores, const int32_t* seg, int32_t groups,

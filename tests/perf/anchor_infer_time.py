@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Anchor-head inference slice at the reference's PointPillars geometries, us per call (host + device, synchronised):
-  KITTI  (configs/_base_/models/hv_pointpillars_secfpn_kitti.py): 248 x 216 x 6 anchors, 3 classes, nms_pre 100, thr 0.01, max 50
-  Waymo  (BASELINE configs[4], hv_pointpillars_secfpn_waymo.py):  468 x 468 x 6 anchors, 3 classes, nms_pre 4096, thr 0.25, max 500
+  KITTI  (configs/_base_/models/hv_pointpillars_secfpn_kitti.py:89-96): 248 x 216 x 6 anchors, 3 classes, nms_pre 4096, nms_thr 0.01,
+         score_thr 0.05, max_num 100, the head's default direction offsets (0, 1)
+  Waymo  (BASELINE configs[4], hv_pointpillars_secfpn_waymo.py:59-60, :101-109): 468 x 468 x 6 anchors, 3 classes, nms_pre 4096,
+         nms_thr 0.25, score_thr 0.1, max_num 500, dir_offset 0.7854, dir_limit_offset 0
 ours  = anchor_head_get_bboxes (score kernel, selection, gather + decode, batched class NMS, collect; one read-back)
 eager = mmdet3d's op sequence (oracle/anchor_infer_torch.py's statement) on device tensors with THIS package's nms_gpu per class
 Asserts equal numbers of detections and equal boxes."""
@@ -63,8 +65,8 @@ def eager_single(cls, bbox, dirs, anchors, cfg, C, dir_offset, dir_limit_offset)
 def main():
     g = torch.Generator().manual_seed(5)
     for name, (B, H, W), cfg, doff, dlim in (
-            ('KITTI 248x216x6, nms_pre 100', (4, 248, 216), dict(use_rotate_nms=True, nms_pre=100, nms_thr=0.01, score_thr=0.1, max_num=50), 0.7854, 0.0),
-            ('Waymo 468x468x6, nms_pre 4096', (1, 468, 468), dict(use_rotate_nms=True, nms_pre=4096, nms_thr=0.25, score_thr=0.1, max_num=500), 0.0, 1.0)):
+            ('KITTI 248x216x6, nms_pre 4096, max_num 100', (4, 248, 216), dict(use_rotate_nms=True, nms_pre=4096, nms_thr=0.01, score_thr=0.05, max_num=100), 0.0, 1.0),
+            ('Waymo 468x468x6, nms_pre 4096, max_num 500', (1, 468, 468), dict(use_rotate_nms=True, nms_pre=4096, nms_thr=0.25, score_thr=0.1, max_num=500), 0.7854, 0.0)):
         cls, bbox, dirs, anchors = [t.to(dev) for t in head_outputs(g, B, 6, 3, H, W, scene=150.0)]
         ours = amd.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim)
         ref = [eager_single(cls[b], bbox[b], dirs[b], anchors, cfg, 3, doff, dlim) for b in range(B)]

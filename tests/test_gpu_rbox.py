@@ -680,3 +680,40 @@ def test_nms_keep_list_survives_an_ulp_of_yaw_on_the_gpu(amd, n, seed, extent, t
         got = amd.nms_gpu(torch.from_numpy(b).cuda(), s, thr, pre_max_size=n)
         assert np.array_equal(got.cpu().numpy(), oracle.nms_gpu_oracle(b, scores, thr, pre_max_size=n))
         assert torch.equal(got, base)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_scored_nms_over_box_sets_equals_the_per_set_calls(amd, mode):
+    """rnms_batched_scored_sets (the class problems of every sample of a batch in one set of launches: group g works on box set
+    g // groups_per_set) against nms_gpu_batched on each set alone: same kept indices (offset by set * n), same counts."""
+    import ctypes
+    from mmdet3d_gaussian_amd import _lib
+    lib = _lib.load()
+    sets, gps, n = 3, 4, 700
+    dev = torch.device('cuda:0')
+    bx, sc = [], []
+    rng = np.random.default_rng(4)
+    for k in range(sets):
+        b, _ = nms_boxes(n, seed=20 + k)
+        bx.append(torch.from_numpy(b))
+        sc.append(torch.from_numpy(rng.random((gps, n)).astype(np.float32)))
+    boxes = torch.stack(bx).to(dev).contiguous()                 # (sets, n, 5)
+    scores = torch.stack(sc).to(dev).contiguous()                # (sets, gps, n)
+    valid = (scores > 0.3).contiguous()
+    valid[1, 2] = False                                          # an empty group
+    th = torch.tensor([0.1, 0.25, 0.5, 0.7] * sets, dtype=torch.float32, device=dev)
+    keep = torch.full((sets * gps, n), -1, dtype=torch.int64, device=dev)
+    num = torch.empty(sets * gps, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.rnms_batched_scored_workspace_bytes(sets * gps, n, n), dtype=torch.uint8, device=dev)
+    rc = lib.rnms_batched_scored_sets(mode, boxes.data_ptr(), scores.data_ptr(), valid.data_ptr(), sets, gps, n, -1, th.data_ptr(), keep.data_ptr(),
+                                      num.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for k in range(sets):
+        ref = amd.nms_gpu_batched(boxes[k], scores[k], [0.1, 0.25, 0.5, 0.7], valid[k], normal=bool(mode))
+        for g in range(gps):
+            m = int(num[k * gps + g])
+            assert m == ref[g].shape[0]
+            assert torch.equal(keep[k * gps + g, :m], ref[g] + k * n)
+    assert int(num[1 * gps + 2]) == 0 and int(num.sum()) > 100
+    assert lib.rnms_batched_scored_sets(mode, boxes.data_ptr(), scores.data_ptr(), valid.data_ptr(), sets, 0, n, -1, th.data_ptr(), keep.data_ptr(),
+                                        num.data_ptr(), ws.data_ptr(), None) == 10001
