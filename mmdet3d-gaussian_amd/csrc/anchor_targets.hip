@@ -11,6 +11,8 @@
 //                            assigner at a time); the sample's boxes sit in LDS as nearest-BEV rectangles;
 //                            per box the best overlap over the assigner's anchors as one 64-bit key (IoU bits, then lowest anchor
 //                            index) — LDS atomicMax per workgroup, one global atomicMax per (workgroup, box) that any anchor touches.
+//   both passes first cull the boxes against the bounding rectangle of the tile's anchors: a tile usually meets none or a few, so
+//   the inner loops are short and both passes stream (pass 2 is bound by writing the six target arrays).
 //   pass 2  assign_kernel  : recomputes the thread's overlaps (same instructions, same bits), applies the assigner's rules in the
 //                            reference's order (negative below neg_iou_thr, positive from pos_iou_thr on, then box after box its
 //                            best anchors when that best reaches min_pos_iou — later boxes overwrite earlier ones), stages the
@@ -132,20 +134,78 @@ __device__ __forceinline__ Item item_of(const anchor_targets_desc& d, int tile_c
   return it;
 }
 
+
+// Boxes that can overlap an anchor of the tile: those whose rectangle meets the bounding rectangle of the tile's anchor rectangles
+// (overlap > 0 needs min(g.x2, a.x2) > max(g.x1, a.x1), hence g.x2 > min_a a.x1 and g.x1 < max_a a.x2; likewise in y — whatever the
+// signs of the sizes).  Every other box has overlap exactly 0 with every anchor of the tile.  s_act receives their indices in
+// ascending order (the order the assigner's rules depend on); returns their number.  Ends with a barrier.
+__device__ __forceinline__ int active_boxes(const Args& a, const Staged& s, int G, const float* tile, int ncell, int* s_act, float* s_red,
+                                            int* s_nact) {
+  const int SR = a.d.num_sizes * a.d.num_rots;
+  float bx1 = INFINITY, by1 = INFINITY, bx2 = -INFINITY, by2 = -INFINITY;
+  for (int j = threadIdx.x; j < ncell * SR; j += T) {
+    const float* an = tile + (size_t)j * 7;
+    const Rect r = nearest_bev(an[0], an[1], an[3], an[4], an[6]);
+    bx1 = fminf(bx1, r.x1);
+    by1 = fminf(by1, r.y1);
+    bx2 = fmaxf(bx2, r.x2);
+    by2 = fmaxf(by2, r.y2);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    bx1 = fminf(bx1, __shfl_xor(bx1, off, 64));
+    by1 = fminf(by1, __shfl_xor(by1, off, 64));
+    bx2 = fmaxf(bx2, __shfl_xor(bx2, off, 64));
+    by2 = fmaxf(by2, __shfl_xor(by2, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    float* o = s_red + (threadIdx.x >> 6) * 4;
+    o[0] = bx1; o[1] = by1; o[2] = bx2; o[3] = by2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    bx1 = fminf(fminf(s_red[0], s_red[4]), fminf(s_red[8], s_red[12]));
+    by1 = fminf(fminf(s_red[1], s_red[5]), fminf(s_red[9], s_red[13]));
+    bx2 = fmaxf(fmaxf(s_red[2], s_red[6]), fmaxf(s_red[10], s_red[14]));
+    by2 = fmaxf(fmaxf(s_red[3], s_red[7]), fmaxf(s_red[11], s_red[15]));
+    const int lane = threadIdx.x;
+    int n = 0;
+    for (int base = 0; base < G; base += 64) {
+      const int g = base + lane;
+      bool act = false;
+      if (g < G) {
+        const Rect r = s.r[g];
+        act = r.x2 >= bx1 && r.x1 <= bx2 && r.y2 >= by1 && r.y1 <= by2;
+      }
+      const unsigned long long m = __ballot(act);
+      if (act) s_act[n + __popcll(m & ((1ull << lane) - 1ull))] = g;
+      n += __popcll(m);
+    }
+    if (lane == 0) *s_nact = n;
+  }
+  __syncthreads();
+  return *s_nact;
+}
+
 __global__ __launch_bounds__(T) void iou_max_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float s_red[16];
+  __shared__ int s_nact;
   const Staged s = carve(smem, a.g_cap);
+  const int K = key_rows(a.d);
   unsigned long long* s_key = (unsigned long long*)s.rest;          // (K, g_cap)
+  int* s_act = (int*)(s.rest + (size_t)K * a.g_cap * 8);            // (g_cap)
   const int b = blockIdx.y;
   const int G = stage(a, b, s);
   if (G == 0) return;
-  const int K = key_rows(a.d);
   for (int k = threadIdx.x; k < K * a.g_cap; k += T) s_key[k] = 0ull;
   __syncthreads();
   const int cell0 = blockIdx.x * a.tile_cells;
   const int ncell = min(a.tile_cells, a.d.cells - cell0);
   const int SR = a.d.num_sizes * a.d.num_rots;
   const float* tile = a.anchors + (size_t)cell0 * SR * 7;
+  const int nact = active_boxes(a, s, G, tile, ncell, s_act, s_red, &s_nact);
+  if (nact == 0) return;                                            // nothing here overlaps anything: no key changes
   const bool one = a.d.num_assigners == 1;
   for (int i = threadIdx.x; i < a.tile_cells * SR; i += T) {
     const Item it = item_of(a.d, a.tile_cells, ncell, i);
@@ -158,7 +218,8 @@ __global__ __launch_bounds__(T) void iou_max_kernel(const Args a) {
     const long long m = one ? n : ((n / SR) * a.d.num_rots + n % a.d.num_rots);
     const unsigned low = 0xffffffffu - (unsigned)m;
     unsigned long long* keys = s_key + (K > 1 ? (size_t)it.q * a.g_cap : 0);
-    for (int g = 0; g < G; ++g) {
+    for (int k = 0; k < nact; ++k) {
+      const int g = s_act[k];
       if (a.d.assign_per_class && s.label[g] != it.q) continue;
       const float v = iou_of(s.r[g], s.area[g], ra, aa);
       if (v > 0.0f) atomicMax(&keys[g], ((unsigned long long)__float_as_uint(v) << 32) | low);
@@ -166,8 +227,8 @@ __global__ __launch_bounds__(T) void iou_max_kernel(const Args a) {
   }
   __syncthreads();
   const int g0 = a.d.gt_start[b];
-  for (int k = threadIdx.x; k < K * G; k += T) {
-    const int row = k / G, g = k - row * G;
+  for (int k = threadIdx.x; k < K * nact; k += T) {
+    const int row = k / nact, g = s_act[k - row * nact];
     const unsigned long long v = s_key[(size_t)row * a.g_cap + g];
     if (v != 0ull) atomicMax(&a.keys[(size_t)row * a.g_total + g0 + g], v);
   }
@@ -175,14 +236,19 @@ __global__ __launch_bounds__(T) void iou_max_kernel(const Args a) {
 
 __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_pos[T / 64], s_neg[T / 64], s_have[ANCHOR_TARGETS_MAX_SIZES];
+  __shared__ int s_pos[T / 64], s_neg[T / 64], s_first[ANCHOR_TARGETS_MAX_SIZES], s_zero[ANCHOR_TARGETS_MAX_SIZES], s_nact;
+  __shared__ float s_red[16];
   const Staged s = carve(smem, a.g_cap);
   const int K = key_rows(a.d);
   float* s_gmax = (float*)s.rest;                                    // (K, g_cap)
   unsigned* s_garg = (unsigned*)(s.rest + (size_t)K * a.g_cap * 4);  // (K, g_cap)
-  float* st = (float*)(s.rest + (size_t)K * a.g_cap * 8);            // staged outputs of the tile: (items, 9) words
+  int* s_act = (int*)(s.rest + (size_t)K * a.g_cap * 8);             // (g_cap)
+  float* st = (float*)(s.rest + (size_t)K * a.g_cap * 8 + (size_t)a.g_cap * 4);   // staged outputs of the tile: (items, 9) words
   const int b = blockIdx.y;
-  if (threadIdx.x < ANCHOR_TARGETS_MAX_SIZES) s_have[threadIdx.x] = 0;
+  if (threadIdx.x < ANCHOR_TARGETS_MAX_SIZES) {
+    s_first[threadIdx.x] = 0x7fffffff;
+    s_zero[threadIdx.x] = -1;
+  }
   const int G = stage(a, b, s);
   const int g0 = a.d.gt_start[b];
   for (int k = threadIdx.x; k < K * G; k += T) {
@@ -192,12 +258,17 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
     s_garg[(size_t)row * a.g_cap + g] = key == 0ull ? 0u : 0xffffffffu - (unsigned)(key & 0xffffffffull);   // argmax of an all-zero row: its first entry
   }
   __syncthreads();
-  // does assigner q have a box at all?  (`len(gt_bboxes) > 0` of anchor_target_single_assigner)
+  // per assigner q: its first box (`len(gt_bboxes) > 0` of anchor_target_single_assigner, and the argmax of an anchor that overlaps
+  // nothing) and its last box that NO anchor overlaps while 0 >= min_pos_iou — such a box "best-matches" every anchor at overlap 0
+  const int Q = a.d.num_assigners;
   for (int g = threadIdx.x; g < G; g += T) {
-    if (!a.d.assign_per_class) {
-      s_have[0] = 1;
-    } else if (s.label[g] >= 0 && s.label[g] < a.d.num_sizes) {
-      s_have[s.label[g]] = 1;
+    const int lab = s.label[g];
+    const int q_lo = a.d.assign_per_class ? lab : 0, q_hi = a.d.assign_per_class ? lab + 1 : Q;
+    if (a.d.assign_per_class && (lab < 0 || lab >= Q)) continue;
+    for (int q = q_lo; q < q_hi; ++q) {
+      atomicMin(&s_first[q], g);
+      const float gm = s_gmax[(K > 1 ? (size_t)q * a.g_cap : 0) + g];
+      if (a.d.match_low_quality && gm == 0.0f && gm >= a.d.min_pos_iou[q]) atomicMax(&s_zero[q], g);
     }
   }
   __syncthreads();
@@ -205,6 +276,7 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
   const int ncell = min(a.tile_cells, a.d.cells - cell0);
   const int SR = a.d.num_sizes * a.d.num_rots;
   const float* tile = a.anchors + (size_t)cell0 * SR * 7;
+  const int nact = G > 0 ? active_boxes(a, s, G, tile, ncell, s_act, s_red, &s_nact) : 0;
   const bool one = a.d.num_assigners == 1;
   int n_pos = 0, n_neg = 0;
   for (int i = threadIdx.x; i < a.tile_cells * SR; i += T) {
@@ -213,7 +285,7 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
     const int q = one ? 0 : it.q;                       // the assigner of this anchor
     const float* an = tile + (size_t)it.j * 7;
     int assigned = 0;                                   // no box for this assigner: every anchor is a negative
-    if (s_have[a.d.assign_per_class ? q : 0]) {
+    if (s_first[q] != 0x7fffffff) {
       const Rect ra = nearest_bev(an[0], an[1], an[3], an[4], an[6]);
       const float aa = rect_area(ra);
       const float pos_thr = a.d.pos_iou_thr[q], neg_thr = a.d.neg_iou_thr[q], min_pos = a.d.min_pos_iou[q];
@@ -221,9 +293,12 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
       const unsigned m = (unsigned)(one ? n : ((n / SR) * a.d.num_rots + n % a.d.num_rots));
       const float* gmax = s_gmax + (K > 1 ? (size_t)q * a.g_cap : 0);
       const unsigned* garg = s_garg + (K > 1 ? (size_t)q * a.g_cap : 0);
-      float best = -1.0f;
-      int arg = -1, low = -1;
-      for (int g = 0; g < G; ++g) {
+      // the boxes outside the active list overlap this anchor by exactly 0: the best overlap starts at 0 with the assigner's first
+      // box as its argmax (first maximum), and only a strictly larger overlap moves it
+      float best = 0.0f;
+      int arg = s_first[q], low = -1;
+      for (int k = 0; k < nact; ++k) {
+        const int g = s_act[k];
         if (a.d.assign_per_class && s.label[g] != q) continue;
         const float v = iou_of(s.r[g], s.area[g], ra, aa);
         if (v > best) {
@@ -235,6 +310,10 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
           if (hit) low = g;                             // the reference's loop runs box after box: the last one stays
         }
       }
+      // a box no anchor overlaps (best overlap 0 >= min_pos_iou) matches every anchor at overlap 0 (gt_max_assign_all), or the
+      // first anchor (its argmax); the last such box competes with the last hit above
+      const int z = s_zero[q];
+      if (z > low && (a.d.gt_max_assign_all || m == 0u)) low = z;
       assigned = -1;
       if (best >= 0.0f && best < neg_thr) assigned = 0;
       if (best >= pos_thr) assigned = arg + 1;
@@ -357,7 +436,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   int tile_cells = 1;
   while (tile_cells * 2 * SR <= 768 && tile_cells < 128) tile_cells *= 2;
   const int g_cap = (g_max + 3) & ~3;
-  const size_t lds1 = (size_t)g_cap * 24 + (size_t)K * g_cap * 8;
+  const size_t lds1 = (size_t)g_cap * 28 + (size_t)K * g_cap * 8;
   const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
   if (lds2 > 64 * 1024) return GD3D_E_TOOLARGE;
   hipError_t e = hipMemsetAsync(workspace, 0, anchor_targets_workspace_bytes(K, g_total), s);
