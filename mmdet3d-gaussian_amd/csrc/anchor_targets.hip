@@ -109,7 +109,7 @@ __device__ __forceinline__ int stage(const Args& a, int b, const Staged& s) {
     s.r[g] = q4;
     s.area[g] = rect_area(q4);
     const long long lab = a.gt_labels[g0 + g];
-    s.label[g] = (lab >= 0 && lab < 0x7fffffffLL) ? (int)lab : -1;
+    s.label[g] = (lab >= 0 && lab < (1 << 24) - 1) ? (int)lab : -1;
   }
   return G;
 }
@@ -353,7 +353,8 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) o[k] = t[k];
     o[7] = lw;
-    ((int*)o)[8] = (lab & 0xffffff) | (dt << 24) | (pos << 31);      // labels < 2^24, direction bins < 128
+    ((int*)o)[8] = ((lab + 1) & 0xffffff) | (dt << 24) | (pos << 31);   // labels in [-1, 2^24 - 2] (a box labelled -1 hands its label on when
+                                                                        // the assigner is not per class), direction bins < 128
   }
   __syncthreads();
   // the tile's outputs are contiguous ranges of the six arrays: written in whole lines
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
   for (int j = threadIdx.x; j < items; j += T) {
     const int packed = ((const int*)st)[(size_t)j * 9 + 8];
     const float w = packed < 0 ? 1.0f : 0.0f;
-    a.labels[o0 + j] = (long long)(packed & 0xffffff);
+    a.labels[o0 + j] = (long long)(packed & 0xffffff) - 1;
     a.dir_t[o0 + j] = (long long)((packed >> 24) & 0x7f);
     a.label_w[o0 + j] = st[(size_t)j * 9 + 7];
     a.dir_w[o0 + j] = w;
@@ -414,7 +415,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
       d.num_rots < 1 || d.num_classes < 1 || d.num_dir_bins < 1)
     return GD3D_E_BADARG;
   if (d.num_assigners != 1 && d.num_assigners != d.num_sizes) return GD3D_E_BADARG;
-  if (d.num_assigners == 1 && d.assign_per_class) return GD3D_E_BADARG;
+  if (d.num_assigners == 1 && d.assign_per_class && d.num_sizes != 1) return GD3D_E_BADARG;   // one assigner per class needs one per size
   if (d.gt_start[0] != 0) return GD3D_E_BADARG;
   int g_max = 0;
   for (int b = 0; b < d.batch; ++b) {
@@ -423,7 +424,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
     if (g > MAX_GT) return GD3D_E_TOOLARGE;
     g_max = g > g_max ? g : g_max;
   }
-  if (d.num_classes >= (1 << 24) || d.num_dir_bins > 127) return GD3D_E_TOOLARGE;
+  if (d.num_classes >= (1 << 24) - 1 || d.num_dir_bins > 127) return GD3D_E_TOOLARGE;
   const int g_total = d.gt_start[d.batch];
   if (g_total > 0 && (gt_boxes == nullptr || gt_labels == nullptr)) return GD3D_E_BADARG;
   const long long N = (long long)d.cells * d.num_sizes * d.num_rots;

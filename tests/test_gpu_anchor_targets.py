@@ -1,7 +1,9 @@
 """GPU parity of the anchor heads' target assignment (csrc/anchor_targets.hip) against the CPU torch restatement
 oracle/anchor_targets_torch.py of mmdet3d's anchor_target_3d chain (called at gd_anchor3d_head.py:206-214).
-Integer / decision outputs (labels, weights, direction bins, counts, which anchors carry targets) bit for bit; the encoded regression
-targets to 2e-6 (device logf vs the CPU's: ulps), their exactly computed columns (x, y, z, yaw deltas) bit for bit."""
+Integer / decision outputs (labels, weights, direction bins, counts, which anchors carry targets) bit for bit; of the encoded regression
+targets the z and yaw columns (+, -, / only) bit for bit, the others to 2e-6: the three size columns go through log (device logf vs the
+CPU's: ulps) and x, y through the anchor's diagonal sqrt(l^2 + w^2), where torch's CPU sqrt is NOT correctly rounded (measured: 0.7 % of
+random inputs differ from the IEEE result in the build container, 18 % on the GPU box's host) while the device's is."""
 import importlib
 import math
 
@@ -49,8 +51,8 @@ def check(ref, got, min_pos=1):
     for k in (0, 1, 3, 4, 5):
         assert torch.equal(got[k].cpu(), ref[k]), names[k]
     bt, rt = got[2].cpu(), ref[2]
-    assert torch.equal(bt[..., [0, 1, 2, 6]], rt[..., [0, 1, 2, 6]])               # +, -, /, sqrt only: the same bits
-    assert torch.allclose(bt[..., 3:6], rt[..., 3:6], rtol=2e-6, atol=2e-7)
+    assert torch.equal(bt[..., [2, 6]], rt[..., [2, 6]])                            # +, -, / only: the same bits
+    assert torch.allclose(bt[..., [0, 1, 3, 4, 5]], rt[..., [0, 1, 3, 4, 5]], rtol=2e-6, atol=2e-7)
     assert got[6] == ref[6] and got[7] == ref[7]
     assert int((ref[0] < 3).sum()) >= min_pos
 
@@ -239,3 +241,51 @@ def test_head_loss_static_form_replays_as_a_hipgraph():
     for gr, t in zip(grads[:3], o2):
         assert torch.equal(gr, t.grad)
     assert eager[1].item() > 0
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_configurations(seed):
+    """random grids (1-4 sizes, 1-3 rotations), thresholds (min_pos_iou 0 now and then), assigner modes, box counts up to 150 per sample,
+    boxes partly outside the grid, partly copied from anchors: every decision equal to the restatement"""
+    rng = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))          # noqa: E731
+    rf = lambda lo, hi: float(torch.rand(1, generator=rng)) * (hi - lo) + lo          # noqa: E731
+    S, R = ri(1, 4), ri(1, 3)
+    H, W = ri(5, 60), ri(5, 70)
+    sizes = [[rf(0.5, 4.5), rf(0.5, 2.0), rf(1.0, 2.0)] for _ in range(S)]
+    ranges = [[0.0, -20.0, -1.0, 0.4 * W, 0.4 * H - 20.0, -1.0]] * S
+    rots = [0.0, 1.57, 0.78][:R]
+    anchors = ORA.range_anchors((H, W), ranges, sizes, rots)[0]
+    mode = seed % 3                                                              # 0: per class, 1: list, all boxes, 2: one assigner
+    def one_cfg():
+        pos = rf(0.3, 0.7)
+        neg = rf(0.1, pos)
+        return dict(type='MaxIoUAssigner', pos_iou_thr=pos, neg_iou_thr=neg, min_pos_iou=0.0 if ri(0, 3) == 0 else rf(0.05, neg),
+                    gt_max_assign_all=seed % 4 != 3, match_low_quality=True)
+    cfgs = [one_cfg() for _ in range(S)]
+    for c in cfgs:
+        c['gt_max_assign_all'] = cfgs[0]['gt_max_assign_all']
+    assigner = cfgs[0] if mode == 2 else cfgs
+    B = ri(1, 3)
+    gts, labels = [], []
+    flat = anchors.reshape(-1, 7)
+    for b in range(B):
+        n = ri(0, 150) if b else ri(1, 150)
+        lab = torch.randint(-1, S + 1, (n,), generator=rng)
+        sz = torch.tensor(sizes)[lab.clamp(0, S - 1)] * (0.7 + 0.6 * torch.rand(n, 3, generator=rng))
+        box = torch.cat([torch.rand(n, 1, generator=rng) * 0.5 * W - 0.05 * W, torch.rand(n, 1, generator=rng) * 0.5 * H - 20.0 - 0.05 * H,
+                         torch.full((n, 1), -1.0), sz, (torch.rand(n, 1, generator=rng) * 2 - 1) * math.pi], dim=-1)
+        k = min(n, 5)
+        if k:
+            box[:k] = flat[torch.randint(0, flat.shape[0], (k,), generator=rng)]          # exact ties with an anchor and its mirror images
+        gts.append(box)
+        labels.append(lab)
+    kw = dict(assign_per_class=(mode == 0), dir_offset=rf(-1, 1), pos_weight=-1 if seed % 2 else 1.5)
+    ref = ORA.anchor_target_3d(anchors, gts, labels, assigner, S, **kw)
+    dev = torch.device('cuda:0')
+    got = pkg.anchor_head_get_targets(anchors.to(dev), [g.to(dev) for g in gts], [l.to(dev) for l in labels], assigner, S, **kw)
+    for k in (0, 1, 3, 4, 5):
+        assert torch.equal(got[k].cpu(), ref[k]), k
+    assert torch.equal(got[2].cpu()[..., [2, 6]], ref[2][..., [2, 6]])
+    assert torch.allclose(got[2].cpu()[..., [0, 1, 3, 4, 5]], ref[2][..., [0, 1, 3, 4, 5]], rtol=2e-6, atol=2e-7)
+    assert got[6] == ref[6] and got[7] == ref[7]
