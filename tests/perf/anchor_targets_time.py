@@ -6,7 +6,9 @@ us per call (synchronised):
             eager = mmdet3d's anchor_target_3d chain (oracle/anchor_targets_torch.py's statement) on device tensors
   loss    : ours = gd_anchor_head_loss eager, static, and static as one hipGraph (forward + backward)
             eager = the restated chain + the reference's loss ops on device tensors (forward + backward)
-Asserts equal labels / counts first."""
+Then the target assignment alone at the Waymo geometry (BASELINE configs[4]; hv_pointpillars_secfpn_waymo.py:46-57, :74-96: 468 x 468 cells x
+3 sizes x 2 rotations = 1 314 144 anchors per sample, three assigners that each see ALL boxes — the head's default assign_per_class=False),
+batch 2, 80 boxes per sample.  Asserts equal labels / counts first."""
 import json
 import os
 import sys
@@ -85,5 +87,30 @@ def main():
                           speedup_graph=round(t_ref / t_graph, 1))), flush=True)
 
 
+def waymo():
+    B, H, W, G = 2, 468, 468, 80
+    rng = [[-74.88, -74.88, -0.0345, 74.88, 74.88, -0.0345], [-74.88, -74.88, -0.1188, 74.88, 74.88, -0.1188], [-74.88, -74.88, 0.0, 74.88, 74.88, 0.0]]
+    sizes = [[4.73, 2.08, 1.77], [1.81, 0.84, 1.77], [0.91, 0.84, 1.74]]
+    cfgs = [dict(type='MaxIoUAssigner', iou_calculator=dict(type='BboxOverlapsNearest3D'), pos_iou_thr=p, neg_iou_thr=n, min_pos_iou=n, ignore_iof_thr=-1)
+            for p, n in ((0.55, 0.4), (0.5, 0.3), (0.5, 0.3))]
+    anchors = ORA.range_anchors((H, W), rng, sizes, [0, 1.57])[0].to(dev)
+    g = torch.Generator().manual_seed(7)
+    gts, labels = [], []
+    for b in range(B):
+        lab = torch.randint(0, 3, (G,), generator=g)
+        sz = torch.tensor(sizes)[lab] * (0.8 + 0.4 * torch.rand(G, 3, generator=g))
+        box = torch.cat([torch.rand(G, 2, generator=g) * 140 - 70, torch.zeros(G, 1), sz, (torch.rand(G, 1, generator=g) * 2 - 1) * 3.14159], dim=-1)
+        gts.append(box.to(dev))
+        labels.append(lab.to(dev))
+    ours = lambda: amd.anchor_head_get_targets(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)          # noqa: E731
+    eager = lambda: ORA.anchor_target_3d(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)                # noqa: E731
+    a, e = ours(), eager()
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and torch.equal(a[4], e[4]) and a[6] == e[6] and a[7] == e[7]
+    t_o, t_e = timeit(ours, 30), timeit(eager, 2, warm=1)
+    print(json.dumps(dict(step='anchor_target_3d', geometry='waymo', batch=B, anchors_per_sample=H * W * 6, boxes_per_sample=G, positives=a[6],
+                          ours_us=round(t_o, 1), reference_ops_on_gpu_us=round(t_e, 1), speedup=round(t_e / t_o, 1))), flush=True)
+
+
 if __name__ == '__main__':
     main()
+    waymo()
