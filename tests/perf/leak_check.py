@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""2000 calls each of the CenterPoint slices with FRESH tensors every time (new addresses defeat the descriptor caches): device
+"""2000 calls each of the CenterPoint and anchor-head slices with FRESH tensors every time (new addresses defeat the descriptor caches): device
 memory in use and host RSS before / after.  Asserts no growth beyond noise."""
 import os
 import sys
@@ -13,6 +13,7 @@ import torch  # noqa: E402
 import mmdet3d_gaussian_amd as amd  # noqa: E402
 from test_gpu_center_infer import NUS, NUS_TEST, make_tasks  # noqa: E402
 from test_gpu_center_targets import NUS as TCFG, TASKS, scene  # noqa: E402
+from test_gpu_anchor_targets import CE, FOCAL, SL1, TRAIN_CFG, head_outputs, kitti_anchors, random_gt  # noqa: E402
 
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
@@ -24,6 +25,12 @@ boxes, labels = scene(g, 80)
 tcfg = dict(TCFG, grid_size=[256, 256, 1], code_weights=[1.0, 1.0, 0.2, 0.2])
 gd = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
 proc = psutil.Process()
+AH, AW = 40, 36
+a_anchors = kitti_anchors(AH, AW)
+a_outs = head_outputs(2, AH, AW, seed=1)
+a_gt = [random_gt(12, seed=5), random_gt(7, seed=6)]
+a_infer_cfg = dict(use_rotate_nms=True, nms_pre=512, nms_thr=0.01, score_thr=0.05, max_num=50)
+kld = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
 
 
 def once():
@@ -34,6 +41,11 @@ def once():
     out = amd.center_gd_head_loss(dict(type='GaussianFocalLoss'), dict(type='L1Loss', loss_weight=0.25), gd, coder, TASKS, tcfg,
                                   [boxes.to(dev)], [labels.to(dev)], pds, static=True)
     sum(out.values()).backward()
+    an = a_anchors.to(dev) + 0.0
+    o = [t.to(dev).requires_grad_(True) for t in a_outs]
+    res = amd.gd_anchor_head_loss(FOCAL, SL1, CE, kld, TRAIN_CFG, 3, an, [o[0]], [o[1]], [o[2]], [b.to(dev) for b, _ in a_gt], [l.to(dev) for _, l in a_gt])
+    (res['loss_cls'][0] + res['loss_bbox'][0] + res['loss_dir'][0]).backward()
+    amd.anchor_head_get_bboxes([o[0].detach()], [o[1].detach()], [o[2].detach()], [an.reshape(-1, 7)], a_infer_cfg, 3, 0.0, 1.0)
 
 
 for _ in range(200):
