@@ -1,0 +1,84 @@
+"""The unpinned anchor-head restatements (oracle/anchor_targets_torch.py, oracle/anchor_cls_torch.py are mmdet / mmdet3d code restated from
+the published text: the reference tree holds neither the code nor a fixture) checked on the CPU against hand-computed cases, so that a
+slip in the restatement itself cannot hide behind GPU == restatement.  CPU only."""
+import math
+
+import torch
+
+from oracle import anchor_targets_torch as ORA
+
+
+def test_nearest_bev_snaps_the_yaw_to_the_nearer_axis():
+    boxes = torch.tensor([[10., 5., 0., 4., 2., 1.5, 0.0],            # along x: 4 x 2
+                          [10., 5., 0., 4., 2., 1.5, 0.7],            # 0.7 < pi/4: still 4 x 2
+                          [10., 5., 0., 4., 2., 1.5, 0.8],            # 0.8 > pi/4: 2 x 4
+                          [10., 5., 0., 4., 2., 1.5, math.pi - 0.1],  # limit_period folds it to -0.1: 4 x 2
+                          [10., 5., 0., 4., 2., 1.5, -1.6]])          # |.| > pi/4: 2 x 4
+    bev = ORA.nearest_bev(boxes)
+    want = torch.tensor([[8., 4., 12., 6.], [8., 4., 12., 6.], [9., 3., 11., 7.], [8., 4., 12., 6.], [9., 3., 11., 7.]])
+    assert torch.equal(bev, want)
+
+
+def test_bbox_overlaps_known_values():
+    a = torch.tensor([[0., 0., 2., 2.], [0., 0., 2., 2.], [5., 5., 6., 6.]])
+    b = torch.tensor([[1., 1., 3., 3.], [0., 0., 2., 2.]])
+    iou = ORA.bbox_overlaps(a, b)
+    assert abs(iou[0, 0].item() - 1.0 / 7.0) < 1e-7 and iou[0, 1].item() == 1.0 and iou[2, 0].item() == 0.0 and iou[2, 1].item() == 0.0
+
+
+def test_max_iou_assigner_rules_in_order():
+    """5 anchors, 2 boxes; thresholds pos 0.6, neg 0.3, min_pos 0.2.
+       anchor 0: best 0.7 with box 0 -> positive of box 0;  anchor 1: best 0.1 -> negative;  anchor 2: best 0.45 -> ignored (-1), but it
+       is box 1's best anchor (0.45 >= min_pos) -> positive of box 1;  anchor 3: ties box 1's best (0.45) -> with gt_max_assign_all also
+       box 1's, without it stays ignored;  anchor 4: 0.65 with box 0 and 0.45 with box 1 -> first the argmax rule gives box 0, then box
+       1's tie rule (gt_max_assign_all) overwrites it."""
+    ov = torch.tensor([[0.7, 0.1, 0.05, 0.0, 0.65],
+                       [0.2, 0.0, 0.45, 0.45, 0.45]])
+    labels = torch.tensor([0, 0])
+    a = ORA.max_iou_assign(ov, labels, 0.6, 0.3, 0.2, gt_max_assign_all=True)
+    assert a.tolist() == [1, 0, 2, 2, 2]
+    a = ORA.max_iou_assign(ov, labels, 0.6, 0.3, 0.2, gt_max_assign_all=False)
+    assert a.tolist() == [1, 0, 2, -1, 1]                 # only the FIRST best anchor of a box (argmax) is taken
+    a = ORA.max_iou_assign(ov, labels, 0.6, 0.3, 0.2, match_low_quality=False)
+    assert a.tolist() == [1, 0, -1, -1, 1]
+    # min_pos_iou = 0 (mmdet's default): a box nothing overlaps "best-matches" every zero-overlap anchor
+    ov0 = torch.tensor([[0.7, 0.1, 0.0], [0.0, 0.0, 0.0]])
+    assert ORA.max_iou_assign(ov0, labels, 0.6, 0.3, 0.0).tolist() == [2, 2, 2]
+    assert ORA.max_iou_assign(ov0, labels, 0.6, 0.3, 0.05).tolist() == [1, 0, 0]
+
+
+def test_delta_encode_and_direction_target_known_values():
+    anchor = torch.tensor([[1.0, 2.0, -1.0, 3.0, 4.0, 2.0, 0.0]])            # w 3, l 4: diagonal 5
+    box = torch.tensor([[2.0, 4.5, -0.5, 3.0 * math.e, 4.0, 1.0, 2.0]])
+    t = ORA.delta_encode(anchor, box)[0]
+    # z: box centre -0.5 + 0.5 = 0.0, anchor centre -1 + 1 = 0.0
+    want = [0.2, 0.5, 0.0, 1.0, 0.0, math.log(0.5), 2.0]
+    assert all(abs(x - y) < 1e-6 for x, y in zip(t.tolist(), want))
+    # direction bin: rot_gt = 2.0; offset 0 -> limit_period(2.0, 0, 2 pi) = 2.0 -> floor(2 / pi) = 0; yaw -1 -> 2 pi - 1 = 5.28 -> bin 1
+    assert ORA.get_direction_target(anchor, t[None], 0.0).item() == 0
+    t2 = t.clone(); t2[6] = -1.0
+    assert ORA.get_direction_target(anchor, t2[None], 0.0).item() == 1
+    # dir_offset pi/4 (the Waymo head's): yaw 0.5 - 0.7854 < 0 wraps to 6.0 -> bin 1;  yaw 1.0 -> 0.21 -> bin 0
+    t3 = t.clone(); t3[6] = 0.5
+    assert ORA.get_direction_target(anchor, t3[None], 0.7854).item() == 1
+    t4 = t.clone(); t4[6] = 1.0
+    assert ORA.get_direction_target(anchor, t4[None], 0.7854).item() == 0
+
+
+def test_single_sample_layout_and_counts():
+    """2 x 1 cells, 2 sizes, 2 rotations; one box identical to the (cell 1, size 1, rotation 0) anchor.  Per class: only size 1's assigner
+    sees it; its anchor (index (1 * 2 + 1) * 2 + 0 = 6) is the positive; its rotated twin overlaps by 2x2 / (8 + 8 - 4) = 1/3 -> between
+    the thresholds of 0.3 and 0.5 -> ignored (weight 0); everything else is a negative with label num_classes and weight 1."""
+    sizes = [[1.0, 1.0, 1.0], [4.0, 2.0, 1.5]]
+    anchors = ORA.range_anchors((1, 2), [[0., 0., -1., 20., 0., -1.]] * 2, sizes, [0.0, 1.57])[0]        # (1, 2, 2, 2, 7): x = 0 and 20
+    assert anchors.shape == (1, 2, 2, 2, 7) and anchors[0, 1, 1, 0].tolist() == [20.0, 0.0, -1.0, 4.0, 2.0, 1.5, 0.0]
+    box = anchors[0, 1, 1, 0].clone()[None]
+    cfg = [dict(pos_iou_thr=0.5, neg_iou_thr=0.3, min_pos_iou=0.3)] * 2
+    lab, lw, bt, bw, dt, dw, pos, neg = ORA.anchor_target_3d_single(anchors, box, torch.tensor([1]), cfg, 2)
+    assert lab.tolist() == [2, 2, 2, 2, 2, 2, 1, 2]
+    assert lw.tolist() == [1, 1, 1, 1, 1, 1, 1, 0]
+    assert bw[:, 0].tolist() == [0, 0, 0, 0, 0, 0, 1, 0] and dw.tolist() == [0, 0, 0, 0, 0, 0, 1, 0]
+    assert bt[6].abs().max().item() == 0.0 and dt.tolist() == [0] * 8
+    assert pos.numel() == 1 and neg.numel() == 6
+    out = ORA.anchor_target_3d(anchors, [box, box[:0]], [torch.tensor([1]), torch.zeros(0, dtype=torch.long)], cfg, 2)
+    assert out[6] == 2 and out[7] == 6 + 8            # sum_b max(positives, 1), sum_b max(negatives, 1)
