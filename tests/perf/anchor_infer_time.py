@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Anchor-head inference slice at the reference's PointPillars geometries, us per call (host + device, synchronised):
   KITTI  (configs/_base_/models/hv_pointpillars_secfpn_kitti.py:89-96): 248 x 216 x 6 anchors, 3 classes, nms_pre 4096, nms_thr 0.01,
-         score_thr 0.05, max_num 100, the head's default direction offsets (0, 1)
+         score_thr 0.05, max_num 100; dir_offset / dir_limit_offset (0, 1) = mmdet3d 0.x's head defaults (1.0 has (-pi/2, 0); the config
+         sets neither, and the function takes both as arguments)
   Waymo  (BASELINE configs[4], hv_pointpillars_secfpn_waymo.py:59-60, :101-109): 468 x 468 x 6 anchors, 3 classes, nms_pre 4096,
          nms_thr 0.25, score_thr 0.1, max_num 500, dir_offset 0.7854, dir_limit_offset 0
 ours  = anchor_head_get_bboxes (score kernel, selection, gather + decode, batched class NMS, collect; one read-back)
