@@ -110,6 +110,37 @@ def waymo():
     print(json.dumps(dict(step='anchor_target_3d', geometry='waymo', batch=B, anchors_per_sample=H * W * 6, boxes_per_sample=G, positives=a[6],
                           ours_us=round(t_o, 1), reference_ops_on_gpu_us=round(t_e, 1), speedup=round(t_e / t_o, 1))), flush=True)
 
+    # the whole loss at this geometry: GWD as the config has it (configs/waymo/hv_pointpillars_secfpn_gwd5_...: loss_weight 5), code_weight only
+    outs = [o.to(dev).requires_grad_(True) for o in head_outputs(B, H, W, seed=2)]
+    mod = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    tcfg = dict(assigner=cfgs, allowed_border=0, code_weight=[1.0] * 7, pos_weight=-1, debug=False)
+    gt_t, gl_t = torch.stack(gts), torch.stack(labels)
+
+    def fn(cls, bbox, dirs, gt, gl, static=True):
+        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), assign_per_class=False,
+                                    dir_offset=0.7854, static=static)
+        return r['loss_cls'][0], r['loss_bbox'][0], r['loss_dir'][0]
+
+    def run(static):
+        for o in outs:
+            o.grad = None
+        l = fn(outs[0], outs[1], outs[2], gt_t, gl_t, static)
+        (l[0] + l[1] + l[2]).backward()
+
+    def ref():
+        for o in outs:
+            o.grad = None
+        tg = ORA.anchor_target_3d(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)
+        avg = float(tg[6])
+        lc, ld = anchor_cls_torch.cls_dir_losses(outs[0], outs[2], tg[0], tg[1], tg[4], tg[5], 3, avg)
+        lb = head_torch.loss_single_bbox(outs[1], tg[2], tg[3], tg[0], anchors.reshape(-1, 7), 3, avg, gd=dict(loss_type='gwd3d', fun='log1p', tau=0.0, loss_weight=5.0),
+                                         sl1=dict(beta=SL1['beta'], loss_weight=SL1['loss_weight']), code_weight=[1.0] * 7, decode_weight=None, diff_rad_by_sin=True)
+        (lc + lb + ld).backward()
+    step = amd.GraphedStep(fn, (outs[0], outs[1], outs[2], gt_t, gl_t))
+    t_eager, t_graph, t_ref = timeit(lambda: run(False), 30), timeit(lambda: step(outs[0], outs[1], outs[2], gt_t, gl_t), 30), timeit(ref, 2, warm=1)
+    print(json.dumps(dict(step='GDAnchor3DHead.loss fwd+bwd', geometry='waymo', batch=B, ours_eager_us=round(t_eager, 1), ours_graph_us=round(t_graph, 1),
+                          reference_ops_on_gpu_us=round(t_ref, 1), speedup_eager=round(t_ref / t_eager, 1), speedup_graph=round(t_ref / t_graph, 1))), flush=True)
+
 
 if __name__ == '__main__':
     main()
