@@ -369,7 +369,22 @@ __global__ __launch_bounds__(T) void assign_kernel(const Args a) {
     a.label_w[o0 + j] = st[(size_t)j * 9 + 7];
     a.dir_w[o0 + j] = w;
   }
-  for (int k = threadIdx.x; k < items * 7; k += T) {
+  const int total = items * 7;
+  const int quads = (((o0 * 7) & 3) == 0) ? total / 4 : 0;          // 16-byte stores where the tile's range is aligned for them
+  float4* t4 = (float4*)(a.bbox_t + o0 * 7);
+  float4* w4 = (float4*)(a.bbox_w + o0 * 7);
+  for (int k4 = threadIdx.x; k4 < quads; k4 += T) {
+    float tv[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k4 * 4 + e, j = k / 7, c = k - j * 7;
+      tv[e] = st[(size_t)j * 9 + c];
+      wv[e] = ((const int*)st)[(size_t)j * 9 + 8] < 0 ? 1.0f : 0.0f;
+    }
+    t4[k4] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    w4[k4] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+  }
+  for (int k = quads * 4 + threadIdx.x; k < total; k += T) {
     const int j = k / 7, c = k - j * 7;
     a.bbox_t[o0 * 7 + k] = st[(size_t)j * 9 + c];
     a.bbox_w[o0 * 7 + k] = ((const int*)st)[(size_t)j * 9 + 8] < 0 ? 1.0f : 0.0f;
@@ -435,7 +450,8 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   // tile: about 768 anchors (3 rounds of the 256 threads), a power of two of cells
   const int SR = d.num_sizes * d.num_rots;
   int tile_cells = 1;
-  while (tile_cells * 2 * SR <= 768 && tile_cells < 128) tile_cells *= 2;
+  while (tile_cells * 2 * SR <= 768 && tile_cells < 128) tile_cells *= 2;   // measured at KITTI geometry: 192 / 384 / 768 / 1536 anchors per
+                                                                          // tile -> 165 / 108 / 83 / 85 us for the two passes
   const int g_cap = (g_max + 3) & ~3;
   const size_t lds1 = (size_t)g_cap * 28 + (size_t)K * g_cap * 8;
   const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
