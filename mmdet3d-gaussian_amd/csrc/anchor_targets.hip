@@ -454,6 +454,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
                                                                           // tile -> 165 / 108 / 83 / 85 us for the two passes
   const int g_cap = (g_max + 3) & ~3;
   const size_t lds1 = (size_t)g_cap * 28 + (size_t)K * g_cap * 8;
+  while (tile_cells > 1 && lds1 + (size_t)tile_cells * SR * 36 > 64 * 1024) tile_cells /= 2;   // many boxes: smaller tiles
   const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
   if (lds2 > 64 * 1024) return GD3D_E_TOOLARGE;
   hipError_t e = hipMemsetAsync(workspace, 0, anchor_targets_workspace_bytes(K, g_total), s);

@@ -136,6 +136,17 @@ def test_no_boxes_at_all_and_padded_form():
     assert torch.equal(res[0].cpu(), ref[0])
 
 
+def test_the_maximum_number_of_boxes_in_a_sample():
+    """1024 boxes in one sample (the LDS stage's capacity; the tile shrinks to make room), next to a sample with 3"""
+    anchors = kitti_anchors(24, 20)
+    b, l = random_gt(1024, seed=31, x=(0, 8), y=(-39, -30))
+    b2, l2 = random_gt(3, seed=32, x=(0, 8), y=(-39, -30), with_ignored=False)
+    ref, got = run_both(anchors, [b, b2], [l, l2], KITTI_ASSIGNERS)
+    check(ref, got)
+    ref, got = run_both(anchors, [b, b2], [l, l2], KITTI_ASSIGNERS, assign_per_class=False)
+    check(ref, got)
+
+
 def test_deterministic_and_argument_checks():
     anchors = kitti_anchors(30, 30)
     dev = torch.device('cuda:0')
