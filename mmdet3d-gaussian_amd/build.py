@@ -3,6 +3,7 @@
 Plain ``hipcc --offload-arch=gfx950``: no torch headers, no hipify, no cmake.  The library is built
 IN-TREE (mmdet3d-gaussian_amd/libgd3d.so) so that it travels to the GPU box with the snapshot.
 """
+import concurrent.futures
 import hashlib
 import os
 import shutil
@@ -78,19 +79,26 @@ def build(force=False, verbose=False):
         raise RuntimeError('hipcc not found: cannot build libgd3d.so')
     objdir = os.path.join(PKG_DIR, 'build', str(os.getpid()))  # per process: ranks may build concurrently
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    jobs = []
     for src, flags in SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.isfile(path):
             continue
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
-        cmd = [hipcc] + COMMON + flags + ['-c', path, '-o', obj]
+        jobs.append((src, obj, [hipcc] + COMMON + flags + ['-c', path, '-o', obj]))
+
+    def compile_one(job):
+        src, obj, cmd = job
         if verbose:
             print(' '.join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
-        objs.append(obj)
+        return obj
+    # the translation units are independent: one hipcc per core, at most 8 (each takes 5-25 s and ~1 GB)
+    workers = max(1, min(8, os.cpu_count() or 1, len(jobs)))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+        objs = list(pool.map(compile_one, jobs))
     tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
