@@ -21,6 +21,8 @@ def _focal_cfg(loss_cls):
         raise RuntimeError(f'anchor_head_cls_dir_loss: loss_cls is {kind!r}; the reference heads configure FocalLoss(use_sigmoid=True)')
     if _get(loss_cls, 'reduction', 'mean') != 'mean':
         raise RuntimeError("anchor_head_cls_dir_loss: loss_cls reduction must be 'mean' (sum / avg_factor)")
+    if _get(loss_cls, 'activated', False):
+        raise RuntimeError('anchor_head_cls_dir_loss: FocalLoss(activated=True) takes probabilities; the head passes logits')
     return float(_get(loss_cls, 'gamma', 2.0)), float(_get(loss_cls, 'alpha', 0.25)), float(_get(loss_cls, 'loss_weight', 1.0))
 
 

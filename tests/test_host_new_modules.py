@@ -63,6 +63,8 @@ def test_anchor_cls_config_parsing_and_cpu_refusal():
         anchor_cls._ce_cfg(dict(type='CrossEntropyLoss', use_sigmoid=True))
     with pytest.raises(RuntimeError, match="'mean'"):
         anchor_cls._focal_cfg(dict(type='FocalLoss', reduction='sum'))
+    with pytest.raises(RuntimeError, match='activated'):
+        anchor_cls._focal_cfg(dict(type='FocalLoss', activated=True))
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.anchor_head_cls_dir_loss(dict(type='FocalLoss'), dict(type='CrossEntropyLoss'), torch.zeros(1, 2, 3, 3), torch.zeros(1, 4, 3, 3),
                                      torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), 1, 1.0)
