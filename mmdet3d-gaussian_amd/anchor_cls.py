@@ -8,7 +8,7 @@ CrossEntropyLoss) — both loss modules third party, absent here, restated from 
 import torch
 
 from . import _lib
-from .gd_loss import guard_double_backward
+from .gd_loss import _is_unit_grad, guard_double_backward
 
 
 def _get(cfg, key, default):
@@ -71,8 +71,9 @@ class _ClsDir(torch.autograd.Function):
     @guard_double_backward
     def backward(ctx, grad_cls, grad_dir):
         gc, gd, dtc, dtd = ctx.state
-        rc = None if gc is None else (gc * grad_cls).to(dtc)
-        rd = None if gd is None else (gd * grad_dir).to(dtd)
+        # the library's own constant 1.0 (gd_loss.unit_grad) is known by address: the stored maps are final, nothing is launched
+        rc = None if gc is None else (gc if _is_unit_grad(grad_cls) else gc * grad_cls).to(dtc)
+        rd = None if gd is None else (gd if _is_unit_grad(grad_dir) else gd * grad_dir).to(dtd)
         return None, None, rc, rd
 
 

@@ -9,6 +9,8 @@ backward and replayed with new values in the same buffers: at KITTI geometry (6 
 """
 import torch
 
+from .gd_loss import unit_grad
+
 
 def _flatten(out):
     """-> (flat list of tensors, function that puts a list of the same length back into the structure of `out`)"""
@@ -73,7 +75,10 @@ class GraphedStep:
         flat, rebuild = _flatten(self._fn(*self._static))
         need = [l for l in flat if l.requires_grad]
         if need:
-            torch.autograd.backward(need, [torch.ones_like(l) for l in need])
+            # 0-dim fp32 losses get the library's constant 1.0 (gd_loss.unit_grad): this package's backward functions recognise it by
+            # address and launch nothing for it; torch's own nodes just read it
+            torch.autograd.backward(need, [unit_grad(l.device) if (l.dim() == 0 and l.dtype == torch.float32) else torch.ones_like(l)
+                                           for l in need])
         return [l.detach() for l in flat], rebuild
 
     def __call__(self, *inputs):

@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .gd_loss import guard_double_backward
+from .gd_loss import _is_unit_grad, guard_double_backward
 
 
 def _prologue(kind, aux, norm_bbox=False, out_size_factor=1.0, voxel_size=(1.0, 1.0), pc_range=(0.0, 0.0)):
@@ -110,6 +110,8 @@ class _AnchorHeadFused(torch.autograd.Function):
             g = _anchor_head_launch(*ctx.replay, True)[1]
         else:  # hand the buffer over (no reference left here: a leaf's AccumulateGrad then keeps it instead of cloning it)
             g, ctx.grad, ctx.used = ctx.grad, None, True
+        if _is_unit_grad(grad_out):     # the library's own constant 1.0 (gd_loss.unit_grad), known by address: nothing to scale
+            return (g,) + (None,) * 10
         go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
         with torch.cuda.device(g.device):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,

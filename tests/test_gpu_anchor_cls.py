@@ -236,3 +236,26 @@ def test_loss_single_without_direction_classifier():
     b = pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, None, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'], g['bw'], g['dt'], g['dw'],
                                        g['anchors'], 5.0)
     assert a[2] is None and a[0].item() == b[0].item() and a[1].item() == b[1].item()
+
+
+def test_unit_gradient_constant_is_recognised_by_address():
+    """torch.autograd.backward(losses, [unit_grad] * n): the stored gradient maps are handed over as they are (no scaling launch);
+    same values as the ordinary backward"""
+    c, C = head_case(9)
+    dev = torch.device('cuda:0')
+    mod = pkg.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    gd_loss = importlib.import_module('mmdet3d-gaussian_amd.gd_loss')
+    res = []
+    for unit in (False, True):
+        g = {k: v.to(dev) for k, v in c.items()}
+        for k in ('cls', 'bbox', 'dirs'):
+            g[k].requires_grad_(True)
+        out = pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'],
+                                             g['bw'], g['dt'], g['dw'], g['anchors'], 13.0)
+        if unit:
+            torch.autograd.backward(list(out), [gd_loss.unit_grad(dev)] * 3)
+        else:
+            torch.autograd.backward(list(out), [torch.ones_like(o) for o in out])
+        res.append([g[k].grad.clone() for k in ('cls', 'bbox', 'dirs')])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
