@@ -200,6 +200,15 @@ int gd3d_anchor_head_bbox_loss(const gd3d_params* params, const gd3d_smooth_l1* 
                                const int64_t* pos_inds, int64_t P, const int64_t* labels,
                                int32_t num_classes, float scale, float* loss_sum,
                                float* grad_bbox_pred, void* workspace, void* stream);
+/* gd3d_anchor_head_bbox_loss, dense form, with the normaliser ON THE DEVICE (ABI 4): scale = gd_weight / *avg_dev and the SmoothL1
+ * scale = sl1_weight / *avg_dev (smooth_l1->scale is ignored), divided in double and rounded once.  gd_weight / sl1_weight are the two
+ * modules' loss_weight. */
+int gd3d_anchor_head_bbox_loss_dyn(const gd3d_params* params, const gd3d_smooth_l1* smooth_l1, const float* bbox_pred,
+                                   int32_t B, int32_t A, int32_t H, int32_t W, const float* bbox_targets,
+                                   const float* bbox_weights, const float* decode_weight, const float* anchors,
+                                   const int64_t* labels, int32_t num_classes, double gd_weight, double sl1_weight,
+                                   const float* avg_dev, float* loss_sum, float* grad_bbox_pred, void* workspace,
+                                   void* stream);
 
 /* CenterGDHead regression losses of up to 8 tasks in ONE launch (gd_centerpoint_head.py:402-441), reading the head
  * outputs where they lie.  Per task (host struct, device pointers):
@@ -762,6 +771,14 @@ int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds,
                              int32_t batch, int32_t num_anchors, int32_t num_classes, int32_t height, int32_t width,
                              float gamma, float alpha, float cls_scale, float dir_scale, float* grad_cls,
                              float* grad_dir, float* losses, void* workspace, void* stream);
+/* The same with the normaliser ON THE DEVICE (no read-back of the positives' count): avg_dev -> one fp32 (num_total_samples, e.g.
+ * sum_b max(positives_b, 1) of anchor_targets_build's counts); the scales are cls_weight / *avg_dev and dir_weight / *avg_dev, divided in
+ * double and rounded once as the host form does. */
+int gd3d_anchor_cls_dir_loss_dyn(const float* cls_score, const float* dir_cls_preds, const int64_t* labels,
+                                 const float* label_weights, const int64_t* dir_targets, const float* dir_weights,
+                                 int32_t batch, int32_t num_anchors, int32_t num_classes, int32_t height, int32_t width,
+                                 float gamma, float alpha, double cls_weight, double dir_weight, const float* avg_dev,
+                                 float* grad_cls, float* grad_dir, float* losses, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Target assignment of the anchor heads for a whole batch, one feature level (ABI 4).  Replaces what GDAnchor3DHead.loss calls at

@@ -126,6 +126,9 @@ SYMBOLS = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp,
                                           ctypes.POINTER(ctypes.c_float), _vp, _vp, _i64, _vp, ctypes.c_int32, _f32, _vp,
                                           _vp, _vp, _vp]),
+    'gd3d_anchor_head_bbox_loss_dyn': (_int, [ctypes.POINTER(Params), ctypes.POINTER(SmoothL1), _vp, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_int32, _vp, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, ctypes.c_int32,
+                                              ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_center_head_workspace_bytes': (_sz, [ctypes.c_int32, _i64]),
     'gd3d_center_head_loss': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), ctypes.POINTER(CenterTask), ctypes.c_int32,
                                      ctypes.POINTER(ctypes.c_float), ctypes.c_int32, _vp, _vp, _vp]),
@@ -192,6 +195,8 @@ SYMBOLS = {
     'gd3d_anchor_cls_dir_workspace_bytes': (_sz, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'gd3d_anchor_cls_dir_loss': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_anchor_cls_dir_loss_dyn': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int32, _f32, _f32, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gd3d_abi_version': (_int, [ctypes.POINTER(ctypes.c_char_p)]),
 }
 

@@ -47,7 +47,7 @@ class _ClsDir(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, targets, cls_score, dir_cls_preds):
         lib = _lib.load()
-        gamma, alpha, cls_scale, dir_scale, C = cfg
+        gamma, alpha, cls_scale, dir_scale, C, avg_dev = cfg
         labels, label_weights, dir_targets, dir_weights = targets
         B, AC, H, W = cls_score.shape
         A = AC // C
@@ -60,10 +60,15 @@ class _ClsDir(torch.autograd.Function):
             out = torch.empty(2, dtype=torch.float32, device=dev)
             ws = torch.empty(lib.gd3d_anchor_cls_dir_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
             ptr = lambda t: None if t is None else t.data_ptr()
-            _lib.check(lib.gd3d_anchor_cls_dir_loss(xc.data_ptr(), ptr(xd), labels.data_ptr(), label_weights.data_ptr(), ptr(dir_targets),
-                                                    ptr(dir_weights), B, A, C, H, W, gamma, alpha, cls_scale, dir_scale, ptr(gc), ptr(gd),
-                                                    out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                       'gd3d_anchor_cls_dir_loss')
+            if avg_dev is not None:       # cls_scale / dir_scale are the loss weights; the kernels divide by *avg_dev
+                rc = lib.gd3d_anchor_cls_dir_loss_dyn(xc.data_ptr(), ptr(xd), labels.data_ptr(), label_weights.data_ptr(), ptr(dir_targets),
+                                                      ptr(dir_weights), B, A, C, H, W, gamma, alpha, cls_scale, dir_scale, avg_dev.data_ptr(),
+                                                      ptr(gc), ptr(gd), out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            else:
+                rc = lib.gd3d_anchor_cls_dir_loss(xc.data_ptr(), ptr(xd), labels.data_ptr(), label_weights.data_ptr(), ptr(dir_targets),
+                                                  ptr(dir_weights), B, A, C, H, W, gamma, alpha, cls_scale, dir_scale, ptr(gc), ptr(gd),
+                                                  out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, 'gd3d_anchor_cls_dir_loss')
         ctx.state = (gc, gd, cls_score.dtype, None if dir_cls_preds is None else dir_cls_preds.dtype)
         return out[0], out[1]          # two outputs of the node (no select nodes in the caller's graph)
 
@@ -84,7 +89,8 @@ def anchor_head_cls_dir_loss(loss_cls, loss_dir, cls_score, dir_cls_preds, label
                           without direction classifier;
     cls_score           : (B, A*C, H, W) the head's raw class maps, NOT permuted;  dir_cls_preds (B, A*2, H, W) or None;
     labels, dir_targets : (B, H*W*A) integer, label == num_classes = background, negative = ignored for the direction term;
-    label_weights, dir_weights : (B, H*W*A);  num_total_samples : the avg_factor of both terms (None = the batch size B, the
+    label_weights, dir_weights : (B, H*W*A);  num_total_samples : the avg_factor of both terms — a number, or a one-element fp32 device
+                          tensor that the kernels divide by (no read-back; e.g. sum_b max(positives_b, 1)) — (None = the batch size B, the
                           reference's fallback `int(cls_score.shape[0])` at :85-86, taken before its permute).
     Returns (loss_cls, loss_dir) 0-dim tensors on the device, differentiable wrt the maps; loss_dir is 0 (still attached to the
     graph) when there is no positive anchor, as `pos_dir_cls_preds.sum()` at :157-158; None without direction classifier."""
@@ -110,10 +116,16 @@ def anchor_head_cls_dir_loss(loss_cls, loss_dir, cls_score, dir_cls_preds, label
             raise RuntimeError(f'anchor_head_cls_dir_loss: a per-anchor tensor has {t.numel()} entries on {t.device}, expected {B * N} on {cls_score.device}')
     if num_total_samples is None:
         num_total_samples = B
-    avg = float(num_total_samples)
-    if not avg > 0:
-        raise RuntimeError(f'anchor_head_cls_dir_loss: num_total_samples = {num_total_samples}')
+    avg_dev = None
+    if isinstance(num_total_samples, torch.Tensor):       # a 0-dim fp32 device tensor: the kernels divide by it (no read-back)
+        from .head_loss import _avg_tensor
+        avg_dev = _avg_tensor(num_total_samples, cls_score.device, 'anchor_head_cls_dir_loss')
+        avg = 1.0
+    else:
+        avg = float(num_total_samples)
+        if not avg > 0:
+            raise RuntimeError(f'anchor_head_cls_dir_loss: num_total_samples = {num_total_samples}')
     targets = (_i64c(labels.detach()), _f32c(label_weights.detach()),
                None if dir_cls_preds is None else _i64c(dir_targets.detach()), None if dir_cls_preds is None else _f32c(dir_weights.detach()))
-    l_cls, l_dir = _ClsDir.apply((gamma, alpha, wc / avg, wd / avg, int(num_classes)), targets, cls_score, dir_cls_preds)
+    l_cls, l_dir = _ClsDir.apply((gamma, alpha, wc / avg, wd / avg, int(num_classes), avg_dev), targets, cls_score, dir_cls_preds)
     return l_cls, (l_dir if dir_cls_preds is not None else None)

@@ -6,6 +6,8 @@ package's two fused slices — `anchor_head_cls_dir_loss` (:84-92, :143-149) and
 four launches forward, with no permuted copies of the head's maps, no `nonzero` and no host read-back: the reference syncs
 twice (`labels.max().item()` at :90, `nonzero` at :101-103).  Static shapes: `GraphedStep` can capture forward and backward.
 """
+import torch
+
 from .anchor_cls import anchor_head_cls_dir_loss
 from .anchor_targets import anchor_head_get_targets
 from .head_loss import anchor_head_bbox_loss
@@ -53,9 +55,9 @@ def gd_anchor_head_loss(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_
     gt_bboxes, gt_labels : the batch's ground truth (see anchor_head_get_targets);  train_cfg: 'assigner', 'pos_weight',
                     'code_weight', 'decode_weight';  the loss modules as in gd_anchor_head_loss_single.
     ONE read-back for the batch: the per-sample (positives, negatives) counts that make the normaliser.
-    static=True   : none at all — the normaliser stays on the device (the three losses are computed for num_total_samples = 1 and
-                    divided there; equal to the eager form within fp32 rounding), so with ground truth padded to a fixed number
-                    of rows (label -1 for the padding) the whole method is one stream-ordered sequence that `GraphedStep` captures.
+    static=True   : none at all — the normaliser stays on the device and the loss kernels divide by it themselves (the same bits as the
+                    eager form), so with ground truth padded to a fixed number of rows (label -1 for the padding) the whole method
+                    is one stream-ordered sequence that `GraphedStep` captures; its backward launches nothing.
     Returns the reference's dict: loss_cls, loss_bbox, loss_dir, each a one-element list."""
     cls_score, bbox_pred = _one(cls_scores, 'cls_scores'), _one(bbox_preds, 'bbox_preds')
     dir_pred = _one(dir_cls_preds, 'dir_cls_preds') if use_direction_classifier else None
@@ -65,12 +67,11 @@ def gd_anchor_head_loss(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_
     labels, label_weights, bbox_targets, bbox_weights, dir_targets, dir_weights = tg[:6]
     flat = anchors.reshape(-1, 7)
     if static:
-        norm = tg[6][:, 0].clamp(min=1).sum().to(cls_score.dtype)                 # sum_b max(positives_b, 1), on the device
+        # sum_b max(positives_b, 1) stays on the device: the loss kernels divide by it themselves, as the host form divides by the number
+        norm = tg[6][:, 0].clamp(min=1).sum().to(torch.float32)
         l_cls, l_bbox, l_dir = gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_cfg, num_classes,
                                                           cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
-                                                          dir_targets, dir_weights, flat, 1.0, diff_rad_by_sin, use_direction_classifier)
-        l_cls, l_bbox = l_cls / norm, l_bbox / norm
-        l_dir = None if l_dir is None else l_dir / norm
+                                                          dir_targets, dir_weights, flat, norm, diff_rad_by_sin, use_direction_classifier)
     else:
         l_cls, l_bbox, l_dir = gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox, train_cfg, num_classes,
                                                           cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,

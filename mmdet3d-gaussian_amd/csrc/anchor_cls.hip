@@ -36,7 +36,19 @@ struct Args {
   float* partial;            // (blocks, 2)
   int A, C, HW;
   float gamma, alpha, cls_scale, dir_scale;
+  const float* avg_dev;      // nullable: the two scales are w_cls / *avg_dev, w_dir / *avg_dev (divided in double, rounded once)
+  double w_cls, w_dir;
 };
+
+__device__ __forceinline__ void scales_of(const Args& a, float& cs, float& ds) {
+  cs = a.cls_scale;
+  ds = a.dir_scale;
+  if (a.avg_dev != nullptr) {
+    const double avg = (double)*a.avg_dev;
+    cs = (float)(a.w_cls / avg);
+    ds = (float)(a.w_dir / avg);
+  }
+}
 
 __device__ __forceinline__ float powg(float x, float g) {
   if (g == 2.0f) return x * x;
@@ -99,6 +111,8 @@ __global__ __launch_bounds__(T) void cls_dir_kernel(const Args a) {
   __syncthreads();
   float lc = 0.0f, ld = 0.0f;
   const float gamma = a.gamma, alpha = a.alpha;
+  float cls_scale, dir_scale;
+  scales_of(a, cls_scale, dir_scale);
 #pragma unroll 2
   for (int i = threadIdx.x; i < TC * A; i += T) {
     const int an = i / TC, cl = i % TC;
@@ -115,14 +129,14 @@ __global__ __launch_bounds__(T) void cls_dir_kernel(const Args a) {
         float l, g;
         focal(x[c], lab == c, gamma, alpha, l, g);
         lc += l * w;
-        if (a.gcls != nullptr) a.gcls[o + (size_t)c * HW] = g * w * a.cls_scale;
+        if (a.gcls != nullptr) a.gcls[o + (size_t)c * HW] = g * w * cls_scale;
       }
     } else {
       for (int c = 0; c < C; ++c) {
         float l, g;
         focal(a.cls[o + (size_t)c * HW], lab == c, gamma, alpha, l, g);
         lc += l * w;
-        if (a.gcls != nullptr) a.gcls[o + (size_t)c * HW] = g * w * a.cls_scale;
+        if (a.gcls != nullptr) a.gcls[o + (size_t)c * HW] = g * w * cls_scale;
       }
     }
     if (a.dir != nullptr) {
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(T) void cls_dir_kernel(const Args a) {
         ld += (fmaxf(z, 0.0f) + log1pf(e)) * dw;                 // logsumexp(d) - d[k] = softplus(z)
         const float r = 1.0f / (1.0f + e);
         const float pw = z >= 0.0f ? r : e * r;                  // softmax probability of the wrong bin
-        const float gs = pw * dw * a.dir_scale;
+        const float gs = pw * dw * dir_scale;
         g0 = k == 0 ? -gs : gs;
         g1 = -g0;
       }
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(T) void cls_dir_kernel(const Args a) {
   }
 }
 
-__global__ __launch_bounds__(T) void cls_dir_finish_kernel(const float* __restrict__ partial, int blocks, float cls_scale, float dir_scale,
+__global__ __launch_bounds__(T) void cls_dir_finish_kernel(const float* __restrict__ partial, int blocks, const Args sc,
                                                            float* __restrict__ losses) {
   __shared__ double s0[T], s1[T];
   double a = 0.0, b = 0.0;
@@ -184,6 +198,8 @@ __global__ __launch_bounds__(T) void cls_dir_finish_kernel(const float* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    float cls_scale, dir_scale;
+    scales_of(sc, cls_scale, dir_scale);
     losses[0] = (float)(s0[0] * (double)cls_scale);
     losses[1] = (float)(s1[0] * (double)dir_scale);
   }
@@ -201,10 +217,11 @@ size_t gd3d_anchor_cls_dir_workspace_bytes(int32_t batch, int32_t height, int32_
   return (blocks * 2 * sizeof(float) + 255) & ~(size_t)255;
 }
 
-int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds, const int64_t* labels, const float* label_weights,
-                             const int64_t* dir_targets, const float* dir_weights, int32_t batch, int32_t num_anchors,
-                             int32_t num_classes, int32_t height, int32_t width, float gamma, float alpha, float cls_scale,
-                             float dir_scale, float* grad_cls, float* grad_dir, float* losses, void* workspace, void* stream) {
+static int cls_dir_impl(const float* cls_score, const float* dir_cls_preds, const int64_t* labels, const float* label_weights,
+                        const int64_t* dir_targets, const float* dir_weights, int32_t batch, int32_t num_anchors, int32_t num_classes,
+                        int32_t height, int32_t width, float gamma, float alpha, float cls_scale, float dir_scale, const float* avg_dev,
+                        double cls_weight, double dir_weight, float* grad_cls, float* grad_dir, float* losses, void* workspace,
+                        void* stream) {
   if (batch < 1 || num_anchors < 1 || num_classes < 1 || height < 1 || width < 1) return GD3D_E_BADARG;
   if (num_anchors > MAX_A || batch > 65535) return GD3D_E_TOOLARGE;
   if (cls_score == nullptr || labels == nullptr || label_weights == nullptr || losses == nullptr || workspace == nullptr) return GD3D_E_BADARG;
@@ -229,6 +246,9 @@ int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds,
   a.alpha = alpha;
   a.cls_scale = cls_scale;
   a.dir_scale = dir_scale;
+  a.avg_dev = avg_dev;
+  a.w_cls = cls_weight;
+  a.w_dir = dir_weight;
   const unsigned gx = (unsigned)((HW + TC - 1) / TC);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)TC * num_anchors * 8;
@@ -240,9 +260,26 @@ int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds,
     case 4: hipLaunchKernelGGL(cls_dir_kernel<4>, grid, block, lds, s, a); break;
     default: hipLaunchKernelGGL(cls_dir_kernel<0>, grid, block, lds, s, a); break;
   }
-  hipLaunchKernelGGL(cls_dir_finish_kernel, dim3(1), dim3(T), 0, s, (const float*)workspace, (int)(gx * (unsigned)batch), cls_scale, dir_scale,
-                     losses);
+  hipLaunchKernelGGL(cls_dir_finish_kernel, dim3(1), dim3(T), 0, s, (const float*)workspace, (int)(gx * (unsigned)batch), a, losses);
   return (int)hipGetLastError();
+}
+
+int gd3d_anchor_cls_dir_loss(const float* cls_score, const float* dir_cls_preds, const int64_t* labels, const float* label_weights,
+                             const int64_t* dir_targets, const float* dir_weights, int32_t batch, int32_t num_anchors,
+                             int32_t num_classes, int32_t height, int32_t width, float gamma, float alpha, float cls_scale,
+                             float dir_scale, float* grad_cls, float* grad_dir, float* losses, void* workspace, void* stream) {
+  return cls_dir_impl(cls_score, dir_cls_preds, labels, label_weights, dir_targets, dir_weights, batch, num_anchors, num_classes, height, width,
+                      gamma, alpha, cls_scale, dir_scale, nullptr, 0.0, 0.0, grad_cls, grad_dir, losses, workspace, stream);
+}
+
+int gd3d_anchor_cls_dir_loss_dyn(const float* cls_score, const float* dir_cls_preds, const int64_t* labels, const float* label_weights,
+                                 const int64_t* dir_targets, const float* dir_weights, int32_t batch, int32_t num_anchors,
+                                 int32_t num_classes, int32_t height, int32_t width, float gamma, float alpha, double cls_weight,
+                                 double dir_weight, const float* avg_dev, float* grad_cls, float* grad_dir, float* losses,
+                                 void* workspace, void* stream) {
+  if (avg_dev == nullptr) return GD3D_E_BADARG;
+  return cls_dir_impl(cls_score, dir_cls_preds, labels, label_weights, dir_targets, dir_weights, batch, num_anchors, num_classes, height, width,
+                      gamma, alpha, 0.0f, 0.0f, avg_dev, cls_weight, dir_weight, grad_cls, grad_dir, losses, workspace, stream);
 }
 
 }  // extern "C"

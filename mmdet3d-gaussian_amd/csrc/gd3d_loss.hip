@@ -457,6 +457,10 @@ struct HeadArgs {
   int sin_diff;                // diff_rad_by_sin: add_sin_difference on the yaw column
   float beta, sl1_scale;       // SmoothL1Loss.beta (0 = L1Loss), loss_weight / avg_factor
   float cw[7];
+  // device-resident normaliser (ABI 4): when avg_dev != NULL the two scales are w_gd / *avg_dev and w_sl1 / *avg_dev, divided in
+  // double and rounded once, as the host does with a host-side avg_factor
+  const float* avg_dev;
+  double w_gd, w_sl1;
 };
 
 template <int LOSS, int FUN, bool FLAG>
@@ -502,7 +506,13 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
     decode_anchor(pe, an, pv, Jp);
     decode_anchor(te, an, tv, Jt);
     const float c[3] = {a.c0, a.c1, a.c2};
-    const float f = a.scale * wi;
+    float gd_scale = a.scale, sl1_scale = a.sl1_scale;
+    if (a.avg_dev != nullptr) {
+      const double avg = (double)*a.avg_dev;
+      gd_scale = (float)(a.w_gd / avg);
+      sl1_scale = (float)(a.w_sl1 / avg);
+    }
+    const float f = gd_scale * wi;
     float g1[7], g2[7];
     const float L = pair_loss<LOSS, FUN, FLAG, false>(pv, tv, c, a.alpha, a.ia2, a.tau, f, g1, g2);
     fl = f * L;
@@ -530,9 +540,9 @@ __global__ __launch_bounds__(HEAD_T) void head_anchor_kernel(const HeadArgs a) {
         const float g = quad ? d[k] / a.beta : sg;
         const float w = a.sl1_cw ? wrow[k] * a.cw[k] : 1.0f;
         ls += l * w;
-        gs[k] = g * w * a.sl1_scale * (k == 6 ? j6 : 1.0f);
+        gs[k] = g * w * sl1_scale * (k == 6 ? j6 : 1.0f);
       }
-      fl += a.sl1_scale * ls;
+      fl += sl1_scale * ls;
     }
     if (a.grad_bbox_pred != nullptr) {
       encode_grad(g1, Jp, true);
@@ -1359,7 +1369,7 @@ static int anchor_head_impl(const gd3d_params* p, const gd3d_smooth_l1* sl1, con
                             const float* decode_weight,
                             const float* anchors, const int64_t* pos_inds, const int64_t* labels, int32_t num_classes,
                             int64_t P, float scale, float* loss_sum, float* grad_bbox_pred, void* workspace,
-                            void* stream) {
+                            void* stream, const float* avg_dev = nullptr, double w_gd = 0.0, double w_sl1 = 0.0) {
   if (p == nullptr || P < 0 || B <= 0 || A <= 0 || H <= 0 || W <= 0) return GD3D_E_BADARG;
   if (p->loss_type < 0 || p->loss_type >= GD3D_NUM_LOSS_TYPES) return GD3D_E_BADARG;
   if (p->loss_type == GD3D_KFIOU3D) {
@@ -1406,6 +1416,9 @@ static int anchor_head_impl(const gd3d_params* p, const gd3d_smooth_l1* sl1, con
     for (int k = 0; k < 7; ++k) a.cw[k] = sl1->code_weight[k];
   }
   a.scale = scale;
+  a.avg_dev = avg_dev;
+  a.w_gd = w_gd;
+  a.w_sl1 = w_sl1;
   a.alpha = p->alpha;
   a.ia2 = gd3d_inv_alpha2(p->alpha);
   a.tau = p->tau;
@@ -1457,6 +1470,17 @@ int gd3d_anchor_head_bbox_loss(const gd3d_params* p, const gd3d_smooth_l1* sl1, 
   if (labels != nullptr) P = (int64_t)B * A * H * W;
   return anchor_head_impl(p, sl1, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, pos_inds,
                           labels, num_classes, P, scale, loss_sum, grad_bbox_pred, workspace, stream);
+}
+
+int gd3d_anchor_head_bbox_loss_dyn(const gd3d_params* p, const gd3d_smooth_l1* sl1, const float* bbox_pred, int32_t B,
+                                   int32_t A, int32_t H, int32_t W, const float* bbox_targets, const float* bbox_weights,
+                                   const float* decode_weight, const float* anchors, const int64_t* labels,
+                                   int32_t num_classes, double gd_weight, double sl1_weight, const float* avg_dev,
+                                   float* loss_sum, float* grad_bbox_pred, void* workspace, void* stream) {
+  if (B <= 0 || A <= 0 || H <= 0 || W <= 0 || labels == nullptr || avg_dev == nullptr) return GD3D_E_BADARG;
+  return anchor_head_impl(p, sl1, bbox_pred, B, A, H, W, bbox_targets, bbox_weights, decode_weight, anchors, nullptr, labels,
+                          num_classes, (int64_t)B * A * H * W, 0.0f, loss_sum, grad_bbox_pred, workspace, stream, avg_dev,
+                          gd_weight, sl1_weight);
 }
 
 int gd3d_anchor_head_loss_dense(const gd3d_params* p, const float* bbox_pred, int32_t B, int32_t A, int32_t H, int32_t W,

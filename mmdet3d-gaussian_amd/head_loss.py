@@ -81,11 +81,18 @@ def _anchor_head_launch(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_l
     wp = None if bbox_weights is None else bbox_weights.data_ptr()
     sel = pos_or_labels.data_ptr()
     with torch.cuda.device(dev):
-        rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
-                                            dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
-                                            int(num_classes), scale, buf[0].data_ptr(),
-                                            None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream)
+        if isinstance(scale, tuple):      # (avg_dev, gd_weight, sl1_weight): the normaliser stays on the device (dense form only)
+            avg_dev, w_gd, w_sl1 = scale
+            rc = lib.gd3d_anchor_head_bbox_loss_dyn(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp, dwp,
+                                                    anchors.data_ptr(), sel, int(num_classes), float(w_gd), float(w_sl1), avg_dev.data_ptr(),
+                                                    buf[0].data_ptr(), None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
+                                                dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
+                                                int(num_classes), scale, buf[0].data_ptr(),
+                                                None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, 'gd3d_anchor_head_bbox_loss')
     return buf[0], grad
 
@@ -117,6 +124,14 @@ class _AnchorHeadFused(torch.autograd.Function):
             _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
                                            torch.cuda.current_stream().cuda_stream), 'gd3d_scale_rows')
         return (g,) + (None,) * 10
+
+
+def _avg_tensor(t, dev, who):
+    """num_total_samples as a device-resident normaliser: one fp32 value on `dev`, detached"""
+    if t.numel() != 1 or t.device != dev:
+        raise RuntimeError(f'{who}: a tensor num_total_samples must hold one value on {dev}, got {tuple(t.shape)} on {t.device}')
+    t = t.detach().reshape(())
+    return t if t.dtype == torch.float32 else t.float()
 
 
 def _seven(w, name):
@@ -226,13 +241,18 @@ def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets,
         return bbox_pred.sum() * 0
     if num_total_samples is None:
         num_total_samples = int(bbox_pred.shape[0])      # loss_single: `int(cls_score.shape[0])`, the batch size (:85-86)
+    dyn = isinstance(num_total_samples, torch.Tensor)    # a 0-dim fp32 device tensor: the kernels divide by it (no read-back)
+    if dyn:
+        if not dense:
+            raise RuntimeError('anchor_head_bbox_loss: a device-resident num_total_samples needs the dense form')
+        avg_dev = _avg_tensor(num_total_samples, bbox_pred.device, 'anchor_head_bbox_loss')
     sl1 = _lib.SmoothL1()
     sl1.beta = beta
-    sl1.scale = lw / float(num_total_samples)
+    sl1.scale = 0.0 if dyn else lw / float(num_total_samples)
     sl1.diff_rad_by_sin = int(bool(diff_rad_by_sin))
     sl1.has_code_weight = int(cw is not None)
     sl1.code_weight = (ctypes.c_float * 7)(*(cw or [1.0] * 7))
-    scale = float(loss_decoded_bbox.loss_weight) / float(num_total_samples)
+    scale = (avg_dev, float(loss_decoded_bbox.loss_weight), lw) if dyn else float(loss_decoded_bbox.loss_weight) / float(num_total_samples)
     return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_decoded_bbox._params({}), dw, scale, bool(dense),
                                   int(num_classes), sl1)
 

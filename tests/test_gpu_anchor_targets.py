@@ -300,3 +300,27 @@ def test_random_configurations(seed):
     assert torch.equal(got[2].cpu()[..., [2, 6]], ref[2][..., [2, 6]])
     assert torch.allclose(got[2].cpu()[..., [0, 1, 3, 4, 5]], ref[2][..., [0, 1, 3, 4, 5]], rtol=2e-6, atol=2e-7)
     assert got[6] == ref[6] and got[7] == ref[7]
+
+
+def test_static_form_equals_the_eager_one_bit_for_bit():
+    """the device-resident normaliser (sum_b max(positives_b, 1), divided inside the loss kernels in double and rounded once) gives the
+    bits of the eager form, which divides on the host; losses and gradients"""
+    H, W = 40, 36
+    anchors = kitti_anchors(H, W)
+    pairs = [random_gt(n, seed=80 + i) for i, n in enumerate((11, 0, 6))]
+    pairs[1] = (torch.zeros(0, 7), torch.zeros(0, dtype=torch.long))
+    dev = torch.device('cuda:0')
+    mod = pkg.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    outs = head_outputs(3, H, W, seed=5)
+    res = []
+    for static in (False, True):
+        g = [o.to(dev).requires_grad_(True) for o in outs]
+        r = pkg.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors.to(dev), g[0], g[1], g[2], [p[0].to(dev) for p in pairs],
+                                    [p[1].to(dev) for p in pairs], static=static)
+        (r['loss_cls'][0] + r['loss_bbox'][0] + r['loss_dir'][0]).backward()
+        res.append(([r[k][0].detach().clone() for k in ('loss_cls', 'loss_bbox', 'loss_dir')], [t.grad.clone() for t in g]))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match='one value'):
+        pkg.anchor_head_cls_dir_loss(FOCAL, CE, g[0], g[2], torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev),
+                                     torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev), 3, torch.ones(2, device=dev))
