@@ -22,6 +22,7 @@ def gd_anchor_head_loss_single(loss_cls, loss_bbox, loss_dir, loss_decoded_bbox,
     cls_score (B, A*C, H, W), bbox_pred (B, A*7, H, W), dir_cls_preds (B, A*2, H, W) : the level's raw outputs;
     labels, label_weights, dir_targets, dir_weights (B, H*W*A), bbox_targets, bbox_weights (B, H*W*A, 7), anchor_list
                     (H*W*A, 7) or (H, W, ..., 7) : what mmdet3d's `anchor_target_3d` hands to loss_single.
+    num_total_samples : a number, or a one-element fp32 device tensor (the kernels divide by it: no read-back).
     The reference's `assert labels.max().item() <= self.num_classes` (:90) is a host sync and is not repeated: a label above
     num_classes is background for every term here, as it is for the reference's one-hot and its positive mask.
     Returns (loss_cls, loss_bbox, loss_dir) as the reference does (loss_dir None without direction classifier)."""

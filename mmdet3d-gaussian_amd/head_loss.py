@@ -212,7 +212,8 @@ def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets,
     SmoothL1Loss / L1Loss module itself or anything with `.beta` (absent/0 = L1), `.loss_weight`, `.reduction`, or a
     config dict (`dict(type='SmoothL1Loss', beta=1/9, loss_weight=2.0)`).  code_weight / decode_weight:
     train_cfg entries (list of 7, scalar, or falsy = weight None, :124-131).  diff_rad_by_sin: add_sin_difference
-    (:150-152).  No positives: 0 with a zero gradient (:160-161)."""
+    (:150-152).  No positives: 0 with a zero gradient (:160-161).  num_total_samples: a number, or a one-element fp32 device tensor
+    that the kernel divides the two loss weights by itself (dense form; no read-back of the positives' count)."""
     from .gd_loss import GDLoss
     assert isinstance(loss_decoded_bbox, GDLoss)
     if loss_decoded_bbox.reduction != 'mean':
