@@ -82,3 +82,47 @@ def test_single_sample_layout_and_counts():
     assert pos.numel() == 1 and neg.numel() == 6
     out = ORA.anchor_target_3d(anchors, [box, box[:0]], [torch.tensor([1]), torch.zeros(0, dtype=torch.long)], cfg, 2)
     assert out[6] == 2 and out[7] == 6 + 8            # sum_b max(positives, 1), sum_b max(negatives, 1)
+
+
+# ---- oracle/anchor_infer_torch.py (mmdet3d's inherited inference path) ---------------------------------------------------------------
+def test_delta_decode_inverts_the_encode_and_limit_period_values():
+    from oracle import anchor_infer_torch as AIT
+    g = torch.Generator().manual_seed(0)
+    anchors = torch.rand(50, 7, generator=g, dtype=torch.float64) * torch.tensor([70, 80, 1, 1.5, 3, 0.5, 1.5]) + torch.tensor([0, -40, -2, .6, .9, 1.4, 0])
+    boxes = anchors + torch.randn(50, 7, generator=g, dtype=torch.float64) * 0.2
+    boxes[:, 3:6] = boxes[:, 3:6].abs() + 0.3
+    enc = ORA.delta_encode(anchors, boxes)
+    assert (AIT.delta_decode(anchors, enc) - boxes).abs().max().item() < 1e-12          # the two coders are inverses
+    v = torch.tensor([0.0, 1.0, 3.0, -3.0, 4.0, 7.0], dtype=torch.float64)
+    # limit_period(v, 0.5, pi): into [-pi/2, pi/2);  (v, 0, 2 pi): into [0, 2 pi);  (v, 1, pi): into [-pi, 0)
+    assert torch.allclose(AIT.limit_period(v, 0.5, math.pi), torch.tensor([0.0, 1.0, 3.0 - math.pi, math.pi - 3.0, 4.0 - math.pi, 7.0 - 2 * math.pi], dtype=torch.float64))
+    assert torch.allclose(AIT.limit_period(v, 0.0, 2 * math.pi), torch.tensor([0.0, 1.0, 3.0, 2 * math.pi - 3.0, 4.0, 7.0 - 2 * math.pi], dtype=torch.float64))
+    assert torch.allclose(AIT.limit_period(v, 1.0, math.pi), torch.tensor([-math.pi, 1.0 - math.pi, 3.0 - math.pi, -3.0, 4.0 - 2 * math.pi, 7.0 - 3 * math.pi], dtype=torch.float64))
+
+
+def test_get_bboxes_single_on_a_hand_case():
+    """1 x 2 cells, 2 anchors per cell, 2 classes: four far-apart unit boxes with zero deltas.  Scores (after the sigmoid) by anchor and class:
+    a0 (.9, .2)  a1 (.1, .8)  a2 (.6, .7)  a3 (.05, .05);  nms_pre 3 keeps a0, a1, a2 (best class .9, .8, .7);  score_thr .3: class 0 has
+    a0 (.9), a2 (.6); class 1 has a1 (.8), a2 (.7) — a2 is reported once per class;  no overlaps, so NMS keeps all; max_num 3 cuts the
+    concatenation [a0 .9, a2 .6 | a1 .8, a2 .7] to the three best: .9 (class 0), .8 (class 1), .7 (class 1).  Direction bins 0, 1, 1 with
+    dir_offset 0, dir_limit_offset 1: yaw = limit_period(0, 1, pi) + pi * bin = -pi + pi * bin."""
+    from oracle import anchor_infer_torch as AIT
+    logit = lambda p: math.log(p / (1 - p))          # noqa: E731
+    s = [[.9, .2], [.1, .8], [.6, .7], [.05, .05]]
+    cls = torch.zeros(4, 1, 2)                       # (A * C, H, W), channel = a * C + c
+    for cell in range(2):
+        for a in range(2):
+            for c in range(2):
+                cls[a * 2 + c, 0, cell] = logit(s[cell * 2 + a][c])
+    bbox = torch.zeros(14, 1, 2)
+    dirs = torch.zeros(4, 1, 2)                      # channel = a * 2 + bin
+    for k, b in enumerate([0, 1, 1, 0]):             # anchor k = cell * 2 + a prefers bin b
+        dirs[(k % 2) * 2 + b, 0, k // 2] = 1.0
+    anchors = torch.tensor([[10.0 * k, 0.0, -1.0, 1.0, 1.0, 1.0, 0.0] for k in range(4)])
+    cfg = dict(use_rotate_nms=True, nms_pre=3, nms_thr=0.5, score_thr=0.3, max_num=3)
+    boxes, scores, labels = AIT.get_bboxes_single([cls], [bbox], [dirs], [anchors], cfg, 2, dir_offset=0.0, dir_limit_offset=1.0)
+    assert labels.tolist() == [0, 1, 1]
+    assert torch.allclose(scores, torch.tensor([0.9, 0.8, 0.7]), atol=1e-6)
+    assert boxes[:, 0].tolist() == [0.0, 10.0, 20.0]
+    assert torch.allclose(boxes[:, 6], torch.tensor([-math.pi, 0.0, 0.0]), atol=1e-6)
+    assert torch.allclose(boxes[:, 1:6], torch.tensor([[0.0, -1.0, 1.0, 1.0, 1.0]]).expand(3, 5))
