@@ -126,3 +126,17 @@ def test_get_bboxes_single_on_a_hand_case():
     assert boxes[:, 0].tolist() == [0.0, 10.0, 20.0]
     assert torch.allclose(boxes[:, 6], torch.tensor([-math.pi, 0.0, 0.0]), atol=1e-6)
     assert torch.allclose(boxes[:, 1:6], torch.tensor([[0.0, -1.0, 1.0, 1.0, 1.0]]).expand(3, 5))
+
+
+def test_product_anchor_grid_equals_the_restatement_and_aligned_form_sits_on_cell_centres():
+    """mmdet3d-gaussian_amd/anchors.py (plain torch ops, any device) against oracle range_anchors bit for bit, and the aligned generator's
+    centres against the closed form (cell centres of the range)"""
+    import mmdet3d_gaussian_amd as amd
+    R = [[0.08, -39.60, -0.6, 68.88, 39.44, -0.6]] * 2 + [[0.08, -39.60, -1.78, 68.88, 39.44, -1.78]]
+    S = [[0.8, 0.6, 1.73], [1.76, 0.6, 1.73], [3.9, 1.6, 1.56]]
+    a = amd.anchor3d_range_anchors((20, 18), R, S, [0, 1.57], 'cpu')
+    assert a.shape == (1, 20, 18, 3, 2, 7) and torch.equal(a, ORA.range_anchors((20, 18), R, S, [0, 1.57]))
+    w = amd.anchor3d_range_anchors((4, 8), [[-8., -4., 0.5, 8., 4., 0.5]], [[1., 2., 3.], [2., 2., 2.]], [0., 1.57], 'cpu', aligned=True)
+    assert w.shape == (1, 4, 8, 2, 2, 7)
+    assert w[0, :, 0, 0, 0, 1].tolist() == [-3.0, -1.0, 1.0, 3.0] and w[0, 0, :, 1, 1, 0].tolist() == [-7.0, -5.0, -3.0, -1.0, 1.0, 3.0, 5.0, 7.0]
+    assert w[0, 2, 3, 1, 1].tolist() == [-1.0, 1.0, 0.5, 2.0, 2.0, 2.0, 1.57]
