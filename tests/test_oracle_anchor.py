@@ -139,4 +139,4 @@ def test_product_anchor_grid_equals_the_restatement_and_aligned_form_sits_on_cel
     w = amd.anchor3d_range_anchors((4, 8), [[-8., -4., 0.5, 8., 4., 0.5]], [[1., 2., 3.], [2., 2., 2.]], [0., 1.57], 'cpu', aligned=True)
     assert w.shape == (1, 4, 8, 2, 2, 7)
     assert w[0, :, 0, 0, 0, 1].tolist() == [-3.0, -1.0, 1.0, 3.0] and w[0, 0, :, 1, 1, 0].tolist() == [-7.0, -5.0, -3.0, -1.0, 1.0, 3.0, 5.0, 7.0]
-    assert w[0, 2, 3, 1, 1].tolist() == [-1.0, 1.0, 0.5, 2.0, 2.0, 2.0, 1.57]
+    assert w[0, 2, 3, 1, 1, :6].tolist() == [-1.0, 1.0, 0.5, 2.0, 2.0, 2.0] and abs(w[0, 2, 3, 1, 1, 6].item() - 1.57) < 1e-6
