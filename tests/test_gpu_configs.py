@@ -373,3 +373,55 @@ def test_config5_waymo_nms_three_classes_bit_exact(amd):
     res = amd.nms_gpu_batched(allb, alls, 0.25, allv, pre_max_size=4096, post_max_size=500)
     for c in range(3):
         assert np.array_equal((res[c] - c * 4096).cpu().numpy(), want[c]), c
+
+
+@pytest.mark.parametrize('name', ['kitti', 'waymo'])
+def test_anchor_head_loss_at_the_configs_real_geometry(amd, name):
+    """BASELINE configs[1] / [4] as the anchor head sees them in training: `GDAnchor3DHead.loss` (target assignment + classification,
+    regression, direction losses, forward + backward) at the real grid — KITTI 248 x 216 x 6 anchors, batch 2, per-class assigners;
+    Waymo 468 x 468 x 6, batch 1, every assigner sees every box (the head's default), dir_offset pi/4, aligned anchors.  No CPU
+    restatement finishes at this size in seconds for the whole method, so the check is by properties: the target counts equal the
+    restatement's on the first sample (labels bit for bit), the read-back-free form equals the eager one bit for bit, the gradients of
+    the regression maps are zero exactly off the positives, and the three losses are finite and positive."""
+    from oracle import anchor_targets_torch as ORA
+    from test_gpu_anchor_targets import CE, FOCAL, KITTI_ASSIGNERS, KITTI_RANGES, KITTI_SIZES, SL1, head_outputs, random_gt
+    dev = torch.device('cuda:0')
+    if name == 'kitti':
+        B, H, W, per_class, dir_offset = 2, 248, 216, True, 0.0
+        anchors = amd.anchor3d_range_anchors((H, W), KITTI_RANGES, KITTI_SIZES, [0, 1.57], dev)[0]
+        assigners, sizes = KITTI_ASSIGNERS, KITTI_SIZES
+        gts = [random_gt(18 + 5 * b, seed=200 + b, with_ignored=False) for b in range(B)]
+        mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    else:
+        B, H, W, per_class, dir_offset = 1, 468, 468, False, 0.7854
+        rng = [[-74.88, -74.88, -0.0345, 74.88, 74.88, -0.0345], [-74.88, -74.88, -0.1188, 74.88, 74.88, -0.1188], [-74.88, -74.88, 0.0, 74.88, 74.88, 0.0]]
+        sizes = [[4.73, 2.08, 1.77], [1.81, 0.84, 1.77], [0.91, 0.84, 1.74]]
+        anchors = amd.anchor3d_range_anchors((H, W), rng, sizes, [0, 1.57], dev, aligned=True)[0]
+        assigners = [dict(type='MaxIoUAssigner', iou_calculator=dict(type='BboxOverlapsNearest3D'), pos_iou_thr=p, neg_iou_thr=n, min_pos_iou=n, ignore_iof_thr=-1)
+                     for p, n in ((0.55, 0.4), (0.5, 0.3), (0.5, 0.3))]
+        g = torch.Generator().manual_seed(9)
+        lab = torch.randint(0, 3, (60,), generator=g)
+        box = torch.cat([torch.rand(60, 2, generator=g) * 140 - 70, torch.zeros(60, 1), torch.tensor(sizes)[lab] * (0.8 + 0.4 * torch.rand(60, 3, generator=g)),
+                         (torch.rand(60, 1, generator=g) * 2 - 1) * 3.14159], dim=-1)
+        gts = [(box, lab)]
+        mod = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
+    tcfg = dict(assigner=assigners, allowed_border=0, code_weight=[1.0] * 7, pos_weight=-1, debug=False)
+    boxes, labels = [p[0].to(dev) for p in gts], [p[1].to(dev) for p in gts]
+    tg = amd.anchor_head_get_targets(anchors, boxes, labels, assigners, 3, assign_per_class=per_class, dir_offset=dir_offset)
+    ref = ORA.anchor_target_3d_single(anchors.cpu(), gts[0][0], gts[0][1], assigners, 3, assign_per_class=per_class, dir_offset=dir_offset)
+    assert torch.equal(tg[0][0].cpu(), ref[0]) and torch.equal(tg[4][0].cpu(), ref[4]) and int((ref[0] < 3).sum()) >= len(gts[0][1])
+    outs = head_outputs(B, H, W, seed=3)
+    res = []
+    for static in (False, True):
+        g3 = [o.to(dev).requires_grad_(True) for o in outs]
+        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, g3[0], g3[1], g3[2], boxes, labels, assign_per_class=per_class,
+                                    dir_offset=dir_offset, static=static)
+        losses = [r[k][0] for k in ('loss_cls', 'loss_bbox', 'loss_dir')]
+        (losses[0] + losses[1] + losses[2]).backward()
+        res.append(([l.detach().clone() for l in losses], [t.grad for t in g3]))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.equal(a, b)
+    assert all(torch.isfinite(l).item() and l.item() > 0 for l in res[0][0])
+    pos = (tg[0] < 3).reshape(B, H, W, 6)                                      # (B, H, W, A)
+    gb = res[0][1][1].reshape(B, 6, 7, H, W).permute(0, 3, 4, 1, 2)              # (B, H, W, A, 7)
+    assert gb[~pos].abs().max().item() == 0.0 and gb[pos].abs().max().item() > 0.0
