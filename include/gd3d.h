@@ -352,6 +352,14 @@ int coder_point_decode(const float* priors, const float* preds, int64_t n, int32
 int coder_point_decode_backward(const float* priors, const float* grad_out, const float* out,
                                 const int32_t* num_rot_parity, int64_t n, int32_t c, float* grad_preds, void* stream);
 
+/* The decode in front of PVRCNNBboxHead.get_bboxes' NMS (/root/reference/mmdet3d_gaussian/models/roi_heads/bbox_heads/pvrcnn_bbox_head.py:
+ * 376-386, with mmdet3d's DeltaXYZWLHRBBoxCoder.decode and rotation_3d_in_axis, third party): rois (n, roi_stride) with the box
+ * [x, y, z, dx, dy, dz, yaw] at columns first_col .. first_col + 6 (1 for the head's [batch_id, box] rows), bbox_pred (n, 7) residuals
+ * -> boxes (n, 7) and, if not NULL, bev_xyxyr (n, 5) = [x - dx/2, y - dy/2, x + dx/2, y + dy/2, yaw] as multi_class_nms builds it (:447-448).
+ * clockwise = 0: the centre is turned counter-clockwise by the roi's yaw (mmdet3d 1.0); 1: the transpose (0.x). */
+int coder_roi_decode(const float* rois, int32_t roi_stride, int32_t first_col, const float* bbox_pred, int64_t n,
+                     int32_t clockwise, float* boxes, float* bev_xyxyr, void* stream);
+
 /* Second stage of the reduction on its own: *loss_sum = fixed-order fp64 sum of the per-workgroup
  * partials that gd3d_loss_fused(..., workspace != NULL) left in `workspace` for the same n.
  * gd3d_loss_fused calls it itself when loss_sum != NULL; it is exported so that a caller can

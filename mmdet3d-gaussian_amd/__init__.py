@@ -14,6 +14,7 @@ Exposes the reference's call surface for the one path this package accelerates:
   * ``center_head_get_targets``— CenterPoint target assignment (heat maps, anno_boxes, pos_inds: gd_centerpoint_head.py:65-156)
   * ``gd_anchor_head_loss``    — GDAnchor3DHead.loss end to end: target assignment + the three losses (gd_anchor3d_head.py:167-240)
   * ``gd_anchor_head_loss_single`` — GDAnchor3DHead.loss_single end to end (gd_anchor3d_head.py:62-161)
+  * ``pvrcnn_head_get_bboxes`` — PVRCNNBboxHead.get_bboxes around its NMS (pvrcnn_bbox_head.py:352-480): decode launch + one batched class NMS
   * ``anchor3d_range_anchors`` — the anchor heads' grid (mmdet3d's [Aligned]Anchor3DRangeGenerator, one level, reshape_out=False): static data
   * ``anchor_head_get_targets`` — the anchor heads' target assignment (mmdet3d's anchor_target_3d, called at gd_anchor3d_head.py:206-214)
   * ``anchor_head_cls_dir_loss`` — the anchor heads' focal classification + direction losses in one pass (gd_anchor3d_head.py:84-92, :143-149)
@@ -36,6 +37,7 @@ from .anchor_infer import anchor_head_get_bboxes
 from .anchor_cls import anchor_head_cls_dir_loss
 from .anchor_targets import anchor_head_get_targets
 from .anchors import anchor3d_range_anchors
+from .pvrcnn_infer import pvrcnn_head_get_bboxes
 from .anchor_head import gd_anchor_head_loss, gd_anchor_head_loss_single
 from .center_targets import center_head_get_targets
 from .heat_loss import center_head_heatmap_loss
@@ -53,6 +55,6 @@ def build(force=False, verbose=False):
 
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'box3d_multiclass_nms', 'circle_nms',
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
-           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'PointBBoxYawCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'anchor_head_cls_dir_loss', 'anchor_head_get_targets', 'anchor3d_range_anchors', 'gd_anchor_head_loss_single', 'gd_anchor_head_loss', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
+           'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'PointBBoxYawCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'anchor_head_cls_dir_loss', 'anchor_head_get_targets', 'anchor3d_range_anchors', 'pvrcnn_head_get_bboxes', 'gd_anchor_head_loss_single', 'gd_anchor_head_loss', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
            'trans_bev', 'match_coco', 'LidarCenterTransBEV', 'LidarIOU3D', 'LidarIOUBEV', 'BaseMatcher', 'MatcherCoCo']

@@ -142,6 +142,7 @@ SYMBOLS = {
     'coder_center_decode_backward': (_int, [ctypes.POINTER(Prologue), _vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp]),
     'coder_center_encode': (_int, [_vp, _i64, ctypes.c_int32, _vp, _vp]),
     'coder_point_decode': (_int, [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
+    'coder_roi_decode': (_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp]),
     'coder_point_decode_backward': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp]),
     'gd3d_loss_reduce': (_int, [_vp, _i64, _vp, _vp]),
     'gd3d_scale_rows': (_int, [_vp, _vp, _int, _i64, _vp]),

@@ -173,6 +173,49 @@ __global__ __launch_bounds__(T) void point_decode_bwd_kernel(const PointBwdArgs 
   for (int j = 9; j < a.c; ++j) gp[j] = g[7 + (j - 9)];
 }
 
+// PVRCNNBboxHead.get_bboxes, the decode in front of its NMS (/root/reference/mmdet3d_gaussian/models/roi_heads/bbox_heads/pvrcnn_bbox_head.py:
+// 376-386): DeltaXYZWLHRBBoxCoder.decode (mmdet3d, third party) of the head's residuals against the roi moved to the origin, the
+// centre turned about z by the roi's yaw (mmdet3d rotation_3d_in_axis, third party: counter-clockwise in 1.0, its transpose in 0.x —
+// `clockwise` selects) and moved back; plus the [x1, y1, x2, y2, yaw] rectangle multi_class_nms feeds to nms_gpu (:447-448).
+struct RoiArgs {
+  const float* rois;   // (n, stride) rows [.., x, y, z, dx, dy, dz, yaw] starting at column `first`
+  const float* pred;   // (n, 7)
+  float* boxes;        // (n, 7)
+  float* bev;          // (n, 5) nullable
+  long long n;
+  int stride, first, clockwise;
+};
+
+__global__ __launch_bounds__(T) void roi_decode_kernel(const RoiArgs a) {
+  const long long i = (long long)blockIdx.x * T + threadIdx.x;
+  if (i >= a.n) return;
+  const float* r = a.rois + i * a.stride + a.first;
+  const float* t = a.pred + i * 7;
+  const float wa = r[3], la = r[4], ha = r[5], ra = r[6];
+  // decode against the anchor (0, 0, 0, wa, la, ha, ra)
+  const float za = 0.0f + ha / 2;
+  const float diagonal = sqrtf(la * la + wa * wa);
+  const float xl = t[0] * diagonal + 0.0f;
+  const float yl = t[1] * diagonal + 0.0f;
+  float zg = t[2] * ha + za;
+  const float lg = expf(t[4]) * la;
+  const float wg = expf(t[3]) * wa;
+  const float hg = expf(t[5]) * ha;
+  const float rg = t[6] + ra;
+  zg = zg - hg / 2;
+  float sn, cs;
+  sincosf(ra, &sn, &cs);
+  const float xr = a.clockwise ? xl * cs + yl * sn : xl * cs - yl * sn;
+  const float yr = a.clockwise ? yl * cs - xl * sn : xl * sn + yl * cs;
+  const float x = xr + r[0], y = yr + r[1], z = zg + r[2];
+  float* o = a.boxes + i * 7;
+  o[0] = x; o[1] = y; o[2] = z; o[3] = wg; o[4] = lg; o[5] = hg; o[6] = rg;
+  if (a.bev != nullptr) {
+    float* b = a.bev + i * 5;
+    b[0] = x - wg / 2; b[1] = y - lg / 2; b[2] = x + wg / 2; b[3] = y + lg / 2; b[4] = rg;
+  }
+}
+
 }  // namespace gdcoder
 
 using namespace gdcoder;
@@ -279,6 +322,26 @@ int coder_point_decode_backward(const float* priors, const float* grad_out, cons
   const long long nb = (n + T - 1) / T;
   if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   hipLaunchKernelGGL(point_decode_bwd_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int coder_roi_decode(const float* rois, int32_t roi_stride, int32_t first_col, const float* bbox_pred, int64_t n, int32_t clockwise,
+                     float* boxes, float* bev_xyxyr, void* stream) {
+  if (n < 0 || roi_stride < 7 || first_col < 0 || first_col + 7 > roi_stride) return GD3D_E_BADARG;
+  if (n == 0) return 0;
+  if (rois == nullptr || bbox_pred == nullptr || boxes == nullptr) return GD3D_E_BADARG;
+  RoiArgs a;
+  a.rois = rois;
+  a.pred = bbox_pred;
+  a.boxes = boxes;
+  a.bev = bev_xyxyr;
+  a.n = n;
+  a.stride = roi_stride;
+  a.first = first_col;
+  a.clockwise = clockwise != 0;
+  const long long nb = (n + T - 1) / T;
+  if (nb > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+  hipLaunchKernelGGL(roi_decode_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
