@@ -11,7 +11,7 @@ between mmdet3d 0.x and 1.0 — `clockwise` selects (default: 1.0's counter-cloc
 import torch
 
 from . import _lib
-from .iou3d import multi_class_nms_batch
+from .iou3d import _thresh_tensor, nms_gpu_batched
 
 
 def pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred, cfg, batch_size=None, clockwise=False, return_decoded=False):
@@ -52,18 +52,30 @@ def pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred,
     probs = torch.cat([p.to(dev) for p in class_pred], dim=0).float()           # sample-major = the order of `order`
     labels = torch.cat([l.to(dev) for l in class_labels], dim=0)
     scores = cls_score.reshape(-1)[order]
-    boxes_s, bev_s, bid_s = boxes[order], bev[order], bid[order]
-    kept = multi_class_nms_batch(probs, bev_s, bid_s, B, get('score_thr'), get('nms_thr'), use_rotate_nms=get('use_rotate_nms'))
+    boxes_s, bev_s = boxes[order], bev[order]
+    # group (sample b, class k) = the rois of sample b (a contiguous range of the sample-major order) with probability >= score_thr[k]:
+    # the class problems of every sample as ONE batched NMS (the per-sample, per-class loops of :393-405 and :455-475), one read-back
+    C = probs.shape[1]
+    st = get('score_thr') if isinstance(get('score_thr'), (list, tuple)) else [get('score_thr')] * C
+    nt = list(get('nms_thr')) if isinstance(get('nms_thr'), (list, tuple)) else [get('nms_thr')] * C
     starts = [0]
     for n in sizes:
         starts.append(starts[-1] + n)
+    above = probs.t() >= _thresh_tensor(st, C, dev).unsqueeze(1)                       # (C, R)
+    pos = torch.arange(R, device=dev)
+    lo = torch.tensor(starts[:-1], device=dev).unsqueeze(1)
+    hi = torch.tensor(starts[1:], device=dev).unsqueeze(1)
+    member = (pos.unsqueeze(0) >= lo) & (pos.unsqueeze(0) < hi)                       # (B, R)
+    valid = (member.unsqueeze(1) & above.unsqueeze(0)).reshape(B * C, R)
+    rank = probs.t().unsqueeze(0).expand(B, C, R).reshape(B * C, R).contiguous()
+    kept = nms_gpu_batched(bev_s, rank, nt * B, valid, normal=not get('use_rotate_nms'))
     out = []
     for b in range(B):
-        sel = kept[b]
-        if isinstance(sel, list):          # nothing kept: the reference indexes with `[]`
-            out.append((boxes_s[starts[b]:starts[b]][:0], scores[:0], labels[:0]))
+        sel = [k for k in kept[b * C:(b + 1) * C] if k.shape[0] > 0]
+        if not sel:                        # nothing kept: the reference indexes with `[]`
+            out.append((boxes_s[:0], scores[:0], labels[:0]))
             continue
-        g = sel + starts[b]
+        g = torch.cat(sel, dim=0) if len(sel) > 1 else sel[0]
         out.append((boxes_s[g], scores[g], labels[g]))
     if return_decoded:
         return out, (boxes, bev)
