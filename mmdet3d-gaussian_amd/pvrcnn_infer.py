@@ -3,7 +3,7 @@
 
 The reference decodes the residuals with ~15 elementwise ops, reads the batch size back (`roi_batch_id.max().item()`), then loops over
 the samples, and inside `multi_class_nms` over the classes with two host syncs each around `nms_gpu`.  Here: one decode launch
-(csrc/coders.hip `roi_decode_kernel`), the class problems of all samples as ONE batched NMS (`multi_class_nms_batch`), one read-back.
+(csrc/coders.hip `roi_decode_kernel`), the class problems of all samples as ONE batched NMS (`nms_gpu_batched` over (sample, class) groups), one read-back.
 mmdet3d's `DeltaXYZWLHRBBoxCoder.decode` and `rotation_3d_in_axis` are third party and absent: restated; the rotation's sense changed
 between mmdet3d 0.x and 1.0 — `clockwise` selects (default: 1.0's counter-clockwise, which the reference's call without the 0.x
 `+ pi / 2` matches).  GPU tensors only.
