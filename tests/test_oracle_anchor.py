@@ -140,3 +140,22 @@ def test_product_anchor_grid_equals_the_restatement_and_aligned_form_sits_on_cel
     assert w.shape == (1, 4, 8, 2, 2, 7)
     assert w[0, :, 0, 0, 0, 1].tolist() == [-3.0, -1.0, 1.0, 3.0] and w[0, 0, :, 1, 1, 0].tolist() == [-7.0, -5.0, -3.0, -1.0, 1.0, 3.0, 5.0, 7.0]
     assert w[0, 2, 3, 1, 1, :6].tolist() == [-1.0, 1.0, 0.5, 2.0, 2.0, 2.0] and abs(w[0, 2, 3, 1, 1, 6].item() - 1.57) < 1e-6
+
+
+def test_pvrcnn_decode_restatement_on_a_hand_case():
+    """oracle/pvrcnn_torch.py decode_rois: a residual of one diagonal along the roi's own x axis puts the centre at
+    roi + diagonal * (cos ry, sin ry) counter-clockwise (mmdet3d 1.0), at (cos ry, -sin ry) clockwise; sizes exp-scaled, yaw added;
+    multi_class_nms keeps class after class and returns [] when nothing reaches the thresholds"""
+    from oracle import pvrcnn_torch as PV
+    rois = torch.tensor([[0., 1.0, 2.0, -1.0, 3.0, 4.0, 2.0, 0.5]])
+    pred = torch.tensor([[1.0, 0.0, 0.25, math.log(2.0), 0.0, math.log(0.5), 0.1]])
+    for cw, sgn in ((False, 1.0), (True, -1.0)):
+        b = PV.decode_rois(rois, pred, clockwise=cw)[0]
+        # z: anchor centre 0 + 2/2 = 1, decoded centre 0.25 * 2 + 1 = 1.5, new height 1 -> bottom 1.0; + roi z -1 -> 0.0
+        want = [1.0 + 5.0 * math.cos(0.5), 2.0 + sgn * 5.0 * math.sin(0.5), 0.0, 6.0, 4.0, 1.0, 0.6]
+        assert all(abs(x - y) < 1e-5 for x, y in zip(b.tolist(), want)), (b.tolist(), want)
+    boxes = torch.tensor([[0., 0., 0., 2., 2., 1., 0.], [0.1, 0., 0., 2., 2., 1., 0.], [10., 0., 0., 2., 2., 1., 0.]])
+    probs = torch.tensor([[0.9, 0.1], [0.8, 0.6], [0.2, 0.7]])
+    sel = PV.multi_class_nms(probs, boxes, [0.5, 0.5], 0.1)
+    assert sel.tolist() == [0, 2, 1]          # class 0: boxes 0, 1 overlap -> 0; class 1: 2 (0.7) then 1 (0.6), far apart
+    assert PV.multi_class_nms(probs, boxes, 0.95, 0.1) == []
