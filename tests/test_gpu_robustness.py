@@ -175,3 +175,44 @@ def test_dispatch_bound_events_time_the_fused_kernel_and_change_nothing(amd):
     assert ms * 1e-3 >= 84.0 * 1_000_003 / 8e12
     del timers[:]
     time.sleep(0)  # timers destroyed here: hipEventDestroy through the ABI must not raise
+
+
+def test_anchor_head_entry_points_take_half_precision_and_strided_inputs(amd):
+    """the round-3 head slices under AMP-like conditions: bf16 / fp16 head maps (computed in fp32, gradients cast back to the maps' dtype),
+    channels-last (non-contiguous) maps, int32 labels, ground truth on another dtype: the same values as the plain fp32 call within the
+    input rounding"""
+    from test_gpu_anchor_targets import CE, FOCAL, SL1, TRAIN_CFG, head_outputs, kitti_anchors, random_gt
+    dev = torch.device('cuda:0')
+    H, W = 24, 20
+    anchors = kitti_anchors(H, W).to(dev)
+    b, l = random_gt(9, seed=3, with_ignored=False)
+    outs = [o.to(dev) for o in head_outputs(2, H, W, seed=2)]
+    mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
+
+    def run(maps, boxes, labels):
+        maps = [m.clone().requires_grad_(True) for m in maps]
+        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, maps[0], maps[1], maps[2], boxes, labels)
+        tot = r['loss_cls'][0] + r['loss_bbox'][0] + r['loss_dir'][0]
+        tot.backward()
+        return [r[k][0].detach().float() for k in ('loss_cls', 'loss_bbox', 'loss_dir')], [m.grad for m in maps]
+    base_l, base_g = run(outs, [b.to(dev)] * 2, [l.to(dev)] * 2)
+    for dtype, tol in ((torch.bfloat16, 3e-2), (torch.float16, 4e-3)):
+        ls, gs = run([o.to(dtype) for o in outs], [b.to(dev).double()] * 2, [l.to(dev).int()] * 2)
+        assert all(g.dtype == dtype for g in gs)
+        for x, y in zip(ls, base_l):
+            assert abs(x.item() - y.item()) <= tol * (1 + abs(y.item()))
+    cl = [o.to(memory_format=torch.channels_last) for o in outs]
+    assert not cl[0].is_contiguous()
+    ls, gs = run(cl, [b.to(dev)] * 2, [l.to(dev)] * 2)
+    for x, y in zip(ls, base_l):
+        assert x.item() == y.item()
+    for g, y in zip(gs, base_g):
+        assert torch.equal(g.contiguous(), y)
+    # inference side: bf16 maps in, fp32 boxes out, same detections as from the maps rounded to bf16 and widened again
+    cfg = dict(use_rotate_nms=True, nms_pre=256, nms_thr=0.01, score_thr=0.05, max_num=50)
+    flat = anchors.reshape(-1, 7)
+    wide = [o.to(torch.bfloat16).float() for o in outs]
+    a = amd.anchor_head_get_bboxes([outs[0].to(torch.bfloat16)], [outs[1].to(torch.bfloat16)], [outs[2].to(torch.bfloat16)], [flat], cfg, 3, 0.0, 1.0)
+    c = amd.anchor_head_get_bboxes([wide[0]], [wide[1]], [wide[2]], [flat], cfg, 3, 0.0, 1.0)
+    for x, y in zip(a, c):
+        assert x[0].shape == y[0].shape and torch.allclose(x[0].float(), y[0], rtol=1e-2, atol=1e-2) and torch.equal(x[2], y[2])
