@@ -61,6 +61,9 @@ grep -E "Name|acls|head_anchor|reduce_partials" /tmp/kt_ac/ac_kernel_stats.csv >
 python3 tests/perf/anchor_targets_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_anchor_targets_time.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_at -o at -- python3 tests/perf/anchor_targets_time.py > /dev/null 2>&1
 grep -E "Name|atgt" /tmp/kt_at/at_kernel_stats.csv > $OUT/${R}_anchor_targets_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_anchor_$c -o p -- python3 tools/anchor_pmc_driver.py > /dev/null 2>&1; done
+python3 tools/pmc_summary.py "/tmp/pmc_anchor_*/**/*counter_collection.csv" --kernel atgt > $OUT/${R}_anchor_pmc.txt
+python3 tools/pmc_summary.py "/tmp/pmc_anchor_*/**/*counter_collection.csv" --kernel acls >> $OUT/${R}_anchor_pmc.txt
 python3 tests/perf/pvrcnn_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_pvrcnn_infer_time.jsonl
 python3 tests/perf/center_head_loss_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_head_loss_time.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_hl -o hl -- python3 tests/perf/center_head_loss_time.py > /dev/null 2>&1
