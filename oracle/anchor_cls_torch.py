@@ -6,6 +6,8 @@ The classification and direction terms of GDAnchor3DHead.loss_single as plain to
 with the two loss modules they call, both mmdet's (third party, absent: restated from the published 2.x text — PARITY UNPINNED):
   FocalLoss(use_sigmoid=True)            py_sigmoid_focal_loss + weight_reduce_loss(mean, avg_factor)
   CrossEntropyLoss(use_sigmoid=False)    F.cross_entropy(reduction='none') * weight, then the same reduction
+(On a GPU mmdet routes the same loss through mmcv's fused sigmoid_focal_loss op, which evaluates log(max(p, FLT_MIN)): the same
+values up to |logit| ~ 87, a clamp beyond; this restatement and the kernel follow the unclamped formula.)
 Never imported by the product package."""
 import torch
 import torch.nn.functional as F
