@@ -191,7 +191,7 @@ __global__ __launch_bounds__(T) void cls_dir_finish_kernel(const float* __restri
   s1[threadIdx.x] = b;
   __syncthreads();
   for (int off = T / 2; off >= 1; off >>= 1) {
-    if (threadIdx.x < off) {
+    if ((int)threadIdx.x < off) {
       s0[threadIdx.x] += s0[threadIdx.x + off];
       s1[threadIdx.x] += s1[threadIdx.x + off];
     }
