@@ -157,7 +157,7 @@ __global__ __launch_bounds__(T) void focal_finish_kernel(const FinArgs a) {
   sp[threadIdx.x] = p;
   __syncthreads();
   for (int off = T / 2; off >= 1; off >>= 1) {
-    if (threadIdx.x < off) {
+    if ((int)threadIdx.x < off) {
       sl[threadIdx.x] += sl[threadIdx.x + off];
       sp[threadIdx.x] += sp[threadIdx.x + off];
     }

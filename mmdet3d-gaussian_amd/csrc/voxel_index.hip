@@ -78,7 +78,7 @@ __global__ __launch_bounds__(T) void extent_kernel(const int* __restrict__ coors
     }
   }
   __syncthreads();
-  if (threadIdx.x < ndim) atomicMax(&ext[threadIdx.x], smax[threadIdx.x] + 1);   // extent = max(coordinate, 0) + 1
+  if ((int)threadIdx.x < ndim) atomicMax(&ext[threadIdx.x], smax[threadIdx.x] + 1);   // extent = max(coordinate, 0) + 1
 }
 
 struct Radix {
