@@ -39,7 +39,7 @@ def _assigner(cfg):
 def anchor_head_get_targets(anchors, gt_bboxes, gt_labels, assigner, num_classes, assign_per_class=True, pos_weight=-1, dir_offset=0.0,
                             num_dir_bins=2, sampling=False, padded=False):
     """anchors    : one level's grid as the generator returns it with reshape_out=False: (H, W, S, R, 7), a leading 1 allowed
-                 ((1, H, W, S, R, 7)); S size classes, R rotations;
+                 ((1, H, W, S, R, 7)); S size classes, R rotations; with a single assigner also the flat (N, 7) list of reshape_out=True;
     gt_bboxes  : per sample a box object with `.tensor` (G, 7+) or a plain (G, 7+) tensor [x, y, z, dx, dy, dz, yaw] (bottom centre,
                  as LiDARInstance3DBoxes stores it);  gt_labels: per sample (G,) integer labels;
     assigner   : train_cfg.assigner — a list of S MaxIoUAssigner configs (dicts or objects with pos_iou_thr, neg_iou_thr, min_pos_iou;
@@ -57,12 +57,16 @@ def anchor_head_get_targets(anchors, gt_bboxes, gt_labels, assigner, num_classes
         raise RuntimeError(f'anchor_head_get_targets: {B} box sets and {len(gt_labels)} label sets')
     if anchors.dim() == 6 and anchors.shape[0] == 1:
         anchors = anchors[0]
+    single = not isinstance(assigner, (list, tuple))
+    if anchors.dim() == 2 and anchors.shape[-1] == 7 and single:
+        # reshape_out=True (the car-only configs): a flat (N, 7) list in the head's order; one assigner sees all of it, so the grid's shape
+        # does not matter
+        anchors = anchors.reshape(-1, 1, 1, 1, 7)
     if anchors.dim() != 5 or anchors.shape[-1] != 7:
         raise RuntimeError(f'anchor_head_get_targets: anchors {tuple(anchors.shape)} are not (H, W, sizes, rotations, 7)')
     if not anchors.is_cuda:
         raise RuntimeError('anchor_head_get_targets: the MI355X implementation has no CPU path')
     H, W, S, R, _ = anchors.shape
-    single = not isinstance(assigner, (list, tuple))
     cfgs = [_assigner(assigner)] if single else [_assigner(c) for c in assigner]
     if not single and len(cfgs) != S:
         raise RuntimeError(f'anchor_head_get_targets: {len(cfgs)} assigners for {S} anchor sizes')

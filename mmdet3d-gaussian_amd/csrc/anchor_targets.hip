@@ -450,7 +450,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   // tile: about 768 anchors (3 rounds of the 256 threads), a power of two of cells
   const int SR = d.num_sizes * d.num_rots;
   int tile_cells = 1;
-  while (tile_cells * 2 * SR <= 768 && tile_cells < 128) tile_cells *= 2;   // measured at KITTI geometry: 192 / 384 / 768 / 1536 anchors per
+  while (tile_cells * 2 * SR <= 768 && tile_cells < 512) tile_cells *= 2;   // measured at KITTI geometry: 192 / 384 / 768 / 1536 anchors per
                                                                           // tile -> 165 / 108 / 83 / 85 us for the two passes
   const int g_cap = (g_max + 3) & ~3;
   const size_t lds1 = (size_t)g_cap * 28 + (size_t)K * g_cap * 8;

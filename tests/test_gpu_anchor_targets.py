@@ -324,3 +324,26 @@ def test_static_form_equals_the_eager_one_bit_for_bit():
     with pytest.raises(RuntimeError, match='one value'):
         pkg.anchor_head_cls_dir_loss(FOCAL, CE, g[0], g[2], torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev),
                                      torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev), 3, torch.ones(2, device=dev))
+
+
+def test_car_only_config_flat_anchors_single_assigner():
+    """configs/kitti/hv_pointpillars_secfpn_6x8_160e_kitti-3d-car.py: one size, reshape_out=True (anchors arrive as a flat (N, 7) list),
+    ONE MaxIoUAssigner (0.6 / 0.45 / 0.45), one class"""
+    H, W = 62, 54
+    grid = ORA.range_anchors((H, W), [[0, -39.68, -1.78, 69.12, 39.68, -1.78]], [[1.6, 3.9, 1.56]], [0, 1.57])[0]      # (H, W, 1, 2, 7)
+    flat = grid.reshape(-1, 7)
+    one = dict(type='MaxIoUAssigner', iou_calculator=dict(type='BboxOverlapsNearest3D'), pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45,
+               ignore_iof_thr=-1)
+    g = torch.Generator().manual_seed(3)
+    boxes = [torch.cat([torch.rand(n, 1, generator=g) * 69, torch.rand(n, 1, generator=g) * 78 - 39, torch.full((n, 1), -1.7),
+                        torch.tensor([[1.6, 3.9, 1.56]]) * (0.8 + 0.4 * torch.rand(n, 3, generator=g)), (torch.rand(n, 1, generator=g) * 2 - 1) * math.pi], -1)
+             for n in (15, 0, 7)]
+    labels = [torch.zeros(b.shape[0], dtype=torch.long) for b in boxes]
+    ref = ORA.anchor_target_3d(grid, boxes, labels, one, 1)
+    dev = torch.device('cuda:0')
+    for an in (flat, grid):
+        got = pkg.anchor_head_get_targets(an.to(dev), [b.to(dev) for b in boxes], [l.to(dev) for l in labels], one, 1)
+        for k in (0, 1, 3, 4, 5):
+            assert torch.equal(got[k].cpu(), ref[k])
+        assert torch.allclose(got[2].cpu(), ref[2], rtol=2e-6, atol=2e-7) and got[6] == ref[6] and got[7] == ref[7]
+    assert int((ref[0] < 1).sum()) >= 10          # a rotated box whose best nearest-BEV overlap stays below min_pos_iou gets no anchor
