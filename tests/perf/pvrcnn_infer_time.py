@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """PVRCNNBboxHead.get_bboxes (pvrcnn_bbox_head.py:352-480) on the GPU, us per call (synchronised): 100 and 512 rois per sample, batch 4,
-3 classes.
+3 classes, the reference's own thresholds (nms_thr 0.01, score_thr 0.1).
 ours  = pvrcnn_head_get_bboxes (decode launch, one batched class NMS for all samples, one read-back)
 eager = the reference's statements (oracle/pvrcnn_torch.py's) on device tensors with THIS package's nms_gpu per (sample, class), incl. the
         reference's `roi_batch_id.max().item()`.  Asserts equal detections first."""
@@ -19,7 +19,8 @@ from oracle import pvrcnn_torch as ORA  # noqa: E402
 from test_gpu_pvrcnn_infer import make  # noqa: E402
 
 dev = torch.device('cuda:0')
-CFG = dict(use_rotate_nms=True, nms_thr=[0.1, 0.2, 0.05], score_thr=[0.3, 0.5, 0.2])
+# test_cfg.rcnn of configs/kitti/hv_pvrcnn_secfpn_4x4_80e_kitti-3d-3class.py:259-262 (rpn nms_post = 100 rois per sample, :253)
+CFG = dict(use_rotate_nms=True, nms_thr=[0.01] * 3, score_thr=[0.1] * 3)
 
 
 def timeit(fn, it, warm=3):
