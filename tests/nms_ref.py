@@ -1,0 +1,139 @@
+"""Helpers of the NMS cross-check against the reference's own rotated-IoU arithmetic (tests/golden/nms_ref_iou.npz).
+
+The reference holds one rotated-IoU implementation: ops/eval/affinity.cpp:51-81 (`iou_bev`) over rbox_utils.hpp:280-302.
+tests/golden/make_golden_nms_ref_iou.py runs the box sets of the NMS call sites (gd_centerpoint_head.py:336-345) through that
+code compiled unchanged (oracle/_ref), and stores per set
+
+    boxes (n,5) [x1,y1,x2,y2,ry], scores (n,), thr, pre, post
+    order (m,)                 stable descending score order, cut to `pre`
+    nz_i, nz_j, nz_iou         every pair i < j (positions in `order`) whose REFERENCE IoU is > 0
+    near_i, near_j, near_exact pairs whose reference IoU lies within BAND of thr, with the fp64 IoU of the same fp32 boxes
+                               (exact_iou_xyxyr below): the arbiter where two fp32 evaluations disagree
+    keep_ref                   greedy keep list (positions in `order`) derived from that matrix: j is dropped iff a kept i < j
+                               has iou_ref(i, j) > thr
+
+A second fp32 evaluation of the same geometry cannot reproduce the reference's IoU values bit for bit (different
+intersection algorithm; both work in absolute coordinates, where a coordinate of 70 m carries 7.6e-6 m of rounding), so a
+decision whose reference IoU sits within `band` of the threshold may legitimately fall either way.  `uncertain()` propagates
+that: a box is uncertain when its own decision, or the state of a box that could suppress it, is within the band.  Outside the
+uncertain set a keep list must agree with `keep_ref` EXACTLY.
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_ref_iou.npz')
+SETS = ('waymo0', 'waymo1', 'waymo2', 'nuscenes', 'pvrcnn', 'rpn9000', 'origin')
+BAND = 1e-4   # |iou_ref - thr| below which a decision is treated as undecidable between two fp32 evaluations
+
+
+def to_eval7(boxes_xyxyr):
+    """[x1,y1,x2,y2,ry] -> the (x, y, ., w, h, ., yaw) rows affinity.cpp reads (:65-66), in fp32 as the NMS kernel forms centre
+    and extent.  mmdet3d's iou3d rotates corners CLOCKWISE by ry (rotate_around_center), rbox_utils.hpp:52-71 counter-clockwise
+    by its angle: yaw = -ry describes the same rectangle (sin(-x) = -sin(x) exactly in fp32)."""
+    b = np.asarray(boxes_xyxyr, np.float32)
+    o = np.zeros((b.shape[0], 7), np.float32)
+    o[:, 0] = (b[:, 0] + b[:, 2]) / np.float32(2)
+    o[:, 1] = (b[:, 1] + b[:, 3]) / np.float32(2)
+    o[:, 3] = b[:, 2] - b[:, 0]
+    o[:, 4] = b[:, 3] - b[:, 1]
+    o[:, 6] = -b[:, 4]
+    return o
+
+
+def exact_iou_xyxyr(a, b):
+    """IoU of two [x1,y1,x2,y2,ry] boxes (fp32 inputs taken as exact) by Sutherland-Hodgman clipping in fp64: the arbiter
+    when two fp32 evaluations disagree.  Pure Python, for a handful of pairs."""
+    def corners(x):
+        x = np.asarray(x, np.float64)
+        cx, cy, w, h = (x[0] + x[2]) / 2, (x[1] + x[3]) / 2, x[2] - x[0], x[3] - x[1]
+        c, s = np.cos(-x[4]), np.sin(-x[4])          # iou3d turns clockwise by ry
+        local = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]])
+        return local @ np.array([[c, s], [-s, c]]) + np.array([cx, cy])
+
+    def area(p):
+        p = np.asarray(p, np.float64).reshape(-1, 2)
+        if len(p) < 3:
+            return 0.0
+        return 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))
+
+    P, Q = corners(a), corners(b)
+    sgn = np.sign(np.sum(Q[:, 0] * np.roll(Q[:, 1], -1) - np.roll(Q[:, 0], -1) * Q[:, 1]))
+    poly = [tuple(p) for p in P]
+    for k in range(4):
+        A, B = Q[k], Q[(k + 1) % 4]
+
+        def side(p):
+            return sgn * ((B[0] - A[0]) * (p[1] - A[1]) - (B[1] - A[1]) * (p[0] - A[0]))
+        nxt = []
+        for i, cur in enumerate(poly):
+            prev = poly[i - 1]
+            dc, dp = side(cur), side(prev)
+            if (dc >= 0) != (dp >= 0):
+                t = dp / (dp - dc)
+                nxt.append((prev[0] + t * (cur[0] - prev[0]), prev[1] + t * (cur[1] - prev[1])))
+            if dc >= 0:
+                nxt.append(cur)
+        poly = nxt
+        if not poly:
+            break
+    inter = area(poly)
+    return inter / max(area(P) + area(Q) - inter, 1e-300)
+
+
+def greedy(m, nz_i, nz_j, nz_iou, thr):
+    """Keep flags of the greedy scan over a sparse upper-triangular IoU matrix (pairs sorted by (i, j))."""
+    dead = np.zeros(m, bool)
+    start = np.searchsorted(nz_i, np.arange(m + 1))
+    over = nz_iou > np.float32(thr)
+    for i in range(m):
+        if dead[i]:
+            continue
+        s, e = start[i], start[i + 1]
+        dead[nz_j[s:e][over[s:e]]] = True
+    return ~dead
+
+
+def uncertain(m, nz_i, nz_j, nz_iou, thr, band=BAND):
+    """(certain_keep, certain_drop, uncertain) boolean arrays over positions 0..m-1; see the module docstring."""
+    thr = np.float64(np.float32(thr))
+    iou = nz_iou.astype(np.float64)
+    # incoming pairs of every j, in increasing i
+    by_j = np.lexsort((nz_i, nz_j))
+    jj, ii, vv = nz_j[by_j], nz_i[by_j], iou[by_j]
+    start = np.searchsorted(jj, np.arange(m + 1))
+    state = np.zeros(m, np.int8)   # 0 certainly kept, 1 certainly dropped, 2 uncertain
+    for j in range(m):
+        s, e = start[j], start[j + 1]
+        if s == e:
+            continue
+        src, v = ii[s:e], vv[s:e]
+        st = state[src]
+        if np.any((st == 0) & (v > thr + band)):
+            state[j] = 1
+        elif np.any((st != 1) & (np.abs(v - thr) <= band)) or np.any((st == 2) & (v > thr)):
+            state[j] = 2
+    return state == 0, state == 1, state == 2
+
+
+def load(name):
+    z = np.load(GOLDEN)
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + '.')}
+    g['thr'] = float(g['thr']); g['pre'] = int(g['pre']); g['post'] = int(g['post'])
+    return g
+
+
+def compare_keep(g, keep_idx, band=BAND):
+    """`keep_idx`: indices into the ORIGINAL box list as nms_gpu returns them (no post cut).  Returns
+    (n_uncertain, n_disagree_outside_uncertain, n_disagree_total)."""
+    order = g['order']
+    m = len(order)
+    pos = np.full(len(g['scores']), -1, np.int64)
+    pos[order] = np.arange(m)
+    got = np.zeros(m, bool)
+    got[pos[np.asarray(keep_idx, np.int64)]] = True
+    ref = np.zeros(m, bool)
+    ref[g['keep_ref']] = True
+    _, _, unc = uncertain(m, g['nz_i'], g['nz_j'], g['nz_iou'], g['thr'], band)
+    dis = got != ref
+    return int(unc.sum()), int((dis & ~unc).sum()), int(dis.sum())
