@@ -37,7 +37,16 @@ already wrote the final gradients (a plain `loss.backward()` costs a ones-fill p
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
 (python -m torch.distributed.run, 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank failed.
 
+Rehearsal of the N > 1 control flow without GPUs: `--device cpu --backend gloo` runs the same rank loop (shard ranges,
+per-step asynchronous gather of the three shard losses, MAX-reduce of the elapsed time, one JSON line from rank 0) on CPU
+tensors through GDLoss's `_cpu` twins (tests/test_bench_rehearsal.py); the line then says "device": "cpu" in `config` and
+carries no roofline claim.
+
 The JSON line also carries
+  value_plain_backward, roofline.frac_step_plain_backward : the same step ending in a plain `(l0 + l1 + l2).backward()` (what
+                 every reference caller does: mmcv's OptimizerHook calls loss.backward()), timed over a second, shorter region
+                 right after the main one (N = 1, eager).  The headline step hands the library's unit gradient to
+                 torch.autograd.backward instead, which saves a ones-fill and three early-exit launches (~10 us per step).
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
                  (88 B/pair) / average launch duration measured with a HIP event pair bound to
                  every fused dispatch, on the stream it is launched on.  `frac` is that kernel alone;
@@ -143,7 +152,40 @@ def cpu_baseline(sample_pairs, seed):
                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall; single thread: {n1} pairs x 3 '
                      f'losses in {dt1:.2f} s'}
     out['torch_chain'] = torch_chain_baseline(min(sample_pairs, 1_000_000), seed, cores)
+    out['product_cpu'] = product_cpu_baseline(min(sample_pairs, 4_000_000), seed, cores)
     return out
+
+
+def product_cpu_baseline(sample_pairs, seed, cores):
+    """The PRODUCT's own CPU path on the same workload: GDLoss on CPU tensors -> gd3d_loss_fused_cpu (the fused kernel's
+    per-pair math compiled for the host, csrc/gd3d_cpu.cpp; what a machine without a GPU runs), forward + backward through
+    the module surface, with all granted cores and with one thread."""
+    import mmdet3d_gaussian_amd as amd
+    pred, tgt = synthetic_pairs(sample_pairs, seed, torch.device('cpu'))
+    mods = [amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0, reduction='mean', loss_weight=5.0))
+            for lt in LOSSES]
+    res = {'unit': 'M box-pairs/s'}
+    keep = torch.get_num_threads()
+    try:
+        for label, nt, n in ((f'threads_{cores}', cores, sample_pairs), ('threads_1', 1, max(sample_pairs // 8, 1))):
+            torch.set_num_threads(nt)
+            p = pred[:n].clone().requires_grad_(True)
+            for m in mods:      # untimed pass: page in, start the thread team
+                m(p[:100_000], tgt[:100_000]).backward()
+            reps, t0 = 0, time.perf_counter()
+            while True:
+                for m in mods:
+                    p.grad = None
+                    m(p, tgt[:n]).backward()
+                reps += 1
+                if time.perf_counter() - t0 >= 2.0 or reps >= 16:
+                    break
+            res[label] = round(3 * n * reps / (time.perf_counter() - t0) / 1e6, 3)
+    finally:
+        torch.set_num_threads(keep)
+    res['sample'] = (f'{sample_pairs} pairs x 3 losses, GDLoss forward + backward on CPU tensors (gd3d_loss_fused_cpu, std::thread '
+                     f'team of torch.get_num_threads()); single thread on {max(sample_pairs // 8, 1)} pairs')
+    return res
 
 
 def cpu_model():
@@ -254,6 +296,13 @@ def measure_traffic(pairs, timeout_s=120):
                  'tallied at half) + WRITE_SIZE x 1024')
 
 
+# Environment every rank needs BEFORE its first HIP call, whoever launched it (this file's self_launch, the driver's
+# `python -m torch.distributed.run ...`, a cluster scheduler).  The reference's launcher sets its rendezvous in
+# tools/dist_train.sh:8-9 and nothing else; on these hosts RCCL additionally needs dmabuf IPC (the legacy IPC mode fails with
+# `hipIpcGetMemHandle: invalid argument`).
+RCCL_ENV_DEFAULTS = {'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -267,7 +316,7 @@ def launch_command(n, argv, port):
             '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(n, argv, visible, cmd=None, out=None, err=None):
+def self_launch(n, argv, visible, cmd=None, out=None, err=None, need_gpus=True):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched
     the GPU and never replaces itself), relay rank 0's JSON line to stdout, everything else the children print to
     stderr, and return their exit status (non-zero if any rank failed, or if no result line appeared).
@@ -275,12 +324,13 @@ def self_launch(n, argv, visible, cmd=None, out=None, err=None):
     import subprocess
     out = out or sys.stdout
     err = err or sys.stderr
-    if visible < n:
+    if need_gpus and visible < n:
         print(f'bench.py: {n} GPUs requested, {visible} visible', file=err, flush=True)
         return 2
     cmd = cmd or launch_command(n, argv, free_port())
     env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on these hosts
+    for k, v in RCCL_ENV_DEFAULTS.items():   # the ranks set them again themselves (main): whichever launcher starts them
+        env.setdefault(k, v)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, text=True, env=env)
     lines = 0
     for line in proc.stdout:
@@ -329,29 +379,50 @@ def main():
                          'region, the kernel durations then come from an eager pass right after it)')
     ap.add_argument('--no-traffic', action='store_true',
                     help='skip the two rocprofv3 --pmc passes that count HBM bytes per launch (roofline.traffic; N = 1 only, ~40 s)')
+    ap.add_argument('--device', choices=('cuda', 'cpu'), default='cuda',
+                    help="cpu: rehearse the rank loop on CPU tensors through GDLoss's _cpu twins (no roofline claim)")
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default=None, help='torch.distributed backend (default: nccl = RCCL on cuda, gloo on cpu)')
+    ap.add_argument('--plain-steps', type=int, default=-1,
+                    help='steps of the second region that ends in a plain (l0+l1+l2).backward() (default: half of --steps, at least 10; 0 = skip)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    for k, v in RCCL_ENV_DEFAULTS.items():   # before anything touches the GPU, on every launch path
+        os.environ.setdefault(k, v)
+    on_gpu = args.device == 'cuda'
+    backend = args.backend or ('nccl' if on_gpu else 'gloo')
 
     if args.pmc_child:
         pmc_child(args.pairs)
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # no launcher around us: be the launcher (device_count() does not initialise the GPU)
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:], torch.cuda.device_count()))
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], torch.cuda.device_count() if on_gpu else 0, need_gpus=on_gpu))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (the metric is a GPU figure; `--device cpu --backend gloo` only rehearses the rank loop)')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    else:
+        dev = torch.device('cpu')
+        torch.set_num_threads(max(1, usable_cores() // max(world, 1)))
     use_dist = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)  # torchrun, even with 1 rank
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    use_graph = (args.graph or world > 1) and not args.no_graph
+        if on_gpu:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    use_graph = on_gpu and (args.graph or world > 1) and not args.no_graph
+    fail_rank = int(os.environ.get('GD3D_BENCH_FAIL_RANK', '-1'))   # tests: this rank dies after the warmup steps
+
+    def device_sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
 
     import mmdet3d_gaussian_amd as amd
     from mmdet3d_gaussian_amd import gd_loss as gdl
@@ -372,18 +443,18 @@ def main():
 
     unit = [gdl.unit_grad(dev)] * len(LOSSES)
 
-    def compute(record):
+    def compute(record, plain=False):
         """gwd3d, kld3d, bd3d: GDLoss forward each, then ONE autograd backward over the three losses (every loss's fused
         kernel has already produced its gradient; with the library's unit gradient as upstream gradient backward launches
-        nothing).  Returns the 3 detached loss scalars (N > 1: stacked into the (3,) tensor the per-step collective
-        sends — inside the captured graph)."""
+        nothing).  `plain`: end in `(l0 + l1 + l2).backward()` as the reference's callers do.  Returns the 3 detached loss
+        scalars (N > 1: stacked into the (3,) tensor the per-step collective sends — inside the captured graph)."""
         losses_ = []
         for lt in LOSSES:
-            gdl.PROFILE_EVENTS = events[lt] if record else None
+            gdl.PROFILE_EVENTS = events[lt] if (record and on_gpu) else None
             preds[lt].grad = None
             losses_.append(mods[lt](preds[lt], tgt))
         gdl.PROFILE_EVENTS = None
-        if args.sum_backward:
+        if args.sum_backward or plain:
             (losses_[0] + losses_[1] + losses_[2]).backward()
         else:
             torch.autograd.backward(losses_, grad_tensors=unit)
@@ -416,9 +487,9 @@ def main():
                 graph = None
                 graph_note = 'hipGraph capture failed on another rank; eager launches'
 
-    def step(record):
+    def step(record, plain=False):
         if graph is None:
-            outs = compute(record)
+            outs = compute(record, plain)
         else:
             graph.replay()   # nothing else enters the stream: no event brackets (marker packets) in the timed region
             # the collective reads its input on RCCL's stream while the next replay may already run: give it a private
@@ -430,10 +501,10 @@ def main():
             last['outs'] = outs
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        device_sync()
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            device_sync()
 
     # a fresh box starts at its idle clocks and a 30 ms benchmark can be over before they have ramped: run untimed
     # steps for a fixed wall time first (same step function; the W warmup steps still follow, then exactly K timed ones)
@@ -444,7 +515,7 @@ def main():
     # more than a plain one on this ROCm (round 3: the same eager step ran 13.7 us over the sum of its three fused kernels
     # without events, tools/step_variants.py, and 28.7 us over it with events on every launch), so timing EVERY launch in
     # the region taxes `value` by 3.5 %; every fifth step keeps the durations in-region and the tax under 1 %.
-    every = max(args.event_every, 0)
+    every = max(args.event_every, 0) if on_gpu else 0
     tick = [0]
 
     def sampled():
@@ -454,13 +525,15 @@ def main():
     if args.prewarm > 0:
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm:
-            for _ in range(20):
+            for _ in range(20 if on_gpu else 1):
                 step(sampled())
-            torch.cuda.synchronize(dev)
+            device_sync()
             for lt in LOSSES:
                 events[lt].clear()
     for _ in range(args.warmup):
         step(sampled())
+    if rank == fail_rank:
+        os._exit(3)
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
@@ -469,18 +542,24 @@ def main():
     for _ in range(args.steps):
         step(sampled())
     host_enqueue = time.perf_counter() - t0   # host time to enqueue all steps (GPU-bound iff this < elapsed)
-    torch.cuda.synchronize(dev)
+    device_sync()
+    if use_dist and not on_gpu:
+        last['pending'].result()                # gloo: the last step's gather is part of the step
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.barrier()
-        torch.cuda.synchronize(dev)
-        elapsed = tt.item()
+        device_sync()
+        return tt.item()
+    elapsed = max_over_ranks(elapsed)
     timing = (f'HIP event pair bound to the fused dispatches of every {every}-th step inside the timed region '
               '(hipExtLaunchKernel start/stop events: begin/end timestamps of the dispatch itself, no marker packets)')
     replay_ms = None
-    if graph is None and not any(events[lt] for lt in LOSSES):   # --event-every 0: an eager pass right after the region
+    if on_gpu and graph is None and not any(events[lt] for lt in LOSSES):   # --event-every 0: an eager pass right after the region
         for it in range(25):
             compute(True)
             if it == 4:
@@ -515,6 +594,23 @@ def main():
         kern_ms[lt] = sum(d) / max(len(d), 1)
         kern_med[lt] = d[len(d) // 2] if d else 0.0
         kern_min[lt] = d[0] if d else 0.0
+    # Second, shorter region: the same step ending in a plain `(l0 + l1 + l2).backward()` — what every reference caller does
+    # (mmcv's OptimizerHook, set up from tools/train.py:213-220).  Eager launches only (a captured graph would need its own
+    # capture of the other backward); same barrier + synchronize brackets and MAX over ranks as the main region.
+    plain_steps = args.plain_steps if args.plain_steps >= 0 else max(10, args.steps // 2)
+    plain_elapsed = None
+    if graph is None and plain_steps > 0 and not args.sum_backward:
+        for _ in range(5):
+            step(False, plain=True)
+        sync_all()
+        tp = time.perf_counter()
+        for _ in range(plain_steps):
+            step(False, plain=True)
+        device_sync()
+        if use_dist and not on_gpu:
+            last['pending'].result()
+        plain_elapsed = max_over_ranks(time.perf_counter() - tp)
+
     if use_dist:
         total, per_rank = last['pending'].result()   # (3,), (world, 3)
         vals = (total / world).tolist()               # mean over ranks of per-rank means (equal shard sizes)
@@ -528,7 +624,7 @@ def main():
     # (measured on every loss's own buffer triple: which three buffers are combined moves both the kernel and the probe by
     #  up to 5 %, DESIGN.md §5.3, so the ceiling that belongs to the dominant kernel is the one of ITS buffers)
     probe_by_loss = {}
-    if rank == 0 and n > 0 and (7 * n) % 4 == 0:
+    if rank == 0 and on_gpu and n > 0 and (7 * n) % 4 == 0:
         lib = amd.load_library()
         stream = torch.cuda.current_stream().cuda_stream
         for lt in LOSSES:
@@ -557,11 +653,11 @@ def main():
         moved = MOVED_BYTES_PER_PAIR * n / dom_s / 1e9 if dom_s > 0 else 0.0
         ceiling = MOVED_BYTES_PER_PAIR * n / (probe_ms * 1e-3) / 1e9 if probe_ms else None
         traffic, traffic_by_loss, traffic_note = None, {}, None
-        if world == 1 and not args.no_traffic and not args.strong:
+        if world == 1 and on_gpu and not args.no_traffic and not args.strong:
             traffic_by_loss, traffic_note = measure_traffic(n)
             traffic = traffic_by_loss.get(dom)
-        if traffic is None:   # the counters could not be collected here: fall back to the committed collection, and say so
-            why = traffic_note if (world == 1 and not args.no_traffic) else 'not collected in this run (--no-traffic or N > 1)'
+        if traffic is None and on_gpu:   # the counters could not be collected here: fall back to the committed collection, and say so
+            why = traffic_note if (world == 1 and on_gpu and not args.no_traffic) else 'not collected in this run (--no-traffic, --device cpu or N > 1)'
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.isfile(tpath):
                 try:
@@ -575,6 +671,10 @@ def main():
             'value': round(value, 2), 'unit': 'M box-pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            # the same step ending in a plain (l0 + l1 + l2).backward(), second region of `plain_backward_steps` steps
+            'value_plain_backward': round(job_value(args.pairs, world, args.strong, plain_steps, plain_elapsed), 2) if plain_elapsed else None,
+            'ms_per_step_plain_backward': round(plain_elapsed / plain_steps * 1e3, 4) if plain_elapsed else None,
+            'plain_backward_steps': plain_steps if plain_elapsed else 0,
             'config': {'workload': (f'{args.pairs} synthetic anchor x gt 7-dof box pairs in total, row ranges of {n} per GPU '
                                     if args.strong else
                                     f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
@@ -584,13 +684,16 @@ def main():
                                    + '; fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
-                       'collective': 'all_gather of (3,) shard losses per step over RCCL, async' if use_dist else None,
+                       'device': 'MI355X (HIP kernels)' if on_gpu else f'cpu (rehearsal: GDLoss _cpu twins, {torch.get_num_threads()} threads per rank; not the metric)',
+                       'collective': (f'all_gather of (3,) shard losses per step over {"RCCL" if backend == "nccl" else backend}, async') if use_dist else None,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
                        'graph_replay_ms_per_step': round(replay_ms, 4) if replay_ms is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4),
                          # the whole timed step priced like the kernel (reduce launches and backward included)
                          'achieved_step': round(step_gbps, 1), 'frac_step': round(step_gbps / HBM_PEAK_GBPS, 4),
+                         'frac_step_plain_backward': (round(BYTES_PER_PAIR * n * len(LOSSES) / (plain_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
+                                                      if plain_elapsed else None),
                          'traffic': traffic,
                          'traffic_source': traffic_note, 'traffic_by_loss': traffic_by_loss or None,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
@@ -611,6 +714,8 @@ def main():
                                                  for k, v in kern_ms.items()}},
             'loss_values': {k: round(v, 6) for k, v in losses.items()},
         }
+        if not on_gpu:   # a rehearsal of the rank loop on host memory: no roofline claim
+            line['roofline'] = None
         if args.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
         print(json.dumps(line), flush=True)

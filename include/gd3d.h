@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD3D_ABI_VERSION 4
+#define GD3D_ABI_VERSION 5
 
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
@@ -372,6 +372,27 @@ int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* st
  * exactly 1.0f, so the common `loss.backward()` costs one empty launch and no HBM traffic
  * and no host sync.  (Replaces the autograd mul nodes of `* self.loss_weight`, :310.) */
 int gd3d_scale_rows(float* grad, const float* g, int per_row, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * `_cpu` twins: the same contracts on HOST memory, no stream, no HIP call — they run on a machine
+ * without a GPU.  The reference's GDLoss.forward is device-agnostic (gaussian_distance_loss.py:280-310: the same op chain
+ * on CPU tensors, BASELINE configs[0]); these entry points are what a CPU tensor takes in this library.  They evaluate the
+ * kernel's own per-pair closed forms and hand-derived gradients (csrc/gd3d_device.h compiled for the host), one pass,
+ * loss and final gradients together, over `nthreads` host threads (<= 0: std::thread::hardware_concurrency()).
+ *   gd3d_loss_fused_cpu : contract of gd3d_loss_fused_w7 (row_weight / weight7 mutually exclusive, n == 0 legal).
+ *       workspace: gd3d_loss_workspace_bytes(n) bytes of host memory, required when loss_sum != NULL; whenever given it
+ *       receives one fp32 partial per 256-pair tile (fp64 accumulation in row order, rounded once).  *loss_sum = the
+ *       fixed-order fp64 sum of those partials, rounded to fp32: independent of nthreads.
+ *   gd3d_loss_reduce_cpu: the second stage alone (twin of gd3d_loss_reduce).
+ *   gd3d_scale_rows_cpu : twin of gd3d_scale_rows (g is host memory; per_row == 0 and g[0] == 1 touches nothing).
+ * The bbox-coder prologues (gd3d_loss_fused_decoded) have no CPU twin: the head-level fusions are GPU-only.
+ * ---------------------------------------------------------------------------------- */
+int gd3d_loss_fused_cpu(const gd3d_params* params, const float* pred, const float* target,
+                        const float* row_weight, const float* weight7, int64_t n, float scale,
+                        float* loss, float* loss_sum, float* grad_pred, float* grad_target,
+                        void* workspace, int32_t nthreads);
+int gd3d_loss_reduce_cpu(const void* workspace, int64_t n, float* loss_sum);
+int gd3d_scale_rows_cpu(float* grad, const float* g, int per_row, int64_t n, int32_t nthreads);
 
 /* ------------------------------------------------------------------------------------
  * Rotated BEV NMS.  Replaces mmdet3d `iou3d_cuda.nms_gpu(boxes, keep, thresh, device)`

@@ -111,6 +111,9 @@ SYMBOLS = {
     'gd3d_one_launch_max_n': (_i64, []),
     'gd3d_loss_fused_one_launch': (_int, [ctypes.POINTER(Params), ctypes.POINTER(Prologue), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
+    'gd3d_loss_fused_cpu': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32]),
+    'gd3d_loss_reduce_cpu': (_int, [_vp, _i64, _vp]),
+    'gd3d_scale_rows_cpu': (_int, [_vp, _vp, _int, _i64, ctypes.c_int32]),
     'gd3d_grad_finish': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(Prologue), _vp]),
     'gd3d_probe_stream': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'gd3d_prof_event_create': (_int, [ctypes.POINTER(_vp)]),
@@ -206,7 +209,7 @@ def lib_path():
     return _build.LIB_PATH
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def _bind(path):

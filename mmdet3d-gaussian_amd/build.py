@@ -35,9 +35,24 @@ SOURCES = {
 }
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
+# host translation units (the `_cpu` twins of include/gd3d.h): compiled by the ROCm toolchain's own clang++ as plain C++
+# (csrc/gd3d_device.h uses clang vector extensions), for the x86-64-v3 level (AVX2 + FMA: the per-pair math is written in
+# explicit fmaf(), which must be an instruction, not a libm call), same contraction mode as the device build of the loss
+HOST_SOURCES = {
+    'gd3d_cpu.cpp': ['-march=x86-64-v3', '-ffp-contract=fast', '-pthread'],
+}
+HOST_COMMON = ['-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+
 
 def hipcc_path():
     return shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+def host_cxx_path():
+    for c in ('/opt/rocm/lib/llvm/bin/clang++', '/opt/rocm/llvm/bin/clang++', shutil.which('amdclang++') or ''):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('the ROCm clang++ (host compiler of the _cpu twins) was not found next to hipcc')
 
 
 def _deps():
@@ -86,6 +101,10 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         jobs.append((src, obj, [hipcc] + COMMON + flags + ['-c', path, '-o', obj]))
+    for src, flags in HOST_SOURCES.items():
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src.replace('.cpp', '.o'))
+        jobs.append((src, obj, [host_cxx_path()] + HOST_COMMON + flags + ['-c', path, '-o', obj]))
 
     def compile_one(job):
         src, obj, cmd = job
@@ -93,14 +112,14 @@ def build(force=False, verbose=False):
             print(' '.join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
+            raise RuntimeError(f'compiling {src} failed:\n{r.stderr[-4000:]}')
         return obj
     # the translation units are independent: one hipcc per core, at most 8 (each takes 5-25 s and ~1 GB)
     workers = max(1, min(8, os.cpu_count() or 1, len(jobs)))
     with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
         objs = list(pool.map(compile_one, jobs))
     tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')

@@ -9,7 +9,11 @@
 // torch autograd applies to the reference graph (clamp: pass-through on the closed interval;
 // clamp(0).sqrt(): 0 for u < 0, +inf slope at u == 0; maximum/minimum: ties split 1/2).
 #pragma once
+#ifdef GD3D_HOST_TWIN   // csrc/gd3d_cpu.cpp: the `_cpu` twins run this same per-pair math on the host
+#include "gd3d_host_math.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include "../../include/gd3d.h"
 

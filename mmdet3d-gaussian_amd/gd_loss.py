@@ -7,7 +7,11 @@ host logic (reduction override, all-zero-weight early-out, (N,7)->(N,) weight me
 loss functions are wrapped in there (:42,109,144,...).  What differs is below the module: the
 reference runs preprocess x2 + ~110-145 ATen ops + autograd; here one fused kernel computes the
 loss AND the final gradient(s) in a single pass over the (N,7) rows (csrc/gd3d_loss.hip), reached
-through the C ABI of include/gd3d.h.  There is no CPU path: CPU tensors raise.
+through the C ABI of include/gd3d.h.
+
+Like the reference module (whose forward is device-agnostic, :280-310), GDLoss follows the device of its tensors: GPU tensors
+take the HIP kernels, CPU tensors the library's `_cpu` twins (gd3d_loss_fused_cpu: the kernel's own per-pair math compiled
+for the host, csrc/gd3d_cpu.cpp).  The two never substitute for each other: a GPU tensor whose kernel cannot run raises.
 """
 import ctypes
 import os
@@ -116,10 +120,8 @@ def _library():
 
 
 def _rows(t):
-    """(…,7) any float dtype -> contiguous fp32 (N,7) on the GPU (the hot path is fp32: heads call it
+    """(…,7) any float dtype -> contiguous fp32 (N,7), on the device it lives on (the hot path is fp32: heads call it
     under @force_fp32, gd_anchor3d_head.py:167)."""
-    if not t.is_cuda:
-        raise RuntimeError('GDLoss: the MI355X implementation has no CPU path; tensors must be on the GPU')
     if t.dim() != 2 or t.shape[1] != 7:
         t = t.reshape(-1, 7)
     if t.dtype != torch.float32:
@@ -186,18 +188,45 @@ def unit_grad(device):
     ADDRESS (no read, no sync): the gradients the fused forward launch wrote are already final and backward launches
     nothing.  Never write to the returned tensor."""
     dev = torch.device(device)
-    if dev.type != 'cuda':
-        raise RuntimeError('unit_grad: the MI355X implementation has no CPU path')
-    idx = dev.index if dev.index is not None else _get_device()
+    if dev.type == 'cpu':
+        idx = 'cpu'
+    elif dev.type == 'cuda':
+        idx = dev.index if dev.index is not None else _get_device()
+    else:
+        raise RuntimeError(f'unit_grad: no implementation for device type {dev.type!r}')
     t = _UNIT_GRAD.get(idx)
     if t is None:
-        t = _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=torch.device('cuda', idx))
+        t = _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=dev if idx == 'cpu' else torch.device('cuda', idx))
     return t
 
 
 def _is_unit_grad(g):
-    t = _UNIT_GRAD.get(g.device.index)
+    t = _UNIT_GRAD.get(g.device.index if g.is_cuda else 'cpu')
     return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0 and g.dtype == torch.float32
+
+
+def _fused_call_cpu(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt):
+    """The `_cpu` twin of the fused launch: host tensors in and out, torch's intra-op thread count as the team size."""
+    lib = _library()
+    n = pred.shape[0]
+    loss = torch.empty(n, dtype=torch.float32) if want_loss else None
+    gp = torch.empty_like(pred) if want_gp else None
+    gt = torch.empty_like(target) if want_gt else None
+    total = ws = None
+    if want_sum:
+        buf = torch.empty(4 + _ws_floats(n), dtype=torch.float32)
+        total, ws = buf[0], buf.data_ptr() + 16
+    w1 = w7 = None
+    if row_weight is not None:
+        if row_weight.dim() == 2:
+            w7 = row_weight.data_ptr()
+        else:
+            w1 = row_weight.data_ptr()
+    rc = lib.gd3d_loss_fused_cpu(params, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale, _ptr(loss), _ptr(total),
+                                 _ptr(gp), _ptr(gt), ws, torch.get_num_threads())
+    if rc != 0:
+        _lib.check(rc, 'gd3d_loss_fused_cpu')
+    return loss, total, gp, gt, None
 
 
 def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None,
@@ -208,6 +237,10 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
                 (gd3d_loss_fused_select); the returned `any_pos` is (buffer that owns it, address) of the int32 device
                 flag backward needs.
     Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None, any_pos|None)."""
+    if not pred.is_cuda:
+        if prologue is not None or select:
+            raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue, on-device weight selection) are GPU-only')
+        return _fused_call_cpu(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt)
     lib = _library()
     n = pred.shape[0]
     dev = pred.device
@@ -305,6 +338,13 @@ class _GDReduced(torch.autograd.Function):
             # the library's own constant 1.0 (unit_grad): known by address, nothing to read, nothing to scale
             return gp, gt, None, None, None, None, None, None
         g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
+        if not pred.is_cuda:   # `_cpu` twin of gd3d_scale_rows (selection never happens on the CPU: GDLoss.forward)
+            g = g.reshape(1)
+            for arr in (gp, gt):
+                if arr is not None:
+                    _lib.check(lib.gd3d_scale_rows_cpu(arr.data_ptr(), g.data_ptr(), 0, pred.shape[0], torch.get_num_threads()),
+                               'gd3d_scale_rows_cpu')
+            return gp, gt, None, None, None, None, None, None
         dev = pred.device
         prev = _get_device()
         switch = prev != dev.index
@@ -407,7 +447,7 @@ class GDLoss(nn.Module):
         # there) for particular shapes, which cannot be decided from the device.
         select = False
         if weight is not None and reduction != 'none':
-            if weight.shape == pred.shape and weight.is_cuda and not _HOST_WEIGHT_CHECK:
+            if weight.shape == pred.shape and weight.is_cuda and pred.is_cuda and not _HOST_WEIGHT_CHECK:
                 select = True
             elif not torch.any(weight > 0):
                 return (pred * weight).sum()
@@ -420,6 +460,10 @@ class GDLoss(nn.Module):
         t = _rows(target)
         if p.shape != t.shape:
             raise RuntimeError(f'pred {tuple(pred.shape)} and target {tuple(target.shape)} disagree')
+        if p.device != t.device:
+            raise RuntimeError(f'pred is on {p.device} and target on {t.device}')
+        if prologue is not None and not p.is_cuda:
+            raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue) are GPU-only')
         n = p.shape[0]
         w = None
         if weight is not None:

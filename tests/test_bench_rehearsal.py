@@ -1,0 +1,126 @@
+"""Rehearsal of bench.py's N > 1 control flow without GPUs: the same rank loop — shard ranges, per-step
+asynchronous gather of the three shard losses, MAX-reduce of the elapsed time, exactly one JSON line from rank 0, non-zero
+exit when a rank dies — under `python -m torch.distributed.run` (the driver's launcher) and under bench.py's own self-launch,
+with `--backend gloo --device cpu` (CPU tensors through GDLoss's `_cpu` twins).  What an 8-GPU node's first run then has left
+to discover is RCCL itself.  Reference counterpart of the launcher: tools/dist_train.sh:8-9."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+COMMON = ['--backend', 'gloo', '--device', 'cpu', '--steps', '4', '--warmup', '2', '--prewarm', '0', '--cpu-sample', '0', '--plain-steps', '3']
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra)
+    return env
+
+
+def _torchrun(n, args, **env):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_port()), BENCH, '--gpus', str(n)] + COMMON + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(**env), cwd=ROOT)
+
+
+def _result_lines(stdout):
+    out = []
+    for line in stdout.splitlines():
+        if line.lstrip().startswith('{'):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if 'metric' in d:
+                out.append(d)
+    return out
+
+
+def _expected_losses(world, rows_of_rank):
+    """Mean over ranks of the per-rank mean loss x 5 (bench.py seeds rank r's pairs with r), from the fp64 oracle."""
+    sys.path.insert(0, ROOT)
+    import bench
+    vals = np.zeros(3)
+    for r in range(world):
+        p, t = bench.synthetic_pairs(rows_of_rank(r), r, torch.device('cpu'))
+        for k, lt in enumerate(bench.LOSSES):
+            n = p.shape[0]
+            vals[k] += oracle.gd_loss(p.numpy(), t.numpy(), oracle.make_params(lt, fun='log1p', tau=1.0), scale=5.0 / n)['loss_sum']
+    return vals / world
+
+
+def test_two_ranks_under_the_drivers_launcher_weak_scaling():
+    r = _torchrun(2, ['--pairs', '20000'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _result_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['roofline'] is None
+    assert d['config']['pairs_per_gpu'] == 20000 and d['config']['parallelism'] == 'pair-sharded x2'
+    assert 'gloo' in d['config']['collective'] and d['config']['device'].startswith('cpu')
+    # whole-job value: 3 losses x 20 000 pairs x 2 ranks x 4 steps over the max-over-ranks time
+    assert abs(d['value'] - 3 * 20000 * 2 * 4 / (d['ms_per_step'] * 4e-3) / 1e6) <= 0.02 * d['value']
+    assert d['plain_backward_steps'] == 3 and d['value_plain_backward'] > 0
+    want = _expected_losses(2, lambda rank: 20000)
+    got = np.array([d['loss_values'][k] for k in ('gwd3d', 'kld3d', 'bd3d')])
+    assert np.all(np.abs(got - want) <= 1e-5 * (1 + np.abs(want))), (got, want)
+
+
+def test_three_ranks_strong_scaling_contiguous_row_ranges():
+    r = _torchrun(3, ['--pairs', '30001', '--strong'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _result_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 3 and d['config']['pairs_per_gpu'] == 30001 * 1 // 3
+    assert abs(d['value'] - 3 * 30001 * 4 / (d['ms_per_step'] * 4e-3) / 1e6) <= 0.02 * d['value']
+
+
+def test_self_launch_starts_the_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it: bench.py is the launcher (children only, never a re-exec)."""
+    cmd = [sys.executable, BENCH, '--gpus', '2', '--pairs', '8000'] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(_result_lines(r.stdout)) == 1 and r.stdout.count('\n') == 1
+
+
+def test_a_dying_rank_fails_the_job_and_prints_no_result():
+    r = _torchrun(2, ['--pairs', '8000'], GD3D_BENCH_FAIL_RANK='1')
+    assert r.returncode != 0
+    assert _result_lines(r.stdout) == []
+    cmd = [sys.executable, BENCH, '--gpus', '2', '--pairs', '8000'] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(GD3D_BENCH_FAIL_RANK='0'), cwd=ROOT)
+    assert r.returncode != 0 and _result_lines(r.stdout) == []
+
+
+def test_every_launch_path_gets_the_rccl_environment_defaults():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; RCCL fails without it on these hosts) is set by main() itself before anything
+    touches the GPU — not only by self_launch — and an explicit setting of the user's survives."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.RCCL_ENV_DEFAULTS == {'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+    src = open(BENCH).read()
+    main_body = src[src.index('def main():'):]
+    assert main_body.index('RCCL_ENV_DEFAULTS') < main_body.index('init_process_group') < main_body.index('import mmdet3d_gaussian_amd')
+    probe = ("import os, sys; sys.argv = ['bench.py', '--pmc-child', '--pairs', '0']; sys.path.insert(0, %r); import bench\n"
+             "try:\n    bench.main()\nexcept BaseException:\n    pass\nprint('IPC=' + os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset'))" % ROOT)
+    env = _env(); env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)
+    r = subprocess.run([sys.executable, '-c', probe], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert 'IPC=0' in r.stdout, (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, '-c', probe], capture_output=True, text=True, timeout=120, env=_env(HSA_ENABLE_IPC_MODE_LEGACY='1'), cwd=ROOT)
+    assert 'IPC=1' in r.stdout

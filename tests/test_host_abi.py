@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_queries_without_gpu():
     lib = amd.load_library()
     arch = ctypes.c_char_p()
-    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 4
+    assert lib.gd3d_abi_version(ctypes.byref(arch)) == 5
     assert arch.value == b'gfx950'
     assert lib.gd3d_loss_workspace_bytes(0) >= 16
     assert lib.gd3d_loss_workspace_bytes(10_000_000) >= 4 * ((10_000_000 + 255) // 256)
@@ -82,18 +82,28 @@ def test_make_params_flags_and_unknown_kwargs():
         amd.make_params('kld3d', 'none', 0.0, 1.0, (0, 0, 0.5), {'normalize': True})      # ref: unexpected kwarg
 
 
-def test_no_cpu_fallback():
+def test_cpu_tensors_take_the_cpu_twin_and_gpu_tensors_never_do():
+    """SURVEY.md §8b `_cpu` twins: GDLoss follows the device of its tensors like the reference module
+    (gaussian_distance_loss.py:280-310).  CPU tensors run gd3d_loss_fused_cpu (the kernel's per-pair math compiled for the
+    host, not the oracle); a tensor that says it is on the GPU goes to the HIP entry points and nowhere else — on this
+    GPU-less machine that attempt fails loudly instead of being answered by the CPU twin.  The GPU-only ops (mmdet3d's nms_gpu
+    has no CPU form either) keep raising on CPU tensors."""
     m = amd.GDLoss('gwd3d')
-    with pytest.raises(RuntimeError, match='no CPU path'):
-        m(torch.rand(4, 7), torch.rand(4, 7))
+    out = m(torch.rand(4, 7) + 0.5, torch.rand(4, 7) + 0.5)
+    assert out.dim() == 0 and torch.isfinite(out)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception) as info:       # the HIP path is taken (and cannot run here); no silent CPU answer
+            m(_FakeCuda(4), _FakeCuda(4))
+        assert not isinstance(info.value, AssertionError)
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.nms_gpu(torch.rand(4, 5), torch.rand(4), 0.5)
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.iou_3d(torch.rand(4, 7), torch.rand(4, 7))
     with pytest.raises(ValueError):
         # avg_factor with reduction='sum' is rejected before any device work (mmdet weight_reduce_loss)
-        amd.GDLoss('gwd3d', reduction='sum')(torch.rand(4, 7).to('meta') if False else _FakeCuda(4), _FakeCuda(4),
-                                             avg_factor=2.0)
+        amd.GDLoss('gwd3d', reduction='sum')(_FakeCuda(4), _FakeCuda(4), avg_factor=2.0)
+    with pytest.raises(ValueError):
+        amd.GDLoss('gwd3d', reduction='sum')(torch.rand(4, 7), torch.rand(4, 7), avg_factor=2.0)
 
 
 class _FakeCuda(torch.Tensor):
