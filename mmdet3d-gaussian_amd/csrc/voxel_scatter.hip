@@ -297,6 +297,193 @@ __global__ __launch_bounds__(256) void spread_grad_v4_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-staged forms for rows that are not whole 16-byte vectors (c = 3, 9, 10: the xyz mean and 3x3 covariance reduces of
+// the reference's PointVoxelStatsCalculator, models/voxel_encoders/utils.py:56,63-64, and its 10-channel pillar features)
+// and for narrow rows in general.  The sub-wave-per-voxel kernels above keep 4 rows x c dwords in flight per voxel: at
+// c = 10 that is 640 B per wave and the kernel sits at 1.9 TB/s, latency-bound.  Here a workgroup owns GV consecutive
+// voxels = one CONTIGUOUS run of `order`; it
+//   1. gathers the run's point rows into LDS as one flat dword stream — thread t moves elements t, t + 256, ... of the
+//      concatenated rows, so a wave instruction covers 64 consecutive dwords = 64 / c whole rows (a handful of cache lines
+//      instead of 64) and every thread has GATHER_U independent loads in flight;
+//   2. reduces from LDS: thread = one (voxel, channel) pair, walking the voxel's points in ascending point id at stride c —
+//      the same visiting order and arithmetic as the kernels above, hence the same bits — and writes `out` as one
+//      contiguous run of GV * c floats.
+// Runs longer than the tile are taken in several tiles with the accumulators carried in registers.
+constexpr int LDS_TILE_FLOATS = 8192;   // point-row floats staged per tile (32 KB)
+constexpr int LDS_MAX_TP = 1024;        // points per tile, at most
+constexpr int LDS_MAX_GV = 128;         // voxels per workgroup, at most
+constexpr int LDS_PAIRS = 2;            // (voxel, channel) pairs per thread: GV * c <= 512
+constexpr int GATHER_U = 8;
+
+struct LdsPlan {
+  int gv, tp;
+  unsigned magic;   // floor(2^32 / c) + 1: f / c == __umulhi(f, magic) for f * c < 2^32
+  size_t lds;
+  long long blocks;
+};
+
+static bool lds_plan(int c, long long n, long long v, bool backward, LdsPlan& p) {
+  if (c > 128 || v <= 0) return false;
+  p.tp = LDS_TILE_FLOATS / c;
+  if (p.tp > LDS_MAX_TP) p.tp = LDS_MAX_TP;
+  p.gv = 256 * LDS_PAIRS / c;
+  if (p.gv > LDS_MAX_GV) p.gv = LDS_MAX_GV;
+  // most workgroups should need ONE tile: voxels per workgroup from the average run length (n / v, known on the host)
+  const double avg = (double)n / (double)v;
+  const int fit = (int)(0.8 * p.tp / (avg > 1.0 ? avg : 1.0));
+  if (fit < p.gv) p.gv = fit < 1 ? 1 : fit;
+  p.magic = (unsigned)(0x100000000ULL / (unsigned)c) + 1u;
+  p.blocks = (v + p.gv - 1) / p.gv;
+  // segl (LDS_MAX_GV + 4 ints) | pids (tp ints) | forward: tile (tp * c floats); backward: vloc (tp ints), rows (2 x GV*c)
+  p.lds = (size_t)(LDS_MAX_GV + 4 + p.tp) * 4 + (backward ? (size_t)(p.tp + 2 * 256 * LDS_PAIRS) * 4 : (size_t)p.tp * c * 4);
+  return true;
+}
+
+template <int REDUCE>
+__global__ __launch_bounds__(256) void reduce_lds_kernel(const float* __restrict__ feats, const int* __restrict__ order,
+                                                         const int* __restrict__ seg, int c, int gv, int tp, unsigned magic,
+                                                         long long v, float* __restrict__ out, int* __restrict__ argmax) {
+  extern __shared__ int lds_i[];
+  int* const segl = lds_i;
+  int* const pids = lds_i + LDS_MAX_GV + 4;
+  float* const tile = reinterpret_cast<float*>(pids + tp);
+  const int tid = threadIdx.x;
+  const long long v0 = (long long)blockIdx.x * gv;
+  const int nv = (int)((v - v0) < gv ? (v - v0) : gv);
+  for (int i = tid; i <= nv; i += 256) segl[i] = seg[v0 + i];
+  __syncthreads();
+  const int pb = segl[0], pe = segl[nv];
+  const int npairs = nv * c;
+  int ch[LDS_PAIRS], b[LDS_PAIRS], e[LDS_PAIRS], arg[LDS_PAIRS];
+  float acc[LDS_PAIRS];
+#pragma unroll
+  for (int j = 0; j < LDS_PAIRS; ++j) {
+    const int pr = tid + 256 * j;
+    const int lv = (int)__umulhi((unsigned)pr, magic);
+    ch[j] = pr - lv * c;
+    const bool own = pr < npairs;
+    b[j] = own ? segl[lv] : 0;
+    e[j] = own ? segl[lv + 1] : 0;
+    acc[j] = (REDUCE == GD3D_REDUCE_MAX) ? -__builtin_inff() : 0.0f;
+    arg[j] = -1;
+  }
+  for (int t0 = pb; t0 < pe; t0 += tp) {  // workgroup-uniform
+    const int np = (pe - t0) < tp ? (pe - t0) : tp;
+    if (t0 != pb) __syncthreads();  // the previous tile has been consumed
+    for (int i = tid; i < np; i += 256) pids[i] = order[t0 + i];
+    __syncthreads();
+    const int nf = np * c;
+    for (int f0 = tid; f0 < nf; f0 += 256 * GATHER_U) {
+      float x[GATHER_U];
+#pragma unroll
+      for (int u = 0; u < GATHER_U; ++u) {
+        const int f = f0 + 256 * u;
+        const int fc = f < nf ? f : nf - 1;
+        const int p = (int)__umulhi((unsigned)fc, magic);
+        x[u] = feats[(long long)pids[p] * c + (fc - p * c)];
+      }
+#pragma unroll
+      for (int u = 0; u < GATHER_U; ++u) {
+        const int f = f0 + 256 * u;
+        if (f < nf) tile[f] = x[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LDS_PAIRS; ++j) {
+      const int lo = (b[j] > t0 ? b[j] : t0) - t0;
+      const int hi = (e[j] < t0 + np ? e[j] : t0 + np) - t0;
+      for (int k = lo; k < hi; ++k) {
+        const float xv = tile[k * c + ch[j]];
+        if (REDUCE == GD3D_REDUCE_MAX) {
+          if (xv > acc[j]) {  // strict: the first (smallest) point index wins ties; NaN never wins
+            acc[j] = xv;
+            arg[j] = pids[k];
+          }
+        } else {
+          acc[j] += xv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LDS_PAIRS; ++j) {
+    const int pr = tid + 256 * j;
+    if (pr >= npairs) continue;
+    float r = acc[j];
+    if (REDUCE == GD3D_REDUCE_MEAN) r = r / (float)(e[j] - b[j]);
+    out[v0 * c + pr] = r;   // (voxel, channel) pairs of consecutive voxels are consecutive addresses
+    if (REDUCE == GD3D_REDUCE_MAX && argmax != nullptr) argmax[v0 * c + pr] = arg[j];
+  }
+}
+
+// Backward in voxel order for any c <= 128: the workgroup's GV gradient rows (one contiguous run of GV * c floats; the mean's
+// division and the max's arg-max row with them) are staged in LDS once, then the run's points are written as a flat dword
+// stream (64 consecutive dwords per wave store = 64 / c whole point rows), nontemporal.
+template <int MODE>
+__global__ __launch_bounds__(256) void spread_lds_kernel(const float* __restrict__ gvox, const int* __restrict__ order,
+                                                         const int* __restrict__ seg, const int* __restrict__ argmax, int c,
+                                                         int gv, int tp, unsigned magic, long long v, unsigned vox_blocks,
+                                                         float* __restrict__ gfeats) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x >= vox_blocks) {  // points in no voxel: the prefix order[0 .. seg[0]) gets zero rows
+    const long long n0 = seg[0];
+    const long long stride = (long long)(gridDim.x - vox_blocks) * 256;
+    for (long long idx = (long long)(blockIdx.x - vox_blocks) * 256 + tid; idx < n0 * c; idx += stride) {
+      const long long i = idx / c;
+      __builtin_nontemporal_store(0.0f, gfeats + (long long)order[i] * c + (idx - i * c));
+    }
+    return;
+  }
+  extern __shared__ int lds_i[];
+  int* const segl = lds_i;
+  int* const pids = lds_i + LDS_MAX_GV + 4;
+  int* const vloc = pids + tp;
+  float* const grow = reinterpret_cast<float*>(vloc + tp);
+  int* const arow = reinterpret_cast<int*>(grow) + 256 * LDS_PAIRS;
+  const long long v0 = (long long)blockIdx.x * gv;
+  const int nv = (int)((v - v0) < gv ? (v - v0) : gv);
+  for (int i = tid; i <= nv; i += 256) segl[i] = seg[v0 + i];
+  __syncthreads();
+  const int pb = segl[0], pe = segl[nv];
+  const int npairs = nv * c;
+  for (int pr = tid; pr < npairs; pr += 256) {
+    float g = gvox[v0 * c + pr];
+    if (MODE == GD3D_REDUCE_MEAN) {
+      const int lv = (int)__umulhi((unsigned)pr, magic);
+      g = g / (float)(segl[lv + 1] - segl[lv]);
+    }
+    grow[pr] = g;
+    if (MODE == GD3D_REDUCE_MAX) arow[pr] = argmax[v0 * c + pr];
+  }
+  for (int t0 = pb; t0 < pe; t0 += tp) {
+    const int np = (pe - t0) < tp ? (pe - t0) : tp;
+    __syncthreads();  // rows staged / the previous tile's pids and vloc consumed
+    for (int i = tid; i < np; i += 256) {
+      pids[i] = order[t0 + i];
+      int lo = 0, hi = nv;  // the voxel of position t0 + i: the last lv with segl[lv] <= t0 + i
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (segl[mid] <= t0 + i) lo = mid;
+        else hi = mid;
+      }
+      vloc[i] = lo;
+    }
+    __syncthreads();
+    const int nf = np * c;
+    for (int f = tid; f < nf; f += 256) {
+      const int p = (int)__umulhi((unsigned)f, magic);
+      const int chn = f - p * c;
+      const int pid = pids[p];
+      const int src = vloc[p] * c + chn;
+      float g = grow[src];
+      if (MODE == GD3D_REDUCE_MAX) g = (arow[src] == pid) ? g : 0.0f;
+      __builtin_nontemporal_store(g, gfeats + (long long)pid * c + chn);
+    }
+  }
+}
+
 // max backward for narrow rows: zero fill + one 4-byte store per (voxel, channel) at the recorded arg max.  Measured
 // (2 M points -> 214 K voxels): c = 16: 40 us vs 85 us for the masked gather; c = 64: 320 us vs 202 us -> used for c < 32.
 __global__ __launch_bounds__(256) void max_grad_kernel(const float* __restrict__ gvox, const int* __restrict__ argmax,
