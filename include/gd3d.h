@@ -573,8 +573,8 @@ int vox_index_build(const int32_t* coors, int64_t n, int32_t ndim, void* workspa
 /* Same gradient, produced in VOXEL order from the forward's grouping (order, seg as in vox_scatter_reduce): each voxel's
  * gradient row is read once and streamed to its points, instead of being re-gathered once per point — about half the
  * HBM traffic of the map-ordered form.  Points in no voxel (the prefix order[0 .. seg[0])) receive zeros.
- * Requires c % 4 == 0, c <= 256 and 16-byte aligned grad_vox / grad_feats / argmax (GD3D_E_BADARG otherwise: use
- * vox_scatter_backward). */
+ * Any c <= 128 (rows staged through LDS and written as a flat dword stream), or c % 4 == 0, c <= 256 with 16-byte aligned
+ * grad_vox / grad_feats / argmax; GD3D_E_BADARG otherwise: use vox_scatter_backward. */
 int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, const int32_t* seg,
                                  const int32_t* argmax, int64_t n, int32_t c, int64_t v, int reduce,
                                  float* grad_feats, void* stream);

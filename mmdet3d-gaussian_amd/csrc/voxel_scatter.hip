@@ -17,6 +17,7 @@
 // HBM-bound: reads N*C*4 + N*4, writes V*C*4 (+ V*C*4 arg max).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/gd3d.h"
 
@@ -159,15 +160,19 @@ __global__ __launch_bounds__(256) void reduce_v4_kernel(const float* __restrict_
 //   max : ... only where argmax[map[i], ch] == i (the forward's recorded arg max), else 0
 // VEC = 4: a thread moves 4 consecutive channels with 16-byte accesses (c % 4 == 0, 16-byte aligned rows).
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+#ifndef GATHER_GU_SCALAR
+#define GATHER_GU_SCALAR 4   // 8 measured no faster (c = 10 sum 39.8 vs 40.5 us) and slower for mean (50.5 vs 45 us)
+#endif
 
 template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void gather_grad_kernel(const float* __restrict__ gvox, const int* __restrict__ map,
                                                           const int* __restrict__ count, const int* __restrict__ argmax,
-                                                          long long n, int c, int shift, float* __restrict__ gfeats) {
+                                                          long long n, int c, int shift, unsigned magic,
+                                                          float* __restrict__ gfeats) {
   // GU items per thread, loads staged (all map loads, then all row loads, then the stores): map -> row is a dependent
   // chain, one item per thread leaves 1 KB in flight per wave and the kernel latency-bound (3.5 TB/s at c = 64).
   // The gradient is written once and not re-read here: nontemporal stores keep the gathered voxel rows in cache.
-  constexpr int GU = 4;
+  constexpr int GU = VEC == 4 ? 4 : GATHER_GU_SCALAR;   // dword items: twice as many in flight (the chain is latency-bound)
   const int cv = c / VEC;  // lanes per point row; shift = log2(cv) when cv is a power of two, else -1
   const long long total = n * cv;
   long long idx[GU], pt[GU];
@@ -176,7 +181,10 @@ __global__ __launch_bounds__(256) void gather_grad_kernel(const float* __restric
   for (int u = 0; u < GU; ++u) {
     idx[u] = ((long long)blockIdx.x * GU + u) * 256 + threadIdx.x;
     const long long ic = idx[u] < total ? idx[u] : total - 1;
-    pt[u] = shift >= 0 ? (ic >> shift) : (long long)((unsigned long long)ic / (unsigned)cv);
+    // index / lanes-per-row: a shift for powers of two; otherwise ONE multiply-high when the host has checked that the
+    // index range allows it (magic = floor(2^32 / cv) + 1 is exact below 2^32 / cv), else a 64-bit division.  The division
+    // used to be taken for every c that is not a power of two and made the c = 10 kernel VALU-bound (40 us for 88 MB).
+    pt[u] = shift >= 0 ? (ic >> shift) : (magic != 0u ? (long long)__umulhi((unsigned)ic, magic) : (long long)((unsigned long long)ic / (unsigned)cv));
     ch[u] = (int)(ic - pt[u] * cv) * VEC;
   }
 #pragma unroll
@@ -298,35 +306,37 @@ __global__ __launch_bounds__(256) void spread_grad_v4_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LDS-staged forms for rows that are not whole 16-byte vectors (c = 3, 9, 10: the xyz mean and 3x3 covariance reduces of
-// the reference's PointVoxelStatsCalculator, models/voxel_encoders/utils.py:56,63-64, and its 10-channel pillar features)
-// and for narrow rows in general.  The sub-wave-per-voxel kernels above keep 4 rows x c dwords in flight per voxel: at
-// c = 10 that is 640 B per wave and the kernel sits at 1.9 TB/s, latency-bound.  Here a workgroup owns GV consecutive
-// voxels = one CONTIGUOUS run of `order`; it
-//   1. gathers the run's point rows into LDS as one flat dword stream — thread t moves elements t, t + 256, ... of the
-//      concatenated rows, so a wave instruction covers 64 consecutive dwords = 64 / c whole rows (a handful of cache lines
-//      instead of 64) and every thread has GATHER_U independent loads in flight;
-//   2. reduces from LDS: thread = one (voxel, channel) pair, walking the voxel's points in ascending point id at stride c —
-//      the same visiting order and arithmetic as the kernels above, hence the same bits — and writes `out` as one
-//      contiguous run of GV * c floats.
-// Runs longer than the tile are taken in several tiles with the accumulators carried in registers.
-constexpr int LDS_TILE_FLOATS = 8192;   // point-row floats staged per tile (32 KB)
-constexpr int LDS_MAX_TP = 1024;        // points per tile, at most
+// Rows that are not whole 16-byte vectors (c = 3, 9, 10: the xyz mean and 3x3 covariance reduces of the reference's
+// PointVoxelStatsCalculator, models/voxel_encoders/utils.py:56,63-64, and its 10-channel pillar features).
+//
+// FORWARD.  These rows stay on reduce_kernel above.  Round 4 built the alternative the sub-wave kernel's 640 B in flight per
+// wave suggested — a workgroup gathers the rows of 51 consecutive voxels into LDS as one flat dword stream (64 consecutive
+// dwords per wave instruction, 8 independent loads per thread) and reduces from LDS in the same visiting order — and
+// measured the SAME time (c = 10, 2 M random points -> 214 K voxels: 50.9-55.6 us against 50.2-51.4 us; c = 16: 52-60 us
+// against 44-47 us for the 16-byte vector kernel), so it was removed.  The counters say why (profiles/r04_scatter_pmc.txt):
+// 2.2-2.6 M L2-miss requests per launch, i.e. every 40-byte row of the 80 MB point array costs 1.1-1.3 fetches of a 128-byte
+// line beyond the XCD's 4 MB L2, 280-330 MB of line traffic at 6.5 TB/s — the rate the memory system gives uniformly random
+// rows (MI355X_MICROARCH.md, "Indexed rows": 7.4-8.6 TB/s for wide rows from the Infinity Cache).  A gather of randomly
+// placed narrow rows is bound by LINES, not by algorithmic bytes; more loads in flight cannot change it.
+//
+// BACKWARD.  For rows narrower than a line the map-ordered gather (gather_grad_kernel) is the right form: its writes stream
+// and the V * c gradient rows it gathers stay in L2.  The voxel-ordered form below exists so that
+// vox_scatter_backward_grouped is total over c <= 128; its stores are partial lines at random rows (c = 10: 118 us against
+// 40 us), and scatter.py does not pick it for c < 32.
+constexpr int LDS_MAX_TP = 1024;        // points per tile
 constexpr int LDS_MAX_GV = 128;         // voxels per workgroup, at most
 constexpr int LDS_PAIRS = 2;            // (voxel, channel) pairs per thread: GV * c <= 512
-constexpr int GATHER_U = 8;
 
 struct LdsPlan {
   int gv, tp;
-  unsigned magic;   // floor(2^32 / c) + 1: f / c == __umulhi(f, magic) for f * c < 2^32
+  unsigned magic;   // floor(2^32 / c) + 1: f / c == __umulhi(f, magic) for f < 2^32 / c
   size_t lds;
   long long blocks;
 };
 
-static bool lds_plan(int c, long long n, long long v, bool backward, LdsPlan& p) {
+static bool lds_plan(int c, long long n, long long v, LdsPlan& p) {
   if (c > 128 || v <= 0) return false;
-  p.tp = LDS_TILE_FLOATS / c;
-  if (p.tp > LDS_MAX_TP) p.tp = LDS_MAX_TP;
+  p.tp = LDS_MAX_TP;
   p.gv = 256 * LDS_PAIRS / c;
   if (p.gv > LDS_MAX_GV) p.gv = LDS_MAX_GV;
   // most workgroups should need ONE tile: voxels per workgroup from the average run length (n / v, known on the host)
@@ -335,90 +345,12 @@ static bool lds_plan(int c, long long n, long long v, bool backward, LdsPlan& p)
   if (fit < p.gv) p.gv = fit < 1 ? 1 : fit;
   p.magic = (unsigned)(0x100000000ULL / (unsigned)c) + 1u;
   p.blocks = (v + p.gv - 1) / p.gv;
-  // segl (LDS_MAX_GV + 4 ints) | pids (tp ints) | forward: tile (tp * c floats); backward: vloc (tp ints), rows (2 x GV*c)
-  p.lds = (size_t)(LDS_MAX_GV + 4 + p.tp) * 4 + (backward ? (size_t)(p.tp + 2 * 256 * LDS_PAIRS) * 4 : (size_t)p.tp * c * 4);
+  // segl (LDS_MAX_GV + 4 ints) | pids (tp ints) | vloc (tp ints) | gradient rows and arg-max rows (GV * c each)
+  p.lds = (size_t)(LDS_MAX_GV + 4 + 2 * p.tp + 2 * 256 * LDS_PAIRS) * 4;
   return true;
 }
 
-template <int REDUCE>
-__global__ __launch_bounds__(256) void reduce_lds_kernel(const float* __restrict__ feats, const int* __restrict__ order,
-                                                         const int* __restrict__ seg, int c, int gv, int tp, unsigned magic,
-                                                         long long v, float* __restrict__ out, int* __restrict__ argmax) {
-  extern __shared__ int lds_i[];
-  int* const segl = lds_i;
-  int* const pids = lds_i + LDS_MAX_GV + 4;
-  float* const tile = reinterpret_cast<float*>(pids + tp);
-  const int tid = threadIdx.x;
-  const long long v0 = (long long)blockIdx.x * gv;
-  const int nv = (int)((v - v0) < gv ? (v - v0) : gv);
-  for (int i = tid; i <= nv; i += 256) segl[i] = seg[v0 + i];
-  __syncthreads();
-  const int pb = segl[0], pe = segl[nv];
-  const int npairs = nv * c;
-  int ch[LDS_PAIRS], b[LDS_PAIRS], e[LDS_PAIRS], arg[LDS_PAIRS];
-  float acc[LDS_PAIRS];
-#pragma unroll
-  for (int j = 0; j < LDS_PAIRS; ++j) {
-    const int pr = tid + 256 * j;
-    const int lv = (int)__umulhi((unsigned)pr, magic);
-    ch[j] = pr - lv * c;
-    const bool own = pr < npairs;
-    b[j] = own ? segl[lv] : 0;
-    e[j] = own ? segl[lv + 1] : 0;
-    acc[j] = (REDUCE == GD3D_REDUCE_MAX) ? -__builtin_inff() : 0.0f;
-    arg[j] = -1;
-  }
-  for (int t0 = pb; t0 < pe; t0 += tp) {  // workgroup-uniform
-    const int np = (pe - t0) < tp ? (pe - t0) : tp;
-    if (t0 != pb) __syncthreads();  // the previous tile has been consumed
-    for (int i = tid; i < np; i += 256) pids[i] = order[t0 + i];
-    __syncthreads();
-    const int nf = np * c;
-    for (int f0 = tid; f0 < nf; f0 += 256 * GATHER_U) {
-      float x[GATHER_U];
-#pragma unroll
-      for (int u = 0; u < GATHER_U; ++u) {
-        const int f = f0 + 256 * u;
-        const int fc = f < nf ? f : nf - 1;
-        const int p = (int)__umulhi((unsigned)fc, magic);
-        x[u] = feats[(long long)pids[p] * c + (fc - p * c)];
-      }
-#pragma unroll
-      for (int u = 0; u < GATHER_U; ++u) {
-        const int f = f0 + 256 * u;
-        if (f < nf) tile[f] = x[u];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < LDS_PAIRS; ++j) {
-      const int lo = (b[j] > t0 ? b[j] : t0) - t0;
-      const int hi = (e[j] < t0 + np ? e[j] : t0 + np) - t0;
-      for (int k = lo; k < hi; ++k) {
-        const float xv = tile[k * c + ch[j]];
-        if (REDUCE == GD3D_REDUCE_MAX) {
-          if (xv > acc[j]) {  // strict: the first (smallest) point index wins ties; NaN never wins
-            acc[j] = xv;
-            arg[j] = pids[k];
-          }
-        } else {
-          acc[j] += xv;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < LDS_PAIRS; ++j) {
-    const int pr = tid + 256 * j;
-    if (pr >= npairs) continue;
-    float r = acc[j];
-    if (REDUCE == GD3D_REDUCE_MEAN) r = r / (float)(e[j] - b[j]);
-    out[v0 * c + pr] = r;   // (voxel, channel) pairs of consecutive voxels are consecutive addresses
-    if (REDUCE == GD3D_REDUCE_MAX && argmax != nullptr) argmax[v0 * c + pr] = arg[j];
-  }
-}
-
-// Backward in voxel order for any c <= 128: the workgroup's GV gradient rows (one contiguous run of GV * c floats; the mean's
+// Backward in voxel order for any c <= 128: a workgroup owns GV consecutive voxels = one contiguous run of `order`; its GV gradient rows (one contiguous run of GV * c floats; the mean's
 // division and the max's arg-max row with them) are staged in LDS once, then the run's points are written as a flat dword
 // stream (64 consecutive dwords per wave store = 64 / c whole point rows), nontemporal.
 template <int MODE>
@@ -511,8 +443,10 @@ static void launch_backward(bool vec, unsigned blocks, hipStream_t s, const floa
     shift = 0;
     while ((1 << shift) < cv) ++shift;
   }
-  if (vec) hipLaunchKernelGGL((gather_grad_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, s, gv, map, count, argmax, n, c, shift, gf);
-  else hipLaunchKernelGGL((gather_grad_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, s, gv, map, count, argmax, n, c, shift, gf);
+  const unsigned long long total = (unsigned long long)n * (unsigned)cv;
+  const unsigned magic = (shift < 0 && total < 0x100000000ULL / (unsigned)cv) ? (unsigned)(0x100000000ULL / (unsigned)cv) + 1u : 0u;
+  if (vec) hipLaunchKernelGGL((gather_grad_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, s, gv, map, count, argmax, n, c, shift, magic, gf);
+  else hipLaunchKernelGGL((gather_grad_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, s, gv, map, count, argmax, n, c, shift, magic, gf);
 }
 
 }  // namespace vox
@@ -571,7 +505,8 @@ int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_
   if (reduce == GD3D_REDUCE_MAX && argmax == nullptr) return GD3D_E_BADARG;
   if (reduce == GD3D_REDUCE_MEAN && count == nullptr) return GD3D_E_BADARG;
   const bool vec = (c % 4 == 0) && ((((uintptr_t)grad_vox | (uintptr_t)grad_feats | (uintptr_t)argmax) & 15) == 0);
-  const long long blocks = ((long long)n * (vec ? c / 4 : c) + 1023) / 1024;  // 256 threads x 4 items
+  const long long per_block = 256LL * (vec ? 4 : GATHER_GU_SCALAR);             // 256 threads x GU items
+  const long long blocks = ((long long)n * (vec ? c / 4 : c) + per_block - 1) / per_block;
   if (blocks > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const unsigned nb = (unsigned)blocks;
   if (reduce == GD3D_REDUCE_MAX && c < 32) {
@@ -596,8 +531,20 @@ int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, co
   if (v == 0) return (int)hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
   if (grad_vox == nullptr || order == nullptr || seg == nullptr) return GD3D_E_BADARG;
   if (reduce == GD3D_REDUCE_MAX && argmax == nullptr) return GD3D_E_BADARG;
-  if ((c % 4) != 0 || c > 256 || ((((uintptr_t)grad_vox | (uintptr_t)grad_feats | (uintptr_t)argmax) & 15) != 0))
-    return GD3D_E_BADARG;  // 16-byte rows only: callers fall back to vox_scatter_backward (map order) otherwise
+  const bool vec = (c % 4) == 0 && c <= 256 && ((((uintptr_t)grad_vox | (uintptr_t)grad_feats | (uintptr_t)argmax) & 15) == 0);
+  LdsPlan plan;
+  if (!vec && lds_plan(c, n, v, plan)) {
+    if (plan.blocks + ZERO_BLOCKS > 0x7fffffffLL) return GD3D_E_TOOLARGE;
+    const dim3 lgrid((unsigned)(plan.blocks + ZERO_BLOCKS)), lblk(256);
+    if (reduce == GD3D_REDUCE_MAX)
+      hipLaunchKernelGGL((spread_lds_kernel<GD3D_REDUCE_MAX>), lgrid, lblk, plan.lds, s, grad_vox, order, seg, argmax, (int)c, plan.gv, plan.tp, plan.magic, (long long)v, (unsigned)plan.blocks, grad_feats);
+    else if (reduce == GD3D_REDUCE_MEAN)
+      hipLaunchKernelGGL((spread_lds_kernel<GD3D_REDUCE_MEAN>), lgrid, lblk, plan.lds, s, grad_vox, order, seg, argmax, (int)c, plan.gv, plan.tp, plan.magic, (long long)v, (unsigned)plan.blocks, grad_feats);
+    else
+      hipLaunchKernelGGL((spread_lds_kernel<GD3D_REDUCE_SUM>), lgrid, lblk, plan.lds, s, grad_vox, order, seg, argmax, (int)c, plan.gv, plan.tp, plan.magic, (long long)v, (unsigned)plan.blocks, grad_feats);
+    return (int)hipGetLastError();
+  }
+  if (!vec) return GD3D_E_BADARG;  // c > 128 and not 16-byte rows: callers use vox_scatter_backward (map order)
   const int lp = pow2_at_least(c / 4);
   const long long vw = (v + (64 / lp) - 1) / (64 / lp);
   const long long vb = (vw + 3) / 4;

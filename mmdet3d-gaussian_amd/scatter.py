@@ -170,8 +170,10 @@ class _ScatterReduce(Function):
         grad_feats = torch.empty((n, c), dtype=torch.float32, device=g.device)
         am = None if argmax is None else argmax.data_ptr()
         with _on_device(g.device) as stream:
-            if c % 4 == 0 and c <= 256 and g.data_ptr() % 16 == 0:
-                # voxel order: every gradient row is read once and streamed to its points (half the HBM traffic)
+            if c % 4 == 0 and 32 <= c <= 256 and g.data_ptr() % 16 == 0:
+                # voxel order: every gradient row is read once and streamed to its points (half the HBM traffic).  Only for
+                # rows of at least one 128-byte line: narrower rows make the voxel-ordered stores partial lines at random
+                # addresses (c = 10: 118 us against 40 us for the map-ordered gather, profiles/r04_scatter_kernel_time.txt)
                 rc = lib.vox_scatter_backward_grouped(g.data_ptr(), order.data_ptr(), seg.data_ptr(), am, n, c, v, ctx.red,
                                                       grad_feats.data_ptr(), stream)
             else:

@@ -104,7 +104,8 @@ def test_gpu_index_build_equals_the_aten_statement_and_the_oracle(n, ndim, dtype
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130), (9000, 16), (7000, 128), (4000, 12)])
+@pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130), (9000, 16), (7000, 128), (4000, 12), (60000, 3), (30000, 33),
+                                 (5000, 127), (2000, 129), (1, 3)])
 @pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
 def test_gpu_scatter_reduce_forward_backward(n, c, red):
     import mmdet3d_gaussian_amd as amd  # noqa: F401
@@ -157,7 +158,7 @@ def test_gpu_scatter_batched_coors_and_determinism():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('c', [4, 16, 64, 100])
+@pytest.mark.parametrize('c', [3, 4, 9, 10, 16, 33, 64, 100, 127])
 @pytest.mark.parametrize('red', [0, 1, 2])
 def test_gpu_backward_voxel_order_equals_map_order(c, red):
     """vox_scatter_backward_grouped (each voxel row read once, streamed to its points) must produce the same bits as the
@@ -256,3 +257,36 @@ def test_gpu_scatter_all_points_outside_and_single_voxel():
             assert int((feats.grad != 0).sum()) == c                  # exactly one winner per channel
         else:
             assert torch.allclose(feats.grad, torch.full_like(feats, 1.0 if red == 'sum' else 1.0 / n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c', [3, 10, 16])
+@pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
+def test_gpu_narrow_rows_long_runs_and_same_bits_as_the_vector_kernels(c, red):
+    """Rows that are not whole 16-byte vectors, and narrow rows, on a skewed cloud: three voxels hold 40 % of the points (runs of
+    thousands of points; in the voxel-ordered backward several LDS tiles per workgroup), the rest are singletons and small
+    voxels.  Every kernel visits a voxel's points in ascending point id: the c channels embedded in the first columns of a
+    64-channel array (which takes the 16-byte vector kernels) give bit-identical sums / means / maxima."""
+    from mmdet3d_gaussian_amd.scatter import Scatter
+    rng = np.random.default_rng(c)
+    n = 50_000
+    coors = np.stack([rng.integers(0, 60, n), rng.integers(0, 60, n), rng.integers(0, 2, n)], -1).astype(np.int32)
+    big = rng.random(n) < 0.4
+    coors[big] = np.array([[5, 5, 0], [30, 31, 1], [59, 59, 1]], np.int32)[rng.integers(0, 3, big.sum())]
+    coors[rng.random(n) < 0.02, 1] = -1
+    feats = rng.normal(0, 1, (n, c)).astype(np.float32)
+    wide = np.zeros((n, 64), np.float32); wide[:, :c] = feats
+    sc = Scatter(torch.from_numpy(coors).cuda())
+    assert int(sc.voxel_pts_counts.max()) > 4000
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    out, _ = sc.reduce(f, red)
+    ref, _ = sc.reduce(torch.from_numpy(wide).cuda(), red)
+    assert torch.equal(out.detach(), ref[:, :c].contiguous())
+    uo, mo, co = vo.scatter_index(coors)
+    want, _ = vo.scatter_reduce(feats, mo, co, red)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-3)   # fp32 running sums over up to 7 000 points
+    gv = torch.randn(out.shape, device='cuda')
+    out.backward(gv)
+    gw = vo.scatter_backward(gv.cpu().numpy(), feats, mo, co, red)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), gw, rtol=2e-6, atol=1e-7)
+    assert (f.grad[sc.pts_voxel_maps < 0] == 0).all()
