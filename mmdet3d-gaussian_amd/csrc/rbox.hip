@@ -434,6 +434,31 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
   return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
 }
+// NW 64-bit words OR-reduced over the wave TOGETHER: the 2 * NW dword chains are independent, so every DPP step of one
+// chain sits in the wait states of the others; the totals are left in LANE 63 (no readlane, no scalar round trip).
+template <int NW>
+__device__ __forceinline__ void wave_or_words_lane63(unsigned long long (&w)[NW]) {
+  unsigned int h[2 * NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    h[2 * k] = (unsigned int)w[k];
+    h[2 * k + 1] = (unsigned int)(w[k] >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x111, 0xf>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x112, 0xf>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x114, 0xf>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x118, 0xf>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x142, 0xa>(h[k]);
+#pragma unroll
+  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x143, 0xc>(h[k]);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) w[k] = ((unsigned long long)h[2 * k + 1] << 32) | h[2 * k];
+}
 
 // ---- greedy scan: one workgroup, phase-shifted waves, one LDS-only barrier per 64-box block ("interval") -------------
 // Measured with the cycle-stamp build (tools/scan_profile.py): a global-memory round trip from this CU is ~2700 cycles,
@@ -456,6 +481,10 @@ constexpr int SCAN_GW = 3;                      // waves per propagate group
 constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW);  // 640 threads
 constexpr int SCAN_NU = 3;                      // urgent words per box
 constexpr int SCAN_RING = 4;
+
+__device__ __forceinline__ unsigned int lds_offset(const void* p) {   // byte offset of a __shared__ object (ds_* address operand)
+  return (unsigned int)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
 
 __device__ __forceinline__ void lds_barrier() {  // orders LDS only: global loads stay in flight across it
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -563,10 +592,23 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       const bool mine = (kept >> lane) & 1ull;
       if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
         keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+      // the kept lanes' urgent words, all three reduced together; lane 63 ends up holding the totals and ORs them into
+      // remv[c+1..c+3] itself (ds_or_b64 with a zero operand is harmless: no test, no scalar round trip per word).
+      // Round 3 reduced the words one after the other and went through SGPRs: ~130 instructions; this is ~60, and the
+      // resolver's stamp-to-stamp time fell 854 -> 792 cycles — but the interval did not move (1868 -> 1840 cycles with
+      // stamps, kernels of rnms_bev 72.5-73.2 -> 71.9-72.2 us at n = 4096): the interval is set by the loader group's ISSUE
+      // phase, not by the resolver (profiles/r04_nms_pmc.txt).
 #pragma unroll
-      for (int k = 0; k < SCAN_NU; ++k) {
-        const unsigned long long o = wave_or_u64(mine ? urg[k] : 0ull);  // uniform; 0 past the last block
-        if (lane == 0 && o && c + 1 + k < cb) atomicOr(&remv[c + 1 + k], o);
+      for (int k = 0; k < SCAN_NU; ++k) urg[k] = mine ? urg[k] : 0ull;
+      wave_or_words_lane63<SCAN_NU>(urg);
+      if (lane == 63) {
+        // ds_or_b64 written out: an atomicOr() here is rewritten by the compiler's wave-level atomic optimisation into a
+        // readlane loop over the "active lanes" (one) plus a scalar round trip — the very cost this form removes
+#pragma unroll
+        for (int k = 0; k < SCAN_NU; ++k)
+          if (c + 1 + k < cb)   // (uniform bound)
+            asm volatile("ds_or_b64 %0, %1" ::"v"(lds_offset(&remv[c + 1 + k])), "v"(urg[k]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS barrier below must see them
       }
       if (mine) klist[c & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = lane;
       count += __builtin_popcountll(kept);

@@ -146,7 +146,12 @@ __global__ __launch_bounds__(T) void finish_kernel(const long long* __restrict__
   }
   if (j == n - 1) {
     const long long v = (long long)scan[j] - has_drop;   // keys are sorted: the last key is >= 0 unless every point is dropped
-    num[0] = v;
+    // the mixed-radix key must fit 63 bits: with up to 8 columns of int32 extents the product can wrap, and wrapped keys
+    // merge voxels or pose as dropped points.  Report it instead: num[0] = -1 (the host raises).
+    long long prod = 1;
+    bool wrapped = false;
+    for (int d = 0; d < ndim; ++d) wrapped |= __builtin_mul_overflow(prod, (long long)ext[d], &prod);
+    num[0] = wrapped ? -1LL : v;
     seg[v] = (int)n;
   }
   if (j == 0) {

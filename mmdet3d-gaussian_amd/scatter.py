@@ -50,7 +50,14 @@ def _index_and_grouping(coors):
         return _index_and_grouping_torch(coors)     # beyond the kernels' limits: the same result from device-side ATen ops
     dev = coors.device
     lib = _lib.load()
-    c32 = coors if coors.dtype == torch.int32 else coors.to(torch.int32)
+    over = None
+    if coors.dtype == torch.int32:
+        c32 = coors
+    else:
+        # wider integers: anything negative is a dropped point whatever its size (clamped to -1 before the cast); a value beyond
+        # int32 cannot be a coordinate of this index (int32 coordinates, as the reference's op) and is reported, not wrapped
+        over = (coors > 2147483647).any()
+        c32 = coors.clamp(min=-1).to(torch.int32)
     c32 = c32.contiguous()
     pmap = torch.empty(n, dtype=torch.int32, device=dev)
     order = torch.empty(n, dtype=torch.int32, device=dev)
@@ -66,7 +73,14 @@ def _index_and_grouping(coors):
         rc = lib.vox_index_build(c32.data_ptr(), n, ndim, ws.data_ptr(), pmap.data_ptr(), order.data_ptr(), seg.data_ptr(),
                                  counts.data_ptr(), vcoors.data_ptr(), num.data_ptr(), stream)
     _lib.check(rc, 'vox_index_build')
-    v = int(num[0].item())                                                     # the one wait: V sizes every output
+    if over is None:
+        v = int(num[0].item())                                                 # the one wait: V sizes every output
+    else:
+        v, bad = torch.stack((num[0], over.to(torch.int64))).tolist()          # still one wait
+        if bad:
+            raise RuntimeError('scatter_index: a coordinate exceeds the int32 range')
+    if v < 0:
+        raise RuntimeError('scatter_index: the product of the per-column extents does not fit a 63-bit voxel key')
     voxel_coors = vcoors[:v]
     if coors.dtype != torch.int32:
         voxel_coors = voxel_coors.to(coors.dtype)

@@ -290,3 +290,22 @@ def test_gpu_narrow_rows_long_runs_and_same_bits_as_the_vector_kernels(c, red):
     gw = vo.scatter_backward(gv.cpu().numpy(), feats, mo, co, red)
     np.testing.assert_allclose(f.grad.cpu().numpy(), gw, rtol=2e-6, atol=1e-7)
     assert (f.grad[sc.pts_voxel_maps < 0] == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_index_reports_key_overflow_and_out_of_range_coordinates():
+    """extents whose product passes 2^63 used to wrap the mixed-radix key (merged voxels, fake dropped points); an
+    int64 coordinate beyond int32 used to wrap in the cast.  Both are errors now; a large negative int64 is a dropped point."""
+    from mmdet3d_gaussian_amd.scatter import scatter_index
+    big = torch.tensor([[2 ** 30, 2 ** 30, 2 ** 30, 5], [1, 2, 3, 4]], dtype=torch.int32, device='cuda')   # product ~ 2^90 x 6
+    with pytest.raises(RuntimeError, match='63-bit'):
+        scatter_index(big)
+    ok = torch.tensor([[2 ** 20, 2 ** 20, 2 ** 20], [1, 2, 3], [1, 2, 3]], dtype=torch.int32, device='cuda')        # 2^60: fits
+    vc, pm, cnt = scatter_index(ok)
+    assert vc.shape[0] == 2 and pm.tolist() == [1, 0, 0] and cnt.tolist() == [2, 1]
+    wide = torch.tensor([[1, 2, 3], [2 ** 40, 0, 0]], dtype=torch.int64, device='cuda')
+    with pytest.raises(RuntimeError, match='int32'):
+        scatter_index(wide)
+    neg = torch.tensor([[1, 2, 3], [-2 ** 40, 0, 0], [1, 2, 3]], dtype=torch.int64, device='cuda')
+    vc, pm, cnt = scatter_index(neg)
+    assert pm.tolist() == [0, -1, 0] and vc.dtype == torch.int64

@@ -17,11 +17,15 @@ for arg in sys.argv[1:]:
         cmd = [b.hipcc_path()] + b.COMMON + fl + flags.split() + ['-c', os.path.join(b.CSRC, src), '-o', obj]
         procs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         objs.append(obj)
+    for src, fl in b.HOST_SOURCES.items():      # the _cpu twins: same object for every variant
+        obj = os.path.join(out, f'{name}_{src}.o')
+        procs.append((name, subprocess.Popen([b.host_cxx_path()] + b.HOST_COMMON + fl + ['-c', os.path.join(b.CSRC, src), '-o', obj], stderr=subprocess.PIPE, text=True)))
+        objs.append(obj)
     procs.append((name, ('link', objs)))
 for name, p in procs:
     if isinstance(p, tuple):
         so = os.path.join(out, f'libgd3d_{name}.so')
-        r = subprocess.run([b.hipcc_path(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + p[1], capture_output=True, text=True)
+        r = subprocess.run([b.hipcc_path(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', so] + p[1], capture_output=True, text=True)
         print(name, 'OK' if r.returncode == 0 else r.stderr[-2000:])
     else:
         _, err = p.communicate()
