@@ -433,7 +433,7 @@ def main():
     # one leaf per loss (same values): the step runs ONE autograd backward over the three losses, as a training step does
     # with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations that are not
     # part of the metric.  (One backward per loss costs ~60 us of autograd-engine thread hand-off each: 3 x that made
-    # the eager step host-bound on boxes with a slow host, see tools/host_profile.py.)
+    # the eager step host-bound on boxes with a slow host, measured in round 2.)
     preds = {lt: pred0.clone().requires_grad_(True) for lt in LOSSES}
     del pred0
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
@@ -510,7 +510,7 @@ def main():
     # steps for a fixed wall time first (same step function; the W warmup steps still follow, then exactly K timed ones)
     # The pre-warm steps are launched exactly like the timed ones (event pairs recorded when the timed region records
     # them, then dropped): the first event pairs created after a few thousand event-free launches cost the host ~100 us
-    # each on this ROCm (tools/step_drift.py), which would make the timed region host-bound.
+    # each on this ROCm (round 2 measurement), which would make the timed region host-bound.
     # Which steps carry event pairs: every `--event-every`-th one.  A dispatch with events bound to it costs ~5 us of GPU time
     # more than a plain one on this ROCm (round 3: the same eager step ran 13.7 us over the sum of its three fused kernels
     # without events, tools/step_variants.py, and 28.7 us over it with events on every launch), so timing EVERY launch in

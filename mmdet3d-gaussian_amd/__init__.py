@@ -42,7 +42,7 @@ from .anchor_head import gd_anchor_head_loss, gd_anchor_head_loss_single
 from .center_targets import center_head_get_targets
 from .heat_loss import center_head_heatmap_loss
 from .center_head import center_gd_head_loss
-from .evaluation import BaseMatcher, LidarCenterTransBEV, LidarIOU3D, LidarIOUBEV, MatcherCoCo, match_coco, trans_bev
+from .evaluation import match_coco, trans_bev
 from .scatter import Scatter, scatter_index, scatter_reduce
 from .head_loss import (anchor_decoded_gd_loss, anchor_head_bbox_loss, anchor_head_decoded_loss,
                         anchor_head_decoded_loss_fused, center_head_gd_loss, center_head_losses)
@@ -57,4 +57,4 @@ __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu
            'boxes_iou_bev', 'iou_bev', 'iou_3d', 'xywhr2xyxyr', 'sharded', 'build', 'load_library', 'lib_path',
            'CenterPointBBoxCoderRev', 'CenterPointBBoxYawCoder', 'DeltaXYZWLHRBBoxCoder', 'PointBBoxYawCoder', 'center_head_get_bboxes', 'anchor_head_get_bboxes', 'anchor_head_cls_dir_loss', 'anchor_head_get_targets', 'anchor3d_range_anchors', 'pvrcnn_head_get_bboxes', 'gd_anchor_head_loss_single', 'gd_anchor_head_loss', 'select_best', 'GraphedStep', 'center_head_get_targets', 'center_head_heatmap_loss', 'center_gd_head_loss', 'anchor_decoded_gd_loss', 'anchor_head_decoded_loss',
            'anchor_head_decoded_loss_fused', 'anchor_head_bbox_loss', 'center_head_gd_loss', 'center_head_losses', 'Scatter', 'scatter_index', 'scatter_reduce',
-           'trans_bev', 'match_coco', 'LidarCenterTransBEV', 'LidarIOU3D', 'LidarIOUBEV', 'BaseMatcher', 'MatcherCoCo']
+           'trans_bev', 'match_coco']

@@ -4,10 +4,9 @@
   as bound in ops/eval/eval_utils.cpp:26-36;
 * ``match_coco`` — ops/eval/matcher.cpp:8-74.
 
-The callables the reference wraps around them (core/evaluation/affinity.py:5-32 `LidarCenterTransBEV`, `LidarIOU3D`, `LidarIOUBEV`;
-matcher.py:6-37 `BaseMatcher`, `MatcherCoCo`: they forward to these functions, the matcher negating affinities and thresholds when a
-larger affinity is closer) are mirrored at the end of this file with the same names, attributes and call signatures, without the
-registries.  The mAP accumulation above them (mean_ap_flexible.py, breakdown.py) is out of this build's scope.
+The callables the reference wraps around them (core/evaluation/affinity.py, matcher.py: a few forwarding lines each) and the mAP
+accumulation above those (mean_ap_flexible.py, breakdown.py) are out of this build's scope: the reference's own
+classes call these two functions unchanged.
 
 The reference computes all of this on the CPU from numpy arrays.  Here the affinity matrix is produced and consumed in
 HBM; numpy inputs are accepted and moved to the current device, results are returned as tensors on that device.
@@ -65,70 +64,3 @@ def match_coco(cost_mat, cost_thrs, is_ignore, is_crowd):
                                                out.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    'eval_match_coco')
     return out
-
-
-# ---- the reference's callables around the functions above (core/evaluation/affinity.py, matcher.py) --------------------------------
-class LidarCenterTransBEV:
-    """affinity.py:5-11: distance between BEV centres; smaller is closer"""
-    LARGER_CLOSER = False
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        return trans_bev(det_bboxes, gt_bboxes)
-
-
-class LidarIOU3D:
-    """affinity.py:14-23"""
-    LARGER_CLOSER = True
-
-    def __init__(self, z_offset=0.5):
-        self.z_offset = z_offset
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOU3D')
-        return iou_3d(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOU3D').to(d.device), self.z_offset)
-
-
-class LidarIOUBEV:
-    """affinity.py:26-32"""
-    LARGER_CLOSER = True
-
-    def __call__(self, det_bboxes, gt_bboxes, gt_iscrowd=None):
-        assert gt_iscrowd is None, 'Does not support crowd annotation yet'
-        d = _dev_tensor(det_bboxes, torch.float32, 'LidarIOUBEV')
-        return iou_bev(d, _dev_tensor(gt_bboxes, torch.float32, 'LidarIOUBEV').to(d.device))
-
-
-class BaseMatcher:
-    """matcher.py:6-30: `affinity_cost_negate` turns a larger-is-closer affinity into the cost the matcher minimises"""
-
-    def __init__(self, match_thrs, affinity_cost_negate=True):
-        self._match_thrs = match_thrs
-        self.negate = affinity_cost_negate
-
-    @property
-    def match_thrs(self):
-        return self._match_thrs
-
-    def __call__(self, affinity, gt_isignore=None, gt_iscrowd=None):
-        aff = _dev_tensor(affinity, torch.float32, 'matcher')
-        G = aff.shape[1]
-        if gt_iscrowd is None:
-            gt_iscrowd = np.zeros(G, dtype=bool)
-        if gt_isignore is None:
-            gt_isignore = np.zeros(G, dtype=bool)
-        thrs = np.array(self.match_thrs, np.float32)
-        if self.negate:
-            return self.match(-aff, -thrs, gt_isignore, gt_iscrowd)
-        return self.match(aff, thrs, gt_isignore, gt_iscrowd)
-
-    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
-        raise NotImplementedError
-
-
-class MatcherCoCo(BaseMatcher):
-    """matcher.py:33-37"""
-
-    def match(self, affinity, match_thrs, gt_isignore=None, gt_iscrowd=None):
-        return match_coco(affinity, match_thrs, gt_isignore, gt_iscrowd)

@@ -719,32 +719,6 @@ def test_scored_nms_over_box_sets_equals_the_per_set_calls(amd, mode):
                                         num.data_ptr(), ws.data_ptr(), None) == 10001
 
 
-def test_reference_evaluation_callables(amd):
-    """core/evaluation/affinity.py and matcher.py mirrored: the three affinity callables equal the functions they forward to, and
-    MatcherCoCo(thrs)(iou) = match_coco(-iou, -thrs, ...) (affinity_cost_negate), = match_coco(dist, thrs, ...) without the negation."""
-    det, gt = eval_boxes(50, seed=4), eval_boxes(40, seed=5)
-    z = 0.3
-    a3 = amd.LidarIOU3D(z_offset=z)(det, gt)
-    assert amd.LidarIOU3D.LARGER_CLOSER and amd.LidarIOUBEV.LARGER_CLOSER and not amd.LidarCenterTransBEV.LARGER_CLOSER
-    assert torch.equal(a3, amd.iou_3d(torch.from_numpy(det).cuda(), torch.from_numpy(gt).cuda(), z))
-    assert torch.equal(amd.LidarIOUBEV()(det, gt), amd.iou_bev(torch.from_numpy(det).cuda(), torch.from_numpy(gt).cuda()))
-    dist = amd.LidarCenterTransBEV()(det, gt)
-    assert torch.equal(dist, amd.trans_bev(det, gt))
-    with pytest.raises(AssertionError, match='crowd'):
-        amd.LidarIOUBEV()(det, gt, gt_iscrowd=np.zeros(40, bool))
-    thrs = [0.3, 0.5, 0.7]
-    ign = np.zeros(40, bool); ign[::7] = True
-    m = amd.MatcherCoCo(thrs)
-    assert m.match_thrs == thrs and m.negate
-    assert torch.equal(m(a3, gt_isignore=ign), amd.match_coco(-a3, -np.array(thrs, np.float32), ign, np.zeros(40, bool)))
-    assert torch.equal(m(a3), amd.match_coco(-a3, -np.array(thrs, np.float32), np.zeros(40, bool), np.zeros(40, bool)))
-    md = amd.MatcherCoCo([0.5, 1.0, 2.0], affinity_cost_negate=False)
-    assert torch.equal(md(dist, ign), amd.match_coco(dist, np.array([0.5, 1.0, 2.0], np.float32), ign, np.zeros(40, bool)))
-    want = oracle.match_coco(-a3.cpu().numpy(), -np.array(thrs, np.float32), ign, np.zeros(40, bool))
-    np.testing.assert_array_equal(m(a3, ign).cpu().numpy(), want)
-    with pytest.raises(NotImplementedError):
-        amd.BaseMatcher(thrs)(a3)
-
 
 # ---- NMS against keep lists derived from the REFERENCE's own rotated-IoU arithmetic (tests/golden/nms_ref_iou.npz) ----
 import nms_ref  # noqa: E402

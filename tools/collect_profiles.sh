@@ -1,17 +1,19 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence for the round into gpurun_out/<round>/.
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r04
+# Hot path only; the frozen extras (DESIGN_EXTRAS.md) are not measured any more.
 # kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
 # and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-traffic"
-SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-traffic"
-# the plain bench line first, on the fresh box (the driver's round-end bench also runs on a fresh one)
-python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-traffic --plain-steps 0"
+# the plain bench line first, on the fresh box: the defaults (100 steps / 20 warmup), then the driver's own N = 1 command
+python3 bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${R}_bench_driver_form.json 2> $OUT/bench_driver_form.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_kernel_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SHORT > $OUT/pmc_$c.log 2>&1
@@ -20,59 +22,24 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
   --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
-# context measurements (not bench lines): HBM ceilings, NMS, small-P / head-level train-step slices
 python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
-[ -x tools/hbm_probe2 ] && ./tools/hbm_probe2 > $OUT/${R}_hbm_probe2.txt 2>&1
 # multi-GPU rehearsal with ONE rank under torch.distributed.run (RCCL backend, hipGraph replay + per-step all_gather): the
-# N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling
+# N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling, and the eager form
 RUN1="python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
 $RUN1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
 $RUN1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
-$RUN1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph > $OUT/${R}_rccl_rehearsal_weak_graph.json 2> $OUT/rehearsal_weak_graph.err
-# the driver's own N = 1 command
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${R}_bench_driver_form.json 2> $OUT/bench_driver_form.err
-python3 tests/perf/multi_nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_multi_nms_time.jsonl
-GD3D_HOST_WEIGHT_CHECK=1 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_hostcheck.jsonl
+$RUN1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-graph > $OUT/${R}_rccl_rehearsal_weak_eager.json 2> $OUT/rehearsal_weak_eager.err
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
-python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
-python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
 cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
+python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
+python3 tests/perf/head_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_head_latency.jsonl
 python3 tests/perf/config_standins.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config_standins.jsonl
-# config 4 as a model sees it (head maps = conv outputs) + the per-kernel table of that step
-python3 tests/perf/config4_head.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_config4_head.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c4 -- python3 tests/perf/config4_head.py > /dev/null 2>&1
-cp $OUT/kt_c4/*/*kernel_stats.csv $OUT/${R}_config4_kernel_stats.csv 2>/dev/null
-# how the step is enqueued (eager / hipGraph, summed / unit-gradient backward), one process, same buffers
 python3 tools/step_variants.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_step_variants.jsonl
 tools/pmc_issue_mix.sh $OUT/${R}_pmc_issue_mix.txt > /dev/null 2>&1
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
-# CenterPoint inference slice (head maps -> detections): end to end vs the reference's op sequence, per-kernel table, the
-# phases inside the selection kernel, the stand-alone sort probe.  The trace goes to /tmp: its raw csv exceeds gpurun's 64 MiB.
-python3 tests/perf/center_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_time.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ci -o ci -- python3 tests/perf/center_infer_time.py > /dev/null 2>&1
-cp /tmp/kt_ci/ci_kernel_stats.csv $OUT/${R}_center_infer_kernel_stats.csv 2>/dev/null
-python3 tests/perf/anchor_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_anchor_infer_time.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ai -o ai -- python3 tests/perf/anchor_infer_time.py > /dev/null 2>&1
-grep -E "Name|ainfer|cinfer|rbox" /tmp/kt_ai/ai_kernel_stats.csv > $OUT/${R}_anchor_infer_kernel_stats.csv
-python3 tests/perf/anchor_cls_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_anchor_cls_time.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ac -o ac -- python3 tests/perf/anchor_cls_time.py > /dev/null 2>&1
-grep -E "Name|acls|head_anchor|reduce_partials" /tmp/kt_ac/ac_kernel_stats.csv > $OUT/${R}_anchor_cls_kernel_stats.csv
-python3 tests/perf/anchor_targets_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_anchor_targets_time.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_at -o at -- python3 tests/perf/anchor_targets_time.py > /dev/null 2>&1
-grep -E "Name|atgt" /tmp/kt_at/at_kernel_stats.csv > $OUT/${R}_anchor_targets_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_anchor_$c -o p -- python3 tools/anchor_pmc_driver.py > /dev/null 2>&1; done
-python3 tools/pmc_summary.py "/tmp/pmc_anchor_*/**/*counter_collection.csv" --kernel atgt > $OUT/${R}_anchor_pmc.txt
-python3 tools/pmc_summary.py "/tmp/pmc_anchor_*/**/*counter_collection.csv" --kernel acls >> $OUT/${R}_anchor_pmc.txt
-python3 tests/perf/pvrcnn_infer_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_pvrcnn_infer_time.jsonl
-python3 tests/perf/center_head_loss_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_head_loss_time.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_hl -o hl -- python3 tests/perf/center_head_loss_time.py > /dev/null 2>&1
-grep -E "Name|hfocal|ctargets|head_center|center_accum|center_scale" /tmp/kt_hl/hl_kernel_stats.csv > $OUT/${R}_center_head_loss_kernel_stats.csv
-python3 tests/perf/center_targets_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_targets_time.jsonl
-python3 tools/center_infer_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_center_infer_phases.txt
-[ -x tools/sort_probe ] && ./tools/sort_probe > $OUT/${R}_sort_probe.txt 2>&1
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
-python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
+python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time_collection.txt
 # accuracy report of THIS build: the test module deletes any older file of that name before it runs and writes it only from
 # the rows it really compared; a failed or empty run leaves no report and is said so loudly
 rm -f $OUT/${R}_accuracy_report.txt
