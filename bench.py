@@ -400,6 +400,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # stdout carries ONE line: the result.  Native libraries print there too (RCCL's five-line version banner at communicator
+    # creation, on every rank): send file descriptor 1 to stderr for the duration of the run and keep the real one for the line.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if on_gpu:
@@ -718,7 +723,8 @@ def main():
             line['roofline'] = None
         if args.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -394,6 +394,19 @@ int gd3d_loss_fused_cpu(const gd3d_params* params, const float* pred, const floa
 int gd3d_loss_reduce_cpu(const void* workspace, int64_t n, float* loss_sum);
 int gd3d_scale_rows_cpu(float* grad, const float* g, int per_row, int64_t n, int32_t nthreads);
 
+/* `_cpu` twins of the rotated-box entry points (declared further down): csrc/rbox_device.h — the geometry of the GPU kernels,
+ * every step one IEEE fp32 operation in a fixed order — compiled for the host with the same -ffp-contract=off, so results
+ * are BIT-IDENTICAL to the HIP kernels'.  Host memory, no stream, no workspace.  The reference's own pairwise IoU helpers are
+ * CPU code (ops/eval/affinity.cpp:8-105); rnms_*_cpu are the greedy scan on one thread (decisions of rnms_bev /
+ * rnms_normal_bev; mmdet3d's nms_gpu itself has no CPU form).  nthreads <= 0: std::thread::hardware_concurrency(). */
+int riou_bev_xyxyr_cpu(const float* a, int64_t na, const float* b, int64_t nb, float* iou, int32_t nthreads);
+int riou_eval_bev_cpu(const float* det, int64_t nd, const float* gt, int64_t ng, float* iou, int32_t nthreads);
+int riou_eval_3d_cpu(const float* det, int64_t nd, const float* gt, int64_t ng, float z_offset, float* iou, int32_t nthreads);
+int riou_eval_trans_bev_cpu(const float* det, int64_t nd, int32_t det_cols, const float* gt, int64_t ng, int32_t gt_cols,
+                            float* dist, int32_t nthreads);
+int rnms_bev_cpu(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep);
+int rnms_normal_bev_cpu(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, int64_t* num_keep);
+
 /* ------------------------------------------------------------------------------------
  * Rotated BEV NMS.  Replaces mmdet3d `iou3d_cuda.nms_gpu(boxes, keep, thresh, device)`
  * behind `nms_gpu(boxes, scores, thresh, pre_max_size, post_max_size)`

@@ -114,6 +114,12 @@ SYMBOLS = {
     'gd3d_loss_fused_cpu': (_int, [ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32]),
     'gd3d_loss_reduce_cpu': (_int, [_vp, _i64, _vp]),
     'gd3d_scale_rows_cpu': (_int, [_vp, _vp, _int, _i64, ctypes.c_int32]),
+    'riou_bev_xyxyr_cpu': (_int, [_vp, _i64, _vp, _i64, _vp, ctypes.c_int32]),
+    'riou_eval_bev_cpu': (_int, [_vp, _i64, _vp, _i64, _vp, ctypes.c_int32]),
+    'riou_eval_3d_cpu': (_int, [_vp, _i64, _vp, _i64, _f32, _vp, ctypes.c_int32]),
+    'riou_eval_trans_bev_cpu': (_int, [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32]),
+    'rnms_bev_cpu': (_int, [_vp, _i64, _f32, _vp, _vp]),
+    'rnms_normal_bev_cpu': (_int, [_vp, _i64, _f32, _vp, _vp]),
     'gd3d_grad_finish': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(Prologue), _vp]),
     'gd3d_probe_stream': (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'gd3d_prof_event_create': (_int, [ctypes.POINTER(_vp)]),

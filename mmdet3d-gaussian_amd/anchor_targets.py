@@ -28,8 +28,11 @@ def _assigner(cfg):
     if ckind != 'BboxOverlapsNearest3D':
         raise RuntimeError(f'anchor_head_get_targets: iou_calculator {ckind!r}; the reference configures BboxOverlapsNearest3D')
     neg = _get(cfg, 'neg_iou_thr')
-    if not isinstance(neg, (int, float)):
-        raise RuntimeError('anchor_head_get_targets: neg_iou_thr must be a number (the tuple form is not implemented)')
+    if isinstance(neg, bool) or not isinstance(neg, float):
+        # mmdet's MaxIoUAssigner applies the negative rule only `if isinstance(self.neg_iou_thr, float)`: with an int (e.g. 0) those
+        # anchors stay at -1 (ignored) there, while the kernel would apply it as a threshold; the tuple form is not implemented
+        raise RuntimeError('anchor_head_get_targets: neg_iou_thr must be a Python float (mmdet skips the negative rule for an int: '
+                           'write 0.0, not 0; the tuple form is not implemented)')
     if _get(cfg, 'ignore_iof_thr', -1) > 0:
         raise RuntimeError('anchor_head_get_targets: ignore_iof_thr > 0 (ignore boxes) is not implemented; the reference configures -1')
     return (float(_get(cfg, 'pos_iou_thr')), float(neg), float(_get(cfg, 'min_pos_iou', 0.0)),

@@ -40,6 +40,7 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno
 # explicit fmaf(), which must be an instruction, not a libm call), same contraction mode as the device build of the loss
 HOST_SOURCES = {
     'gd3d_cpu.cpp': ['-march=x86-64-v3', '-ffp-contract=fast', '-pthread'],
+    'rbox_cpu.cpp': ['-march=x86-64-v3', '-ffp-contract=off', '-pthread'],   # same single-operation sequence as rbox.hip: bit-identical decisions
 }
 HOST_COMMON = ['-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -18,8 +18,8 @@
 
 #include <algorithm>
 #include <cstring>
-#include <thread>
-#include <vector>
+
+#include "host_threads.h"
 
 namespace {
 
@@ -110,32 +110,10 @@ TileFn pick(const gd3d_params* p, bool gt) {
   }
 }
 
-int team_size(int32_t nthreads, int64_t tiles) {
-  int64_t t = nthreads > 0 ? nthreads : (int64_t)std::thread::hardware_concurrency();
-  t = std::max<int64_t>(1, std::min<int64_t>(t, tiles / 16));   // at least 16 tiles (4096 pairs) per thread
-  return tiles < INLINE_TILES ? 1 : (int)std::min<int64_t>(t, 1024);
+int team_size(int32_t nthreads, int64_t tiles) {   // at least 16 tiles (4096 pairs) per thread; < 64 tiles run inline
+  return gd3d_host::team_size(nthreads, tiles, 16, INLINE_TILES);
 }
-
-template <typename F>
-int parallel_ranges(int64_t units, int team, F&& body) {   // body(first, last) over [0, units), contiguous per thread
-  if (team <= 1) {
-    body((int64_t)0, units);
-    return 0;
-  }
-  std::vector<std::thread> th;
-  th.reserve((size_t)team - 1);
-  int rc = 0;
-  auto range = [&](int r) { return units * r / team; };
-  try {
-    for (int r = 1; r < team; ++r) th.emplace_back([&, r] { body(range(r), range(r + 1)); });
-  } catch (...) {   // thread creation failed (resource limit): the calling thread takes over what was not started
-    rc = (int)th.size() + 1;
-  }
-  body(range(0), range(1));
-  if (rc != 0) body(range(rc), units);
-  for (auto& t : th) t.join();
-  return 0;
-}
+using gd3d_host::parallel_ranges;
 
 double sum_partials(const float* partials, int64_t tiles) {
   double s = 0.0;

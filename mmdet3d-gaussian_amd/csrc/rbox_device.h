@@ -12,7 +12,11 @@
 // polynomial sequences, so the suppression mask is reproducible bit for bit by a CPU evaluation of
 // the same sequence — which is how the keep indices are verified.
 #pragma once
+#ifdef GD3D_HOST_TWIN   // csrc/rbox_cpu.cpp: the `_cpu` twins run this same geometry on the host
+#include "gd3d_host_math.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 namespace rbox {
 

@@ -10,7 +10,7 @@ classes call these two functions unchanged.
 
 The reference computes all of this on the CPU from numpy arrays.  Here the affinity matrix is produced and consumed in
 HBM; numpy inputs are accepted and moved to the current device, results are returned as tensors on that device.
-There is no CPU implementation behind these functions.
+CPU tensors take the library's `_cpu` twin in `trans_bev` (and in `iou_3d` / `iou_bev`); `match_coco` is GPU-only.
 """
 import numpy as np
 import torch
@@ -19,25 +19,33 @@ from . import _lib
 from .iou3d import iou_3d, iou_bev
 
 
-def _dev_tensor(x, dtype, name):
+def _dev_tensor(x, dtype, name, cpu_ok=False):
+    """numpy arrays (what the reference's evaluation passes) go to the current GPU when there is one; torch tensors stay on
+    their device.  What ends up on the CPU is legal only where a `_cpu` twin exists (`cpu_ok`)."""
+    from_numpy = not isinstance(x, torch.Tensor)
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x))
     if not isinstance(x, torch.Tensor):
         x = torch.as_tensor(x)
     if not x.is_cuda:
-        if not torch.cuda.is_available():
-            raise RuntimeError(f'{name}: the MI355X implementation has no CPU path and no GPU is visible')
-        x = x.cuda()
+        if from_numpy and torch.cuda.is_available():
+            x = x.cuda()
+        elif not cpu_ok:
+            raise RuntimeError(f'{name}: this function has no CPU path' + ('' if torch.cuda.is_available() else ' and no GPU is visible'))
     return x.to(dtype).contiguous()
 
 
 def trans_bev(det_bboxes, gt_bboxes):
     """(D,C>=2),(G,C'>=2) -> (D,G) distance between BEV centres (columns 0,1), affinity.cpp:83-105."""
-    d = _dev_tensor(det_bboxes, torch.float32, 'trans_bev')
-    g = _dev_tensor(gt_bboxes, torch.float32, 'trans_bev').to(d.device)
+    d = _dev_tensor(det_bboxes, torch.float32, 'trans_bev', cpu_ok=True)
+    g = _dev_tensor(gt_bboxes, torch.float32, 'trans_bev', cpu_ok=True).to(d.device)
     if d.dim() != 2 or g.dim() != 2 or d.shape[1] < 2 or g.shape[1] < 2:
         raise RuntimeError(f'trans_bev: expected (D,>=2) and (G,>=2), got {tuple(d.shape)} and {tuple(g.shape)}')
     out = torch.empty((d.shape[0], g.shape[0]), dtype=torch.float32, device=d.device)
+    if not d.is_cuda:   # the reference's own helper is CPU code (affinity.cpp:83-105): the `_cpu` twin
+        _lib.check(_lib.load().riou_eval_trans_bev_cpu(d.data_ptr(), d.shape[0], d.shape[1], g.data_ptr(), g.shape[0], g.shape[1],
+                                                       out.data_ptr(), torch.get_num_threads()), 'riou_eval_trans_bev_cpu')
+        return out
     with torch.cuda.device(d.device):
         _lib.check(_lib.load().riou_eval_trans_bev(d.data_ptr(), d.shape[0], d.shape[1], g.data_ptr(), g.shape[0],
                                                    g.shape[1], out.data_ptr(),

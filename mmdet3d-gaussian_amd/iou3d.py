@@ -11,6 +11,10 @@ final count crosses to the host (the returned tensor has a data-dependent length
 
 ``iou_bev`` / ``iou_3d`` are GPU counterparts of the reference's CPU eval helpers
 (/root/reference/mmdet3d_gaussian/ops/eval/affinity.cpp:8-81), ``(D,7) x (G,7) -> (D,G)``.
+
+Device follows the tensors: CPU tensors take the library's `_cpu` twins (csrc/rbox_cpu.cpp: the kernels' own geometry source
+compiled for the host, bit-identical results) in ``nms_gpu`` / ``nms_normal_gpu`` / ``boxes_iou_bev`` / ``iou_bev`` / ``iou_3d``;
+the batched, segmented and scored forms are GPU-only.
 """
 import ctypes
 
@@ -27,17 +31,42 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _check_boxes(boxes, cols, name):
-    if not boxes.is_cuda:
+def _check_boxes(boxes, cols, name, cpu_ok=False):
+    if not boxes.is_cuda and not cpu_ok:
         raise RuntimeError(f'{name}: the MI355X implementation has no CPU path; tensors must be on the GPU')
     if boxes.dim() != 2 or boxes.shape[1] != cols:
         raise RuntimeError(f'{name}: expected (N,{cols}) boxes, got {tuple(boxes.shape)}')
     return boxes.to(torch.float32).contiguous()
 
 
+def _same_device(a, b, name):
+    if a.device != b.device:
+        raise RuntimeError(f'{name}: operands live on different devices ({a.device}, {b.device})')
+
+
+def _nms_cpu(lib, boxes, scores, thresh, n, post_max_size, normal, padded):
+    """CPU tensors: torch's stable descending sort (the order mmdet3d's nms_gpu takes), then the `_cpu` twin of the greedy scan
+    (rnms_bev_cpu: the mask kernel's own predicate on one thread, same decisions bit for bit)."""
+    order = torch.sort(scores.reshape(-1).float() if scores.dtype != torch.float64 else scores.reshape(-1),
+                       descending=True, stable=True)[1][:n]
+    sb = boxes[order].contiguous()
+    keep = torch.empty(n, dtype=torch.int64)
+    num = torch.zeros(1, dtype=torch.int64)
+    fn = lib.rnms_normal_bev_cpu if normal else lib.rnms_bev_cpu
+    _lib.check(fn(sb.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr()), 'rnms_bev_cpu')
+    k = int(num[0])
+    if padded:
+        out = torch.zeros(n if post_max_size is None else min(n, post_max_size), dtype=torch.int64)
+        kk = min(k, out.numel())
+        out[:kk] = order[keep[:kk]]
+        return out, torch.tensor([kk], dtype=torch.int64)
+    keep = order[keep[:k]]
+    return keep if post_max_size is None else keep[:post_max_size]
+
+
 def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=False):
     name = 'nms_normal_gpu' if normal else 'nms_gpu'
-    boxes = _check_boxes(boxes, 5, name)
+    boxes = _check_boxes(boxes, 5, name, cpu_ok=True)
     if scores.shape[0] != boxes.shape[0]:
         raise RuntimeError(f'{name}: {boxes.shape[0]} boxes but {scores.shape[0]} scores')
     lib = _lib.load()
@@ -51,6 +80,8 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
     if n == 0:
         empty = torch.zeros((0,), dtype=torch.int64, device=dev)
         return (empty, torch.zeros(1, dtype=torch.int64, device=dev)) if padded else empty
+    if not boxes.is_cuda:
+        return _nms_cpu(lib, boxes, scores, thresh, n, post_max_size, normal, padded)
     # up to 16384 candidates (the heads cut to nms_pre first) the library orders the scores itself (rank by counting, prep
     # scattered to the rank: no torch.sort); float64 scores keep torch.sort (their order may differ after rounding to fp32)
     fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
@@ -374,10 +405,15 @@ def circle_nms(dets, thresh, post_max_size=83):
 
 def boxes_iou_bev(boxes_a, boxes_b):
     """Pairwise rotated BEV IoU of [x1,y1,x2,y2,ry] boxes: (M,5),(N,5) -> (M,N) (mmdet3d `boxes_iou_bev`)."""
-    a = _check_boxes(boxes_a, 5, 'boxes_iou_bev')
-    b = _check_boxes(boxes_b, 5, 'boxes_iou_bev')
+    a = _check_boxes(boxes_a, 5, 'boxes_iou_bev', cpu_ok=True)
+    b = _check_boxes(boxes_b, 5, 'boxes_iou_bev', cpu_ok=True)
     lib = _lib.load()
+    _same_device(a, b, 'boxes_iou_bev')
     out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if not a.is_cuda:
+        _lib.check(lib.riou_bev_xyxyr_cpu(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), torch.get_num_threads()),
+                   'riou_bev_xyxyr_cpu')
+        return out
     with torch.cuda.device(a.device):
         _lib.check(lib.riou_bev_xyxyr(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream(a.device)),
                    'riou_bev_xyxyr')
@@ -386,10 +422,15 @@ def boxes_iou_bev(boxes_a, boxes_b):
 
 def iou_bev(det, gt):
     """(D,7),(G,7) [x,y,z,w,h,l,yaw] -> (D,G) BEV IoU; GPU counterpart of ops/eval `iou_bev`."""
-    d = _check_boxes(det, 7, 'iou_bev')
-    g = _check_boxes(gt, 7, 'iou_bev')
+    d = _check_boxes(det, 7, 'iou_bev', cpu_ok=True)
+    g = _check_boxes(gt, 7, 'iou_bev', cpu_ok=True)
     lib = _lib.load()
+    _same_device(d, g, 'iou_bev')
     out = torch.empty((d.shape[0], g.shape[0]), dtype=torch.float32, device=d.device)
+    if not d.is_cuda:   # the reference's own helper is CPU code (affinity.cpp:51-81): the `_cpu` twin
+        _lib.check(lib.riou_eval_bev_cpu(d.data_ptr(), d.shape[0], g.data_ptr(), g.shape[0], out.data_ptr(), torch.get_num_threads()),
+                   'riou_eval_bev_cpu')
+        return out
     with torch.cuda.device(d.device):
         _lib.check(lib.riou_eval_bev(_ptr(d), d.shape[0], _ptr(g), g.shape[0], _ptr(out), _stream(d.device)),
                    'riou_eval_bev')
@@ -398,10 +439,15 @@ def iou_bev(det, gt):
 
 def iou_3d(det, gt, z_offset=0.5):
     """(D,7),(G,7) -> (D,G) 3D IoU with the reference's `z_offset` convention (affinity.cpp:26-29)."""
-    d = _check_boxes(det, 7, 'iou_3d')
-    g = _check_boxes(gt, 7, 'iou_3d')
+    d = _check_boxes(det, 7, 'iou_3d', cpu_ok=True)
+    g = _check_boxes(gt, 7, 'iou_3d', cpu_ok=True)
     lib = _lib.load()
+    _same_device(d, g, 'iou_3d')
     out = torch.empty((d.shape[0], g.shape[0]), dtype=torch.float32, device=d.device)
+    if not d.is_cuda:
+        _lib.check(lib.riou_eval_3d_cpu(d.data_ptr(), d.shape[0], g.data_ptr(), g.shape[0], float(z_offset), out.data_ptr(),
+                                        torch.get_num_threads()), 'riou_eval_3d_cpu')
+        return out
     with torch.cuda.device(d.device):
         _lib.check(lib.riou_eval_3d(_ptr(d), d.shape[0], _ptr(g), g.shape[0], float(z_offset), _ptr(out),
                                     _stream(d.device)), 'riou_eval_3d')

@@ -49,6 +49,11 @@ def pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred,
     sizes = [int(p.shape[0]) for p in class_pred]
     if sum(sizes) != R:
         raise RuntimeError(f'pvrcnn_head_get_bboxes: class_pred holds {sum(sizes)} rows for {R} rois')
+    # the b-th run of the stable sort must have exactly len(class_pred[b]) rows: equal SUMS with different per-sample counts (or batch
+    # ids outside 0..B-1) would pair probabilities with the wrong rois silently, where the reference fails on a shape mismatch
+    per_sample = torch.bincount(bid.clamp(min=0), minlength=len(sizes)).tolist() if R else [0] * len(sizes)
+    if (R and int(bid.min()) < 0) or per_sample != sizes:
+        raise RuntimeError(f'pvrcnn_head_get_bboxes: rois per sample {per_sample} do not match the class_pred sizes {sizes}')
     probs = torch.cat([p.to(dev) for p in class_pred], dim=0).float()           # sample-major = the order of `order`
     labels = torch.cat([l.to(dev) for l in class_labels], dim=0)
     scores = cls_score.reshape(-1)[order]

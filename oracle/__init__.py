@@ -5,7 +5,7 @@ compiled reference helpers (oracle/_ref, built from /root/reference sources wher
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this package, and only as the checker / the reported CPU baseline.  The product package
-(``mmdet3d-gaussian_amd/``) never imports it and has no CPU fallback.
+(``mmdet3d-gaussian_amd/``) never imports it; the product's own CPU path (the _cpu twins) is compiled from its kernel source, not from here.
 """
 import ctypes
 import importlib.util

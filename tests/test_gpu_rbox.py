@@ -767,3 +767,20 @@ def test_riou_bev_xyxyr_against_the_reference_iou(amd, name):
     for t in out:
         ex = nms_ref.exact_iou_xyxyr(bs[ni[t]], bs[nj[t]])
         assert abs(own[t] - ex) <= 1e-4 < abs(nv[t] - ex)
+
+
+def test_cpu_twins_equal_the_hip_kernels(amd):
+    """csrc/rbox_cpu.cpp compiles the kernels' own geometry source for the host with the same -ffp-contract=off: pairwise IoU
+    (both box formats), centre distances and NMS keep lists are the same BITS on CPU tensors and on GPU tensors."""
+    d, g = eval_boxes(200, 7), eval_boxes(150, 8)
+    dt, gt = torch.from_numpy(d), torch.from_numpy(g)
+    assert torch.equal(amd.iou_bev(dt, gt), amd.iou_bev(dt.cuda(), gt.cuda()).cpu())
+    assert torch.equal(amd.iou_3d(dt, gt, 0.3), amd.iou_3d(dt.cuda(), gt.cuda(), 0.3).cpu())
+    assert torch.equal(amd.trans_bev(dt, gt), amd.trans_bev(dt.cuda(), gt.cuda()).cpu())
+    b, s = nms_boxes(3000, seed=12)
+    bt, st = torch.from_numpy(b), torch.from_numpy(s)
+    assert torch.equal(amd.boxes_iou_bev(bt[:500], bt), amd.boxes_iou_bev(bt[:500].cuda(), bt.cuda()).cpu())
+    for thr, pre, post in ((0.25, None, None), (0.7, 2048, 300)):
+        assert torch.equal(amd.nms_gpu(bt, st, thr, pre_max_size=pre, post_max_size=post),
+                           amd.nms_gpu(bt.cuda(), st.cuda(), thr, pre_max_size=pre, post_max_size=post).cpu())
+    assert torch.equal(amd.nms_normal_gpu(bt, st, 0.4), amd.nms_normal_gpu(bt.cuda(), st.cuda(), 0.4).cpu())

@@ -86,8 +86,7 @@ def test_cpu_tensors_take_the_cpu_twin_and_gpu_tensors_never_do():
     """SURVEY.md §8b `_cpu` twins: GDLoss follows the device of its tensors like the reference module
     (gaussian_distance_loss.py:280-310).  CPU tensors run gd3d_loss_fused_cpu (the kernel's per-pair math compiled for the
     host, not the oracle); a tensor that says it is on the GPU goes to the HIP entry points and nowhere else — on this
-    GPU-less machine that attempt fails loudly instead of being answered by the CPU twin.  The GPU-only ops (mmdet3d's nms_gpu
-    has no CPU form either) keep raising on CPU tensors."""
+    GPU-less machine that attempt fails loudly instead of being answered by the CPU twin."""
     m = amd.GDLoss('gwd3d')
     out = m(torch.rand(4, 7) + 0.5, torch.rand(4, 7) + 0.5)
     assert out.dim() == 0 and torch.isfinite(out)
@@ -95,10 +94,16 @@ def test_cpu_tensors_take_the_cpu_twin_and_gpu_tensors_never_do():
         with pytest.raises(Exception) as info:       # the HIP path is taken (and cannot run here); no silent CPU answer
             m(_FakeCuda(4), _FakeCuda(4))
         assert not isinstance(info.value, AssertionError)
+    # the rotated-box entry points with a `_cpu` twin follow their tensors too; the batched / scored forms, the matcher and the
+    # scatter ops are GPU-only (no CPU form in the reference either) and say so
+    assert amd.nms_gpu(torch.rand(4, 5), torch.rand(4), 0.5).device.type == 'cpu'
+    assert amd.iou_3d(torch.rand(4, 7) + 0.5, torch.rand(4, 7) + 0.5).shape == (4, 4)
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.nms_gpu(torch.rand(4, 5), torch.rand(4), 0.5)
+        amd.nms_gpu_batched(torch.rand(4, 5), torch.rand(1, 4), 0.5)
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.iou_3d(torch.rand(4, 7), torch.rand(4, 7))
+        amd.match_coco(torch.rand(3, 2), torch.tensor([0.5]), torch.zeros(2, dtype=torch.bool), torch.zeros(2, dtype=torch.bool))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        amd.scatter_index(torch.zeros(4, 3, dtype=torch.int32))
     with pytest.raises(ValueError):
         # avg_factor with reduction='sum' is rejected before any device work (mmdet weight_reduce_loss)
         amd.GDLoss('gwd3d', reduction='sum')(_FakeCuda(4), _FakeCuda(4), avg_factor=2.0)
