@@ -414,6 +414,12 @@ extern "C" {
 
 int32_t anchor_targets_max_gt(void) { return MAX_GT; }
 
+__global__ __launch_bounds__(256) static void atgt_zero_kernel(unsigned* a, long long na, unsigned* b, long long nb) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+}
+
 size_t anchor_targets_workspace_bytes(int32_t num_assigners, int32_t gt_total) {
   if (num_assigners < 1 || gt_total < 0) return 256;
   return (((size_t)num_assigners * (size_t)(gt_total > 0 ? gt_total : 1) * 8) + 255) & ~(size_t)255;
@@ -457,10 +463,15 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   while (tile_cells > 1 && lds1 + (size_t)tile_cells * SR * 36 > 64 * 1024) tile_cells /= 2;   // many boxes: smaller tiles
   const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
   if (lds2 > 64 * 1024) return GD3D_E_TOOLARGE;
-  hipError_t e = hipMemsetAsync(workspace, 0, anchor_targets_workspace_bytes(K, g_total), s);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * d.batch, s);
-  if (e != hipSuccess) return (int)e;
+  // cleared by a kernel, not by hipMemsetAsync: inside a captured hipGraph a memset node was found not to be reliably ordered
+  // against the kernels around it on this ROCm (round 4, csrc/rbox.hip rank_count_kernel), and this call is replayed in graphs
+  {
+    const size_t w4 = anchor_targets_workspace_bytes(K, g_total) / 4, c4 = (size_t)2 * d.batch;
+    const size_t most = w4 > c4 ? w4 : c4;
+    unsigned zb = (unsigned)((most + 255) / 256);
+    if (zb > 1024) zb = 1024;
+    hipLaunchKernelGGL(atgt_zero_kernel, dim3(zb), dim3(256), 0, s, (unsigned*)workspace, (long long)w4, (unsigned*)counts, (long long)c4);
+  }
   Args a;
   a.d = d;
   a.anchors = anchors;

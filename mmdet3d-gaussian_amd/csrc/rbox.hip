@@ -18,6 +18,8 @@
 #include <stdint.h>
 
 #include "../../include/gd3d.h"
+#include <stdlib.h>
+
 #include "rbox_device.h"
 
 namespace rbox {
@@ -39,12 +41,22 @@ struct NmsArgs {
 
 __device__ __forceinline__ int group_n(const NmsArgs& a, int g) {
   if (a.counts == nullptr) return a.n;
-  const int c = a.counts[g];
+  const int c = __hip_atomic_load(&a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return c < 0 ? 0 : (c > a.cap ? a.cap : c);
 }
 
 // `order` (nullable): score order computed by the caller; box i of the NMS is boxes[order[i]] (saves the gather pass)
-__global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* __restrict__ out) {
+// `zero_words` (nullable): control words of the queued mask form, cleared here so that no separate fill sits in the stream
+// (zero_n words PER GROUP; the first workgroup of group blockIdx.y clears that group's words)
+__device__ __forceinline__ void zero_control_words(unsigned* zero_words, int zero_n) {
+  if (zero_words != nullptr && blockIdx.x == 0)
+    for (int k = threadIdx.x; k < zero_n; k += blockDim.x) zero_words[(size_t)blockIdx.y * zero_n + k] = 0u;
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* words, int per_group) { zero_control_words(words, per_group); }
+
+__global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* __restrict__ out, unsigned* zero_words, int zero_n) {
+  zero_control_words(zero_words, zero_n);
   const int g = blockIdx.y;
   const int n = group_n(a, g);
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -86,9 +98,14 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
 // array and ranks only those — O(sum n_g^2) compares and O(G * slices * n_max) workspace instead of the dense (G, G n)
 // matrices; `n` is then the LARGEST group size (grid extent, prank stride), indices inside a group are local.
 __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores_, const unsigned char* __restrict__ valid_,
-                                                        const int* __restrict__ seg, int n, int* __restrict__ prank_) {
+                                                        const int* __restrict__ seg, int n, int* __restrict__ prank_,
+                                                        int* __restrict__ zero_counts) {
   __shared__ int spart[4][64];
   const int tid = threadIdx.x, lane = tid & 63;
+  // counts[group] (rank_scatter_kernel adds to it) is cleared HERE, not by a hipMemsetAsync in front of the launches: inside a
+  // captured hipGraph the memset node was not reliably ordered against the kernels around it on this ROCm (round 4: replays of a
+  // graph holding rnms_batched_scored_sets returned counts of 0 or of twice the boxes, profiles/r04_nms_queue_ab.txt)
+  if (zero_counts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) zero_counts[blockIdx.z] = 0;
   const int part = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = quarter of the slice
   const int base = seg != nullptr ? seg[blockIdx.z] : 0;
   const int ng = seg != nullptr ? seg[blockIdx.z + 1] - base : n;
@@ -128,7 +145,9 @@ template <bool PREP>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ valid_,
                                                           const int* __restrict__ seg, const int* __restrict__ prank_, int n,
                                                           int slices, int n_keep, long long* __restrict__ order_,
-                                                          OBox* __restrict__ ob_, int* __restrict__ counts, int gps) {
+                                                          OBox* __restrict__ ob_, int* __restrict__ counts, int gps,
+                                                          unsigned* zero_words, int zero_n) {
+  zero_control_words(zero_words, zero_n);
   const int g = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   // gps > 0: every gps consecutive groups share one set of n boxes, set k at rows [k n, (k + 1) n) of the flat box array
@@ -258,41 +277,36 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
 // selects the (earlier box, row box) pairs that are evaluated in greedy operand order for colm[] — as in the plain kernel.
 // A pair that fails the circle test has overlap exactly 0 and IoU +0, which is "> thresh" only for thresh < 0: for such a
 // threshold (or a NaN one) every valid pair is queued, so the result stays that of the plain kernel.
-#ifndef MASK_STAMP   // tools/mask_probe.hip: cycle stamps of one wave of the mask kernel; nothing in the product
-#define MASK_STAMP(k) do { } while (0)
-#define MASK_NOTE(v) do { } while (0)
-#define MASK_STAMP_SYNC(k) do { } while (0)
-#endif
 constexpr int CQ_ROWS = 16;                 // rows per chunk between drains (<= 32: one bit per row in a lane's mask)
 constexpr int CQ_CAP = CQ_ROWS * 64 + 64;   // worst case of one chunk + the carried remainder (< 64)
 
-__global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
-                                                              unsigned long long* __restrict__ mask_,
-                                                              unsigned long long* __restrict__ colm_) {
-  __shared__ VertexScratch<64> vs;
-  __shared__ unsigned short queue[CQ_CAP];
-  __shared__ unsigned long long words[64];
-  const int lane = threadIdx.x;
-  const int g = blockIdx.y;
-  const int n = group_n(a, g);
-  const int cb = (n + 63) >> 6;
-  const int rows = a.rows;
-  const int groups = 64 / rows;
-  const unsigned pair = blockIdx.x / groups;
-  if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
-  const int r0 = (int)(blockIdx.x % groups) * rows;
-  const OBox* ob = ob_ + (size_t)g * a.cap;
-  unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
-  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
-  const bool all_pairs = !(thresh >= 0.0f);
-  int rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
+// block pair index of the upper triangle (row-major over row blocks) -> (row block rb, column block c >= rb)
+__device__ __forceinline__ void pair_blocks(unsigned pair, int cb, int& rb, int& c) {
+  rb = (int)((2.0f * cb + 1.0f - sqrtf((2.0f * cb + 1.0f) * (2.0f * cb + 1.0f) - 8.0f * (float)pair)) * 0.5f);
   rb = max(0, min(rb, cb - 1));
   while (rb > 0 && (unsigned)(rb * cb - rb * (rb - 1) / 2) > pair) --rb;
   while ((unsigned)((rb + 1) * cb - (rb + 1) * rb / 2) <= pair) ++rb;
-  const int c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
+  c = rb + (int)(pair - (unsigned)(rb * cb - rb * (rb - 1) / 2));
+}
+
+struct CompactLds {
+  VertexScratch<64> vs;
+  unsigned short queue[CQ_CAP];
+  unsigned long long words[64];
+};
+
+// one wave: `rows` row boxes (from row r0 of row block rb) x column block c of group g -> final mask words (and colm on a
+// diagonal block).  The whole job of nms_mask_compact_kernel for one workgroup; also the overflow path of the queued form.
+__device__ __forceinline__ void compact_pair(const NmsArgs& a, const OBox* __restrict__ ob, unsigned long long* __restrict__ mask,
+                                             unsigned long long* __restrict__ colm, int n, int rb, int c, int r0, int rows,
+                                             float thresh, CompactLds& L) {
+  VertexScratch<64>& vs = L.vs;
+  unsigned short* const queue = L.queue;
+  unsigned long long* const words = L.words;
+  const int lane = threadIdx.x & 63;
+  const bool all_pairs = !(thresh >= 0.0f);
   const int i0 = rb * 64 + r0;  // first row box of this wave
   if (i0 >= n) return;
-  MASK_STAMP(0);
   const int nrows = min(rows, n - i0);
   const int j = c * 64 + lane;
   const bool jv = j < n;
@@ -314,7 +328,6 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
   }
   words[lane] = 0ull;
   __syncthreads();
-  MASK_STAMP(1);
   int qn = 0;  // queued candidates (wave-uniform)
   for (int rbase = 0; rbase < nrows; rbase += CQ_ROWS) {
     const int rend = min(rbase + CQ_ROWS, nrows);
@@ -359,28 +372,22 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
       }
     }
     qn += __builtin_amdgcn_readlane(incl, 63);
-    MASK_NOTE(__builtin_amdgcn_readlane(incl, 63));
     __syncthreads();
-    MASK_STAMP(2 + 2 * (rbase / CQ_ROWS));
     const bool last = rend >= nrows;
     int done = 0;
     while (qn - done >= 64 || (last && done < qn)) {
       const int q = done + lane;
-      MASK_STAMP(10);
       if (q < qn) {
         const int e = queue[q];
         const int r = e >> 6, jl = e & 63;
         const int i = i0 + r, jj = c * 64 + jl;
         const OBox A = ob[i];
         const OBox B = ob[jj];
-        MASK_STAMP_SYNC(11);
         const bool low = jj < i;  // diagonal block only: the lane's box precedes the row box -> it goes first
         const OBox F = low ? B : A, S = low ? A : B;
         const bool hit = iou_bev<64>(F, S, vs, lane) > thresh;
-        MASK_STAMP_SYNC(12);
         if (hit) atomicOr(&words[r], 1ull << jl);
       }
-      MASK_STAMP_SYNC(13);
       done += 64;
     }
     if (!last && done > 0) {  // carry the < 64 leftover candidates to the front of the queue
@@ -392,7 +399,6 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
       qn = rem;
     }
     __syncthreads();
-    MASK_STAMP(3 + 2 * (rbase / CQ_ROWS));
   }
   if (lane < nrows) {
     const int i = i0 + lane;
@@ -401,10 +407,195 @@ __global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, c
       const int il = i & 63;
       const unsigned long long below = (1ull << il) - 1ull;
       mask[(size_t)i * a.cbs + c] = word & ~(below | (1ull << il));
-      colm_[(size_t)g * a.cap + i] = word & below;
+      colm[i] = word & below;
     } else {
       mask[(size_t)i * a.cbs + c] = word;
     }
+  }
+}
+
+__global__ __launch_bounds__(64) void nms_mask_compact_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
+                                                              unsigned long long* __restrict__ mask_,
+                                                              unsigned long long* __restrict__ colm_) {
+  __shared__ CompactLds L;
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const int rows = a.rows;
+  const int groups = 64 / rows;
+  const unsigned pair = blockIdx.x / groups;
+  if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
+  int rb, c;
+  pair_blocks(pair, cb, rb, c);
+  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
+  compact_pair(a, ob_ + (size_t)g * a.cap, mask_ + (size_t)g * a.cap * a.cbs, colm_ + (size_t)g * a.cap, n, rb, c,
+               (int)(blockIdx.x % groups) * rows, rows, thresh, L);
+}
+
+// ---- Rotated mode, QUEUED (round 4): circle test and clipping as two kernels, every clipping pass full. -----------------------
+// In the compacted kernel above every wave ends with one partly filled clipping pass (~1 % of a 64 x 64 block pair's 4096
+// pairs survive the circle test: ~41 live lanes of 64) and the kernel lasts as long as its slowest waves (pairs with > 64
+// survivors run two passes, the diagonal blocks evaluate every pair twice): profiles/r04_nms_pmc.txt.  Here
+//   nms_circle_queue_kernel  one wave per block pair: zeroes the pair's mask words, runs ONLY the circle tests and appends the
+//                            survivors (i << 16 | j, i < j) to a per-group queue in HBM (one wave-aggregated atomicAdd);
+//                            a diagonal block queues every unordered pair ONCE (the compacted kernel evaluates it twice,
+//                            as row i / lane j and as row j / lane i, with the same operand order and the same result);
+//   nms_clip_queue_kernel    a fixed grid of waves walks the queue 64 entries at a time: lane l evaluates entry l with the
+//                            full predicate and ORs its bit into mask[i][j / 64] — and, inside a diagonal block, into
+//                            colm[j] as well (integer atomics: the words are the same whatever the order).
+// Same predicate, same operand order (earlier box first), same bits.  A wave whose survivors do not fit the queue
+// (128 entries per box over 64 shards; only pathological clouds get there) records its block pair instead and the clip kernel runs
+// compact_pair() on it afterwards.
+constexpr unsigned QUEUE_SENTINEL = 0xffffffffu;   // (65535, 65535): never a queued pair (i < j)
+// The queue is cut into QUEUE_SHARDS sub-queues (block pair p appends to shard p % QUEUE_SHARDS), each with its own counter in
+// its own 128-byte line: returning atomics on ONE word saturate at ~88 per us on this chip (MI355X_MICROARCH.md, "dequeue"), and
+// the 2080 appends of an n = 4096 call through one counter cost 24 us — more than the clipping they were meant to feed.
+constexpr unsigned QUEUE_SHARDS = 64;
+constexpr unsigned CTL_STRIDE = 32;                                  // words: one 128-byte line per counter
+constexpr unsigned CTL_WORDS = (QUEUE_SHARDS + 1) * CTL_STRIDE;      // per group: shard counters, then the overflow counter
+struct QueueArgs {
+  unsigned* queue;   // (G, QUEUE_SHARDS, scap)
+  unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
+  unsigned* ovl;     // (G, npairs) overflowed block pair ids
+  unsigned scap, npairs;   // scap: entries per shard
+};
+
+__global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
+                                                              unsigned long long* __restrict__ mask_,
+                                                              unsigned long long* __restrict__ colm_, const QueueArgs q) {
+  const int lane = threadIdx.x;
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  const int cb = (n + 63) >> 6;
+  const unsigned pair = blockIdx.x;
+  if (pair >= (unsigned)(cb * (cb + 1) / 2)) return;  // grid is sized for `cap`
+  int rb, c;
+  pair_blocks(pair, cb, rb, c);
+  const OBox* ob = ob_ + (size_t)g * a.cap;
+  unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
+  const int i0 = rb * 64;
+  const int nrows = min(64, n - i0);
+  const int j = c * 64 + lane;
+  const bool jv = j < n;
+  float bcx = 0.0f, bcy = 0.0f, bext = 0.0f;
+  if (jv) {
+    const OBox& B = ob[j];
+    bcx = B.cx;
+    bcy = B.cy;
+    bext = fabsf(B.x2 - B.x1) + fabsf(B.y2 - B.y1);
+  }
+  float rcx = 0.0f, rcy = 0.0f, rext = 0.0f;
+  if (lane < nrows) {
+    const OBox& R = ob[i0 + lane];
+    rcx = R.cx;
+    rcy = R.cy;
+    rext = fabsf(R.x2 - R.x1) + fabsf(R.y2 - R.y1);
+    mask[(size_t)(i0 + lane) * a.cbs + c] = 0ull;                 // the clip kernel ORs into these
+    if (rb == c) colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
+  }
+  // circle tests, straight-line as in compact_pair: lane l (column box j) against the 64 row boxes; bit r of `cand` = the
+  // pair (row i0 + r, column j) survives.  On the diagonal block only the pairs with the column box AFTER the row box.
+  unsigned long long cand = 0ull;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const float acx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r));
+    const float acy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r));
+    const float aext = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r));
+    const float ddx = acx - bcx, ddy = acy - bcy;   // box_overlap's early-out, same operations (symmetric in the boxes)
+    const float reach = 0.5f * (aext + bext) + 1e-2f;
+    const bool near = !(ddx * ddx + ddy * ddy > reach * reach * 1.0001f);
+    cand |= near ? (1ull << r) : 0ull;
+  }
+  cand &= nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
+  if (rb == c) cand &= (1ull << lane) - 1ull;        // rows r < lane only: i = i0 + r < j = i0 + lane
+  if (!jv) cand = 0ull;
+  const int cntl = __popcll(cand);
+  int incl = cntl;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1 (out-of-row reads 0)
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  unsigned* const ctl = q.ctl + (size_t)g * CTL_WORDS;
+  unsigned* const novf = ctl + QUEUE_SHARDS * CTL_STRIDE;
+  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
+  if (!(thresh >= 0.0f)) {   // uniform: a negative or NaN threshold makes EVERY valid pair a candidate (IoU +0 > thresh):
+    if (lane == 0) {   // compact_pair's all-pairs case
+      const unsigned k = atomicAdd(novf, 1u);
+      if (k < q.npairs) q.ovl[(size_t)g * q.npairs + k] = pair;
+    }
+    return;
+  }
+  if (total == 0) return;   // uniform
+  const unsigned shard = pair % QUEUE_SHARDS;
+  unsigned base = 0u;
+  if (lane == 0) base = atomicAdd(&ctl[shard * CTL_STRIDE], (unsigned)total);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  unsigned* const queue = q.queue + ((size_t)g * QUEUE_SHARDS + shard) * q.scap;
+  unsigned pos = base + (unsigned)(incl - cntl);
+  if (base + (unsigned)total > q.scap) {   // uniform: does not fit -> this block pair goes to the overflow list,
+    if (lane == 0) {   // what was reserved is voided
+      const unsigned k = atomicAdd(novf, 1u);
+      if (k < q.npairs) q.ovl[(size_t)g * q.npairs + k] = pair;
+    }
+    for (int k = 0; k < cntl; ++k, ++pos)
+      if (pos < q.scap) queue[pos] = QUEUE_SENTINEL;
+    return;
+  }
+  while (cand != 0ull) {
+    const int r = __builtin_ctzll(cand);
+    cand &= cand - 1ull;
+    queue[pos++] = ((unsigned)(i0 + r) << 16) | (unsigned)j;
+  }
+}
+
+__global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
+                                                            unsigned long long* __restrict__ mask_,
+                                                            unsigned long long* __restrict__ colm_, const QueueArgs q) {
+  __shared__ CompactLds L;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.y;
+  const int n = group_n(a, g);
+  if (n == 0) return;
+  const OBox* ob = ob_ + (size_t)g * a.cap;
+  unsigned long long* mask = mask_ + (size_t)g * a.cap * a.cbs;
+  unsigned long long* colm = colm_ + (size_t)g * a.cap;
+  const float thresh = a.thresh_dev != nullptr ? a.thresh_dev[g] : a.thresh;
+  const unsigned* const ctl = q.ctl + (size_t)g * CTL_WORDS;
+  // wave w serves shard w % QUEUE_SHARDS (the grid is a multiple of QUEUE_SHARDS waves), every (grid / QUEUE_SHARDS)-th chunk of it
+  const unsigned shard = blockIdx.x % QUEUE_SHARDS, per_shard = gridDim.x / QUEUE_SHARDS;
+  // device-scope atomic loads: the counters were produced by the atomics of the previous kernel; a plain (scalar-cache) load of
+  // a word that the same graph's previous replay also read is not guaranteed to be refetched
+  const unsigned reserved = __hip_atomic_load(&ctl[shard * CTL_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned count = reserved < q.scap ? reserved : q.scap;
+  const unsigned* const queue = q.queue + ((size_t)g * QUEUE_SHARDS + shard) * q.scap;
+  for (unsigned b0 = (blockIdx.x / QUEUE_SHARDS) * 64u; b0 < count; b0 += per_shard * 64u) {   // uniform bounds
+    const unsigned e = (b0 + lane < count) ? queue[b0 + lane] : QUEUE_SENTINEL;
+    const int ei = (int)(e >> 16), ej = (int)(e & 0xffffu);
+    if (e != QUEUE_SENTINEL && ei < ej && ej < n) {   // (the bounds cannot fail for an entry this call queued: they fence off garbage)
+      const int i = ei, j = ej;   // i < j: the earlier box goes first, as in the greedy order
+      const OBox A = ob[i];
+      const OBox B = ob[j];
+      if (iou_bev<64>(A, B, L.vs, lane) > thresh) {
+        atomicOr(&mask[(size_t)i * a.cbs + (j >> 6)], 1ull << (j & 63));
+        if ((i >> 6) == (j >> 6)) atomicOr(&colm[j], 1ull << (i & 63));
+      }
+    }
+  }
+  unsigned novf = __hip_atomic_load(&ctl[QUEUE_SHARDS * CTL_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (novf == 0u) return;
+  const int cb = (n + 63) >> 6;
+  const unsigned npairs_now = (unsigned)(cb * (cb + 1) / 2);
+  novf = novf < npairs_now ? novf : npairs_now;
+  for (unsigned k = blockIdx.x; k < novf; k += gridDim.x) {   // block pairs that did not fit the queue: the compacted form
+    const unsigned op = q.ovl[(size_t)g * q.npairs + k];
+    if (op >= npairs_now) continue;   // (cannot happen for an entry this call recorded)
+    int rb, c;
+    pair_blocks(op, cb, rb, c);
+    __syncthreads();
+    compact_pair(a, ob, mask, colm, n, rb, c, 0, 64, thresh, L);
   }
 }
 
@@ -477,8 +668,8 @@ __device__ __forceinline__ void wave_or_words_lane63(unsigned long long (&w)[NW]
 //   Block b's rows therefore reach remv[w >= b+4] during interval b+3, one barrier before block b+4 is resolved; words
 //   b+1..b+3 are covered by the urgent words.  Every wave executes exactly cb barriers.
 // History: one scalar readlane step per kept box + load->use inside the interval: 1.2-3.8 us per block.
-constexpr int SCAN_GW = 3;                      // waves per propagate group
-constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW);  // 640 threads
+constexpr int SCAN_GW = 3;                          // waves per propagate group
+constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW + 3);  // 832 threads: resolver, 3 x 3 row waves, 3 field waves
 constexpr int SCAN_NU = 3;                      // urgent words per box
 constexpr int SCAN_RING = 4;
 
@@ -608,14 +799,14 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
         for (int k = 0; k < SCAN_NU; ++k)
           if (c + 1 + k < cb)   // (uniform bound)
             asm volatile("ds_or_b64 %0, %1" ::"v"(lds_offset(&remv[c + 1 + k])), "v"(urg[k]) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS barrier below must see them
-      }
+      }   // (they are waited for right before the barrier below, behind the rest of the block's bookkeeping)
       if (mine) klist[c & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = lane;
       count += __builtin_popcountll(kept);
       if (lane == 0) {
         skept[c & 3] = kept;
         if (windowed) gkept[c] = kept;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lane 63's ds_or_b64 above are inline asm: the compiler does not count them
       SCAN_STAMP(3);
       lds_barrier();
       SCAN_STAMP(5);
@@ -623,11 +814,40 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
     if (lane == 0) num_keep[g] = count;
   } else {
     // ---------------------------------------------------------------- propagate / loader groups
-    const int grp = (wave - 1) / SCAN_GW, rank = (wave - 1) - grp * SCAN_GW;
+    // Round 4: the resolver's inputs (five fields per box of block t + 3) are fetched by three FIELD waves of their own, one
+    // per phase; the nine row waves only spread kept rows.  Until then rank 0 / 1 / 2 of a group also loaded two / two / one
+    // field, and the group's issue interval (~250 dependent instructions at the 5-6 cycles a lone wave pays each) was as long
+    // as the whole interval — the scan's critical stream together with the resolver (profiles/r04_nms_pmc.txt).
+    const bool field_wave = wave > 3 * SCAN_GW;
+    const int grp = field_wave ? wave - 1 - 3 * SCAN_GW : (wave - 1) / SCAN_GW;
+    const int rank = field_wave ? 0 : (wave - 1) - grp * SCAN_GW;
     const int lead = min(grp, NB);
     const int S = (NB - lead) / 3;
     const int trail = NB - lead - 3 * S;
     for (int q = 0; q < lead; ++q) lds_barrier();
+    if (field_wave) {
+      for (int s2 = 0; s2 < S; ++s2) {
+        const int t0 = c_begin + grp + 3 * s2;
+        // ---- interval t0: issue the loads of block t0 + 3's inputs (constant field ids: a run-time id cost ~430 cycles per field)
+        unsigned long long in[2 + SCAN_NU];
+#pragma unroll
+        for (int f = 0; f < 2 + SCAN_NU; ++f) in[f] = load_field(t0 + 3, f);
+        lds_barrier();
+        // ---- interval t0+1: the loads fly
+        lds_barrier();
+        // ---- interval t0+2: into the ring (first USE of the loaded registers pinned here, see the row waves)
+#pragma unroll
+        for (int f = 0; f < 2 + SCAN_NU; ++f) asm volatile("" : "+v"(in[f]));
+        if (t0 + 3 < cb) {
+          const int slot = (t0 + 3) & (SCAN_RING - 1);
+#pragma unroll
+          for (int f = 0; f < 2 + SCAN_NU; ++f) rin[slot][f][lane] = in[f];
+        }
+        lds_barrier();
+      }
+      for (int q = 0; q < trail; ++q) lds_barrier();
+      return;
+    }
     for (int s2 = 0; s2 < S; ++s2) {
       const int t0 = c_begin + grp + 3 * s2;
       [[maybe_unused]] const int c = t0;  // (SCAN_STAMP index)
@@ -642,25 +862,16 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       // per instruction: walking the kept bits with ffbl / and / compare cost more than the memory round trip)
       const int cnt = __builtin_popcountll(kb);
       const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
-      const int myl = (lane < m) ? klist[bk & 3][rank + SCAN_GW * lane] : 0;
+      // (unconditional: a lane beyond m reads a stale or foreign slot that no readlane below ever selects; predicating the read
+      //  on lane < m made it wait for the kept word's own LDS round trip first)
+      const int myl = klist[bk & 3][(rank + SCAN_GW * lane) & 63];
       if (wave == 1) SCAN_STAMP_SYNC(13);
       const unsigned long long* blk = mask + (size_t)(max(bk, c_begin) * 64) * cbs;
-      // the resolver's inputs for block t0+3, two fields per wave of the group: rank 0 {col, id}, 1 {urgent 1, 2}, 2 {3}
-      const int fa = rank == 0 ? 0 : (rank == 1 ? 1 : 3), fb = rank == 0 ? 1 + SCAN_NU : (rank == 1 ? 2 : -1);
-      unsigned long long in[2];
-      if (rank == 0) {  // one uniform branch, then constant field ids (a run-time id cost ~430 cycles per field)
-        in[0] = load_field(t0 + 3, 0);
-        in[1] = load_field(t0 + 3, 1 + SCAN_NU);
-      } else if (rank == 1) {
-        in[0] = load_field(t0 + 3, 1);
-        in[1] = load_field(t0 + 3, 2);
-      } else {
-        in[0] = load_field(t0 + 3, 3);
-        in[1] = 0ull;
-      }
       // Loads are unconditional per lane: the word index is clamped into the row (w < cb is the same for every row of a
       // chunk, so the surplus lanes are masked ONCE, at consume time) — a per-row lane predicate cost ~100 cycles per
-      // row in exec-mask handling.
+      // row in exec-mask handling.  (Leaving the registers of absent row pairs unwritten and guarding their use at consume time
+      // was tried in round 4: the compiler then copies every loaded value at the end of its conditional block — a use right
+      // behind the load, one memory round trip per pair: 500 cycles each.  The zero fill below is the cheap form.)
       unsigned long long v[U][CH];
       unsigned int wcl[CH];
 #pragma unroll
@@ -705,8 +916,6 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) asm volatile("" : "+v"(v[u][ch]));
-      asm volatile("" : "+v"(in[0]));
-      asm volatile("" : "+v"(in[1]));
 #pragma unroll
       for (int ch = 0; ch < CH; ++ch) {
         unsigned long long acc = 0ull;
@@ -714,11 +923,6 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
         for (int u = 0; u < U; ++u) acc |= v[u][ch];
         const int w = first + ch * 64 + lane;
         if (w < cb && acc) atomicOr(&remv[w], acc);  // ds_or_b64: waves merge into the same words
-      }
-      if (t0 + 3 < cb) {
-        const int slot = (t0 + 3) & (SCAN_RING - 1);
-        rin[slot][fa][lane] = in[0];
-        if (fb >= 0) rin[slot][fb][lane] = in[1];
       }
       if (wave == 1) SCAN_STAMP(9);
       lds_barrier();
@@ -815,29 +1019,48 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 using namespace rbox;
 
-static const int64_t RNMS_MAX_N = 65536;  // 1024 mask words per row; removed-set = 8 KiB of LDS
+static const int64_t RNMS_MAX_N = 65536;  // 1024 mask words per row; removed-set = 8 KiB of LDS; queue entries hold two 16-bit box indices
+static const int64_t QUEUE_MIN_N = 512;   // below: the compacted one-kernel form (profiles/r04_nms_queue_ab.txt)
 
 extern "C" {
 
+// workspace of G groups of up to `cap` boxes:
+//   OBox records | mask (cap x cbs words) | colm (cap words) | gremv, gkept (cbs words each: two-level scan) |
+//   candidate queue of the queued mask form (QUEUE_PER_BOX entries per box) | its control words | overflowed block pairs
+constexpr size_t QUEUE_PER_BOX = 128;
+struct WsLayout {
+  size_t mask, colm, gremv, queue, qctl, ovl, total;
+  unsigned scap, npairs;
+};
+static WsLayout ws_layout(size_t G, size_t cap) {
+  const size_t cb = (cap + 63) / 64;
+  WsLayout L;
+  L.mask = align_up(G * cap * sizeof(OBox), 256);
+  L.colm = L.mask + align_up(G * cap * cb * sizeof(unsigned long long), 256);
+  L.gremv = L.colm + align_up(G * cap * sizeof(unsigned long long), 256);
+  L.queue = L.gremv + align_up(2 * G * cb * sizeof(unsigned long long), 256);
+  L.scap = (unsigned)((cap * QUEUE_PER_BOX + QUEUE_SHARDS - 1) / QUEUE_SHARDS);   // entries per shard
+  L.npairs = (unsigned)(cb * (cb + 1) / 2);
+  L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
+  L.ovl = L.qctl + align_up(G * CTL_WORDS * sizeof(unsigned), 256);
+  L.total = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
+  return L;
+}
+
 size_t rnms_workspace_bytes(int64_t n) {
   if (n <= 0) return 16;
-  const size_t cb = (size_t)((n + 63) / 64);
-  return align_up((size_t)n * sizeof(OBox), 256) + align_up((size_t)n * cb * sizeof(unsigned long long), 256) +
-         align_up((size_t)n * sizeof(unsigned long long), 256) + 2 * cb * sizeof(unsigned long long);
+  return ws_layout(1, (size_t)n).total;
 }
 
 size_t rnms_batched_workspace_bytes(int32_t groups, int64_t cap) {
   if (groups <= 0 || cap <= 0) return 16;
-  const size_t cb = (size_t)((cap + 63) / 64);
-  return align_up((size_t)groups * cap * sizeof(OBox), 256) +
-         align_up((size_t)groups * cap * cb * sizeof(unsigned long long), 256) +
-         align_up((size_t)groups * cap * sizeof(unsigned long long), 256) + 2 * (size_t)groups * cb * sizeof(unsigned long long);
+  return ws_layout((size_t)groups, (size_t)cap).total;
 }
 
 // shared by the single and the batched entry points: G groups of up to `cap` boxes
 static int rnms_launch(int mode, const float* boxes, const int64_t* order, const int32_t* counts, int32_t G, int64_t cap,
                        float thresh, double thresh_d, const float* thresh_dev, int64_t* keep, int64_t* num_keep,
-                       void* workspace, void* stream, bool prepped = false) {
+                       void* workspace, void* stream, bool prepped = false, bool ctl_zeroed = false) {
   hipStream_t s = (hipStream_t)stream;
   if (cap > RNMS_MAX_N) return GD3D_E_TOOLARGE;
   if (G > 65535) return GD3D_E_TOOLARGE;
@@ -851,11 +1074,10 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   a.cbs = ((int)cap + 63) / 64;
   a.thresh = thresh;
   a.thresh_d = thresh_d;
+  const WsLayout W = ws_layout((size_t)G, (size_t)cap);
   OBox* ob = (OBox*)workspace;
-  unsigned long long* mask =
-      (unsigned long long*)((char*)workspace + align_up((size_t)G * cap * sizeof(OBox), 256));
-  unsigned long long* colm =  // per box: the earlier boxes of its own 64-block that suppress it
-      (unsigned long long*)((char*)mask + align_up((size_t)G * cap * a.cbs * sizeof(unsigned long long), 256));
+  unsigned long long* mask = (unsigned long long*)((char*)workspace + W.mask);
+  unsigned long long* colm = (unsigned long long*)((char*)workspace + W.colm);  // per box: the earlier boxes of its own 64-block that suppress it
   const long long pairs = (long long)a.cbs * (a.cbs + 1) / 2;
   int rows;
   if (mode == MODE_ROT) {
@@ -870,8 +1092,36 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   a.rows = rows;
   if (pairs * (64 / rows) > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const dim3 mgrid((unsigned)(pairs * (64 / rows)), (unsigned)G);
-  if (mode == MODE_ROT) {
-    if (!prepped) hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob);
+  // queued form (circle tests and clipping as two kernels): from QUEUE_MIN_N boxes on, with a threshold every group shares and
+  // that is a plain non-negative number (a negative or NaN threshold makes EVERY pair a candidate: the compacted kernel's case)
+  static const long long queue_min_n = [] {
+    const char* e = getenv("RNMS_QUEUE_MIN_N");   // measurement override (tests/perf/nms_time.py A/B)
+    return e != nullptr ? atoll(e) : (long long)QUEUE_MIN_N;
+  }();
+  const bool queued = mode == MODE_ROT && cap >= queue_min_n && pairs <= 0x7fffffffLL && (thresh_dev != nullptr || thresh >= 0.0f);   // (per-group device thresholds are checked in the kernel)
+  if (mode == MODE_ROT && queued) {
+    QueueArgs q;
+    q.queue = (unsigned*)((char*)workspace + W.queue);
+    q.ctl = (unsigned*)((char*)workspace + W.qctl);
+    q.ovl = (unsigned*)((char*)workspace + W.ovl);
+    q.scap = W.scap;
+    q.npairs = W.npairs;
+    // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_scatter_kernel:
+    // `ctl_zeroed`); only a caller that prepared the records itself pays a fill in the stream (4.4 us in the trace)
+    const int zero_n = (int)CTL_WORDS;   // per group
+    if (!prepped)
+      hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob, q.ctl, zero_n);
+    else if (!ctl_zeroed) {
+      hipLaunchKernelGGL(zero_words_kernel, dim3(1, (unsigned)G), dim3(256), 0, s, q.ctl, zero_n);   // (a kernel, not a memset node)
+    }
+    hipLaunchKernelGGL(nms_circle_queue_kernel, dim3((unsigned)pairs, (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
+    // clipping waves: a multiple of the shard count, about one per block pair, at most 2048 (two per SIMD)
+    long long per = (pairs + QUEUE_SHARDS - 1) / QUEUE_SHARDS;
+    per = per < 1 ? 1 : (per > 32 ? 32 : per);
+    hipLaunchKernelGGL(nms_clip_queue_kernel, dim3((unsigned)(per * QUEUE_SHARDS), (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
+  } else if (mode == MODE_ROT) {
+    if (!prepped)
+      hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob, (unsigned*)nullptr, 0);
     hipLaunchKernelGGL(nms_mask_compact_kernel, mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else if (mode == MODE_NORMAL) {
     hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
@@ -899,7 +1149,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   }
   // two-level scan: super-blocks of SCAN_SB blocks resolved one after the other by the scan workgroup (rows stay inside
   // the super-block: one chunk), the rows of the kept boxes spread to everything right of it by nms_propagate_kernel
-  win.gremv = (unsigned long long*)((char*)colm + align_up((size_t)G * cap * sizeof(unsigned long long), 256));
+  win.gremv = (unsigned long long*)((char*)workspace + W.gremv);
   win.gkept = win.gremv + (size_t)G * a.cbs;
   for (int c0 = 0; c0 < a.cbs; c0 += SCAN_SB) {
     win.c_begin = c0;
@@ -981,18 +1231,19 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
   const int slices = (int)rank_slices(n_all);
   hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores,
-                     (const unsigned char*)nullptr, (const int*)nullptr, (int)n_all, prank);
+                     (const unsigned char*)nullptr, (const int*)nullptr, (int)n_all, prank, (int*)nullptr);
   const dim3 sg((unsigned)((n_all + 255) / 256));
+  unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout(1, (size_t)n).qctl);   // control words of the queued mask form
   if (normal)
     hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0);
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, (unsigned*)nullptr, 0);
   else
     hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0);
+                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, qctl, (int)CTL_WORDS);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
-                     num_keep, workspace, stream, /*prepped=*/true);
+                     num_keep, workspace, stream, /*prepped=*/true, /*ctl_zeroed=*/!normal);
 }
 
 size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t cap) {
@@ -1021,21 +1272,21 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   p += align_up((size_t)groups * sizeof(int), 256);
   int* prank = (int*)p;
   const int slices = (int)rank_slices(n);
-  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)groups, s);
-  if (e != hipSuccess) return (int)e;
+  hipError_t e;
   hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)slices, (unsigned)groups), dim3(256), 0, s, scores,
-                     (const unsigned char*)valid, (const int*)seg, (int)n, prank);
+                     (const unsigned char*)valid, (const int*)seg, (int)n, prank, counts);
   const dim3 sg((unsigned)((n + 255) / 256), (unsigned)groups);
+  unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout((size_t)groups, (size_t)cap).qctl);
   if (mode == MODE_ROT)
     hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps);
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps, qctl, (int)CTL_WORDS);
   else
     hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps);
+                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)nullptr, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
-                     workspace, stream, /*prepped=*/mode == MODE_ROT);
+                     workspace, stream, /*prepped=*/mode == MODE_ROT, /*ctl_zeroed=*/mode == MODE_ROT);
 }
 
 int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,

@@ -190,11 +190,19 @@ def _mask_words(amd, bs, thr):
     (200, 0.5, 'same'),         # every pair is a candidate and a hit: full queue in every chunk
     (450, -0.5, 'clutter'),     # negative threshold: IoU 0 of far-apart pairs is a hit too (all-pairs mode)
     (450, float('nan'), 'clutter'),  # NaN threshold: nothing is ever suppressed
+    # from 512 boxes on the QUEUED form (circle-test kernel -> candidate queue in HBM -> clipping kernel, csrc/rbox.hip):
+    (1200, 0.4, 'same'),        # every pair a candidate: 719 400 > 128 per box -> most block pairs take the overflow list
+    (3000, 0.25, 'pile'),       # 1500 boxes on one spot: queue filled to capacity AND overflowed block pairs in one call
+    (1500, -0.5, 'clutter'),    # negative threshold on the queued form: every block pair is routed to the all-pairs path
+    (1500, float('nan'), 'clutter'),
+    (4096, 0.25, 'clutter'),    # BASELINE configs[4] size: nothing overflows
+    (577, 0.6, 'clutter'),      # ragged last block
 ])
 def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
-    """The rotated mask kernel packs the pairs that survive the bounding-circle test densely before clipping them
-    (nms_mask_compact_kernel): queue overflow / carry, 8-64 rows per wave and the thresholds for which a far-apart pair
-    is NOT a non-hit must all give the oracle's words."""
+    """The rotated mask kernels pack the pairs that survive the bounding-circle test densely before clipping them — inside one
+    wave below 512 boxes (nms_mask_compact_kernel), through a queue in HBM between two kernels above: queue overflow / carry,
+    8-64 rows per wave, the overflow list, and the thresholds for which a far-apart pair is NOT a non-hit must all give the
+    oracle's words."""
     boxes, scores = nms_boxes(n, seed=n, clutter=(kind != 'same'))
     if kind == 'pile':
         boxes[: n // 2] = boxes[0] + np.random.default_rng(5).normal(0, 0.05, (n // 2, 5)).astype(np.float32)
@@ -784,3 +792,52 @@ def test_cpu_twins_equal_the_hip_kernels(amd):
         assert torch.equal(amd.nms_gpu(bt, st, thr, pre_max_size=pre, post_max_size=post),
                            amd.nms_gpu(bt.cuda(), st.cuda(), thr, pre_max_size=pre, post_max_size=post).cpu())
     assert torch.equal(amd.nms_normal_gpu(bt, st, 0.4), amd.nms_normal_gpu(bt.cuda(), st.cuda(), 0.4).cpu())
+
+
+@pytest.mark.parametrize('n', [300, 1000])
+def test_batched_scored_sets_replay_in_a_hipgraph_with_a_persistent_workspace(amd, n):
+    """rnms_batched_scored_sets (2 box sets x 3 class problems: the shape of the anchor heads' inference NMS) captured ONCE into a
+    hipGraph and replayed five times on new boxes / scores / valid masks, workspace and outputs persistent across replays: every
+    replay equals an eager call on a zeroed workspace.  Regression test of round 4: the per-group counts used to be cleared by a
+    hipMemsetAsync in front of the launches, and as a graph MEMSET NODE that clear was not reliably ordered against the kernels
+    around it on this ROCm — later replays saw counts of 0 or of twice the boxes (groups keeping nothing, or everything).  n = 300
+    takes the compacted mask kernel, n = 1000 the queued form (counters and queue in the persistent workspace)."""
+    lib = amd.load_library()
+    sets, gps = 2, 3
+    G = sets * gps
+    dev = torch.device('cuda:0')
+
+    def data(seed):
+        rng = np.random.default_rng(seed)
+        bx = torch.stack([torch.from_numpy(nms_boxes(n, seed=seed * 10 + k)[0]) for k in range(sets)]).to(dev).contiguous()
+        sc = torch.from_numpy(rng.random((G, n)).astype(np.float32)).to(dev)
+        va = torch.from_numpy((rng.random((G, n)) < float(rng.uniform(0.5, 1.0))).astype(np.uint8)).to(dev)
+        return bx, sc, va
+
+    thr = torch.full((G,), 0.1, device=dev)
+    wsb = lib.rnms_batched_scored_workspace_bytes(G, n, n)
+
+    def run(bx, sc, va, ws, keep, num):
+        assert lib.rnms_batched_scored_sets(0, bx.data_ptr(), sc.data_ptr(), va.data_ptr(), sets, gps, n, -1, thr.data_ptr(), keep.data_ptr(),
+                                            num.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+
+    sb, ss, sv = data(0)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    keep = torch.empty(G, n, dtype=torch.int64, device=dev)
+    num = torch.empty(G, dtype=torch.int64, device=dev)
+    run(sb, ss, sv, ws, keep, num)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(sb, ss, sv, ws, keep, num)
+    for seed in (1, 2, 1, 1, 3):
+        bx, sc, va = data(seed)
+        sb.copy_(bx); ss.copy_(sc); sv.copy_(va)
+        graph.replay()
+        torch.cuda.synchronize()
+        ws2 = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        k2, n2 = torch.empty_like(keep), torch.empty_like(num)
+        run(bx, sc, va, ws2, k2, n2)
+        torch.cuda.synchronize()
+        for g in range(G):
+            assert int(num[g]) == int(n2[g]) > 0 and torch.equal(keep[g, :int(num[g])], k2[g, :int(n2[g])]), (seed, g, num.tolist(), n2.tolist())
