@@ -1,7 +1,8 @@
-"""Multi-process (gloo, world_size 2, CPU) tests of the pair-sharding + tiny-collective path used at N > 1.
-The product's fused op needs a GPU, so each rank's LOCAL loss is produced by an oracle-backed stand-in with
-GDLoss's forward signature; everything around it (shard ranges, global normaliser, all_gather of per-shard
-losses, rank-ordered sum, local gradients, async join) is the product code of mmdet3d-gaussian_amd/sharded.py."""
+"""Multi-process (gloo, world_size 2, CPU) tests of the pair-sharding + tiny-collective path used at N > 1: shard ranges,
+global normaliser, all_gather of per-shard losses, rank-ordered sum, local gradients, async join
+(mmdet3d-gaussian_amd/sharded.py).  Each rank's LOCAL loss comes (a) from an oracle-backed stand-in with GDLoss's forward
+signature in fp64 (exact comparison of the collective path), and (b) from the PRODUCT's own GDLoss on CPU tensors — the `_cpu`
+twins of round 4 — i.e. the whole product combination of N > 1 minus the GPU."""
 import os
 import socket
 
@@ -49,7 +50,7 @@ def _pairs(n, seed):
     return torch.from_numpy(p), torch.from_numpy(t)
 
 
-def _worker(rank, world, port, n, lt, reduction, q):
+def _worker(rank, world, port, n, lt, reduction, q, product=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -57,8 +58,14 @@ def _worker(rank, world, port, n, lt, reduction, q):
         pred, tgt = _pairs(n, 0)
         w = torch.linspace(0.5, 1.5, n, dtype=torch.float64)
         lo, hi = sharded.shard_range(n, rank, world)
+        if product:
+            import mmdet3d_gaussian_amd as amd
+            pred, tgt, w = pred.float(), tgt.float(), w.float()
+            local = amd.GDLoss(lt, reduction=reduction, loss_weight=5.0)
+        else:
+            local = OracleGDLoss(lt, reduction=reduction, loss_weight=5.0)
         p = pred[lo:hi].clone().requires_grad_(True)
-        mod = sharded.ShardedGDLoss(OracleGDLoss(lt, reduction=reduction, loss_weight=5.0))
+        mod = sharded.ShardedGDLoss(local)
         out = mod(p, tgt[lo:hi], w[lo:hi])           # total_pairs discovered with one all_reduce
         out.backward()
         # async path used by bench.py
@@ -98,6 +105,32 @@ def test_two_rank_sharded_loss_matches_single_process(lt, reduction, n):
         assert parts.shape == (world,)
         np.testing.assert_allclose(grad, ref['grad_pred'][lo:hi], rtol=1e-12, atol=1e-15)
     # every rank holds the identical global value (rank-ordered sum)
+    assert res[0][3] == res[1][3] and res[0][5] == res[1][5]
+
+
+@pytest.mark.parametrize('lt,reduction,n', [('gwd3d', 'mean', 1001), ('bd3d', 'sum', 20_001), ('kld3d', 'mean', 3)])
+def test_two_rank_sharded_product_loss_on_cpu_tensors(lt, reduction, n):
+    """The same two-rank run with the PRODUCT's GDLoss as the local loss (CPU tensors -> gd3d_loss_fused_cpu): global value and
+    local gradients against the fp64 oracle at the loss's fp32 tolerance; both ranks hold the identical global value."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, lt, reduction, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pred, tgt = _pairs(n, 0)
+    w = np.linspace(0.5, 1.5, n).astype(np.float32)
+    scale = 5.0 / n if reduction == 'mean' else 5.0
+    ref = oracle.gd_loss(pred.float().numpy(), tgt.float().numpy(), oracle.make_params(lt), row_weight=w, scale=scale)
+    gscale = 1.0 + np.abs(ref['grad_pred']).max()
+    for rank, lo, hi, out, grad, total, parts in res:
+        assert abs(out - ref['loss_sum']) <= 1e-5 * (1 + abs(ref['loss_sum'])) and abs(total - ref['loss_sum']) <= 1e-5 * (1 + abs(ref['loss_sum']))
+        assert np.abs(grad - ref['grad_pred'][lo:hi]).max() <= 2e-5 * gscale
     assert res[0][3] == res[1][3] and res[0][5] == res[1][5]
 
 
