@@ -41,7 +41,7 @@ struct NmsArgs {
 
 __device__ __forceinline__ int group_n(const NmsArgs& a, int g) {
   if (a.counts == nullptr) return a.n;
-  const int c = __hip_atomic_load(&a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int c = a.counts[g];
   return c < 0 ? 0 : (c > a.cap ? a.cap : c);
 }
 
@@ -625,32 +625,6 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
   return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
 }
-// NW 64-bit words OR-reduced over the wave TOGETHER: the 2 * NW dword chains are independent, so every DPP step of one
-// chain sits in the wait states of the others; the totals are left in LANE 63 (no readlane, no scalar round trip).
-template <int NW>
-__device__ __forceinline__ void wave_or_words_lane63(unsigned long long (&w)[NW]) {
-  unsigned int h[2 * NW];
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    h[2 * k] = (unsigned int)w[k];
-    h[2 * k + 1] = (unsigned int)(w[k] >> 32);
-  }
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x111, 0xf>(h[k]);
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x112, 0xf>(h[k]);
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x114, 0xf>(h[k]);
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x118, 0xf>(h[k]);
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x142, 0xa>(h[k]);
-#pragma unroll
-  for (int k = 0; k < 2 * NW; ++k) h[k] = dpp_or<0x143, 0xc>(h[k]);
-#pragma unroll
-  for (int k = 0; k < NW; ++k) w[k] = ((unsigned long long)h[2 * k + 1] << 32) | h[2 * k];
-}
-
 // ---- greedy scan: one workgroup, phase-shifted waves, one LDS-only barrier per 64-box block ("interval") -------------
 // Measured with the cycle-stamp build (tools/scan_profile.py): a global-memory round trip from this CU is ~2700 cycles,
 // a resolved block ~1200.  So no wave may load and use a value inside one interval:
@@ -668,8 +642,9 @@ __device__ __forceinline__ void wave_or_words_lane63(unsigned long long (&w)[NW]
 //   Block b's rows therefore reach remv[w >= b+4] during interval b+3, one barrier before block b+4 is resolved; words
 //   b+1..b+3 are covered by the urgent words.  Every wave executes exactly cb barriers.
 // History: one scalar readlane step per kept box + load->use inside the interval: 1.2-3.8 us per block.
-constexpr int SCAN_GW = 3;                          // waves per propagate group
-constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW + 3);  // 832 threads: resolver, 3 x 3 row waves, 3 field waves
+constexpr int SCAN_GW = 4;                          // row waves per propagate group
+constexpr int SCAN_U = 16;                          // rows in flight per row wave: SCAN_GW x SCAN_U = 64 = every box of a block
+constexpr int SCAN_T = 64 * (1 + 3 * SCAN_GW + 3);  // 1024 threads: resolver, 3 x 4 row waves, 3 field waves
 constexpr int SCAN_NU = 3;                      // urgent words per box
 constexpr int SCAN_RING = 4;
 
@@ -783,18 +758,31 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       const bool mine = (kept >> lane) & 1ull;
       if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
         keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
-      // the kept lanes' urgent words, all three reduced together; lane 63 ends up holding the totals and ORs them into
-      // remv[c+1..c+3] itself (ds_or_b64 with a zero operand is harmless: no test, no scalar round trip per word).
-      // Round 3 reduced the words one after the other and went through SGPRs: ~130 instructions; this is ~60, and the
-      // resolver's stamp-to-stamp time fell 854 -> 792 cycles — but the interval did not move (1868 -> 1840 cycles with
-      // stamps, kernels of rnms_bev 72.5-73.2 -> 71.9-72.2 us at n = 4096): the interval is set by the loader group's ISSUE
-      // phase, not by the resolver (profiles/r04_nms_pmc.txt).
+      // the kept lanes' urgent words: OR-reduced inside every QUAD of lanes on the DPP network (two steps for all six dwords
+      // together), then lanes 3, 7, ... 63 OR their quad's totals into remv[c+1..c+3] with ds_or_b64 — 16 same-address LDS
+      // atomics per word, which the LDS works off while the wave goes on (they are only waited for before the barrier).
+      // History: three full wave reductions one after the other, results through SGPRs: ~130 instructions (round 3); one
+      // interleaved full reduction with lane 63 storing: ~60 (round 4, -62 cycles); this form: ~25.  A ds_or_b64 from EVERY kept
+      // lane needs no reduction at all but serialises up to 64 atomics per word on a sparse scene.
 #pragma unroll
       for (int k = 0; k < SCAN_NU; ++k) urg[k] = mine ? urg[k] : 0ull;
-      wave_or_words_lane63<SCAN_NU>(urg);
-      if (lane == 63) {
+      {
+        unsigned int h[2 * SCAN_NU];
+#pragma unroll
+        for (int k = 0; k < SCAN_NU; ++k) {
+          h[2 * k] = (unsigned int)urg[k];
+          h[2 * k + 1] = (unsigned int)(urg[k] >> 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * SCAN_NU; ++k) h[k] = dpp_or<0x111, 0xf>(h[k]);   // row_shr:1
+#pragma unroll
+        for (int k = 0; k < 2 * SCAN_NU; ++k) h[k] = dpp_or<0x112, 0xf>(h[k]);   // row_shr:2 -> lane 4q+3 holds quad q
+#pragma unroll
+        for (int k = 0; k < SCAN_NU; ++k) urg[k] = ((unsigned long long)h[2 * k + 1] << 32) | h[2 * k];
+      }
+      if ((lane & 3) == 3) {
         // ds_or_b64 written out: an atomicOr() here is rewritten by the compiler's wave-level atomic optimisation into a
-        // readlane loop over the "active lanes" (one) plus a scalar round trip — the very cost this form removes
+        // readlane loop over the active lanes plus a scalar round trip — the very cost this form removes
 #pragma unroll
         for (int k = 0; k < SCAN_NU; ++k)
           if (c + 1 + k < cb)   // (uniform bound)
@@ -876,7 +864,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       unsigned int wcl[CH];
 #pragma unroll
       for (int ch = 0; ch < CH; ++ch) wcl[ch] = (unsigned int)min(first + ch * 64 + lane, cb - 1);
-      static_assert(U % 2 == 0, "rows are issued in pairs");
+      static_assert(U % 2 == 0 && U * SCAN_GW >= 64, "rows are issued in pairs; a group's waves cover a whole block");
       const int mlast = max(m - 1, 0);
 #pragma unroll
       for (int u = 0; u < U; u += 2) {  // pairs: half the uniform branches; an odd tail re-loads its last row (OR is idempotent)
@@ -1139,11 +1127,11 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   // two-level: n = 9000 339 -> 237 us (72 % kept), 208 -> 207 (25 % kept), 400 -> 237 (79 % kept); n = 16384 1052 -> 476 us;
   // it loses below (n = 6000: 117 -> 128 us: five launches instead of one) — profiles/r02_nms_scan_levels.txt.
   if (a.cbs <= 128 + 1 + SCAN_NU) {
-    if (a.cbs <= 64 + 1 + SCAN_NU)  // one 64-word chunk right of any block (n <= 4352): 22 rows x 1 chunk in flight
-      hipLaunchKernelGGL((nms_scan_kernel<22, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+    if (a.cbs <= 64 + 1 + SCAN_NU)  // one 64-word chunk right of any block (n <= 4352): 16 rows x 1 chunk in flight per row wave
+      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
                          (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     else
-      hipLaunchKernelGGL((nms_scan_kernel<22, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
                          (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     return (int)hipGetLastError();
   }
@@ -1154,7 +1142,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   for (int c0 = 0; c0 < a.cbs; c0 += SCAN_SB) {
     win.c_begin = c0;
     win.c_end = c0 + SCAN_SB < a.cbs ? c0 + SCAN_SB : a.cbs;
-    hipLaunchKernelGGL((nms_scan_kernel<22, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+    hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
                        (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     if (win.c_end < a.cbs) {
       const int wchunks = (a.cbs - win.c_end + 63) / 64;
