@@ -1008,7 +1008,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 using namespace rbox;
 
 static const int64_t RNMS_MAX_N = 65536;  // 1024 mask words per row; removed-set = 8 KiB of LDS; queue entries hold two 16-bit box indices
-static const int64_t QUEUE_MIN_N = 512;   // below: the compacted one-kernel form (profiles/r04_nms_queue_ab.txt)
+static const int64_t QUEUE_MIN_N = 768;   // below: the compacted one-kernel form (3 us faster at 128-256 boxes, equal at 512-768,
+                                          // 1 us slower at 1000, 4 at 4096, 34 at 9000: sweep in profiles/r04_nms_queue_ab.txt)
 
 extern "C" {
 
@@ -1103,9 +1104,11 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
       hipLaunchKernelGGL(zero_words_kernel, dim3(1, (unsigned)G), dim3(256), 0, s, q.ctl, zero_n);   // (a kernel, not a memset node)
     }
     hipLaunchKernelGGL(nms_circle_queue_kernel, dim3((unsigned)pairs, (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
-    // clipping waves: a multiple of the shard count, about one per block pair, at most 2048 (two per SIMD)
+    // clipping waves: a multiple of the shard count, about one per block pair, at most 2048 (two per SIMD) and at least 8 per
+    // shard: with few block pairs few shards are in use, and one wave per shard walked its ~90 entries in two passes one after
+    // the other (n = 256: 25 us for 900 candidates; waves that find their shard empty leave after one load)
     long long per = (pairs + QUEUE_SHARDS - 1) / QUEUE_SHARDS;
-    per = per < 1 ? 1 : (per > 32 ? 32 : per);
+    per = per < 8 ? 8 : (per > 32 ? 32 : per);
     hipLaunchKernelGGL(nms_clip_queue_kernel, dim3((unsigned)(per * QUEUE_SHARDS), (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
   } else if (mode == MODE_ROT) {
     if (!prepped)

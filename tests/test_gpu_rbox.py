@@ -190,17 +190,18 @@ def _mask_words(amd, bs, thr):
     (200, 0.5, 'same'),         # every pair is a candidate and a hit: full queue in every chunk
     (450, -0.5, 'clutter'),     # negative threshold: IoU 0 of far-apart pairs is a hit too (all-pairs mode)
     (450, float('nan'), 'clutter'),  # NaN threshold: nothing is ever suppressed
-    # from 512 boxes on the QUEUED form (circle-test kernel -> candidate queue in HBM -> clipping kernel, csrc/rbox.hip):
+    # from 768 boxes on the QUEUED form (circle-test kernel -> candidate queue in HBM -> clipping kernel, csrc/rbox.hip):
     (1200, 0.4, 'same'),        # every pair a candidate: 719 400 > 128 per box -> most block pairs take the overflow list
     (3000, 0.25, 'pile'),       # 1500 boxes on one spot: queue filled to capacity AND overflowed block pairs in one call
     (1500, -0.5, 'clutter'),    # negative threshold on the queued form: every block pair is routed to the all-pairs path
     (1500, float('nan'), 'clutter'),
     (4096, 0.25, 'clutter'),    # BASELINE configs[4] size: nothing overflows
-    (577, 0.6, 'clutter'),      # ragged last block
+    (833, 0.6, 'clutter'),      # ragged last block, just above the switch-over
+    (767, 0.6, 'clutter'),      # ... and the largest set the one-kernel form still takes
 ])
 def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
     """The rotated mask kernels pack the pairs that survive the bounding-circle test densely before clipping them — inside one
-    wave below 512 boxes (nms_mask_compact_kernel), through a queue in HBM between two kernels above: queue overflow / carry,
+    wave below 768 boxes (nms_mask_compact_kernel), through a queue in HBM between two kernels above: queue overflow / carry,
     8-64 rows per wave, the overflow list, and the thresholds for which a far-apart pair is NOT a non-hit must all give the
     oracle's words."""
     boxes, scores = nms_boxes(n, seed=n, clutter=(kind != 'same'))
