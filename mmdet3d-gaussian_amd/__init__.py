@@ -49,8 +49,11 @@ from .head_loss import (anchor_decoded_gd_loss, anchor_head_bbox_loss, anchor_he
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into mmdet3d-gaussian_amd/libgd3d.so."""
-    return _build_mod.build(force=force, verbose=verbose)
+    """Compile csrc/*.hip for gfx950 into mmdet3d-gaussian_amd/libgd3d.so, and csrc/torch_node.cpp (GDLoss's autograd node,
+    host C++ above the C ABI) into mmdet3d-gaussian_amd/_gd3d_node.so.  Returns the library's path."""
+    path = _build_mod.build(force=force, verbose=verbose)
+    _build_mod.build_node(force=force, verbose=verbose)
+    return path
 
 
 __all__ = ['GDLoss', 'LOSSES', 'Registry', 'build_loss', 'make_params', 'nms_gpu', 'nms_normal_gpu', 'nms_gpu_batched', 'nms_gpu_multi', 'multi_class_nms', 'multi_class_nms_batch', 'box3d_multiclass_nms', 'circle_nms',

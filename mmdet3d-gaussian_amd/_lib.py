@@ -256,6 +256,38 @@ def load():
     return _lib
 
 
+_node = None
+
+
+def load_node():
+    """The C++ autograd node of GDLoss (csrc/torch_node.cpp -> _gd3d_node.so), bound to the loaded libgd3d.so.  Like the
+    library it is built in-tree on first use and never substituted: a failed compile or a missing compiler raises."""
+    global _node
+    if _node is not None:
+        return _node
+    load()
+    if _build.node_is_stale():
+        if os.path.exists(_build.host_cxx_path()):
+            _build.build_node()
+        elif os.path.isfile(_build.NODE_PATH):
+            import warnings
+            warnings.warn('_gd3d_node.so does not match its sources and the ROCm clang++ is not available to rebuild it: '
+                          'running the binary as it is')
+        else:
+            raise RuntimeError('_gd3d_node.so (the autograd node of GDLoss) is missing and the ROCm clang++ is not available '
+                               'to build it; there is no Python substitute for it in this package')
+    import importlib.util
+    import torch  # noqa: F401  (libtorch must be loaded before the node is)
+    spec = importlib.util.spec_from_file_location('_gd3d_node', _build.NODE_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ver = mod.bind(os.environ.get('GD3D_LIB') or _build.LIB_PATH)
+    if ver != ABI_VERSION:
+        raise RuntimeError(f'_gd3d_node.so bound a library of ABI version {ver} != {ABI_VERSION}')
+    _node = mod
+    return _node
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f'{what} failed with code {rc}' + (' (bad argument)' if rc == 10001 else ''))

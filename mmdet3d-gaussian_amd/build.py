@@ -1,7 +1,9 @@
-"""Build recipe of libgd3d.so (hand-written HIP for gfx950 behind the C ABI of include/gd3d.h).
+"""Build recipe of libgd3d.so (hand-written HIP for gfx950 behind the C ABI of include/gd3d.h) and of _gd3d_node.so
+(the C++ autograd node GDLoss calls it through).
 
-Plain ``hipcc --offload-arch=gfx950``: no torch headers, no hipify, no cmake.  The library is built
-IN-TREE (mmdet3d-gaussian_amd/libgd3d.so) so that it travels to the GPU box with the snapshot.
+libgd3d.so: plain ``hipcc --offload-arch=gfx950``: no torch headers, no hipify, no cmake.  _gd3d_node.so: one host
+translation unit (csrc/torch_node.cpp) against the torch headers of the running interpreter, no kernel in it.  Both are
+built IN-TREE (mmdet3d-gaussian_amd/) so that they travel to the GPU box with the snapshot.
 """
 import concurrent.futures
 import hashlib
@@ -56,10 +58,15 @@ def host_cxx_path():
     raise RuntimeError('the ROCm clang++ (host compiler of the _cpu twins) was not found next to hipcc')
 
 
+NODE_SOURCE = 'torch_node.cpp'
+NODE_PATH = os.path.join(PKG_DIR, '_gd3d_node.so')
+NODE_HASH_PATH = NODE_PATH + '.srchash'
+
+
 def _deps():
     out = []
     for root, _, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files]
+        out += [os.path.join(root, f) for f in files if f != NODE_SOURCE]
     out.append(os.path.join(PKG_DIR, '..', 'include', 'gd3d.h'))
     out.append(os.path.abspath(__file__))
     return out
@@ -132,5 +139,59 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def node_source_hash():
+    """The node is rebuilt when its source, the C header or the torch it was compiled against change."""
+    import torch
+    h = hashlib.sha256()
+    h.update(torch.__version__.encode())
+    for d in (os.path.join(CSRC, NODE_SOURCE), os.path.join(PKG_DIR, '..', 'include', 'gd3d.h')):
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(repr(node_command('OUT')).encode())
+    return h.hexdigest()
+
+
+def node_command(out):
+    import sysconfig
+    import torch
+    tdir = os.path.dirname(os.path.abspath(torch.__file__))
+    tlib = os.path.join(tdir, 'lib')
+    return [host_cxx_path(), '-std=c++17', '-O2', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
+            '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1', '-DTORCH_EXTENSION_NAME=_gd3d_node',
+            f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
+            '-isystem', os.path.join(tdir, 'include'), '-isystem', os.path.join(tdir, 'include', 'torch', 'csrc', 'api', 'include'),
+            '-isystem', '/opt/rocm/include', '-isystem', sysconfig.get_paths()['include'],
+            os.path.join(CSRC, NODE_SOURCE), '-o', out,
+            '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10', '-lc10_hip', '-ltorch_hip', '-ltorch_python', '-ldl',
+            '-Wl,-rpath,' + tlib]
+
+
+def node_is_stale():
+    if not os.path.isfile(NODE_PATH) or not os.path.isfile(NODE_HASH_PATH):
+        return True
+    with open(NODE_HASH_PATH) as f:
+        return f.read().strip() != node_source_hash()
+
+
+def build_node(force=False, verbose=False):
+    """Compile csrc/torch_node.cpp (host C++, ~25 s) into _gd3d_node.so.  It resolves the C ABI from libgd3d.so at run
+    time (`bind`), so the two are built independently."""
+    if not force and not node_is_stale():
+        return NODE_PATH
+    tmp = f'{NODE_PATH}.{os.getpid()}.tmp'
+    cmd = node_command(tmp)
+    if verbose:
+        print(' '.join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'compiling {NODE_SOURCE} failed:\n{r.stderr[-4000:]}')
+    os.replace(tmp, NODE_PATH)
+    with open(NODE_HASH_PATH + f'.{os.getpid()}', 'w') as f:
+        f.write(node_source_hash())
+    os.replace(NODE_HASH_PATH + f'.{os.getpid()}', NODE_HASH_PATH)
+    return NODE_PATH
+
+
 if __name__ == '__main__':
     print(build(force=True, verbose=True))
+    print(build_node(force=True, verbose=True))

@@ -1,0 +1,303 @@
+// torch_node.cpp — the autograd node of GDLoss's reduced forms (reduction 'mean' / 'sum'), in C++.
+//
+// Why this exists.  A training-size GDLoss call (64-4096 positives, gd_anchor3d_head.py:137-141) is one 6 us launch; as a
+// Python torch.autograd.Function it cost 15 us in forward and 35-60 us per call under backward(), of which 3.8 / 23-41 us
+// are what an EMPTY Python Function costs (profiles/r04_small_p_latency.jsonl): the engine thread has to take the GIL
+// and walk the Python ctx for every node.  A C++ node is called by the engine directly.  This file is host plumbing above
+// the C ABI of include/gd3d.h and nothing else: every launch goes through the same extern "C" entry points the ctypes
+// layer binds, with raw pointers taken from the tensors; it contains no kernel and no arithmetic on box data.
+//
+// What it mirrors: the reduce / weight / early-out semantics of gaussian_distance_loss.py:280-310 + mmdet's
+// weight_reduce_loss are decided in gd_loss.py (GDLoss.forward) and arrive here as `scale`, `row_weight` and `select`.
+//   forward : ONE fused launch writes the loss sum AND the final gradients (csrc/gd3d_loss.hip); the gradients wait in the
+//             node.
+//   backward: hands them over — scaled by the upstream gradient on the device (gd3d_grad_finish; no host sync), or
+//             untouched when the upstream gradient is the library's own constant 1.0 (gd_loss.unit_grad, known by address).
+//             A second backward under retain_graph recomputes them.  Differentiating the result again raises (the
+//             gradients were written by a kernel: there is no graph behind them), as torch's once_differentiable does.
+#include <torch/extension.h>
+#include <torch/csrc/autograd/functions/basic_ops.h>
+#include <torch/csrc/autograd/functions/utils.h>
+#include <torch/csrc/autograd/saved_variable.h>
+#include <c10/hip/HIPStream.h>
+#include <ATen/Parallel.h>
+
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/gd3d.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::variable_list;
+
+// The entry points of include/gd3d.h this node calls, resolved from the library the ctypes layer loaded (`bind(path)`:
+// dlopen of a loaded library returns the same image, so an experimental build selected with GD3D_LIB is the one used here too).
+struct Abi {
+  decltype(&::gd3d_loss_fused_decoded) loss_fused_decoded = nullptr;
+  decltype(&::gd3d_loss_fused_timed) loss_fused_timed = nullptr;
+  decltype(&::gd3d_loss_fused_select) loss_fused_select = nullptr;
+  decltype(&::gd3d_loss_fused_one_launch) loss_fused_one_launch = nullptr;
+  decltype(&::gd3d_grad_finish) grad_finish = nullptr;
+  decltype(&::gd3d_loss_fused_cpu) loss_fused_cpu = nullptr;
+  decltype(&::gd3d_scale_rows_cpu) scale_rows_cpu = nullptr;
+  decltype(&::gd3d_abi_version) abi_version = nullptr;
+  bool bound = false;
+} abi;
+
+template <typename F>
+void resolve(void* image, const char* name, F& slot) {
+  slot = reinterpret_cast<F>(dlsym(image, name));
+  TORCH_CHECK(slot != nullptr, "gd3d node: libgd3d.so does not export ", name);
+}
+
+int bind(const std::string& path) {
+  void* image = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+  TORCH_CHECK(image != nullptr, "gd3d node: cannot open ", path, ": ", dlerror());
+  resolve(image, "gd3d_loss_fused_decoded", abi.loss_fused_decoded);
+  resolve(image, "gd3d_loss_fused_timed", abi.loss_fused_timed);
+  resolve(image, "gd3d_loss_fused_select", abi.loss_fused_select);
+  resolve(image, "gd3d_loss_fused_one_launch", abi.loss_fused_one_launch);
+  resolve(image, "gd3d_grad_finish", abi.grad_finish);
+  resolve(image, "gd3d_loss_fused_cpu", abi.loss_fused_cpu);
+  resolve(image, "gd3d_scale_rows_cpu", abi.scale_rows_cpu);
+  resolve(image, "gd3d_abi_version", abi.abi_version);
+  const int version = abi.abi_version(nullptr);
+  TORCH_CHECK(version == GD3D_ABI_VERSION, "gd3d node: built against ABI ", GD3D_ABI_VERSION, ", the library reports ", version);
+  abi.bound = true;
+  return version;
+}
+
+std::atomic<int64_t> g_finish_calls{0};   // gd3d_grad_finish launches made so far (tests: unit_grad must make none)
+
+constexpr int MAX_DEVICES = 64;
+const void* g_unit_grad[MAX_DEVICES + 1] = {};   // [MAX_DEVICES] = the CPU's
+
+void fail(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed with code ", rc, rc == GD3D_E_BADARG ? " (bad argument)" : "");
+}
+
+inline float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+void* current_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+bool is_unit_grad(const Tensor& g) {
+  const int slot = g.is_cuda() ? (int)g.device().index() : MAX_DEVICES;
+  return slot >= 0 && slot <= MAX_DEVICES && g_unit_grad[slot] != nullptr && g.dim() == 0 &&
+         g.scalar_type() == at::kFloat && g.data_ptr() == g_unit_grad[slot];
+}
+
+struct Weights {
+  const float* w1 = nullptr;
+  const float* w7 = nullptr;
+  explicit Weights(const Tensor& w) {
+    if (w.defined()) (w.dim() == 2 ? w7 : w1) = w.data_ptr<float>();
+  }
+};
+
+struct ReducedBackward : public torch::autograd::Node {
+  torch::autograd::SavedVariable pred_, target_;
+  Tensor weight_, aux_, gp_, gt_, buf_;   // aux_: the tensor behind prologue_.aux; buf_: owns the any-positive flag
+  gd3d_params params_;
+  gd3d_prologue prologue_;
+  bool has_prologue_ = false, select_ = false, used_ = false, want_gp_ = false, want_gt_ = false;
+  float scale_ = 1.0f;
+  int64_t n_ = 0;
+
+  std::string name() const override { return "GDLossReducedBackward"; }
+
+  void release_variables() override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    pred_.reset_data();
+    target_.reset_data();
+    weight_.reset();
+    aux_.reset();
+    gp_.reset();
+    gt_.reset();
+    buf_.reset();
+  }
+
+  variable_list apply(variable_list&& grads) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    const bool twice = at::GradMode::is_enabled();   // create_graph=True: the only case with grad mode ON in here
+    at::AutoGradMode no_grad(false);
+    variable_list out(2);
+    const Tensor pred = pred_.unpack(), target = target_.unpack();   // raises after a released graph
+    const Tensor& g_in = grads[0];
+    if (!g_in.defined() || (!want_gp_ && !want_gt_)) return out;
+    Tensor gp, gt;
+    const gd3d_prologue* pro = has_prologue_ ? &prologue_ : nullptr;
+    const bool cuda = pred.is_cuda();
+    c10::OptionalDeviceGuard device_guard;
+    if (cuda) device_guard.reset_device(pred.device());
+    if (used_) {   // retain_graph replay: the buffers of the first backward were handed over (and scaled in place)
+      if (want_gp_) gp = at::empty_like(pred);
+      if (want_gt_) gt = at::empty_like(target);
+      const Weights w(weight_);
+      if (cuda)
+        fail(abi.loss_fused_decoded(&params_, pro, fp(pred), fp(target), w.w1, w.w7, n_, scale_, nullptr, nullptr, fp(gp),
+                                     fp(gt), nullptr, current_stream(pred)), "gd3d_loss_fused_decoded");
+      else
+        fail(abi.loss_fused_cpu(&params_, fp(pred), fp(target), w.w1, w.w7, n_, scale_, nullptr, nullptr, fp(gp), fp(gt),
+                                 nullptr, at::get_num_threads()), "gd3d_loss_fused_cpu");
+    } else {   // hand the buffers over: with no reference left here a leaf's AccumulateGrad keeps them instead of cloning
+      gp = std::move(gp_);
+      gt = std::move(gt_);
+      gp_ = Tensor();
+      gt_ = Tensor();
+      used_ = true;
+    }
+    if (select_ || !is_unit_grad(g_in)) {
+      Tensor g = g_in.scalar_type() == at::kFloat ? g_in : g_in.to(at::kFloat);
+      if (!cuda) {
+        g = g.reshape({1});
+        for (Tensor* arr : {&gp, &gt})
+          if (arr->defined())
+            fail(abi.scale_rows_cpu(fp(*arr), fp(g), 0, n_, at::get_num_threads()), "gd3d_scale_rows_cpu");
+      } else {
+        // one launch for both arrays: reads g (and the any-positive flag) on the device; leaves without touching memory when
+        // g == 1 and the normal branch was taken (no host sync)
+        const int32_t* flag = select_ ? (const int32_t*)(buf_.data_ptr<float>() + 1) : nullptr;
+        g_finish_calls.fetch_add(1, std::memory_order_relaxed);
+        fail(abi.grad_finish(fp(gp), fp(gt), fp(g), n_, flag, select_ ? fp(weight_) : nullptr,
+                              (select_ && has_prologue_) ? fp(pred) : nullptr, select_ ? pro : nullptr, current_stream(pred)),
+             "gd3d_grad_finish");
+      }
+    }
+    out[0] = std::move(gp);
+    out[1] = std::move(gt);
+    if (twice) {   // what torch.autograd.function.once_differentiable does: an Error node behind detached aliases
+      variable_list alias;
+      for (auto& v : out) {
+        Tensor a;
+        if (v.defined()) {
+          a = v.detach();
+          a.set_requires_grad(true);
+        }
+        alias.push_back(a);
+      }
+      auto err = std::make_shared<torch::autograd::DelayedError>(
+          "trying to differentiate twice a function that was marked with @once_differentiable", (int64_t)alias.size());
+      at::AutoGradMode grad_on(true);
+      return (*err)(std::move(alias));
+    }
+    return out;
+  }
+};
+
+// One fused launch for a reduced GDLoss call.  Returns (loss sum as a 0-dim fp32 tensor, the int32 any-positive flag (1,) or
+// None).  params / prologue: addresses of gd3d_params / gd3d_prologue (copied); aux: the tensor prologue->aux points into;
+// ticket: device int32 of gd3d_loss_fused_one_launch or 0 (two-stage form); ev_start / ev_stop: hipEvent_t from
+// gd3d_prof_event_create or 0; ws_floats: gd3d_loss_workspace_bytes(n) / 4.
+std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tensor& target, const c10::optional<Tensor>& weight,
+                                                  int64_t params_addr, int64_t prologue_addr, const c10::optional<Tensor>& aux,
+                                                  double scale, bool select, int64_t ticket, int64_t ev_start, int64_t ev_stop,
+                                                  int64_t ws_floats, bool want_flag) {
+  TORCH_CHECK(pred.dim() == 2 && pred.size(1) == 7 && pred.scalar_type() == at::kFloat && pred.is_contiguous() &&
+                  target.sizes() == pred.sizes() && target.scalar_type() == at::kFloat && target.is_contiguous() &&
+                  target.device() == pred.device(),
+              "gd3d node: pred / target must be contiguous fp32 (N, 7) tensors on one device");
+  TORCH_CHECK(pred.is_cuda() || pred.is_cpu(), "gd3d node: no implementation for device ", pred.device());
+  TORCH_CHECK(abi.bound, "gd3d node: bind(path of libgd3d.so) has not been called");
+  const int64_t n = pred.size(0);
+  Tensor w;
+  if (weight.has_value() && weight->defined()) {
+    w = *weight;
+    TORCH_CHECK(w.scalar_type() == at::kFloat && w.is_contiguous() && w.device() == pred.device() && w.size(0) == n &&
+                    (w.dim() == 1 || (w.dim() == 2 && w.size(1) == 7)),
+                "gd3d node: weight must be a contiguous fp32 (N,) or (N, 7) tensor on pred's device");
+  }
+  TORCH_CHECK(!select || (w.defined() && w.dim() == 2 && pred.is_cuda()), "gd3d node: select needs an (N, 7) weight on the GPU");
+  TORCH_CHECK(prologue_addr == 0 || pred.is_cuda(), "GDLoss: the head-level fusions (bbox-coder prologue) are GPU-only");
+  const bool grad_mode = at::GradMode::is_enabled();
+  const bool need_gp = grad_mode && pred.requires_grad(), need_gt = grad_mode && target.requires_grad();
+
+  std::shared_ptr<ReducedBackward> node;
+  if (need_gp || need_gt) {
+    node = std::shared_ptr<ReducedBackward>(new ReducedBackward(), torch::autograd::deleteNode);
+    node->set_next_edges(torch::autograd::collect_next_edges(pred, target));
+  }
+  gd3d_params params;
+  std::memcpy(&params, (const void*)params_addr, sizeof(params));
+  gd3d_prologue prologue;
+  const gd3d_prologue* pro = nullptr;
+  if (prologue_addr != 0) {
+    std::memcpy(&prologue, (const void*)prologue_addr, sizeof(prologue));
+    pro = &prologue;
+  }
+  Tensor gp, gt, buf, total;
+  {
+    at::AutoDispatchBelowADInplaceOrView below_autograd;
+    c10::OptionalDeviceGuard device_guard;
+    if (pred.is_cuda()) device_guard.reset_device(pred.device());
+    if (need_gp) gp = at::empty_like(pred);
+    if (need_gt) gt = at::empty_like(target);
+    // one allocation: [0] = the fp32 result, [1] = the int32 any-positive flag, [4:] = workspace (16-byte aligned)
+    buf = at::empty({4 + ws_floats}, pred.options());
+    float* base = buf.data_ptr<float>();
+    const Weights ws(w);
+    if (!pred.is_cuda()) {
+      fail(abi.loss_fused_cpu(&params, fp(pred), fp(target), ws.w1, ws.w7, n, (float)scale, nullptr, base, fp(gp), fp(gt), base + 4,
+                               at::get_num_threads()), "gd3d_loss_fused_cpu");
+    } else {
+      void* stream = current_stream(pred);
+      int32_t* flag = select ? (int32_t*)(base + 1) : nullptr;
+      if (ticket != 0)   // training-size call: ONE launch, the last workgroup finishes the sum
+        fail(abi.loss_fused_one_launch(&params, pro, fp(pred), fp(target), ws.w1, ws.w7, n, (float)scale, base, flag, fp(gp),
+                                        fp(gt), base + 4, (int32_t*)ticket, stream), "gd3d_loss_fused_one_launch");
+      else if (select)
+        fail(abi.loss_fused_select(&params, pro, fp(pred), fp(target), ws.w7, n, (float)scale, base, flag, fp(gp), fp(gt), base + 4,
+                                    stream, (void*)ev_start, (void*)ev_stop), "gd3d_loss_fused_select");
+      else
+        fail(abi.loss_fused_timed(&params, pro, fp(pred), fp(target), ws.w1, ws.w7, n, (float)scale, nullptr, base, fp(gp), fp(gt),
+                                   base + 4, stream, (void*)ev_start, (void*)ev_stop), "gd3d_loss_fused_timed");
+    }
+    total = buf.select(0, 0);
+  }
+  c10::optional<Tensor> flag_out;
+  if (want_flag) {
+    at::AutoDispatchBelowADInplaceOrView below_autograd;
+    flag_out = buf.narrow(0, 1, 1).view(at::kInt);
+  }
+  if (node) {
+    node->pred_ = torch::autograd::SavedVariable(pred, false);
+    node->target_ = torch::autograd::SavedVariable(target, false);
+    node->weight_ = w;
+    if (aux.has_value()) node->aux_ = *aux;
+    node->gp_ = std::move(gp);
+    node->gt_ = std::move(gt);
+    if (select) node->buf_ = buf;
+    node->params_ = params;
+    node->has_prologue_ = pro != nullptr;
+    if (pro != nullptr) node->prologue_ = prologue;
+    node->select_ = select;
+    node->want_gp_ = need_gp;
+    node->want_gt_ = need_gt;
+    node->scale_ = (float)scale;
+    node->n_ = n;
+    torch::autograd::set_history(total, node);
+  }
+  return {total, flag_out};
+}
+
+void set_unit_grad(int64_t device_index, int64_t address) {
+  const int slot = device_index < 0 ? MAX_DEVICES : (int)device_index;
+  TORCH_CHECK(slot <= MAX_DEVICES, "gd3d node: device index ", device_index);
+  g_unit_grad[slot] = (const void*)address;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_gd3d_node, m) {
+  m.doc() = "C++ autograd node of GDLoss's reduced forms above the C ABI of libgd3d.so";
+  m.def("reduced", &reduced, py::arg("pred"), py::arg("target"), py::arg("weight"), py::arg("params"), py::arg("prologue"),
+        py::arg("aux"), py::arg("scale"), py::arg("select"), py::arg("ticket"), py::arg("ev_start"), py::arg("ev_stop"),
+        py::arg("ws_floats"), py::arg("want_flag"));
+  m.def("set_unit_grad", &set_unit_grad);
+  m.def("finish_calls", []() { return g_finish_calls.load(); }, "gd3d_grad_finish launches made by backward so far");
+  m.def("bind", &bind, "resolve the C ABI from the loaded libgd3d.so; returns its ABI version");
+}

@@ -119,6 +119,20 @@ def _library():
     return _LIB
 
 
+_NODE = None
+
+
+def _node():
+    """csrc/torch_node.cpp: the reduced forms' autograd node in C++ (a Python autograd.Function costs 4 us per forward and
+    23-41 us per backward before it does anything: profiles/r04_small_p_latency.jsonl)."""
+    global _NODE
+    if _NODE is None:
+        _NODE = _lib.load_node()
+        for idx, t in _UNIT_GRAD.items():
+            _NODE.set_unit_grad(-1 if idx == 'cpu' else idx, t.data_ptr())
+    return _NODE
+
+
 def _rows(t):
     """(…,7) any float dtype -> contiguous fp32 (N,7), on the device it lives on (the hot path is fp32: heads call it
     under @force_fp32, gd_anchor3d_head.py:167)."""
@@ -197,6 +211,7 @@ def unit_grad(device):
     t = _UNIT_GRAD.get(idx)
     if t is None:
         t = _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=dev if idx == 'cpu' else torch.device('cuda', idx))
+        _node().set_unit_grad(-1 if idx == 'cpu' else idx, t.data_ptr())   # the C++ node knows it by address too
     return t
 
 
@@ -205,44 +220,32 @@ def _is_unit_grad(g):
     return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0 and g.dtype == torch.float32
 
 
-def _fused_call_cpu(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt):
-    """The `_cpu` twin of the fused launch: host tensors in and out, torch's intra-op thread count as the team size."""
+def _weight_ptrs(row_weight):
+    if row_weight is None:
+        return None, None
+    if row_weight.dim() == 2:   # (N,7): the kernel takes the row mean itself
+        return None, row_weight.data_ptr()
+    return row_weight.data_ptr(), None
+
+
+def per_pair_call(params, pred, target, row_weight, scale, want_loss, want_gp, want_gt, prologue=None):
+    """One launch of the fused kernel without the reduce stage, on the current stream of pred's device (CPU tensors: the
+    `_cpu` twin, torch's intra-op thread count as the team size).  `prologue`: None or a _lib.Prologue (bbox-coder decode
+    fused into the kernel, head_loss.py).  Returns (loss|None, grad_pred|None, grad_target|None)."""
     lib = _library()
     n = pred.shape[0]
-    loss = torch.empty(n, dtype=torch.float32) if want_loss else None
-    gp = torch.empty_like(pred) if want_gp else None
-    gt = torch.empty_like(target) if want_gt else None
-    total = ws = None
-    if want_sum:
-        buf = torch.empty(4 + _ws_floats(n), dtype=torch.float32)
-        total, ws = buf[0], buf.data_ptr() + 16
-    w1 = w7 = None
-    if row_weight is not None:
-        if row_weight.dim() == 2:
-            w7 = row_weight.data_ptr()
-        else:
-            w1 = row_weight.data_ptr()
-    rc = lib.gd3d_loss_fused_cpu(params, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale, _ptr(loss), _ptr(total),
-                                 _ptr(gp), _ptr(gt), ws, torch.get_num_threads())
-    if rc != 0:
-        _lib.check(rc, 'gd3d_loss_fused_cpu')
-    return loss, total, gp, gt, None
-
-
-def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt, prologue=None,
-               select=False):
-    """One launch of the fused kernel (+ its reduce stage) on the current stream of pred's device.
-    `prologue`: None or a _lib.Prologue (bbox-coder decode fused into the kernel, head_loss.py).
-    `select`  : row_weight is (N,7) and the reference's no-positive-weight early-out is resolved on the device
-                (gd3d_loss_fused_select); the returned `any_pos` is (buffer that owns it, address) of the int32 device
-                flag backward needs.
-    Returns (loss|None, loss_sum|None, grad_pred|None, grad_target|None, any_pos|None)."""
+    w1, w7 = _weight_ptrs(row_weight)
     if not pred.is_cuda:
-        if prologue is not None or select:
-            raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue, on-device weight selection) are GPU-only')
-        return _fused_call_cpu(params, pred, target, row_weight, scale, want_loss, want_sum, want_gp, want_gt)
-    lib = _library()
-    n = pred.shape[0]
+        if prologue is not None:
+            raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue) are GPU-only')
+        loss = torch.empty(n, dtype=torch.float32) if want_loss else None
+        gp = torch.empty_like(pred) if want_gp else None
+        gt = torch.empty_like(target) if want_gt else None
+        rc = lib.gd3d_loss_fused_cpu(params, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale, _ptr(loss), None, _ptr(gp),
+                                     _ptr(gt), None, torch.get_num_threads())
+        if rc != 0:
+            _lib.check(rc, 'gd3d_loss_fused_cpu')
+        return loss, gp, gt
     dev = pred.device
     prev = _get_device()
     switch = prev != dev.index
@@ -252,118 +255,38 @@ def fused_call(params, pred, target, row_weight, scale, want_loss, want_sum, wan
         loss = torch.empty(n, dtype=torch.float32, device=dev) if want_loss else None
         gp = torch.empty_like(pred) if want_gp else None
         gt = torch.empty_like(target) if want_gt else None
-        total = ws = any_pos = None
-        if want_sum:
-            # one allocation: [0] = the fp32 result, [1] = the int32 any-positive flag, [4:] = workspace (16-byte aligned)
-            buf = torch.empty(4 + _ws_floats(n), dtype=torch.float32, device=dev)
-            total, ws = buf[0], buf.data_ptr() + 16
-        ev = PROFILE_EVENTS
-        stream = _raw_stream(dev.index)
-        tm = None
-        if ev is not None:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
-            tm = DispatchTimer()
-            ev.append(tm)
-        ticket = _ticket(dev.index, stream) if (want_sum and ev is None and n <= _one_launch_max()) else None
-        if ticket is not None:
-            # training-size call: ONE launch, the last workgroup finishes the sum (per-stream arrival ticket, zeroed once)
-            w1 = w7 = None
-            if row_weight is not None:
-                if row_weight.dim() == 2:
-                    w7 = row_weight.data_ptr()
-                else:
-                    w1 = row_weight.data_ptr()
-            if select:
-                any_pos = (buf, ws - 12)   # buf[1], read as int32
-            rc = lib.gd3d_loss_fused_one_launch(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
-                                                ws - 16, any_pos[1] if select else None, _ptr(gp), _ptr(gt), ws, ticket,
-                                                stream)
-        elif select:
-            any_pos = (buf, ws - 12)
-            rc = lib.gd3d_loss_fused_select(params, prologue, pred.data_ptr(), target.data_ptr(), row_weight.data_ptr(), n,
-                                            scale, ws - 16, any_pos[1], _ptr(gp), _ptr(gt), ws, stream,
-                                            tm.start if tm else None, tm.stop if tm else None)
-        else:
-            w1 = w7 = None
-            if row_weight is not None:  # (N,) row weights, or (N,7) whose row mean the kernel takes itself
-                if row_weight.dim() == 2:
-                    w7 = row_weight.data_ptr()
-                else:
-                    w1 = row_weight.data_ptr()
-            if tm is None:
-                rc = lib.gd3d_loss_fused_decoded(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
-                                                 _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), ws, stream)
-            else:
-                rc = lib.gd3d_loss_fused_timed(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale,
-                                               _ptr(loss), _ptr(total), _ptr(gp), _ptr(gt), ws, stream, tm.start, tm.stop)
+        rc = lib.gd3d_loss_fused_decoded(params, prologue, pred.data_ptr(), target.data_ptr(), w1, w7, n, scale, _ptr(loss), None,
+                                         _ptr(gp), _ptr(gt), None, _raw_stream(dev.index))
     finally:
         if switch:
             _set_device(prev)
     if rc != 0:
         _lib.check(rc, 'gd3d_loss_fused')
-    return loss, total, gp, gt, any_pos
+    return loss, gp, gt
 
 
-class _GDReduced(torch.autograd.Function):
-    """scale * sum_i w_i L_i  with the final gradients produced by the SAME launch.  With `select` the value and the
-    gradient are those of the reference's early-out `(pred * weight).sum()` when no weight entry is > 0."""
-
-    @staticmethod
-    def forward(ctx, pred, target, row_weight, params, scale, prologue=None, select=False, flag_box=None):
-        need_gp, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        _, total, gp, gt, any_pos = fused_call(params, pred, target, row_weight, scale, False, True, need_gp, need_gt,
-                                               prologue, select)
-        ctx.gp, ctx.gt, ctx.any_pos = gp, gt, any_pos
-        ctx.used, ctx.want = False, (need_gp, need_gt)
-        ctx.replay = (pred, target, row_weight, params, scale, prologue, select)
-        if flag_box is not None:   # the any-positive flag leaves through a side door: a second autograd OUTPUT that is a
-            # view of the same buffer as `total` makes every backward pay view bookkeeping
-            flag_box.append(any_pos[0][1:2].view(torch.int32))
-        return total
-
-    @staticmethod
-    @guard_double_backward
-    def backward(ctx, grad_out):
-        lib = _library()
-        pred, target, row_weight, params, scale, prologue, select = ctx.replay
-        if ctx.used:  # retain_graph replay: the saved buffers were scaled in place; recompute
-            _, _, gp, gt, _ = fused_call(params, pred, target, row_weight, scale, False, False, ctx.want[0], ctx.want[1],
-                                         prologue)
-        else:  # hand the buffers over: with no reference left here a leaf's AccumulateGrad keeps them instead of cloning
-            gp, gt = ctx.gp, ctx.gt
-            ctx.gp = ctx.gt = None
-            ctx.used = True
-        if gp is None and gt is None:
-            return (None,) * 8
-        if not select and _is_unit_grad(grad_out):
-            # the library's own constant 1.0 (unit_grad): known by address, nothing to read, nothing to scale
-            return gp, gt, None, None, None, None, None, None
-        g = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
-        if not pred.is_cuda:   # `_cpu` twin of gd3d_scale_rows (selection never happens on the CPU: GDLoss.forward)
-            g = g.reshape(1)
-            for arr in (gp, gt):
-                if arr is not None:
-                    _lib.check(lib.gd3d_scale_rows_cpu(arr.data_ptr(), g.data_ptr(), 0, pred.shape[0], torch.get_num_threads()),
-                               'gd3d_scale_rows_cpu')
-            return gp, gt, None, None, None, None, None, None
-        dev = pred.device
-        prev = _get_device()
-        switch = prev != dev.index
-        if switch:
-            _set_device(dev.index)
-        try:
-            # one launch for both arrays: reads g (and the any-positive flag) on the device; leaves without touching
-            # memory when g == 1 and the normal branch was taken (no host sync)
-            rc = lib.gd3d_grad_finish(_ptr(gp), _ptr(gt), g.data_ptr(), pred.shape[0],
-                                      ctx.any_pos[1] if ctx.any_pos is not None else None,
-                                      row_weight.data_ptr() if select else None,
-                                      pred.data_ptr() if (select and prologue is not None) else None,
-                                      prologue if select else None, _raw_stream(dev.index))
-        finally:
-            if switch:
-                _set_device(prev)
-        if rc != 0:
-            _lib.check(rc, 'gd3d_grad_finish')
-        return gp, gt, None, None, None, None, None, None
+def reduced_call(params, pred, target, row_weight, scale, prologue=None, select=False, want_flag=False):
+    """scale * sum_i w_i L_i as a 0-dim tensor whose autograd node (C++, csrc/torch_node.cpp) holds the final gradients the
+    SAME launch produced.  With `select` the value and the gradient are those of the reference's early-out
+    `(pred * weight).sum()` when no weight entry is > 0; `want_flag` also returns the int32 (1,) any-positive flag.
+    Backward: the gradients are handed over, scaled by the upstream gradient on the device (gd3d_grad_finish) unless that is
+    `unit_grad`; a second backward under retain_graph recomputes them; differentiating them again raises."""
+    node = _node()
+    n = pred.shape[0]
+    ticket = ev0 = ev1 = 0
+    if pred.is_cuda:
+        ev = PROFILE_EVENTS
+        if ev is not None:  # profiling: the same single call, with a HIP event pair bound to the fused kernel's own dispatch
+            tm = DispatchTimer()
+            ev.append(tm)
+            ev0, ev1 = tm.start, tm.stop
+        elif n <= _one_launch_max():
+            # training-size call: ONE launch, the last workgroup finishes the sum (per-stream arrival ticket, zeroed once)
+            idx = pred.device.index
+            ticket = _ticket(idx, _raw_stream(idx)) or 0
+    return node.reduced(pred, target, row_weight, ctypes.addressof(params), 0 if prologue is None else ctypes.addressof(prologue),
+                        None if prologue is None else getattr(prologue, "_keepalive", None), scale, select, ticket, ev0, ev1, _ws_floats(n),
+                        want_flag)
 
 
 class _GDPerPair(torch.autograd.Function):
@@ -371,7 +294,7 @@ class _GDPerPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target, row_weight, params, scale, prologue=None):
-        loss = fused_call(params, pred, target, row_weight, scale, True, False, False, False, prologue)[0]
+        loss = per_pair_call(params, pred, target, row_weight, scale, True, False, False, prologue)[0]
         ctx.replay = (pred, target, row_weight, params, scale, prologue)
         return loss
 
@@ -383,8 +306,8 @@ class _GDPerPair(torch.autograd.Function):
         if row_weight is not None:
             rw = rw * (row_weight.mean(dim=-1) if row_weight.dim() == 2 else row_weight)
         rw = rw.contiguous()
-        _, _, gp, gt, _ = fused_call(params, pred, target, rw, scale, False, False, ctx.needs_input_grad[0],
-                                     ctx.needs_input_grad[1], prologue)
+        _, gp, gt = per_pair_call(params, pred, target, rw, scale, False, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  prologue)
         return gp, gt, None, None, None, None
 
 
@@ -490,11 +413,11 @@ class GDLoss(nn.Module):
         if reduction == 'none':
             out = _GDPerPair.apply(p, t, w, params, float(scale), prologue)
         else:
-            box = [] if (select and post_div is not None) else None
-            out = _GDReduced.apply(p, t, w, params, float(scale), prologue, select, box)
+            want_flag = select and post_div is not None
+            out, flag = reduced_call(params, p, t, w, float(scale), prologue, select, want_flag)
             if post_div is not None:
                 if select:  # the early-out value is not divided by avg_factor (it returns before the loss is called)
-                    post_div = torch.where(box[0].reshape(()) != 0, post_div.to(torch.float32), 1.0)
+                    post_div = torch.where(flag.reshape(()) != 0, post_div.to(torch.float32), 1.0)
                 out = out / post_div
             if n == 0 and reduction == 'mean' and avg_factor is None and not select:
                 out = out + float('nan')  # torch: mean of an empty tensor is nan
