@@ -127,7 +127,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'mmdet3d-gaussian_amd')
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith(('.py', '.hip', '.h')):
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt and 'oracle/' not in txt, f
 
