@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD3D_ABI_VERSION 5
+#define GD3D_ABI_VERSION 6
 
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
@@ -544,6 +544,12 @@ int riou_eval_trans_bev(const float* det, int64_t nd, int32_t det_cols, const fl
 int eval_match_coco(const float* cost, const float* cost_thrs, const uint8_t* is_ignore,
                     const uint8_t* is_crowd, int64_t nd, int64_t ng, int64_t nt, int32_t* matched,
                     void* stream);
+/* `_cpu` twin (ABI 6): the same contract on HOST memory — the reference's matcher IS CPU code (matcher.cpp:8-74, numpy in
+ * and out), so an evaluation without a GPU keeps working.  Thresholds are spread over `nthreads` std::threads (<= 0: hardware
+ * concurrency).  Same integers as the kernel and as the reference. */
+int eval_match_coco_cpu(const float* cost, const float* cost_thrs, const uint8_t* is_ignore,
+                        const uint8_t* is_crowd, int64_t nd, int64_t ng, int64_t nt, int32_t* matched,
+                        int32_t nthreads);
 
 /* ------------------------------------------------------------------------------------
  * Dynamic point-to-voxel scatter-reduce.  Replaces

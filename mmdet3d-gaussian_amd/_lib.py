@@ -176,6 +176,7 @@ SYMBOLS = {
     'riou_eval_3d': (_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp]),
     'riou_eval_trans_bev': (_int, [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _vp]),
     'eval_match_coco': (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    'eval_match_coco_cpu': (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_int32]),
     'vox_scatter_reduce': (_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp, _vp]),
     'vox_scatter_backward': (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _i64, _int, _vp, _vp]),
     'vox_index_workspace_bytes': (_sz, [_i64, ctypes.c_int32]),
@@ -215,7 +216,7 @@ def lib_path():
     return _build.LIB_PATH
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def _bind(path):

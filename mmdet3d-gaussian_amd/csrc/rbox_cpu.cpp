@@ -12,6 +12,9 @@
 #include "../../include/gd3d.h"
 #include "host_threads.h"
 
+#include <cstring>
+#include <vector>
+
 namespace {
 
 using namespace rbox;
@@ -84,6 +87,50 @@ int riou_eval_trans_bev_cpu(const float* det, int64_t nd, int32_t det_cols, cons
         const float dx = det[i * det_cols] - gt[j * gt_cols], dy = det[i * det_cols + 1] - gt[j * gt_cols + 1];
         dist[i * ng + j] = std::sqrt(dx * dx + dy * dy);   // affinity.cpp:98-100 in fp32, correctly rounded
       }
+  });
+  return 0;
+}
+
+// match_coco on the host: the matcher kernel's own statement of matcher.cpp:8-74 (csrc/eval_match.hip) — per threshold the
+// detections in row order, each taking the minimum of key = (is_ignore, cost, -index) over the gts with cost <= thr that are
+// still free (or crowd): a non-ignore gt beats any ignore gt, ties go to the later gt, NaN never matches, -0 == +0.
+// Integer output: bit-exact with the kernel and with the reference.  Thresholds are independent: one contiguous run per thread.
+int eval_match_coco_cpu(const float* cost, const float* cost_thrs, const uint8_t* is_ignore, const uint8_t* is_crowd, int64_t nd,
+                        int64_t ng, int64_t nt, int32_t* matched, int32_t nthreads) {
+  // the argument rules of eval_match_coco (csrc/eval_match.hip), sizes included
+  if (nd < 0 || ng < 0 || nt < 0) return GD3D_E_BADARG;
+  if (nt == 0 || nd == 0) return 0;
+  if (matched == nullptr || cost_thrs == nullptr) return GD3D_E_BADARG;
+  if (ng > 0 && (cost == nullptr || is_ignore == nullptr || is_crowd == nullptr)) return GD3D_E_BADARG;
+  if (nd > 0x7fffffffLL || nt > 0x7fffffffLL || ng > 1048576) return GD3D_E_TOOLARGE;
+  auto ordered = [](float v) -> uint32_t {   // order-preserving bits of a float; -0 -> +0 (the reference compares floats)
+    v += 0.0f;
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  };
+  parallel_ranges(nt, gd3d_host::team_size(nthreads, nt, 1, nd * ng < 65536 ? (int64_t)1 << 40 : 2), [&](int64_t t0, int64_t t1) {
+    std::vector<unsigned char> taken((size_t)ng);
+    for (int64_t t = t0; t < t1; ++t) {
+      std::fill(taken.begin(), taken.end(), (unsigned char)0);
+      const float thr = cost_thrs[t];
+      for (int64_t d = 0; d < nd; ++d) {
+        const float* row = cost + d * ng;
+        uint64_t best = ~0ull;
+        for (int64_t g = 0; g < ng; ++g) {
+          if (!((!taken[(size_t)g] || is_crowd[g]) && row[g] <= thr)) continue;
+          const uint64_t key = ((uint64_t)(is_ignore[g] ? 1u : 0u) << 63) | ((uint64_t)ordered(row[g]) << 31) |
+                               (uint64_t)(0x7fffffffu - (uint32_t)g);
+          if (key < best) best = key;
+        }
+        int32_t m = -1;
+        if (best != ~0ull) {
+          m = (int32_t)(0x7fffffffu - (uint32_t)(best & 0x7fffffffull));
+          taken[(size_t)m] = 1;
+        }
+        matched[t * nd + d] = m;
+      }
+    }
   });
   return 0;
 }

@@ -10,7 +10,7 @@ classes call these two functions unchanged.
 
 The reference computes all of this on the CPU from numpy arrays.  Here the affinity matrix is produced and consumed in
 HBM; numpy inputs are accepted and moved to the current device, results are returned as tensors on that device.
-CPU tensors take the library's `_cpu` twin in `trans_bev` (and in `iou_3d` / `iou_bev`); `match_coco` is GPU-only.
+CPU tensors (and numpy inputs on a machine without a GPU) take the library's `_cpu` twins — the reference's own helpers are CPU code.
 """
 import numpy as np
 import torch
@@ -55,18 +55,22 @@ def trans_bev(det_bboxes, gt_bboxes):
 
 def match_coco(cost_mat, cost_thrs, is_ignore, is_crowd):
     """(D,G) costs, (T) thresholds, (G) bool flags -> (T,D) int32 tensor: matched gt index or -1 (matcher.cpp:8-74)."""
-    cost = _dev_tensor(cost_mat, torch.float32, 'match_coco')
+    cost = _dev_tensor(cost_mat, torch.float32, 'match_coco', cpu_ok=True)
     if cost.dim() != 2:
         raise RuntimeError(f'match_coco: cost matrix must be 2-D, got {tuple(cost.shape)}')
     dev = cost.device
-    thrs = _dev_tensor(cost_thrs, torch.float32, 'match_coco').to(dev).reshape(-1)
-    ign = _dev_tensor(is_ignore, torch.uint8, 'match_coco').to(dev).reshape(-1)
-    crowd = _dev_tensor(is_crowd, torch.uint8, 'match_coco').to(dev).reshape(-1)
+    thrs = _dev_tensor(cost_thrs, torch.float32, 'match_coco', cpu_ok=True).to(dev).reshape(-1)
+    ign = _dev_tensor(is_ignore, torch.uint8, 'match_coco', cpu_ok=True).to(dev).reshape(-1)
+    crowd = _dev_tensor(is_crowd, torch.uint8, 'match_coco', cpu_ok=True).to(dev).reshape(-1)
     D, G = cost.shape
     if ign.numel() != G or crowd.numel() != G:
         raise RuntimeError(f'match_coco: {G} gts but {ign.numel()} ignore / {crowd.numel()} crowd flags')
     T = thrs.numel()
     out = torch.empty((T, D), dtype=torch.int32, device=dev)
+    if not cost.is_cuda:   # the reference's matcher is CPU code (matcher.cpp:8-74): the `_cpu` twin
+        _lib.check(_lib.load().eval_match_coco_cpu(cost.data_ptr(), thrs.data_ptr(), ign.data_ptr(), crowd.data_ptr(), D, G, T,
+                                                   out.data_ptr(), torch.get_num_threads()), 'eval_match_coco_cpu')
+        return out
     with torch.cuda.device(dev):
         _lib.check(_lib.load().eval_match_coco(cost.data_ptr(), thrs.data_ptr(), ign.data_ptr(), crowd.data_ptr(), D, G, T,
                                                out.data_ptr(), torch.cuda.current_stream().cuda_stream),

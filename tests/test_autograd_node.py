@@ -23,7 +23,7 @@ def _pair(n=64, seed=0):
 def test_node_is_built_in_tree_and_binds_the_loaded_library():
     node = _lib.load_node()
     assert os.path.dirname(node.__file__) == os.path.join(ROOT, 'mmdet3d-gaussian_amd')
-    assert node.bind(amd.lib_path()) == _lib.ABI_VERSION == 5          # binding again is harmless
+    assert node.bind(amd.lib_path()) == _lib.ABI_VERSION == 6          # binding again is harmless
     with pytest.raises(RuntimeError, match='cannot open'):
         node.bind(os.path.join(ROOT, 'no_such_library.so'))
     src = open(os.path.join(ROOT, 'mmdet3d-gaussian_amd', 'csrc', 'torch_node.cpp')).read()

@@ -263,4 +263,4 @@ def test_c_abi_argument_validation_of_the_cpu_entries():
     per = np.arange(n, dtype=np.float32)
     assert lib.gd3d_scale_rows_cpu(vp(rows), vp(per), 1, n, 1) == 0 and np.all(rows[:, 0] == 2.0 * per)
     assert lib.gd3d_scale_rows_cpu(vp(rows), None, 0, n, 1) == 10001
-    assert _lib.ABI_VERSION == 5
+    assert _lib.ABI_VERSION == 6

@@ -90,3 +90,51 @@ def test_c_abi_argument_validation_of_the_cpu_entries():
     assert lib.rnms_bev_cpu(vp(b), 4, 0.5, vp(keep), vp(num)) == 0 and 1 <= num[0] <= 4
     assert lib.rnms_bev_cpu(None, 0, 0.5, None, vp(num)) == 0 and num[0] == 0
     assert lib.rnms_bev_cpu(vp(b), 4, 0.5, vp(keep), None) == 10001 and lib.rnms_normal_bev_cpu(None, 4, 0.5, vp(keep), vp(num)) == 10001
+
+
+def test_match_coco_on_cpu_against_the_compiled_reference_fixtures():
+    """The matcher's `_cpu` twin (eval_match_coco_cpu) on numpy / CPU-tensor inputs vs the vectors of the reference's own compiled
+    matcher.cpp (tests/golden/match_coco.npz): the reference's matcher is CPU code, so an evaluation without a GPU must work."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'match_coco.npz'))
+    for name in g['cases']:
+        args = [torch.from_numpy(np.ascontiguousarray(g[f'{name}.{k}'])) for k in ('cost', 'thrs', 'ignore', 'crowd')]
+        got = amd.match_coco(*args)
+        assert got.dtype == torch.int32 and got.device.type == 'cpu' and np.array_equal(got.numpy(), g[f'{name}.matched']), name
+        if not torch.cuda.is_available():   # numpy in (what the reference's evaluation passes): the same path on a GPU-less machine
+            assert np.array_equal(amd.match_coco(*[g[f'{name}.{k}'] for k in ('cost', 'thrs', 'ignore', 'crowd')]).numpy(), g[f'{name}.matched'])
+
+
+@pytest.mark.parametrize('D,G,T', [(3000, 50, 10), (200, 5000, 3), (1, 1, 1), (64, 64, 4), (500, 65, 2), (7, 0, 3), (0, 5, 2)])
+def test_match_coco_cpu_twin_vs_oracle_ties_signed_zeros_empty_sides_and_threads(D, G, T):
+    rng = np.random.default_rng(D + G)
+    cost = np.round(-rng.uniform(0, 1, (D, G)), 2).astype(np.float32)        # rounded: plenty of exact ties
+    cost[rng.uniform(0, 1, (D, G)) < 0.01] = -0.0                             # signed zeros compare equal to +0
+    if D * G > 100:
+        cost[rng.uniform(0, 1, (D, G)) < 0.005] = np.nan                      # NaN never matches
+    thrs = -np.linspace(0.0, 0.9, T).astype(np.float32)
+    ign = rng.uniform(0, 1, G) < 0.3
+    crowd = rng.uniform(0, 1, G) < 0.1
+    want = oracle.match_coco(cost, thrs, ign, crowd) if D and G else np.full((T, D), -1, np.int32)
+    t = [torch.from_numpy(x) for x in (cost, thrs, ign, crowd)]
+    got = amd.match_coco(*t)
+    assert got.shape == (T, D) and np.array_equal(got.numpy(), want)
+    lib = amd.load_library()
+    out = np.empty((T, D), np.int32)
+    c8, i8 = np.ascontiguousarray(crowd.astype(np.uint8)), np.ascontiguousarray(ign.astype(np.uint8))
+    for threads in (1, 3):   # thresholds are independent: the team size cannot show in the result
+        out.fill(7)
+        assert lib.eval_match_coco_cpu(cost.ctypes.data, thrs.ctypes.data, i8.ctypes.data, c8.ctypes.data, D, G, T, out.ctypes.data, threads) == 0
+        assert np.array_equal(out, want) or D == 0
+
+
+def test_match_coco_cpu_entry_argument_rules():
+    lib = amd.load_library()
+    one = np.zeros(4, np.float32)
+    flags = np.zeros(4, np.uint8)
+    out = np.zeros(4, np.int32)
+    call = lambda *a: lib.eval_match_coco_cpu(*a)
+    assert call(one.ctypes.data, one.ctypes.data, flags.ctypes.data, flags.ctypes.data, -1, 1, 1, out.ctypes.data, 1) == 10001
+    assert call(None, one.ctypes.data, flags.ctypes.data, flags.ctypes.data, 1, 1, 1, out.ctypes.data, 1) == 10001
+    assert call(one.ctypes.data, one.ctypes.data, flags.ctypes.data, flags.ctypes.data, 1, 1, 1, None, 1) == 10001
+    assert call(one.ctypes.data, one.ctypes.data, flags.ctypes.data, flags.ctypes.data, 1, (1 << 20) + 1, 1, out.ctypes.data, 1) == 10002
+    assert call(None, one.ctypes.data, None, None, 0, 0, 0, None, 1) == 0      # nothing to do

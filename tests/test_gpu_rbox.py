@@ -573,6 +573,8 @@ def test_match_coco_large_vs_oracle(amd, D, G, T):
     want = oracle.match_coco(cost, thrs, ign, crowd)
     got = amd.match_coco(torch.from_numpy(cost).cuda(), thrs, torch.from_numpy(ign).cuda(), crowd)
     assert np.array_equal(got.cpu().numpy(), want)
+    twin = amd.match_coco(*[torch.from_numpy(x) for x in (cost, thrs, ign, crowd)])     # CPU tensors: eval_match_coco_cpu
+    assert twin.device.type == 'cpu' and np.array_equal(twin.numpy(), want)
 
 
 def test_iou_to_matches_pipeline_on_the_device(amd):
