@@ -86,24 +86,33 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
     # scattered to the rank: no torch.sort); float64 scores keep torch.sort (their order may differ after rounding to fp32)
     fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
                                                                                      torch.bfloat16)
-    with torch.cuda.device(dev):
+    # raw device / stream accessors and a memoised workspace size: the call is a handful of launches (30-70 us of device time at
+    # inference sizes) and the Python around it was a third of nms_gpu's end-to-end time
+    prev = _get_device()
+    if prev != dev.index:
+        _set_device(dev.index)
+    try:
         keep = torch.empty(n, dtype=torch.int64, device=dev)
         num = torch.empty(1, dtype=torch.int64, device=dev)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _raw_stream(dev.index)
         if fused_sort:
             sc = scores if scores.dtype == torch.float32 else scores.float()
             sc = sc if sc.is_contiguous() else sc.contiguous()
-            ws = torch.empty(lib.rnms_scored_workspace_bytes(n_all, n), dtype=torch.uint8, device=dev)
-            _lib.check(lib.rnms_scored(int(normal), boxes.data_ptr(), sc.data_ptr(), n_all, n, float(thresh), keep.data_ptr(),
-                                       num.data_ptr(), ws.data_ptr(), stream), name)
+            ws = torch.empty(_ws_bytes(lib, True, n_all, n), dtype=torch.uint8, device=dev)
+            rc = lib.rnms_scored(int(normal), boxes.data_ptr(), sc.data_ptr(), n_all, n, float(thresh), keep.data_ptr(),
+                                 num.data_ptr(), ws.data_ptr(), stream)
         else:
             order = scores.sort(dim=0, descending=True, stable=True)[1]   # ties: lower index first
             order = order[:n].contiguous()
-            ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            ws = torch.empty(_ws_bytes(lib, False, n, n), dtype=torch.uint8, device=dev)
             # the kernels read boxes[order[i]] themselves and emit kept indices in the caller's numbering
             fn = lib.rnms_normal_bev_ordered if normal else lib.rnms_bev_ordered
-            _lib.check(fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
-                          ws.data_ptr(), stream), name)
+            rc = fn(boxes.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(), ws.data_ptr(), stream)
+    finally:
+        if prev != dev.index:
+            _set_device(prev)
+    if rc != 0:
+        _lib.check(rc, name)
     if padded:   # nothing read back: (kept indices padded to n rows, count on the device); the post_max_size cut applies to both
         if post_max_size is not None:
             keep, num = keep[:post_max_size], num.clamp(max=max(int(post_max_size), 0))
@@ -116,6 +125,21 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
 
 
 _SCORED_MAX = None
+_WS_BYTES = {}
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_get_device = torch._C._cuda_getDevice
+_set_device = torch._C._cuda_setDevice
+
+
+def _ws_bytes(lib, scored, n_all, n):
+    """rnms_scored_workspace_bytes(n_all, n) / rnms_workspace_bytes(n), memoised (one ctypes call less per NMS)."""
+    key = (scored, n_all, n)
+    b = _WS_BYTES.get(key)
+    if b is None:
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        b = _WS_BYTES[key] = int(lib.rnms_scored_workspace_bytes(n_all, n) if scored else lib.rnms_workspace_bytes(n))
+    return b
 
 
 def _scored_max(lib):
