@@ -371,6 +371,9 @@ def main():
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1; at N = 1 it is 5 us per step slower than eager launches)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
+    ap.add_argument('--separate-inputs', action='store_true',
+                    help='one torch allocation per input array (target + one prediction leaf per loss) instead of row ranges of '
+                         'ONE allocation: exposes the placement lottery of DESIGN.md 5.3')
     ap.add_argument('--sum-backward', action='store_true',
                     help="round 2's step: (l0 + l1 + l2).backward() instead of one autograd.backward with unit gradients")
     ap.add_argument('--event-every', type=int, default=5,
@@ -439,7 +442,22 @@ def main():
     # with its loss dict, and separate leaves keep autograd from adding 2 x 280 MB gradient accumulations that are not
     # part of the metric.  (One backward per loss costs ~60 us of autograd-engine thread hand-off each: 3 x that made
     # the eager step host-bound on boxes with a slow host, measured in round 2.)
-    preds = {lt: pred0.clone().requires_grad_(True) for lt in LOSSES}
+    if args.separate_inputs:
+        preds = {lt: pred0.clone().requires_grad_(True) for lt in LOSSES}
+    else:
+        # The four input arrays are row ranges of ONE allocation.  Streams read from separately allocated 280 MB buffers
+        # collide in the memory system on some draws of their physical placement (a 2-read-1-write pass over three such
+        # buffers: 122-134 us by triple; over three ranges of one allocation: 121-126 us on every draw, whether the
+        # allocation is made first, after others, or after others were freed: profiles/r04_placement_scan.txt part 3).
+        # `--separate-inputs` restores one torch allocation per array.
+        arena = torch.empty((len(LOSSES) + 1) * n, 7, dtype=torch.float32, device=dev)
+        arena[:n].copy_(tgt)
+        tgt = arena[:n]
+        preds = {}
+        for k, lt in enumerate(LOSSES):
+            view = arena[(k + 1) * n:(k + 2) * n]
+            view.copy_(pred0)
+            preds[lt] = view.detach().requires_grad_(True)
     del pred0
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
                                     reduction='mean', loss_weight=5.0)) for lt in LOSSES}
@@ -689,6 +707,8 @@ def main():
                                    + '; fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
+                       'input_allocation': 'one torch allocation per array' if args.separate_inputs else
+                                           'target and the three prediction leaves are row ranges of one allocation',
                        'device': 'MI355X (HIP kernels)' if on_gpu else f'cpu (rehearsal: GDLoss _cpu twins, {torch.get_num_threads()} threads per rank; not the metric)',
                        'collective': (f'all_gather of (3,) shard losses per step over {"RCCL" if backend == "nccl" else backend}, async') if use_dist else None,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
