@@ -244,6 +244,31 @@ __global__ __launch_bounds__(64) void match_coco_small_kernel(const float* __res
   if (tail0 + lane < nd) matched[(size_t)t * nd + tail0 + lane] = mreg;
 }
 
+// Clears (or fills) small or large device buffers from a KERNEL.  Not hipMemsetAsync: inside a captured hipGraph a memset node was
+// found not to be reliably ordered against the kernels around it on this ROCm (profiles/r04_nms_queue_ab.txt) —
+// rule of this library: no memset nodes in paths a caller may capture.
+__global__ __launch_bounds__(256) void fill_words_kernel(unsigned* __restrict__ p, long long nwords, unsigned value) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const long long nv = nwords >> 2;
+    const uint4 v4 = make_uint4(value, value, value, value);
+    for (long long k = i; k < nv; k += stride) p4[k] = v4;
+    for (long long k = (nv << 2) + i; k < nwords; k += stride) p[k] = value;
+    return;
+  }
+  for (; i < nwords; i += stride) p[i] = value;
+}
+static int fill_words(void* p, size_t bytes, unsigned value, hipStream_t s) {   // bytes: a multiple of 4
+  const long long nwords = (long long)(bytes / 4);
+  if (nwords == 0) return 0;
+  long long blocks = (nwords / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, nwords, value);
+  return (int)hipGetLastError();
+}
+
 }  // namespace evalm
 
 extern "C" {
@@ -267,7 +292,7 @@ int eval_match_coco(const float* cost, const float* cost_thrs, const uint8_t* is
   if (nt == 0 || nd == 0) return 0;
   if (matched == nullptr || cost_thrs == nullptr) return GD3D_E_BADARG;
   if (ng == 0)  // no ground truth: every detection is unmatched (-1 = all-ones bytes); the kernels index gt ng - 1
-    return (int)hipMemsetAsync(matched, 0xff, sizeof(int32_t) * (size_t)nt * (size_t)nd, (hipStream_t)stream);
+    return evalm::fill_words(matched, sizeof(int32_t) * (size_t)nt * (size_t)nd, 0xffffffffu, (hipStream_t)stream);
   if (cost == nullptr || is_ignore == nullptr || is_crowd == nullptr) return GD3D_E_BADARG;
   if (nd > 0x7fffffffLL || nt > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   if (ng > 1048576) return GD3D_E_TOOLARGE;  // taken bitmask: 128 KiB of the 160 KiB LDS

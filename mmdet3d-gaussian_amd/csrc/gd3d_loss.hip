@@ -881,6 +881,32 @@ __global__ __launch_bounds__(256) void center_scale_kernel(const CenterArgs a, c
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < nflt; k += (long long)gridDim.x * 256) gmap[k] *= gs;
 }
 
+
+// Clears (or fills) small or large device buffers from a KERNEL.  Not hipMemsetAsync: inside a captured hipGraph a memset node was
+// found not to be reliably ordered against the kernels around it on this ROCm (profiles/r04_nms_queue_ab.txt) —
+// rule of this library: no memset nodes in paths a caller may capture.
+__global__ __launch_bounds__(256) void fill_words_kernel(unsigned* __restrict__ p, long long nwords, unsigned value) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const long long nv = nwords >> 2;
+    const uint4 v4 = make_uint4(value, value, value, value);
+    for (long long k = i; k < nv; k += stride) p4[k] = v4;
+    for (long long k = (nv << 2) + i; k < nwords; k += stride) p[k] = value;
+    return;
+  }
+  for (; i < nwords; i += stride) p[i] = value;
+}
+static int fill_words(void* p, size_t bytes, unsigned value, hipStream_t s) {   // bytes: a multiple of 4
+  const long long nwords = (long long)(bytes / 4);
+  if (nwords == 0) return 0;
+  long long blocks = (nwords / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, nwords, value);
+  return (int)hipGetLastError();
+}
+
 // second stage: fixed-order fp64 sum of the per-block partials -> one fp32.  One workgroup; the kernel is pure latency
 // (39 K floats at 10 M pairs): every thread issues ALL its 16-byte loads of a 48 K-partial round before the first add
 // (one memory round trip at 10 M pairs), then one barrier: thread t of wave 0 adds 16 consecutive per-thread sums from
@@ -1241,10 +1267,10 @@ static int loss_launch(const gd3d_params* p, const gd3d_prologue* pro, const flo
   if (n == 0) {
     // no rows: sum 0; torch.any() of an empty weight is False, so a selecting call takes the early-out, whose value is 0 too
     if (any_positive != nullptr) {
-      const hipError_t e0 = hipMemsetAsync(any_positive, 0, sizeof(int32_t), s);
-      if (e0 != hipSuccess) return (int)e0;
+      const int e0 = fill_words(any_positive, sizeof(int32_t), 0u, s);
+      if (e0 != 0) return e0;
     }
-    if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+    if (loss_sum != nullptr) return fill_words(loss_sum, sizeof(float), 0u, s);
     return 0;
   }
   if (loss_sum == nullptr && loss == nullptr && grad_pred == nullptr && grad_target == nullptr && workspace == nullptr)
@@ -1357,7 +1383,7 @@ int gd3d_probe_stream(const float* x, const float* y, float* z, int64_t n_floats
 int gd3d_loss_reduce(const void* workspace, int64_t n, float* loss_sum, void* stream) {
   if (n < 0 || loss_sum == nullptr) return GD3D_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+  if (n == 0) return fill_words(loss_sum, sizeof(float), 0u, s);
   if (workspace == nullptr) return GD3D_E_BADARG;
   const long long nparts = (n + TILE - 1) / TILE;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nparts, loss_sum);
@@ -1379,7 +1405,7 @@ static int anchor_head_impl(const gd3d_params* p, const gd3d_smooth_l1* sl1, con
   }
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) {
-    if (loss_sum != nullptr) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), s);
+    if (loss_sum != nullptr) return fill_words(loss_sum, sizeof(float), 0u, s);
     return 0;
   }
   if (bbox_pred == nullptr || bbox_targets == nullptr || anchors == nullptr) return GD3D_E_BADARG;
@@ -1588,7 +1614,7 @@ static int center_stage(const gd3d_params* p, const gd3d_prologue* coder, const 
     return GD3D_E_BADARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (max_n == 0) return launch ? (int)hipMemsetAsync(losses, 0, sizeof(float) * 2 * (size_t)num_tasks, s) : 0;
+  if (max_n == 0) return launch ? fill_words(losses, sizeof(float) * 2 * (size_t)num_tasks, 0u, s) : 0;
   if (workspace == nullptr) return GD3D_E_BADARG;
   if (a.pstride > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   if (!launch) return 0;

@@ -1001,6 +1001,31 @@ __global__ __launch_bounds__(EVAL_T) void riou_eval_kernel(const float* __restri
   out[idx] = eval_iou<IS3D, EVAL_T>(d, g, z_offset, hs, threadIdx.x);
 }
 
+// Clears (or fills) small or large device buffers from a KERNEL.  Not hipMemsetAsync: inside a captured hipGraph a memset node was
+// found not to be reliably ordered against the kernels around it on this ROCm (profiles/r04_nms_queue_ab.txt) —
+// rule of this library: no memset nodes in paths a caller may capture.
+__global__ __launch_bounds__(256) void fill_words_kernel(unsigned* __restrict__ p, long long nwords, unsigned value) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const long long nv = nwords >> 2;
+    const uint4 v4 = make_uint4(value, value, value, value);
+    for (long long k = i; k < nv; k += stride) p4[k] = v4;
+    for (long long k = (nv << 2) + i; k < nwords; k += stride) p[k] = value;
+    return;
+  }
+  for (; i < nwords; i += stride) p[i] = value;
+}
+static int fill_words(void* p, size_t bytes, unsigned value, hipStream_t s) {   // bytes: a multiple of 4
+  const long long nwords = (long long)(bytes / 4);
+  if (nwords == 0) return 0;
+  long long blocks = (nwords / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, nwords, value);
+  return (int)hipGetLastError();
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace rbox
@@ -1159,7 +1184,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
 static int rnms_impl(int mode, const float* boxes, const int64_t* order, int64_t n, float thresh, double thresh_d,
                      int64_t* keep, int64_t* num_keep, void* workspace, void* stream) {
   if (n < 0 || num_keep == nullptr) return GD3D_E_BADARG;
-  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), (hipStream_t)stream);
+  if (n == 0) return fill_words(num_keep, sizeof(int64_t), 0u, (hipStream_t)stream);
   if (boxes == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
   return rnms_launch(mode, boxes, order, nullptr, 1, n, thresh, thresh_d, nullptr, keep, num_keep, workspace, stream);
 }
@@ -1169,7 +1194,7 @@ int rnms_batched(int32_t mode, const float* boxes, const int64_t* order, const i
   if (mode < MODE_ROT || mode > MODE_CIRCLE || groups < 0 || cap < 0) return GD3D_E_BADARG;
   if (groups == 0) return 0;
   if (num_keep == nullptr) return GD3D_E_BADARG;
-  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, (hipStream_t)stream);
+  if (cap == 0) return fill_words(num_keep, sizeof(int64_t) * (size_t)groups, 0u, (hipStream_t)stream);
   if (boxes == nullptr || order == nullptr || counts == nullptr || thresh == nullptr || keep == nullptr ||
       workspace == nullptr)
     return GD3D_E_BADARG;
@@ -1181,7 +1206,7 @@ int rnms_batched_prepared(const float* boxes, const int64_t* order, const int32_
   if (groups < 0 || cap < 0) return GD3D_E_BADARG;
   if (groups == 0) return 0;
   if (num_keep == nullptr) return GD3D_E_BADARG;
-  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, (hipStream_t)stream);
+  if (cap == 0) return fill_words(num_keep, sizeof(int64_t) * (size_t)groups, 0u, (hipStream_t)stream);
   if (boxes == nullptr || order == nullptr || counts == nullptr || thresh == nullptr || keep == nullptr ||
       workspace == nullptr)
     return GD3D_E_BADARG;
@@ -1216,7 +1241,7 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   if (n_all > RANK_MAX) return GD3D_E_TOOLARGE;
   const int64_t n = (pre_max >= 0 && pre_max < n_all) ? pre_max : n_all;
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t), s);
+  if (n == 0) return fill_words(num_keep, sizeof(int64_t), 0u, s);
   if (boxes == nullptr || scores == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
   long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
   int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
@@ -1254,7 +1279,7 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   if (n > RANK_MAX || groups > 65535) return GD3D_E_TOOLARGE;
   const int64_t cap = (pre_max >= 0 && pre_max < n) ? pre_max : n;
   hipStream_t s = (hipStream_t)stream;
-  if (cap == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int64_t) * (size_t)groups, s);
+  if (cap == 0) return fill_words(num_keep, sizeof(int64_t) * (size_t)groups, 0u, s);
   if (boxes == nullptr || scores == nullptr || thresh == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
   char* p = (char*)workspace + align_up(rnms_batched_workspace_bytes(groups, cap), 256);
   long long* order = (long long*)p;

@@ -449,6 +449,31 @@ static void launch_backward(bool vec, unsigned blocks, hipStream_t s, const floa
   else hipLaunchKernelGGL((gather_grad_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, s, gv, map, count, argmax, n, c, shift, magic, gf);
 }
 
+// Clears (or fills) small or large device buffers from a KERNEL.  Not hipMemsetAsync: inside a captured hipGraph a memset node was
+// found not to be reliably ordered against the kernels around it on this ROCm (profiles/r04_nms_queue_ab.txt) —
+// rule of this library: no memset nodes in paths a caller may capture.
+__global__ __launch_bounds__(256) void fill_words_kernel(unsigned* __restrict__ p, long long nwords, unsigned value) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const long long nv = nwords >> 2;
+    const uint4 v4 = make_uint4(value, value, value, value);
+    for (long long k = i; k < nv; k += stride) p4[k] = v4;
+    for (long long k = (nv << 2) + i; k < nwords; k += stride) p[k] = value;
+    return;
+  }
+  for (; i < nwords; i += stride) p[i] = value;
+}
+static int fill_words(void* p, size_t bytes, unsigned value, hipStream_t s) {   // bytes: a multiple of 4
+  const long long nwords = (long long)(bytes / 4);
+  if (nwords == 0) return 0;
+  long long blocks = (nwords / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, nwords, value);
+  return (int)hipGetLastError();
+}
+
 }  // namespace vox
 
 using namespace vox;
@@ -500,7 +525,7 @@ int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_
   if (n == 0) return 0;
   if (grad_feats == nullptr) return GD3D_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (v == 0) return (int)hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
+  if (v == 0) return fill_words(grad_feats, (size_t)n * c * sizeof(float), 0u, s);
   if (grad_vox == nullptr || map == nullptr) return GD3D_E_BADARG;
   if (reduce == GD3D_REDUCE_MAX && argmax == nullptr) return GD3D_E_BADARG;
   if (reduce == GD3D_REDUCE_MEAN && count == nullptr) return GD3D_E_BADARG;
@@ -510,8 +535,8 @@ int vox_scatter_backward(const float* grad_vox, const int32_t* map, const int32_
   if (blocks > 0x7fffffffLL) return GD3D_E_TOOLARGE;
   const unsigned nb = (unsigned)blocks;
   if (reduce == GD3D_REDUCE_MAX && c < 32) {
-    hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    const int e = fill_words(grad_feats, (size_t)n * c * sizeof(float), 0u, s);
+    if (e != 0) return e;
     long long mb = (v * c + 255) / 256;
     if (mb > 8192) mb = 8192;
     hipLaunchKernelGGL(vox::max_grad_kernel, dim3((unsigned)mb), dim3(256), 0, s, grad_vox, argmax, (long long)v, (int)c, grad_feats);
@@ -528,7 +553,7 @@ int vox_scatter_backward_grouped(const float* grad_vox, const int32_t* order, co
   if (n == 0) return 0;
   if (grad_feats == nullptr) return GD3D_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (v == 0) return (int)hipMemsetAsync(grad_feats, 0, (size_t)n * c * sizeof(float), s);
+  if (v == 0) return fill_words(grad_feats, (size_t)n * c * sizeof(float), 0u, s);
   if (grad_vox == nullptr || order == nullptr || seg == nullptr) return GD3D_E_BADARG;
   if (reduce == GD3D_REDUCE_MAX && argmax == nullptr) return GD3D_E_BADARG;
   const bool vec = (c % 4) == 0 && c <= 256 && ((((uintptr_t)grad_vox | (uintptr_t)grad_feats | (uintptr_t)argmax) & 15) == 0);

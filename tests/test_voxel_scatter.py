@@ -309,3 +309,49 @@ def test_gpu_index_reports_key_overflow_and_out_of_range_coordinates():
     neg = torch.tensor([[1, 2, 3], [-2 ** 40, 0, 0], [1, 2, 3]], dtype=torch.int64, device='cuda')
     vc, pm, cnt = scatter_index(neg)
     assert pm.tolist() == [0, -1, 0] and vc.dtype == torch.int64
+
+
+@pytest.mark.gpu
+def test_gpu_backward_with_its_zero_fill_replays_in_a_hipgraph():
+    """The arg-max backward at narrow rows clears grad_feats and then routes the voxel gradients: the clear is a KERNEL of the
+    library, not a hipMemsetAsync — a memset node of a captured graph was found not to be reliably ordered against the kernels
+    around it on this ROCm (round 4, rotated NMS).  Five replays on a poisoned output buffer must equal the eager result; the
+    degenerate calls whose whole effect is a clear (no voxels; an empty loss call) are captured alongside."""
+    import ctypes
+    import mmdet3d_gaussian_amd as amd
+    from mmdet3d_gaussian_amd.scatter import Scatter, group_points
+    lib = amd.load_library()
+    n, c, red = 30000, 10, 2
+    coors, feats = _cloud(n, 321, c=c, neg_frac=0.03)
+    sc = Scatter(torch.from_numpy(coors).cuda())
+    order, seg = group_points(sc.pts_voxel_maps, sc.voxel_pts_counts)
+    v = sc.voxel_coors.shape[0]
+    f = torch.from_numpy(feats).cuda()
+    out = torch.empty(v, c, device='cuda'); arg = torch.empty(v, c, dtype=torch.int32, device='cuda')
+    assert lib.vox_scatter_reduce(f.data_ptr(), order.data_ptr(), seg.data_ptr(), n, c, v, red, out.data_ptr(), arg.data_ptr(), None) == 0
+    gv = torch.randn(v, c, device='cuda')
+    want = torch.full((n, c), float('nan'), device='cuda')
+    assert lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), arg.data_ptr(), n, c, v,
+                                    red, want.data_ptr(), None) == 0
+    got = torch.full((n, c), float('nan'), device='cuda')
+    none = torch.full((64, c), float('nan'), device='cuda')          # a call with v == 0: its whole effect is the clear
+    lsum = torch.full((1,), float('nan'), device='cuda')             # gd3d_loss_reduce with n == 0: writes 0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        s = ctypes.c_void_p(side.cuda_stream)
+        with torch.cuda.graph(graph, stream=side):
+            assert lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), arg.data_ptr(),
+                                            n, c, v, red, got.data_ptr(), s) == 0
+            assert lib.vox_scatter_backward(gv.data_ptr(), sc.pts_voxel_maps.data_ptr(), sc.voxel_pts_counts.data_ptr(), None,
+                                            64, c, 0, 0, none.data_ptr(), s) == 0
+            assert lib.gd3d_loss_reduce(None, 0, lsum.data_ptr(), s) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(5):
+        got.fill_(float('nan')); none.fill_(float('nan')); lsum.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert (none == 0).all() and lsum.item() == 0.0
