@@ -124,3 +124,21 @@ def test_every_launch_path_gets_the_rccl_environment_defaults():
     assert 'IPC=0' in r.stdout, (r.stdout, r.stderr[-500:])
     r = subprocess.run([sys.executable, '-c', probe], capture_output=True, text=True, timeout=120, env=_env(HSA_ENABLE_IPC_MODE_LEGACY='1'), cwd=ROOT)
     assert 'IPC=1' in r.stdout
+
+
+def test_input_allocation_forms_give_the_same_losses_and_say_which_one_ran():
+    """The input arrays are row ranges of ONE allocation by default (separately allocated read streams collide on
+    some draws of their physical placement); `--separate-inputs` restores one torch allocation per array.  Same values, same
+    gradients path; the result line names the form."""
+    lines = []
+    for extra in ([], ['--separate-inputs']):
+        r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--pairs', '20000'] + COMMON + extra, capture_output=True, text=True,
+                           timeout=300, env=_env(), cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = _result_lines(r.stdout)
+        assert len(got) == 1
+        lines.append(got[0])
+    a, b = lines
+    assert 'row ranges of one allocation' in a['config']['input_allocation']
+    assert b['config']['input_allocation'] == 'one torch allocation per array'
+    assert a['loss_values'] == b['loss_values']
