@@ -496,8 +496,8 @@ int rnms_batched_scored_sets(int32_t mode, const float* boxes, const float* scor
 
 /* The same for G problems that each own a CONTIGUOUS run of one flat box / score array (the per-sample x per-task NMS
  * calls of CenterHeadRev.get_bboxes, gd_centerpoint_head.py:233-345, concatenated): group g = boxes [seg[g], seg[g+1]).
- * Every group ranks only its own slice — O(sum n_g^2) key compares and O(G * n_max^2 / 256) workspace, where the dense
- * (G, N) form above would compare every key in every group.
+ * Every group ranks only its own slice — O(sum n_g^2) key compares, where the dense (G, N) form above would compare every
+ * key in every group.
  *   scores (N_total) fp32;  seg (groups+1) int32 on the DEVICE, ascending;  max_seg >= every group size (host value:
  *   the caller knows the sizes from its tensor shapes), <= rnms_scored_max_n();  cap = min(max_seg, pre_max).
  *   keep (groups, cap) int64 GLOBAL indices into `boxes`; num_keep (groups) int64.

@@ -464,7 +464,7 @@ int anchor_targets_build(const anchor_targets_desc* desc, const float* anchors, 
   const size_t lds2 = lds1 + (size_t)tile_cells * SR * 36;
   if (lds2 > 64 * 1024) return GD3D_E_TOOLARGE;
   // cleared by a kernel, not by hipMemsetAsync: inside a captured hipGraph a memset node was found not to be reliably ordered
-  // against the kernels around it on this ROCm (round 4, csrc/rbox.hip rank_count_kernel), and this call is replayed in graphs
+  // against the kernels around it on this ROCm (round 4, csrc/rbox.hip rank_place_kernel), and this call is replayed in graphs
   {
     const size_t w4 = anchor_targets_workspace_bytes(K, g_total) / 4, c4 = (size_t)2 * d.batch;
     const size_t most = w4 > c4 ? w4 : c4;

@@ -2,8 +2,8 @@
 // (include/gd3d.h).  Geometry: rbox_device.h.  Compiled with -ffp-contract=off (see build.py).
 //
 // NMS (replaces mmdet3d iou3d_cuda.nms_gpu, whose mask goes D->H and is scanned on the host):
-//   0. (nms_gpu path, <= 16384 candidates) rank_count_kernel + rank_scatter_kernel: the score order by counting larger
-//      (score, -index) keys over the whole chip — no sort — with the per-box prep scattered straight to its rank.
+//   0. (nms_gpu path, <= 16384 candidates) rank_place_kernel: the score order by counting larger (score, -index) keys — no
+//      sort — with the per-box prep scattered straight to its rank, one launch.
 //   1. obox_prep_kernel (pre-sorted / caller-ordered paths): one thread per box: sin/cos + rotated corners once ->
 //      64-byte OBox records.
 //   2. nms_mask_compact_kernel (rotated) / nms_mask_kernel (axis-aligned, circle): one wave per (8..64 row boxes,
@@ -75,12 +75,8 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
 // yields.  Every box gets one UNIQUE 64-bit key — (order-preserving map of the float) << 32 | ~index — so its position
 // in the order is simply the number of larger keys.  That count is embarrassingly parallel (a single-workgroup bitonic
 // sort of 4096 keys is LDS-bandwidth-bound at ~50 us; rocPRIM's radix sort behind torch.sort takes 16-24 us + launches):
-//   rank_count_kernel   grid (ceil(n/64), P): 64 boxes (lanes) x one 1/P slice of all keys, a quarter of the slice per
-//                       wave; partial counts go to prank[slice][box] — no atomics, deterministic;
-//   rank_scatter_kernel thread i sums its P partial counts = its rank r; if r < n_keep: order[r] = i and, for rotated
-//                       NMS, the OBox record of box i is written to slot r (this IS the prep kernel, scattered).
+// rank_place_kernel below.
 constexpr int RANK_MAX = 16384;
-constexpr int RANK_SLICE = 256;   // keys per slice (64 per wave: one register chunk)
 
 __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
   unsigned u = __float_as_uint(s);
@@ -92,39 +88,52 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
 }
 
-// blockIdx.z = group (batched form): scores / valid are (G, n) rows, prank is (G, slices, n).  A box that is not `valid`
-// in its group (nullable mask) gets key 0: it is below every real key and is never scattered.
-// Segmented form (seg != nullptr, (G+1) int32 on the device): group g owns the boxes [seg[g], seg[g+1]) of ONE flat score
-// array and ranks only those — O(sum n_g^2) compares and O(G * slices * n_max) workspace instead of the dense (G, G n)
-// matrices; `n` is then the LARGEST group size (grid extent, prank stride), indices inside a group are local.
-__global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict__ scores_, const unsigned char* __restrict__ valid_,
-                                                        const int* __restrict__ seg, int n, int* __restrict__ prank_,
-                                                        int* __restrict__ zero_counts) {
-  __shared__ int spart[4][64];
+// rank_place_kernel: a 16-wave workgroup owns 64 boxes (lanes) of a group and ALL of the group's keys — wave w counts, for the
+// workgroup's 64 boxes, the keys of the w-th sixteenth that are greater: lane l builds key jb + l in registers, the 64 of them are
+// broadcast by v_readlane (a loop over an LDS copy paid one dependent LDS round trip per key); the sixteen partial ranks meet in
+// LDS and wave 0 places its boxes right away: order[r] = i and, for rotated NMS, the OBox record of box i in slot r (this IS the
+// prep kernel, scattered).  No atomics, deterministic.  (Rounds 2-3 ran it as two launches — partial counts per 256-key slice in
+// HBM, then a scatter kernel: n = 1000 4.0 + 3.6 us -> 5.8-7.0 us as one; equal from 4096 boxes on, where 64 workgroups of 16
+// waves keep only a quarter of the CUs busy.)
+// counts[g] (nullable) = min(#valid boxes of the group, n_keep): every workgroup sees all of the group's valid flags while it
+// counts, so workgroup 0 WRITES the number — nothing is cleared and then added to (the round-3 form cleared counts with a memset
+// that a captured hipGraph did not order reliably: profiles/r04_nms_queue_ab.txt).
+// blockIdx.y = group.  Dense form: scores / valid are (G, n) rows; a box that is not `valid` in its group (nullable mask) gets
+// key 0: below every real key, never placed.  Segmented form (seg != nullptr, (G+1) int32 on the device): group g owns the boxes
+// [seg[g], seg[g+1]) of ONE flat score array and ranks only those — O(sum n_g^2) compares instead of the dense (G, G n) matrices;
+// `n` is then the LARGEST group size (grid extent), indices inside a group are local.  gps > 0: every gps consecutive groups share
+// one set of n boxes, set k at rows [k n, (k + 1) n) of the flat box array.
+template <bool PREP>
+__global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restrict__ boxes, const float* __restrict__ scores_,
+                                                          const unsigned char* __restrict__ valid_, const int* __restrict__ seg,
+                                                          int n, int n_keep, long long* __restrict__ order_,
+                                                          OBox* __restrict__ ob_, int* __restrict__ counts, int gps,
+                                                          unsigned* zero_words, int zero_n) {
+  __shared__ int spart[16][64];
+  __shared__ int svalid[16];
+  zero_control_words(zero_words, zero_n);
   const int tid = threadIdx.x, lane = tid & 63;
-  // counts[group] (rank_scatter_kernel adds to it) is cleared HERE, not by a hipMemsetAsync in front of the launches: inside a
-  // captured hipGraph the memset node was not reliably ordered against the kernels around it on this ROCm (round 4: replays of a
-  // graph holding rnms_batched_scored_sets returned counts of 0 or of twice the boxes, profiles/r04_nms_queue_ab.txt)
-  if (zero_counts != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) zero_counts[blockIdx.z] = 0;
-  const int part = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = quarter of the slice
-  const int base = seg != nullptr ? seg[blockIdx.z] : 0;
-  const int ng = seg != nullptr ? seg[blockIdx.z + 1] - base : n;
-  if ((int)blockIdx.x * 64 >= ng) return;                       // uniform: no box of this group in this lane block
-  const size_t grow = (size_t)blockIdx.z * n;
-  const float* scores = seg != nullptr ? scores_ + base : scores_ + grow;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y;
+  const int sbase = seg != nullptr ? seg[g] : 0;                       // first score / box of the group in the flat arrays
+  const int ng = seg != nullptr ? seg[g + 1] - sbase : n;
+  if (ng <= 0) {                                                       // uniform: an empty group places nothing
+    if (counts != nullptr && blockIdx.x == 0 && tid == 0) counts[g] = 0;
+    return;
+  }
+  if ((int)blockIdx.x * 64 >= ng) return;                              // uniform: no box of this group in this lane block
+  const size_t grow = (size_t)g * n;
+  const float* scores = seg != nullptr ? scores_ + sbase : scores_ + grow;
   const unsigned char* valid = (valid_ != nullptr && seg == nullptr) ? valid_ + grow : nullptr;
-  int* prank = prank_ + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * n;
-  const int j0 = blockIdx.y * RANK_SLICE, j1 = min(j0 + RANK_SLICE, ng);
   const int i = blockIdx.x * 64 + lane;
   const unsigned long long mine = i < ng ? score_key(scores[i], (unsigned)i) : ~0ull;
-  const int len = max(j1 - j0, 0), q = (len + 3) >> 2;
-  const int b = j0 + part * q, e = min(b + q, j1);
-  int cnt = 0;
-  // 64 keys at a time: lane l builds key b+l in registers, the 64 of them are broadcast by v_readlane (a loop over an LDS
-  // copy paid one dependent LDS round trip per key: 15 us per launch)
+  const int q = (((ng + 15) >> 4) + 63) & ~63;                         // keys per wave: a sixteenth, in whole chunks of 64
+  const int b = wave * q, e = min(b + q, ng);
+  int cnt = 0, nvalid = 0;
   for (int jb = b; jb < e; jb += 64) {
     const int j = jb + lane;
     const bool use = j < e && (valid == nullptr || valid[j] != 0);
+    nvalid += __popcll(__ballot(use));
     const unsigned long long kj = use ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
     const unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
 #pragma unroll
@@ -134,47 +143,32 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
       cnt += kk > mine ? 1 : 0;
     }
   }
-  spart[part][lane] = cnt;
+  spart[wave][lane] = cnt;
+  if (lane == 0) svalid[wave] = nvalid;
   __syncthreads();
-  if (tid < 64 && i < ng) prank[i] = (spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]);
-}
-
-// counts (nullable, zeroed by the caller): counts[group] += boxes placed, i.e. min(#valid, n_keep) — integer atomics.
-// Segmented form: thread i is box seg[g] + i of the flat arrays; `order` receives that GLOBAL index.
-template <bool PREP>
-__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ valid_,
-                                                          const int* __restrict__ seg, const int* __restrict__ prank_, int n,
-                                                          int slices, int n_keep, long long* __restrict__ order_,
-                                                          OBox* __restrict__ ob_, int* __restrict__ counts, int gps,
-                                                          unsigned* zero_words, int zero_n) {
-  zero_control_words(zero_words, zero_n);
-  const int g = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  // gps > 0: every gps consecutive groups share one set of n boxes, set k at rows [k n, (k + 1) n) of the flat box array
-  const int base = seg != nullptr ? seg[g] : (gps > 0 ? (g / gps) * n : 0);
-  const int ng = seg != nullptr ? seg[g + 1] - base : n;
-  const int* prank = prank_ + (size_t)g * slices * n;
-  bool placed = false;
-  if (i < ng && (valid_ == nullptr || seg != nullptr || valid_[(size_t)g * n + i] != 0)) {
-    int r = 0;
-    const int used = (ng + RANK_SLICE - 1) / RANK_SLICE;         // slices beyond the group's own keys were never written
-    for (int s2 = 0; s2 < used; ++s2) r += prank[(size_t)s2 * n + i];
-    if (r < n_keep) {
-      placed = true;
-      order_[(size_t)g * n_keep + r] = (long long)(base + i);
-      if (PREP) {
-        float b[5];
+  if (wave != 0) return;
+  if (counts != nullptr && blockIdx.x == 0 && lane == 0) {
+    int total = 0;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) b[q] = boxes[(size_t)(base + i) * 5 + q];
+    for (int w = 0; w < 16; ++w) total += svalid[w];
+    counts[g] = min(total, n_keep);
+  }
+  if (i < ng && (valid == nullptr || valid[i] != 0)) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) r += spart[w][lane];
+    if (r < n_keep) {
+      const int bbase = seg != nullptr ? sbase : (gps > 0 ? (g / gps) * n : 0);
+      order_[(size_t)g * n_keep + r] = (long long)(bbase + i);
+      if (PREP) {
+        float bx[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) bx[k] = boxes[(size_t)(bbase + i) * 5 + k];
         OBox o;
-        obox_make(b, o);
+        obox_make(bx, o);
         ob_[(size_t)g * n_keep + r] = o;
       }
     }
-  }
-  if (counts != nullptr) {
-    const int c = __popcll(__ballot(placed));
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicAdd(&counts[g], c);
   }
 }
 
@@ -1120,7 +1114,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     q.ovl = (unsigned*)((char*)workspace + W.ovl);
     q.scap = W.scap;
     q.npairs = W.npairs;
-    // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_scatter_kernel:
+    // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_place_kernel:
     // `ctl_zeroed`); only a caller that prepared the records itself pays a fill in the stream (4.4 us in the trace)
     const int zero_n = (int)CTL_WORDS;   // per group
     if (!prepped)
@@ -1226,13 +1220,10 @@ int rnms_bev(const float* boxes_sorted, int64_t n, float thresh, int64_t* keep, 
 
 int rnms_scored_max_n(void) { return RANK_MAX; }
 
-static int64_t rank_slices(int64_t n_all) { return (n_all + RANK_SLICE - 1) / RANK_SLICE; }
-
 size_t rnms_scored_workspace_bytes(int64_t n_all, int64_t n_keep) {
   if (n_all < 1) n_all = 1;
   if (n_keep < 1) n_keep = 1;
-  return align_up(rnms_workspace_bytes(n_keep), 256) + align_up((size_t)n_keep * sizeof(int64_t), 256) +
-         (size_t)rank_slices(n_all) * (size_t)n_all * sizeof(int);
+  return align_up(rnms_workspace_bytes(n_keep), 256) + align_up((size_t)n_keep * sizeof(int64_t), 256);   // NMS workspace | order
 }
 
 int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t n_all, int64_t pre_max, float thresh,
@@ -1244,18 +1235,14 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   if (n == 0) return fill_words(num_keep, sizeof(int64_t), 0u, s);
   if (boxes == nullptr || scores == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
   long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
-  int* prank = (int*)((char*)order + align_up((size_t)n * sizeof(int64_t), 256));
-  const int slices = (int)rank_slices(n_all);
-  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n_all + 63) / 64), (unsigned)slices), dim3(256), 0, s, scores,
-                     (const unsigned char*)nullptr, (const int*)nullptr, (int)n_all, prank, (int*)nullptr);
-  const dim3 sg((unsigned)((n_all + 255) / 256));
+  const dim3 sg((unsigned)((n_all + 63) / 64));   // one 16-wave workgroup per 64 boxes: counts their ranks and places them
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout(1, (size_t)n).qctl);   // control words of the queued mask form
   if (normal)
-    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, (unsigned*)nullptr, 0);
+    hipLaunchKernelGGL((rank_place_kernel<false>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)nullptr,
+                       (const int*)nullptr, (int)n_all, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, (unsigned*)nullptr, 0);
   else
-    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)nullptr, (const int*)nullptr,
-                       (const int*)prank, (int)n_all, slices, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, qctl, (int)CTL_WORDS);
+    hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)nullptr,
+                       (const int*)nullptr, (int)n_all, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, qctl, (int)CTL_WORDS);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
@@ -1267,7 +1254,7 @@ size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t ca
   if (n < 1) n = 1;
   if (cap < 1) cap = 1;
   return align_up(rnms_batched_workspace_bytes(groups, cap), 256) + align_up((size_t)groups * cap * sizeof(int64_t), 256) +
-         align_up((size_t)groups * sizeof(int), 256) + (size_t)groups * rank_slices(n) * (size_t)n * sizeof(int);
+         align_up((size_t)groups * sizeof(int), 256);   // NMS workspace | order | counts
 }
 
 static int batched_scored_impl(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, const int32_t* seg,
@@ -1285,20 +1272,15 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   long long* order = (long long*)p;
   p += align_up((size_t)groups * cap * sizeof(int64_t), 256);
   int* counts = (int*)p;
-  p += align_up((size_t)groups * sizeof(int), 256);
-  int* prank = (int*)p;
-  const int slices = (int)rank_slices(n);
   hipError_t e;
-  hipLaunchKernelGGL(rank_count_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)slices, (unsigned)groups), dim3(256), 0, s, scores,
-                     (const unsigned char*)valid, (const int*)seg, (int)n, prank, counts);
-  const dim3 sg((unsigned)((n + 255) / 256), (unsigned)groups);
+  const dim3 sg((unsigned)((n + 63) / 64), (unsigned)groups);
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout((size_t)groups, (size_t)cap).qctl);
   if (mode == MODE_ROT)
-    hipLaunchKernelGGL((rank_scatter_kernel<true>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps, qctl, (int)CTL_WORDS);
+    hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
+                       (int)n, (int)cap, order, (OBox*)workspace, counts, gps, qctl, (int)CTL_WORDS);
   else
-    hipLaunchKernelGGL((rank_scatter_kernel<false>), sg, dim3(256), 0, s, boxes, (const unsigned char*)valid, (const int*)seg,
-                       (const int*)prank, (int)n, slices, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)nullptr, 0);
+    hipLaunchKernelGGL((rank_place_kernel<false>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
+                       (int)n, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)nullptr, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
