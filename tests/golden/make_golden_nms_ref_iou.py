@@ -42,7 +42,9 @@ SETS = [('waymo0', lambda: nms_boxes(4096, seed=200), 0.25, 4096, 500),     # BA
         ('nuscenes', lambda: nms_boxes(1000, seed=77, extent=51.2), 0.2, 1000, 83),    # centerpoint nus test_cfg: pre 1000, post 83, thr 0.2
         ('pvrcnn', lambda: nms_boxes(1500, seed=310, extent=40.0), 0.7, 1024, 100),   # PV-RCNN rpn test_cfg shape: nms_pre 1024, nms_post 100, thr 0.7
         ('rpn9000', lambda: nms_boxes(9000, seed=311, extent=70.4), 0.8, 9000, 512),  # PV-RCNN rpn train_cfg shape: 9000 / 512 / 0.8
-        ('origin', lambda: origin_boxes(256, 5), 0.5, 256, 256)]
+        ('origin', lambda: origin_boxes(256, 5), 0.5, 256, 256),
+        # PointPillars KITTI test_cfg (configs/_base_/models/hv_pointpillars_secfpn_kitti.py:92-96): thr 0.01 — boxes that barely touch
+        ('kitti', lambda: nms_boxes(4096, seed=400, extent=40.0), 0.01, 4096, 100)]
 
 
 def sparse_ref_iou(ev, sorted_boxes, chunk=256):

@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'nms_ref_iou.npz')
-SETS = ('waymo0', 'waymo1', 'waymo2', 'nuscenes', 'pvrcnn', 'rpn9000', 'origin')
+SETS = ('waymo0', 'waymo1', 'waymo2', 'nuscenes', 'pvrcnn', 'rpn9000', 'origin', 'kitti')
 BAND = 1e-4   # |iou_ref - thr| below which a decision is treated as undecidable between two fp32 evaluations
 
 

@@ -43,7 +43,7 @@ def test_twins_equal_the_oracle_restatement_bit_for_bit():
     assert np.array_equal(got.numpy(), oracle.nms_gpu_oracle(b, s, 0.3, normal=True))
 
 
-@pytest.mark.parametrize('name', ['waymo0', 'waymo2', 'nuscenes', 'pvrcnn', 'origin'])
+@pytest.mark.parametrize('name', ['waymo0', 'waymo2', 'nuscenes', 'pvrcnn', 'origin', 'kitti'])
 def test_nms_on_cpu_tensors_against_the_reference_derived_keep_lists(name):
     from test_nms_ref_iou import MAX_UNCERTAIN
     g = nms_ref.load(name)
