@@ -47,6 +47,9 @@ The JSON line also carries
                  every reference caller does: mmcv's OptimizerHook calls loss.backward()), timed over a second, shorter region
                  right after the main one (N = 1, eager).  The headline step hands the library's unit gradient to
                  torch.autograd.backward instead, which saves a ones-fill and three early-exit launches (~10 us per step).
+  value_separate_inputs : the headline step again on inputs that are one torch allocation EACH (third region, N = 1, eager). The
+                 main region's four input arrays are row ranges of ONE allocation: two read streams from separate allocations
+                 collide in the memory system on some draws of their physical placement (5-8 % of the kernel time).
   roofline     : HBM roofline of the dominant kernel (the fused fwd+grad kernel): algorithmic bytes
                  (88 B/pair) / average launch duration measured with a HIP event pair bound to
                  every fused dispatch, on the stream it is launched on.  `frac` is that kernel alone;
@@ -459,6 +462,7 @@ def main():
             view.copy_(pred0)
             preds[lt] = view.detach().requires_grad_(True)
     del pred0
+    cur = {'tgt': tgt}   # the arrays the step reads (the third region swaps in separately allocated copies)
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
                                     reduction='mean', loss_weight=5.0)) for lt in LOSSES}
     events = {lt: [] for lt in LOSSES}
@@ -475,7 +479,7 @@ def main():
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if (record and on_gpu) else None
             preds[lt].grad = None
-            losses_.append(mods[lt](preds[lt], tgt))
+            losses_.append(mods[lt](preds[lt], cur['tgt']))
         gdl.PROFILE_EVENTS = None
         if args.sum_backward or plain:
             (losses_[0] + losses_[1] + losses_[2]).backward()
@@ -634,6 +638,31 @@ def main():
             last['pending'].result()
         plain_elapsed = max_over_ranks(time.perf_counter() - tp)
 
+    # Third region (N = 1, eager, GPU): the same unit-gradient step on inputs that are one torch allocation EACH — the form of
+    # rounds 1-3 and of a caller who does not carve its arrays from one allocation.  Its value moves with the physical placement
+    # the process draws (70-74 G pairs/s); reported beside `value`, never as it.
+    sep_elapsed = None
+    if graph is None and not use_dist and on_gpu and plain_steps > 0 and not args.separate_inputs and not args.sum_backward:
+        held = (cur['tgt'], dict(preds))
+        cur['tgt'] = held[0].clone()
+        for lt in LOSSES:
+            preds[lt].grad = None
+            preds[lt] = held[1][lt].detach().clone().requires_grad_(True)
+        for _ in range(5):
+            step(False)
+        sync_all()
+        tp = time.perf_counter()
+        for _ in range(plain_steps):
+            step(False)
+        device_sync()
+        sep_elapsed = time.perf_counter() - tp
+        for lt in LOSSES:     # back to the arrays of the main region (the copy probe below runs on them)
+            preds[lt].grad = None
+            preds[lt] = held[1][lt]
+        cur['tgt'] = held[0]
+        step(False)
+        device_sync()
+
     if use_dist:
         total, per_rank = last['pending'].result()   # (3,), (world, 3)
         vals = (total / world).tolist()               # mean over ranks of per-rank means (equal shard sizes)
@@ -651,7 +680,7 @@ def main():
         lib = amd.load_library()
         stream = torch.cuda.current_stream().cuda_stream
         for lt in LOSSES:
-            x, y, z = preds[lt].detach(), tgt, preds[lt].grad
+            x, y, z = preds[lt].detach(), cur['tgt'], preds[lt].grad
             if z is None:
                 continue
             tms = []
@@ -698,6 +727,9 @@ def main():
             'value_plain_backward': round(job_value(args.pairs, world, args.strong, plain_steps, plain_elapsed), 2) if plain_elapsed else None,
             'ms_per_step_plain_backward': round(plain_elapsed / plain_steps * 1e3, 4) if plain_elapsed else None,
             'plain_backward_steps': plain_steps if plain_elapsed else 0,
+            # the unit-gradient step again on inputs that are one torch allocation each (third region, N = 1): placement lottery
+            'value_separate_inputs': round(job_value(args.pairs, world, args.strong, plain_steps, sep_elapsed), 2) if sep_elapsed else None,
+            'ms_per_step_separate_inputs': round(sep_elapsed / plain_steps * 1e3, 4) if sep_elapsed else None,
             'config': {'workload': (f'{args.pairs} synthetic anchor x gt 7-dof box pairs in total, row ranges of {n} per GPU '
                                     if args.strong else
                                     f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
