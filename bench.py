@@ -561,6 +561,9 @@ def main():
         step(sampled())
     if rank == fail_rank:
         os._exit(3)
+    import gc
+    gc.collect()
+    gc.disable()   # a generation-2 collection inside a 8 ms region is a millisecond of host stall with the queue still shallow
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
@@ -573,6 +576,7 @@ def main():
     if use_dist and not on_gpu:
         last['pending'].result()                # gloo: the last step's gather is part of the step
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     def max_over_ranks(seconds):
         if not use_dist:
