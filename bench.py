@@ -549,21 +549,31 @@ def main():
         tick[0] += 1
         return every > 0 and tick[0] % every == 0
 
+    prewarm_blocks = []
     if args.prewarm > 0:
+        # at least `--prewarm` seconds; on the GPU then on until two consecutive 20-step blocks agree to 1.5 % (at most 5 x as
+        # long): insurance against a box that is still ramping.  (Tried and dropped: gc.collect() + gc.disable() around the timed
+        # region, against a host stall with the queue still shallow — the timed steps then ran 10-15 % SLOWER, 139-150 us per fused
+        # kernel instead of 130: the collection reshuffles which 280 MB blocks the gradient allocations draw.)
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.prewarm:
+        while True:
+            tb = time.perf_counter()
             for _ in range(20 if on_gpu else 1):
                 step(sampled())
             device_sync()
+            prewarm_blocks.append(time.perf_counter() - tb)
             for lt in LOSSES:
                 events[lt].clear()
+            spent = time.perf_counter() - t_pre
+            if spent < args.prewarm:
+                continue
+            settled = len(prewarm_blocks) >= 2 and abs(prewarm_blocks[-1] - prewarm_blocks[-2]) <= 0.015 * prewarm_blocks[-2]
+            if not on_gpu or settled or spent >= 5.0 * args.prewarm:
+                break
     for _ in range(args.warmup):
         step(sampled())
     if rank == fail_rank:
         os._exit(3)
-    import gc
-    gc.collect()
-    gc.disable()   # a generation-2 collection inside a 8 ms region is a millisecond of host stall with the queue still shallow
     sync_all()
     for lt in LOSSES:
         events[lt].clear()
@@ -576,7 +586,6 @@ def main():
     if use_dist and not on_gpu:
         last['pending'].result()                # gloo: the last step's gather is part of the step
     elapsed = time.perf_counter() - t0
-    gc.enable()
 
     def max_over_ranks(seconds):
         if not use_dist:
@@ -743,6 +752,7 @@ def main():
                                    + '; fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
+                       'prewarm_s': round(sum(prewarm_blocks), 2),
                        'input_allocation': 'one torch allocation per array' if args.separate_inputs else
                                            'target and the three prediction leaves are row ranges of one allocation',
                        'device': 'MI355X (HIP kernels)' if on_gpu else f'cpu (rehearsal: GDLoss _cpu twins, {torch.get_num_threads()} threads per rank; not the metric)',
