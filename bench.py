@@ -552,9 +552,10 @@ def main():
     prewarm_blocks = []
     if args.prewarm > 0:
         # at least `--prewarm` seconds; on the GPU then on until two consecutive 20-step blocks agree to 1.5 % (at most 5 x as
-        # long): insurance against a box that is still ramping.  (Tried and dropped: gc.collect() + gc.disable() around the timed
-        # region, against a host stall with the queue still shallow — the timed steps then ran 10-15 % SLOWER, 139-150 us per fused
-        # kernel instead of 130: the collection reshuffles which 280 MB blocks the gradient allocations draw.)
+        # long): insurance against a box that is still ramping.  Nothing slow may sit between the warm-up steps and the timed ones:
+        # a gc.collect() placed there (tried, against host stalls inside the region) leaves the GPU idle for ~0.1 s, its clocks drop,
+        # and the 20 timed steps that follow run 10-15 % slow (fused kernels 139-150 us instead of 130; same memory, same three
+        # gradient blocks: profiles/r04_bench_three_boxes.txt).
         t_pre = time.perf_counter()
         while True:
             tb = time.perf_counter()
