@@ -90,7 +90,8 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
 
 // rank_place_kernel: a 16-wave workgroup owns 64 boxes (lanes) of a group and ALL of the group's keys — wave w counts, for the
 // workgroup's 64 boxes, the keys of the w-th sixteenth that are greater: lane l builds key jb + l in registers, the 64 of them are
-// broadcast by v_readlane (a loop over an LDS copy paid one dependent LDS round trip per key); the sixteen partial ranks meet in
+// broadcast by v_readlane (a loop over an LDS copy paid one dependent LDS round trip per key; rotating the keys through the lanes
+// with v_mov_b32_dpp wave_ror:1 instead: 15.1 vs 13.2 us at n = 4096, 29.4 vs 25.8 at 9000 — slower); the sixteen partial ranks meet in
 // LDS and wave 0 places its boxes right away: order[r] = i and, for rotated NMS, the OBox record of box i in slot r (this IS the
 // prep kernel, scattered).  No atomics, deterministic.  (Rounds 2-3 ran it as two launches — partial counts per 256-key slice in
 // HBM, then a scatter kernel: n = 1000 4.0 + 3.6 us -> 5.8-7.0 us as one; equal from 4096 boxes on, where 64 workgroups of 16
