@@ -566,10 +566,16 @@ def main():
             for lt in LOSSES:
                 events[lt].clear()
             spent = time.perf_counter() - t_pre
-            if spent < args.prewarm:
-                continue
             settled = len(prewarm_blocks) >= 2 and abs(prewarm_blocks[-1] - prewarm_blocks[-2]) <= 0.015 * prewarm_blocks[-2]
-            if not on_gpu or settled or spent >= 5.0 * args.prewarm:
+            more = spent < args.prewarm or (on_gpu and not settled and spent < 5.0 * args.prewarm)
+            if use_dist:
+                # every step carries a collective: all ranks must leave the loop after the SAME number of blocks (a clock- or
+                # settle-based decision taken per rank would leave the ranks with different collective counts and the job hanging
+                # in its last gather) — go on while ANY rank wants more
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = bool(flag.item())
+            if not more:
                 break
     for _ in range(args.warmup):
         step(sampled())

@@ -142,3 +142,15 @@ def test_input_allocation_forms_give_the_same_losses_and_say_which_one_ran():
     assert 'row ranges of one allocation' in a['config']['input_allocation']
     assert b['config']['input_allocation'] == 'one torch allocation per array'
     assert a['loss_values'] == b['loss_values']
+
+
+def test_prewarm_with_collectives_leaves_every_rank_with_the_same_step_count():
+    """The pre-warm loop runs for a wall-clock time (and, on the GPU, until step times settle) and every step carries a
+    collective: the decision to stop must be taken by all ranks together, or the ranks end up with different collective counts
+    and the job hangs in its last gather (latent through round 3: the rehearsals ran with --prewarm 0, the driver does not)."""
+    args = [a for a in COMMON]
+    args[args.index('--prewarm') + 1] = '0.4'
+    r = _torchrun(3, args + ['--pairs', '30000'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = _result_lines(r.stdout)
+    assert len(got) == 1 and got[0]['n_gpus'] == 3 and got[0]['config']['prewarm_s'] >= 0.4
