@@ -24,10 +24,11 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SAL
   --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1
 python3 tools/build_probes.py > /dev/null; [ -x tools/hbm_probe ] && ./tools/hbm_probe > $OUT/${R}_hbm_probe.txt 2>&1
 # multi-GPU rehearsal with ONE rank under torch.distributed.run (RCCL backend, hipGraph replay + per-step all_gather): the
-# N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling, and the eager form
+# N > 1 code path of bench.py as far as one GPU can exercise it; weak and strong scaling (--graph: one rank alone would launch
+# eagerly, N > 1 ranks replay a graph), and the eager form
 RUN1="python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
-$RUN1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
-$RUN1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
+$RUN1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph > $OUT/${R}_rccl_rehearsal_weak.json 2> $OUT/rehearsal_weak.err
+$RUN1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
 $RUN1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-graph > $OUT/${R}_rccl_rehearsal_weak_eager.json 2> $OUT/rehearsal_weak_eager.err
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
