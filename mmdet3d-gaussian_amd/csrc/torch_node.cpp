@@ -56,7 +56,7 @@ void resolve(void* image, const char* name, F& slot) {
 }
 
 int bind(const std::string& path) {
-  void* image = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+  void* image = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);   // the image ctypes already mapped: same handle, nothing promoted
   TORCH_CHECK(image != nullptr, "gd3d node: cannot open ", path, ": ", dlerror());
   resolve(image, "gd3d_loss_fused_decoded", abi.loss_fused_decoded);
   resolve(image, "gd3d_loss_fused_timed", abi.loss_fused_timed);
@@ -285,8 +285,8 @@ std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tens
 }
 
 void set_unit_grad(int64_t device_index, int64_t address) {
-  const int slot = device_index < 0 ? MAX_DEVICES : (int)device_index;
-  TORCH_CHECK(slot <= MAX_DEVICES, "gd3d node: device index ", device_index);
+  TORCH_CHECK(device_index < MAX_DEVICES, "gd3d node: device index ", device_index);
+  const int slot = device_index < 0 ? MAX_DEVICES : (int)device_index;   // < 0: the CPU's constant
   g_unit_grad[slot] = (const void*)address;
 }
 
