@@ -1,4 +1,5 @@
-// torch_node.cpp — the autograd node of GDLoss's reduced forms (reduction 'mean' / 'sum'), in C++.
+// torch_node.cpp — host glue above the C ABI, in C++: the autograd node of GDLoss's reduced forms (reduction 'mean' / 'sum'), and
+// the allocate-launch-read-back sequence of nms_gpu's scored path (nms_scored, at the end).
 //
 // Why this exists.  A training-size GDLoss call (64-4096 positives, gd_anchor3d_head.py:137-141) is one 6 us launch; as a
 // Python torch.autograd.Function it cost 15 us in forward and 35-60 us per call under backward(), of which 3.8 / 23-41 us
@@ -46,6 +47,8 @@ struct Abi {
   decltype(&::gd3d_loss_fused_cpu) loss_fused_cpu = nullptr;
   decltype(&::gd3d_scale_rows_cpu) scale_rows_cpu = nullptr;
   decltype(&::gd3d_abi_version) abi_version = nullptr;
+  decltype(&::rnms_scored) nms_scored = nullptr;
+  decltype(&::rnms_scored_workspace_bytes) nms_scored_workspace_bytes = nullptr;
   bool bound = false;
 } abi;
 
@@ -66,6 +69,8 @@ int bind(const std::string& path) {
   resolve(image, "gd3d_loss_fused_cpu", abi.loss_fused_cpu);
   resolve(image, "gd3d_scale_rows_cpu", abi.scale_rows_cpu);
   resolve(image, "gd3d_abi_version", abi.abi_version);
+  resolve(image, "rnms_scored", abi.nms_scored);
+  resolve(image, "rnms_scored_workspace_bytes", abi.nms_scored_workspace_bytes);
   const int version = abi.abi_version(nullptr);
   TORCH_CHECK(version == GD3D_ABI_VERSION, "gd3d node: built against ABI ", GD3D_ABI_VERSION, ", the library reports ", version);
   abi.bound = true;
@@ -284,6 +289,32 @@ std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tens
   return {total, flag_out};
 }
 
+// nms_gpu's scored path (mmdet3d-gaussian_amd/iou3d.py: <= rnms_scored_max_n() candidates, fp32 scores): the three allocations, the
+// launch and — unless `padded` — the one read-back of the count and the cut to it, without the Python in between (a third of
+// nms_gpu's end-to-end time at inference sizes was host code).  boxes (N,5) / scores (N) contiguous fp32 on one GPU.
+// Returns (keep, num): padded: keep (n_keep) int64 whose first num[0] entries are valid, num (1) int64 on the device;
+// otherwise keep is already cut to the count (and to post_max when >= 0) and num is undefined.
+std::tuple<Tensor, Tensor> nms_scored(const Tensor& boxes, const Tensor& scores, double thresh, int64_t n_keep, bool normal,
+                                      bool padded, int64_t post_max) {
+  TORCH_CHECK(abi.bound, "gd3d node: bind(path of libgd3d.so) has not been called");
+  TORCH_CHECK(boxes.is_cuda() && boxes.dim() == 2 && boxes.size(1) == 5 && boxes.scalar_type() == at::kFloat && boxes.is_contiguous() &&
+                  scores.dim() == 1 && scores.size(0) == boxes.size(0) && scores.scalar_type() == at::kFloat &&
+                  scores.is_contiguous() && scores.device() == boxes.device() && n_keep > 0 && n_keep <= boxes.size(0),
+              "gd3d node: nms_scored takes contiguous fp32 (N,5) boxes and (N) scores on one GPU and 0 < n_keep <= N");
+  const int64_t n_all = boxes.size(0);
+  c10::DeviceGuard device_guard(boxes.device());
+  const auto longs = boxes.options().dtype(at::kLong);
+  Tensor keep = at::empty({n_keep}, longs), num = at::empty({1}, longs);
+  Tensor ws = at::empty({(int64_t)abi.nms_scored_workspace_bytes(n_all, n_keep)}, boxes.options().dtype(at::kByte));
+  fail(abi.nms_scored(normal ? 1 : 0, boxes.data_ptr<float>(), scores.data_ptr<float>(), n_all, n_keep, (float)thresh,
+                      keep.data_ptr<int64_t>(), num.data_ptr<int64_t>(), ws.data_ptr(), current_stream(boxes)),
+       normal ? "nms_normal_gpu" : "nms_gpu");
+  if (padded) return {keep, num};
+  int64_t k = num.item<int64_t>();   // the one unavoidable sync: the result length is data dependent
+  if (post_max >= 0 && k > post_max) k = post_max;
+  return {keep.narrow(0, 0, k), Tensor()};
+}
+
 void set_unit_grad(int64_t device_index, int64_t address) {
   TORCH_CHECK(device_index < MAX_DEVICES, "gd3d node: device index ", device_index);
   const int slot = device_index < 0 ? MAX_DEVICES : (int)device_index;   // < 0: the CPU's constant
@@ -297,6 +328,8 @@ PYBIND11_MODULE(_gd3d_node, m) {
   m.def("reduced", &reduced, py::arg("pred"), py::arg("target"), py::arg("weight"), py::arg("params"), py::arg("prologue"),
         py::arg("aux"), py::arg("scale"), py::arg("select"), py::arg("ticket"), py::arg("ev_start"), py::arg("ev_stop"),
         py::arg("ws_floats"), py::arg("want_flag"));
+  m.def("nms_scored", &nms_scored, py::arg("boxes"), py::arg("scores"), py::arg("thresh"), py::arg("n_keep"), py::arg("normal"),
+        py::arg("padded"), py::arg("post_max"));
   m.def("set_unit_grad", &set_unit_grad);
   m.def("finish_calls", []() { return g_finish_calls.load(); }, "gd3d_grad_finish launches made by backward so far");
   m.def("bind", &bind, "resolve the C ABI from the loaded libgd3d.so; returns its ABI version");

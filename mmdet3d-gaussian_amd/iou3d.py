@@ -86,6 +86,15 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
     # scattered to the rank: no torch.sort); float64 scores keep torch.sort (their order may differ after rounding to fp32)
     fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
                                                                                      torch.bfloat16)
+    if fused_sort and scores.dtype == torch.float32 and scores.is_contiguous():
+        # the usual call: allocations, launch, count read-back and cut in the C++ glue (csrc/torch_node.cpp nms_scored)
+        post = int(post_max_size) if (post_max_size is not None and post_max_size >= 0 and not padded) else -1
+        keep, num = _lib.load_node().nms_scored(boxes, scores, float(thresh), n, bool(normal), bool(padded), post)
+        if padded:
+            if post_max_size is not None:
+                keep, num = keep[:post_max_size], num.clamp(max=max(int(post_max_size), 0))
+            return keep, num
+        return keep if (post_max_size is None or post_max_size >= 0) else keep[:post_max_size]   # a negative bound: Python slicing
     # raw device / stream accessors and a memoised workspace size: the call is a handful of launches (30-70 us of device time at
     # inference sizes) and the Python around it was a third of nms_gpu's end-to-end time
     prev = _get_device()
