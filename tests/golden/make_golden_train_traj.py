@@ -27,7 +27,11 @@ CASES = [('gwd3d_log1p_tau1', 'gwd3d', dict(fun='log1p', tau=1.0, loss_weight=5.
          ('kld3d_log1p_tau1', 'kld3d', dict(fun='log1p', tau=1.0, loss_weight=5.0), False),       # configs/kitti/*kld5tau1*
          ('bd3d_log1p_tau1', 'bd3d', dict(fun='log1p', tau=1.0, loss_weight=5.0), True),          # configs/kitti/*bd5tau1*, (N,7) weights + avg_factor
          ('gwd3d_none_tau0', 'gwd3d', dict(fun='none', tau=0.0, loss_weight=5.0), False),         # README row "GWD, tau=0, f(x)=x"
-         ('kfiou3d', 'kfiou3d', dict(fun='none', loss_weight=1.0), False)]
+         ('kfiou3d', 'kfiou3d', dict(fun='none', loss_weight=1.0), False),
+         ('jd3d_log1p_tau1', 'jd3d', dict(fun='log1p', tau=1.0, loss_weight=5.0), False),
+         ('kld3d_symmax_log1p', 'kld3d_symmax', dict(fun='log1p', tau=1.0, loss_weight=5.0), False),
+         ('kld3d_symmin_none', 'kld3d_symmin', dict(fun='none', tau=0.0, loss_weight=1.0), False),
+         ('kld3d_none_nosqrt', 'kld3d', dict(fun='none', tau=0.0, loss_weight=1.0, sqrt=False), False)]
 
 
 def start_and_target(seed):
