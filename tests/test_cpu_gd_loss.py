@@ -264,3 +264,24 @@ def test_c_abi_argument_validation_of_the_cpu_entries():
     assert lib.gd3d_scale_rows_cpu(vp(rows), vp(per), 1, n, 1) == 0 and np.all(rows[:, 0] == 2.0 * per)
     assert lib.gd3d_scale_rows_cpu(vp(rows), None, 0, n, 1) == 10001
     assert _lib.ABI_VERSION == 6
+
+
+def test_module_survives_deepcopy_pickle_and_torch_save(tmp_path):
+    """mmcv builds the loss from its config, but hooks deep-copy models (EMA) and users pickle them: the module — with its cached
+    gd3d_params structure populated by a call — must come back working and give the same value; like the reference's module it has
+    no parameters or buffers (empty state_dict)."""
+    import copy
+    import pickle
+    m = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0, sqrt=True)
+    g = torch.Generator().manual_seed(3)
+    t = torch.rand(16, 7, generator=g) + 0.5
+    p = t + 0.1 * torch.randn(16, 7, generator=g)
+    a = m(p, t)
+    assert torch.equal(copy.deepcopy(m)(p, t), a)
+    assert torch.equal(pickle.loads(pickle.dumps(m))(p, t), a)
+    holder = torch.nn.Sequential(torch.nn.Linear(7, 7))
+    holder.loss = m
+    path = str(tmp_path / 'm.pt')
+    torch.save(holder, path)
+    assert torch.equal(torch.load(path, weights_only=False).loss(p, t), a)
+    assert len(m.state_dict()) == 0
