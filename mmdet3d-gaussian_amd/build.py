@@ -68,6 +68,7 @@ def _deps():
     for root, _, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files if f != NODE_SOURCE]
     out.append(os.path.join(PKG_DIR, '..', 'include', 'gd3d.h'))
+    out.append(os.path.join(PKG_DIR, '..', 'include', 'gd3d_extras.h'))
     out.append(os.path.abspath(__file__))
     return out
 

@@ -24,7 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/gd3d.h"
+#include "../../include/gd3d_extras.h"
 
 namespace atgt {
 

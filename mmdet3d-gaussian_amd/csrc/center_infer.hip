@@ -33,7 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/gd3d.h"
+#include "../../include/gd3d_extras.h"
 #include "coder_device.h"
 #include "lds_sort.h"
 #include "rbox_device.h"

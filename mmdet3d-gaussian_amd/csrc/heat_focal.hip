@@ -19,7 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/gd3d.h"
+#include "../../include/gd3d_extras.h"
 
 namespace hfocal {
 

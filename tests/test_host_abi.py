@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
+    # gd3d.h: the hot path's boundary; gd3d_extras.h: the frozen extras (DESIGN_EXTRAS.md).  One library exports both.
+    txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read() + open(os.path.join(ROOT, 'include', 'gd3d_extras.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(?:int|size_t|int64_t|int32_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets|anchor_infer|anchor_targets)_\w+)\s*\(', txt)))
 
@@ -178,7 +179,7 @@ def test_center_infer_struct_layouts_match_the_header():
     """sizeof / offsetof of center_infer_task and center_infer_desc as gcc sees include/gd3d.h against the ctypes mirrors."""
     import subprocess
     import tempfile
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d_extras.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(center_infer_task), offsetof(center_infer_task, sample_stride), offsetof(center_infer_task, classes),'
            'offsetof(center_infer_task, nms_thresh), sizeof(center_infer_desc), offsetof(center_infer_desc, out_size_factor),'
            'offsetof(center_infer_desc, score_threshold), offsetof(center_infer_desc, limit_range), offsetof(center_infer_desc, tasks));return 0;}\n')
@@ -229,7 +230,7 @@ def test_center_infer_queries_and_argument_checks_without_gpu():
 def test_center_targets_struct_layout_and_argument_checks():
     import subprocess
     import tempfile
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d_extras.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(center_targets_desc), offsetof(center_targets_desc, classes), offsetof(center_targets_desc, sample_start),'
            'offsetof(center_targets_desc, pc_range), offsetof(center_targets_desc, out_size_factor),'
            'offsetof(center_targets_desc, gaussian_overlap));return 0;}\n')
@@ -273,7 +274,7 @@ def test_center_task_struct_layout_matches_header():
 def test_anchor_targets_struct_layout_and_argument_checks():
     import subprocess
     import tempfile
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "gd3d_extras.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(anchor_targets_desc), offsetof(anchor_targets_desc, num_dir_bins), offsetof(anchor_targets_desc, gt_start),'
            'offsetof(anchor_targets_desc, pos_iou_thr), offsetof(anchor_targets_desc, min_pos_iou),'
            'offsetof(anchor_targets_desc, dir_offset));return 0;}\n')
