@@ -48,6 +48,10 @@ struct Abi {
   decltype(&::gd3d_scale_rows_cpu) scale_rows_cpu = nullptr;
   decltype(&::gd3d_abi_version) abi_version = nullptr;
   decltype(&::rnms_scored) nms_scored = nullptr;
+  decltype(&::gd3d_anchor_head_bbox_loss) anchor_head = nullptr;
+  decltype(&::gd3d_anchor_head_bbox_loss_dyn) anchor_head_dyn = nullptr;
+  decltype(&::gd3d_scale_rows) scale_rows = nullptr;
+  decltype(&::gd3d_loss_workspace_bytes) loss_workspace_bytes = nullptr;
   decltype(&::rnms_scored_workspace_bytes) nms_scored_workspace_bytes = nullptr;
   bool bound = false;
 } abi;
@@ -70,6 +74,10 @@ int bind(const std::string& path) {
   resolve(image, "gd3d_scale_rows_cpu", abi.scale_rows_cpu);
   resolve(image, "gd3d_abi_version", abi.abi_version);
   resolve(image, "rnms_scored", abi.nms_scored);
+  resolve(image, "gd3d_anchor_head_bbox_loss", abi.anchor_head);
+  resolve(image, "gd3d_anchor_head_bbox_loss_dyn", abi.anchor_head_dyn);
+  resolve(image, "gd3d_scale_rows", abi.scale_rows);
+  resolve(image, "gd3d_loss_workspace_bytes", abi.loss_workspace_bytes);
   resolve(image, "rnms_scored_workspace_bytes", abi.nms_scored_workspace_bytes);
   const int version = abi.abi_version(nullptr);
   TORCH_CHECK(version == GD3D_ABI_VERSION, "gd3d node: built against ABI ", GD3D_ABI_VERSION, ", the library reports ", version);
@@ -289,6 +297,160 @@ std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tens
   return {total, flag_out};
 }
 
+// ---- the anchor-head regression slice (head_loss.py, SURVEY.md §8 f1: gd_anchor3d_head.py:95-161) as one node ---------------------
+// Selection / gather of the positives + decode x2 + loss(es) + the gradient scattered into the NCHW head output: ONE launch
+// (gd3d_anchor_head_bbox_loss[_dyn]); the zero-filled-then-scattered gradient waits in the node and backward hands it over
+// (scaled by the upstream gradient on the device unless that is the library's unit gradient).  A second backward under
+// retain_graph launches again.  Argument meaning as in head_loss._anchor_head_launch, which this replaces.
+struct AnchorHeadCall {
+  Tensor bbox_pred, bbox_targets, bbox_weights, anchors, sel, avg_dev;   // sel: (P,) positives or the (M,) label map (dense)
+  gd3d_params params;
+  gd3d_smooth_l1 sl1;
+  bool has_sl1 = false, has_dw = false, dense = false, dyn = false;
+  float dw[7];
+  int32_t num_classes = 0;
+  float scale = 0.0f;
+  double w_gd = 0.0, w_sl1 = 0.0;
+
+  // returns (loss scalar tensor, gradient | undefined)
+  std::pair<Tensor, Tensor> launch(bool need_grad) const {
+    const int64_t B = bbox_pred.size(0), C = bbox_pred.size(1), H = bbox_pred.size(2), W = bbox_pred.size(3);
+    const int64_t P = sel.numel();
+    c10::DeviceGuard device_guard(bbox_pred.device());
+    Tensor grad = need_grad ? at::zeros_like(bbox_pred) : Tensor();
+    Tensor buf = at::empty({4 + (int64_t)(abi.loss_workspace_bytes(P) / 4)}, bbox_pred.options());
+    float* base = buf.data_ptr<float>();
+    const gd3d_smooth_l1* sl = has_sl1 ? &sl1 : nullptr;
+    const float* wp = bbox_weights.defined() ? bbox_weights.data_ptr<float>() : nullptr;
+    const float* dwp = has_dw ? dw : nullptr;
+    void* stream = current_stream(bbox_pred);
+    int rc;
+    if (dyn)
+      rc = abi.anchor_head_dyn(&params, sl, fp(bbox_pred), (int32_t)B, (int32_t)(C / 7), (int32_t)H, (int32_t)W, fp(bbox_targets), wp, dwp,
+                               fp(anchors), sel.data_ptr<int64_t>(), num_classes, w_gd, w_sl1, fp(avg_dev), base, fp(grad), base + 4,
+                               stream);
+    else
+      rc = abi.anchor_head(&params, sl, fp(bbox_pred), (int32_t)B, (int32_t)(C / 7), (int32_t)H, (int32_t)W, fp(bbox_targets), wp, dwp,
+                           fp(anchors), dense ? nullptr : sel.data_ptr<int64_t>(), P, dense ? sel.data_ptr<int64_t>() : nullptr,
+                           num_classes, scale, base, fp(grad), base + 4, stream);
+    fail(rc, "gd3d_anchor_head_bbox_loss");
+    return {buf.select(0, 0), grad};
+  }
+};
+
+struct AnchorHeadBackward : public torch::autograd::Node {
+  AnchorHeadCall call_;
+  torch::autograd::SavedVariable pred_;
+  Tensor grad_;
+  bool used_ = false;
+
+  std::string name() const override { return "GDAnchorHeadBackward"; }
+  void release_variables() override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    pred_.reset_data();
+    grad_.reset();
+    call_ = AnchorHeadCall();
+  }
+  variable_list apply(variable_list&& grads) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    const bool twice = at::GradMode::is_enabled();
+    at::AutoGradMode no_grad(false);
+    variable_list out(1);
+    const Tensor pred = pred_.unpack();   // raises after a released graph; checks in-place edits of the head output
+    const Tensor& g_in = grads[0];
+    if (!g_in.defined()) return out;
+    Tensor g;
+    if (used_) {   // retain_graph replay: the first gradient was handed over (and scaled in place): launch again
+      AnchorHeadCall again = call_;
+      again.bbox_pred = pred;
+      g = again.launch(true).second;
+    } else {
+      g = std::move(grad_);
+      grad_ = Tensor();
+      used_ = true;
+    }
+    if (!is_unit_grad(g_in)) {
+      const Tensor go = g_in.scalar_type() == at::kFloat ? g_in : g_in.to(at::kFloat);
+      c10::DeviceGuard device_guard(g.device());
+      fail(abi.scale_rows(fp(g), fp(go), 0, g.numel() / 7, current_stream(g)), "gd3d_scale_rows");
+    }
+    out[0] = std::move(g);
+    if (twice) {
+      Tensor a = out[0].detach();
+      a.set_requires_grad(true);
+      auto err = std::make_shared<torch::autograd::DelayedError>(
+          "trying to differentiate twice a function that was marked with @once_differentiable", (int64_t)1);
+      at::AutoGradMode grad_on(true);
+      return (*err)(variable_list{a});
+    }
+    return out;
+  }
+};
+
+Tensor anchor_head(const Tensor& bbox_pred, const Tensor& bbox_targets, const c10::optional<Tensor>& bbox_weights,
+                   const Tensor& anchors, const Tensor& sel, int64_t params_addr, int64_t sl1_addr,
+                   const c10::optional<std::vector<double>>& dw, bool dense, int64_t num_classes, double scale,
+                   const c10::optional<Tensor>& avg_dev, double w_gd, double w_sl1) {
+  TORCH_CHECK(abi.bound, "gd3d node: bind(path of libgd3d.so) has not been called");
+  TORCH_CHECK(bbox_pred.is_cuda() && bbox_pred.dim() == 4 && bbox_pred.size(1) % 7 == 0 && bbox_pred.scalar_type() == at::kFloat &&
+                  bbox_pred.is_contiguous(), "gd3d node: bbox_pred must be a contiguous fp32 (B, A*7, H, W) tensor on the GPU");
+  for (const Tensor* t : {&bbox_targets, &anchors})
+    TORCH_CHECK(t->scalar_type() == at::kFloat && t->is_contiguous() && t->device() == bbox_pred.device(),
+                "gd3d node: targets / anchors must be contiguous fp32 tensors on bbox_pred's device");
+  TORCH_CHECK(sel.scalar_type() == at::kLong && sel.is_contiguous() && sel.device() == bbox_pred.device(),
+              "gd3d node: the positive list / label map must be a contiguous int64 tensor on bbox_pred's device");
+  AnchorHeadCall call;
+  call.bbox_pred = bbox_pred;
+  call.bbox_targets = bbox_targets;
+  if (bbox_weights.has_value() && bbox_weights->defined()) {
+    TORCH_CHECK(bbox_weights->scalar_type() == at::kFloat && bbox_weights->is_contiguous() && bbox_weights->device() == bbox_pred.device(),
+                "gd3d node: bbox_weights must be a contiguous fp32 tensor on bbox_pred's device");
+    call.bbox_weights = *bbox_weights;
+  }
+  call.anchors = anchors;
+  call.sel = sel;
+  std::memcpy(&call.params, (const void*)params_addr, sizeof(call.params));
+  if (sl1_addr != 0) {
+    std::memcpy(&call.sl1, (const void*)sl1_addr, sizeof(call.sl1));
+    call.has_sl1 = true;
+  }
+  if (dw.has_value()) {
+    TORCH_CHECK(dw->size() == 7, "gd3d node: decode_weight must hold 7 values");
+    for (int k = 0; k < 7; ++k) call.dw[k] = (float)(*dw)[k];
+    call.has_dw = true;
+  }
+  call.dense = dense;
+  call.num_classes = (int32_t)num_classes;
+  call.scale = (float)scale;
+  if (avg_dev.has_value() && avg_dev->defined()) {
+    TORCH_CHECK(dense && avg_dev->scalar_type() == at::kFloat && avg_dev->numel() == 1 && avg_dev->device() == bbox_pred.device(),
+                "gd3d node: a device-resident normaliser needs the dense form and one fp32 value on bbox_pred's device");
+    call.avg_dev = *avg_dev;
+    call.dyn = true;
+    call.w_gd = w_gd;
+    call.w_sl1 = w_sl1;
+  }
+  const bool need_grad = at::GradMode::is_enabled() && bbox_pred.requires_grad();
+  std::shared_ptr<AnchorHeadBackward> node;
+  if (need_grad) {
+    node = std::shared_ptr<AnchorHeadBackward>(new AnchorHeadBackward(), torch::autograd::deleteNode);
+    node->set_next_edges(torch::autograd::collect_next_edges(bbox_pred));
+  }
+  Tensor loss, grad;
+  {
+    at::AutoDispatchBelowADInplaceOrView below_autograd;
+    std::tie(loss, grad) = call.launch(need_grad);
+  }
+  if (node) {
+    node->pred_ = torch::autograd::SavedVariable(bbox_pred, false);
+    call.bbox_pred = Tensor();   // the saved variable holds it (no second owner: the in-place check stays meaningful)
+    node->call_ = std::move(call);
+    node->grad_ = std::move(grad);
+    torch::autograd::set_history(loss, node);
+  }
+  return loss;
+}
+
 // nms_gpu's scored path (mmdet3d-gaussian_amd/iou3d.py: <= rnms_scored_max_n() candidates, fp32 scores): the three allocations, the
 // launch and — unless `padded` — the one read-back of the count and the cut to it, without the Python in between (a third of
 // nms_gpu's end-to-end time at inference sizes was host code).  boxes (N,5) / scores (N) contiguous fp32 on one GPU.
@@ -330,6 +492,9 @@ PYBIND11_MODULE(_gd3d_node, m) {
         py::arg("ws_floats"), py::arg("want_flag"));
   m.def("nms_scored", &nms_scored, py::arg("boxes"), py::arg("scores"), py::arg("thresh"), py::arg("n_keep"), py::arg("normal"),
         py::arg("padded"), py::arg("post_max"));
+  m.def("anchor_head", &anchor_head, py::arg("bbox_pred"), py::arg("bbox_targets"), py::arg("bbox_weights"), py::arg("anchors"),
+        py::arg("sel"), py::arg("params"), py::arg("sl1"), py::arg("decode_weight"), py::arg("dense"), py::arg("num_classes"),
+        py::arg("scale"), py::arg("avg_dev"), py::arg("w_gd"), py::arg("w_sl1"));
   m.def("set_unit_grad", &set_unit_grad);
   m.def("finish_calls", []() { return g_finish_calls.load(); }, "gd3d_grad_finish launches made by backward so far");
   m.def("bind", &bind, "resolve the C ABI from the loaded libgd3d.so; returns its ABI version");

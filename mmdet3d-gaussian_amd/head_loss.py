@@ -67,63 +67,19 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
                                   avg_factor=num_total_samples)
 
 
-def _anchor_head_launch(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense,
-                        num_classes, sl1, need_grad):
-    """One gd3d_anchor_head_bbox_loss launch -> (loss scalar tensor, zero-filled-then-scattered NCHW gradient | None)."""
-    lib = _lib.load()
-    B, C, H, W = bbox_pred.shape
-    A = C // 7
-    P = pos_or_labels.numel()
-    dev = bbox_pred.device
-    grad = torch.zeros_like(bbox_pred) if need_grad else None
-    buf = torch.empty(4 + lib.gd3d_loss_workspace_bytes(P) // 4, dtype=torch.float32, device=dev)
-    dwp = None if dw is None else (ctypes.c_float * 7)(*[float(x) for x in dw])
-    wp = None if bbox_weights is None else bbox_weights.data_ptr()
-    sel = pos_or_labels.data_ptr()
-    with torch.cuda.device(dev):
-        if isinstance(scale, tuple):      # (avg_dev, gd_weight, sl1_weight): the normaliser stays on the device (dense form only)
-            avg_dev, w_gd, w_sl1 = scale
-            rc = lib.gd3d_anchor_head_bbox_loss_dyn(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp, dwp,
-                                                    anchors.data_ptr(), sel, int(num_classes), float(w_gd), float(w_sl1), avg_dev.data_ptr(),
-                                                    buf[0].data_ptr(), None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
-                                                    torch.cuda.current_stream().cuda_stream)
-        else:
-            rc = lib.gd3d_anchor_head_bbox_loss(params, sl1, bbox_pred.data_ptr(), B, A, H, W, bbox_targets.data_ptr(), wp,
-                                                dwp, anchors.data_ptr(), None if dense else sel, P, sel if dense else None,
-                                                int(num_classes), scale, buf[0].data_ptr(),
-                                                None if grad is None else grad.data_ptr(), buf[4:].data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, 'gd3d_anchor_head_bbox_loss')
-    return buf[0], grad
-
-
-class _AnchorHeadFused(torch.autograd.Function):
-    """selection/gather of the positives + decode x2 + loss(es) + gradient scatter into the NCHW head output: one launch.
-    `pos_or_labels` is either the (P,) int64 positive list (dense=False) or the (M,) int64 label map (dense=True)."""
-
-    @staticmethod
-    def forward(ctx, bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
-                num_classes=0, sl1=None):
-        args = (bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense, num_classes, sl1)
-        loss, grad = _anchor_head_launch(*args, ctx.needs_input_grad[0])
-        ctx.grad, ctx.used, ctx.replay = grad, False, args
-        return loss
-
-    @staticmethod
-    @guard_double_backward
-    def backward(ctx, grad_out):
-        lib = _lib.load()
-        if ctx.used:  # retain_graph replay: the saved gradient was scaled in place (and may have become .grad): recompute
-            g = _anchor_head_launch(*ctx.replay, True)[1]
-        else:  # hand the buffer over (no reference left here: a leaf's AccumulateGrad then keeps it instead of cloning it)
-            g, ctx.grad, ctx.used = ctx.grad, None, True
-        if _is_unit_grad(grad_out):     # the library's own constant 1.0 (gd_loss.unit_grad), known by address: nothing to scale
-            return (g,) + (None,) * 10
-        go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
-        with torch.cuda.device(g.device):
-            _lib.check(lib.gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7,
-                                           torch.cuda.current_stream().cuda_stream), 'gd3d_scale_rows')
-        return (g,) + (None,) * 10
+def _anchor_head_fused(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
+                       num_classes=0, sl1=None):
+    """selection / gather of the positives + decode x2 + loss(es) + gradient scatter into the NCHW head output: one launch,
+    behind the C++ autograd node of csrc/torch_node.cpp (`anchor_head`: the zero-filled-then-scattered gradient waits in the
+    node; backward hands it over, scaled on the device unless the upstream gradient is gd_loss.unit_grad; a second backward
+    under retain_graph launches again; differentiating the gradient raises).  `pos_or_labels` is either the (P,) int64
+    positive list (dense=False) or the (M,) int64 label map (dense=True); `scale` a float or, for a device-resident
+    normaliser (dense form only), the tuple (avg_dev, gd_weight, sl1_weight)."""
+    avg_dev, w_gd, w_sl1 = (scale if isinstance(scale, tuple) else (None, 0.0, 0.0))
+    return _lib.load_node().anchor_head(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, ctypes.addressof(params),
+                                        0 if sl1 is None else ctypes.addressof(sl1), None if dw is None else [float(x) for x in dw],
+                                        bool(dense), int(num_classes), 0.0 if avg_dev is not None else float(scale), avg_dev,
+                                        float(w_gd), float(w_sl1))
 
 
 def _avg_tensor(t, dev, who):
@@ -196,8 +152,7 @@ def anchor_head_decoded_loss_fused(loss_module, bbox_pred, bbox_targets, bbox_we
         num_total_samples = int(bbox_pred.shape[0])      # loss_single: `int(cls_score.shape[0])`, the batch size (:85-86)
     den = num_total_samples if loss_module.reduction == 'mean' else 1.0
     scale = float(loss_module.loss_weight) / float(den)
-    return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_module._params({}), dw, scale, bool(dense),
-                                  int(num_classes), None)
+    return _anchor_head_fused(bp, bt, weights, anchors, sel, loss_module._params({}), dw, scale, bool(dense), int(num_classes), None)
 
 
 def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets, bbox_weights, labels, anchor_list,
@@ -254,8 +209,7 @@ def anchor_head_bbox_loss(loss_decoded_bbox, loss_bbox, bbox_pred, bbox_targets,
     sl1.has_code_weight = int(cw is not None)
     sl1.code_weight = (ctypes.c_float * 7)(*(cw or [1.0] * 7))
     scale = (avg_dev, float(loss_decoded_bbox.loss_weight), lw) if dyn else float(loss_decoded_bbox.loss_weight) / float(num_total_samples)
-    return _AnchorHeadFused.apply(bp, bt, weights, anchors, sel, loss_decoded_bbox._params({}), dw, scale, bool(dense),
-                                  int(num_classes), sl1)
+    return _anchor_head_fused(bp, bt, weights, anchors, sel, loss_decoded_bbox._params({}), dw, scale, bool(dense), int(num_classes), sl1)
 
 
 def center_head_gd_loss(loss_module, coder, pos_ind, pred, anno_boxes, num_pos):
