@@ -642,3 +642,33 @@ def test_device_point_coder_vs_reference_golden(amd):
     with pytest.raises(RuntimeError, match='different box counts'):
         coder.decode(priors[:, :-1], p7, correct_yaw=False)
     assert coder.decode(priors[:0], p7[:0], correct_yaw=False).shape == (0, 200, 7)
+
+
+def test_anchor_head_node_guards_double_backward_in_place_edits_and_released_graphs(amd):
+    """The anchor-head slice's autograd node lives in the C++ glue (csrc/torch_node.cpp `anchor_head`): like the loss node it hands
+    out kernel-written gradients, so differentiating them again must raise; an in-place edit of the head output between forward
+    and backward is detected (the node saved it for a possible replay); a released graph says so."""
+    anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(33)
+    mod = amd.GDLoss('gwd3d', fun='log1p', tau=1.0, loss_weight=5.0)
+    args = (bbox_targets.cuda(), bbox_weights.cuda(), labels.cuda(), anchors.cuda(), C, 17.0)
+    sl1 = dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0)
+    bp = bbox_pred.cuda().requires_grad_(True)
+    out = amd.anchor_head_bbox_loss(mod, sl1, bp, *args, code_weight=[1.0] * 7, decode_weight=1)
+    assert out.grad_fn.name() == 'GDAnchorHeadBackward'
+    (g,) = torch.autograd.grad(out, bp, create_graph=True)
+    with pytest.raises(RuntimeError, match='differentiate twice'):
+        g.sum().backward()
+    (g2,) = torch.autograd.grad(amd.anchor_head_bbox_loss(mod, sl1, bp, *args, code_weight=[1.0] * 7, decode_weight=1), bp)
+    assert torch.equal(g.detach(), g2)
+    x = bp * 1.0
+    out = amd.anchor_head_bbox_loss(mod, sl1, x, *args, code_weight=[1.0] * 7, decode_weight=1)
+    with torch.no_grad():
+        x.add_(1.0)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        out.backward()
+    out = amd.anchor_head_bbox_loss(mod, sl1, bp, *args, code_weight=[1.0] * 7, decode_weight=1)
+    out.backward()
+    with pytest.raises(RuntimeError, match='second time'):
+        out.backward()
+    with torch.no_grad():
+        assert not amd.anchor_head_bbox_loss(mod, sl1, bp, *args, code_weight=[1.0] * 7, decode_weight=1).requires_grad
