@@ -52,6 +52,9 @@ struct Abi {
   decltype(&::gd3d_anchor_head_bbox_loss_dyn) anchor_head_dyn = nullptr;
   decltype(&::gd3d_scale_rows) scale_rows = nullptr;
   decltype(&::gd3d_loss_workspace_bytes) loss_workspace_bytes = nullptr;
+  decltype(&::vox_scatter_reduce) scatter_reduce = nullptr;
+  decltype(&::vox_scatter_backward) scatter_backward = nullptr;
+  decltype(&::vox_scatter_backward_grouped) scatter_backward_grouped = nullptr;
   decltype(&::rnms_scored_workspace_bytes) nms_scored_workspace_bytes = nullptr;
   bool bound = false;
 } abi;
@@ -78,6 +81,9 @@ int bind(const std::string& path) {
   resolve(image, "gd3d_anchor_head_bbox_loss_dyn", abi.anchor_head_dyn);
   resolve(image, "gd3d_scale_rows", abi.scale_rows);
   resolve(image, "gd3d_loss_workspace_bytes", abi.loss_workspace_bytes);
+  resolve(image, "vox_scatter_reduce", abi.scatter_reduce);
+  resolve(image, "vox_scatter_backward", abi.scatter_backward);
+  resolve(image, "vox_scatter_backward_grouped", abi.scatter_backward_grouped);
   resolve(image, "rnms_scored_workspace_bytes", abi.nms_scored_workspace_bytes);
   const int version = abi.abi_version(nullptr);
   TORCH_CHECK(version == GD3D_ABI_VERSION, "gd3d node: built against ABI ", GD3D_ABI_VERSION, ", the library reports ", version);
@@ -451,6 +457,76 @@ Tensor anchor_head(const Tensor& bbox_pred, const Tensor& bbox_targets, const c1
   return loss;
 }
 
+// ---- dynamic scatter-reduce (scatter.py, SURVEY.md §8 f4: ops/voxel/scatter.py:29-72) as one node ----------------------------------
+// forward: vox_scatter_reduce over the grouped points (order / seg from scatter.group_points); backward: the voxel-ordered form for
+// rows of 128 bytes and more (c % 4 == 0, 32 <= c <= 256, aligned), the map-ordered gather otherwise — the choice scatter.py made.
+struct ScatterReduceBackward : public torch::autograd::Node {
+  Tensor pmap_, count_, argmax_, order_, seg_;
+  int red_ = 0;
+  int64_t n_ = 0, c_ = 0, v_ = 0;
+  at::ScalarType in_dtype_ = at::kFloat;
+
+  std::string name() const override { return "GDScatterReduceBackward"; }
+  void release_variables() override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    pmap_.reset(); count_.reset(); argmax_.reset(); order_.reset(); seg_.reset();
+  }
+  variable_list apply(variable_list&& grads) override {
+    std::lock_guard<std::mutex> lock(mutex_);
+    variable_list out(1);
+    if (!grads[0].defined()) return out;
+    TORCH_CHECK(order_.defined(), "Trying to backward through the graph a second time (the scatter node's index tensors were freed)");
+    at::AutoGradMode no_grad(false);
+    const Tensor g = grads[0].contiguous().to(at::kFloat);
+    c10::DeviceGuard device_guard(g.device());
+    Tensor gf = at::empty({n_, c_}, g.options());
+    const int32_t* am = argmax_.defined() ? argmax_.data_ptr<int32_t>() : nullptr;
+    void* stream = current_stream(g);
+    int rc;
+    if (c_ % 4 == 0 && c_ >= 32 && c_ <= 256 && ((uintptr_t)g.data_ptr() & 15) == 0)
+      rc = abi.scatter_backward_grouped(fp(g), order_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf),
+                                        stream);
+    else
+      rc = abi.scatter_backward(fp(g), pmap_.data_ptr<int32_t>(), count_.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf), stream);
+    fail(rc, "vox_scatter_backward");
+    out[0] = in_dtype_ == at::kFloat ? gf : gf.to(in_dtype_);
+    return out;
+  }
+};
+
+Tensor scatter_reduce(const Tensor& feats, const Tensor& pmap, const Tensor& count, int64_t red, const Tensor& order, const Tensor& seg) {
+  TORCH_CHECK(abi.bound, "gd3d node: bind(path of libgd3d.so) has not been called");
+  TORCH_CHECK(feats.is_cuda() && feats.dim() == 2, "scatter_reduce: feats must be an (N, C) tensor on the GPU");
+  for (const Tensor* t : {&pmap, &count, &order, &seg})
+    TORCH_CHECK(t->scalar_type() == at::kInt && t->is_contiguous() && t->device() == feats.device(),
+                "scatter_reduce: map / count / order / seg must be contiguous int32 tensors on feats' device");
+  const int64_t n = feats.size(0), c = feats.size(1), v = count.numel();
+  TORCH_CHECK(pmap.numel() == n && seg.numel() == v + 1 && red >= 0 && red <= 2, "scatter_reduce: inconsistent index tensors");
+  const bool need_grad = at::GradMode::is_enabled() && feats.requires_grad();
+  std::shared_ptr<ScatterReduceBackward> node;
+  if (need_grad) {
+    node = std::shared_ptr<ScatterReduceBackward>(new ScatterReduceBackward(), torch::autograd::deleteNode);
+    node->set_next_edges(torch::autograd::collect_next_edges(feats));
+  }
+  Tensor out, argmax, result;
+  {
+    at::AutoDispatchBelowADInplaceOrView below_autograd;
+    c10::DeviceGuard device_guard(feats.device());
+    const Tensor f32 = feats.scalar_type() == at::kFloat ? feats.contiguous() : feats.to(at::kFloat).contiguous();
+    out = at::empty({v, c}, f32.options());
+    if (red == 2) argmax = at::empty({v, c}, f32.options().dtype(at::kInt));
+    fail(abi.scatter_reduce(fp(f32), order.data_ptr<int32_t>(), seg.data_ptr<int32_t>(), n, (int32_t)c, v, (int)red, fp(out),
+                            argmax.defined() ? argmax.data_ptr<int32_t>() : nullptr, current_stream(feats)), "vox_scatter_reduce");
+    result = feats.scalar_type() == at::kFloat ? out : out.to(feats.scalar_type());
+  }
+  if (node) {
+    node->pmap_ = pmap; node->count_ = count; node->argmax_ = argmax; node->order_ = order; node->seg_ = seg;
+    node->red_ = (int)red; node->n_ = n; node->c_ = c; node->v_ = v; node->in_dtype_ = feats.scalar_type();
+    torch::autograd::set_history(result, node);
+  }
+  return result;
+}
+
 // nms_gpu's scored path (mmdet3d-gaussian_amd/iou3d.py: <= rnms_scored_max_n() candidates, fp32 scores): the three allocations, the
 // launch and — unless `padded` — the one read-back of the count and the cut to it, without the Python in between (a third of
 // nms_gpu's end-to-end time at inference sizes was host code).  boxes (N,5) / scores (N) contiguous fp32 on one GPU.
@@ -495,6 +571,8 @@ PYBIND11_MODULE(_gd3d_node, m) {
   m.def("anchor_head", &anchor_head, py::arg("bbox_pred"), py::arg("bbox_targets"), py::arg("bbox_weights"), py::arg("anchors"),
         py::arg("sel"), py::arg("params"), py::arg("sl1"), py::arg("decode_weight"), py::arg("dense"), py::arg("num_classes"),
         py::arg("scale"), py::arg("avg_dev"), py::arg("w_gd"), py::arg("w_sl1"));
+  m.def("scatter_reduce", &scatter_reduce, py::arg("feats"), py::arg("point2voxel_map"), py::arg("voxel_points_count"), py::arg("reduce"),
+        py::arg("order"), py::arg("seg"));
   m.def("set_unit_grad", &set_unit_grad);
   m.def("finish_calls", []() { return g_finish_calls.load(); }, "gd3d_grad_finish launches made by backward so far");
   m.def("bind", &bind, "resolve the C ABI from the loaded libgd3d.so; returns its ABI version");

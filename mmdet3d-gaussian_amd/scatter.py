@@ -8,7 +8,6 @@ the by-voxel grouping of the points that the atomic-free reduce / backward kerne
 the host (`_index_and_grouping`).  `scatter_reduce` keeps the reference's signature.
 """
 import torch
-from torch.autograd import Function
 
 from . import _lib
 
@@ -146,64 +145,32 @@ def group_points(point2voxel_map, voxel_points_count):
     return order.contiguous(), seg.contiguous()
 
 
-class _ScatterReduce(Function):
-    @staticmethod
-    def forward(ctx, feats, point2voxel_map, voxel_points_count, reduce_type='max', grouping=None):
-        if not feats.is_cuda:
-            raise RuntimeError('scatter_reduce: the MI355X implementation has no CPU path '
-                               '(neither has the reference: voxelization.h:46)')
-        lib = _lib.load()
-        if feats.size(0) == 0:
-            return feats.clone().detach()
-        feats32 = feats.contiguous() if feats.dtype == torch.float32 else feats.float().contiguous()
-        n, c = feats32.shape
-        if point2voxel_map.numel() != n or point2voxel_map.dtype != torch.int32 or \
-                voxel_points_count.dtype != torch.int32:
-            raise RuntimeError('scatter_reduce: point2voxel_map must be an int32 tensor with one entry per point and '
-                               'voxel_points_count int32 (as scatter_index returns them)')
-        v = voxel_points_count.numel()
-        order, seg = grouping if grouping is not None else group_points(point2voxel_map, voxel_points_count)
-        out = torch.empty((v, c), dtype=torch.float32, device=feats.device)
-        red = REDUCE[reduce_type]
-        argmax = torch.empty((v, c), dtype=torch.int32, device=feats.device) if red == 2 else None
-        with _on_device(feats.device) as stream:
-            rc = lib.vox_scatter_reduce(feats32.data_ptr(), order.data_ptr(), seg.data_ptr(), n, c, v, red,
-                                        out.data_ptr(), None if argmax is None else argmax.data_ptr(), stream)
-        _lib.check(rc, 'vox_scatter_reduce')
-        ctx.red, ctx.shape, ctx.in_dtype = red, (n, c, v), feats.dtype
-        ctx.save_for_backward(point2voxel_map.contiguous(), voxel_points_count.contiguous(), argmax, order, seg)
-        ctx.mark_non_differentiable(point2voxel_map, voxel_points_count)
-        return out if feats.dtype == torch.float32 else out.to(feats.dtype)
-
-    @staticmethod
-    def backward(ctx, grad_voxel_feats):
-        lib = _lib.load()
-        pmap, count, argmax, order, seg = ctx.saved_tensors
-        n, c, v = ctx.shape
-        g = grad_voxel_feats.contiguous().float()
-        grad_feats = torch.empty((n, c), dtype=torch.float32, device=g.device)
-        am = None if argmax is None else argmax.data_ptr()
-        with _on_device(g.device) as stream:
-            if c % 4 == 0 and 32 <= c <= 256 and g.data_ptr() % 16 == 0:
-                # voxel order: every gradient row is read once and streamed to its points (half the HBM traffic).  Only for
-                # rows of at least one 128-byte line: narrower rows make the voxel-ordered stores partial lines at random
-                # addresses (c = 10: 118 us against 40 us for the map-ordered gather, profiles/r04_scatter_kernel_time.txt)
-                rc = lib.vox_scatter_backward_grouped(g.data_ptr(), order.data_ptr(), seg.data_ptr(), am, n, c, v, ctx.red,
-                                                      grad_feats.data_ptr(), stream)
-            else:
-                rc = lib.vox_scatter_backward(g.data_ptr(), pmap.data_ptr(), count.data_ptr(), am, n, c, v, ctx.red,
-                                              grad_feats.data_ptr(), stream)
-        _lib.check(rc, 'vox_scatter_backward')
-        if ctx.in_dtype != torch.float32:
-            grad_feats = grad_feats.to(ctx.in_dtype)
-        return grad_feats, None, None, None, None
+def _scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce_type='max', grouping=None):
+    """The reduce with its autograd node in the C++ glue (csrc/torch_node.cpp `scatter_reduce`: forward vox_scatter_reduce over
+    the grouped points; backward the voxel-ordered form for rows of one 128-byte line and more (c % 4 == 0, 32 <= c <= 256:
+    every gradient row read once and streamed to its points), the map-ordered gather for narrower rows (c = 10: 40 us against
+    118 us, profiles/r04_scatter_kernel_time.txt)).  As a Python autograd.Function the call was host-bound at 110 us
+    forward + backward below ~0.5 M points — slower than torch's index_add for `sum`."""
+    if not feats.is_cuda:
+        raise RuntimeError('scatter_reduce: the MI355X implementation has no CPU path '
+                           '(neither has the reference: voxelization.h:46)')
+    if feats.size(0) == 0:
+        return feats.clone().detach()
+    n = feats.shape[0]
+    if point2voxel_map.numel() != n or point2voxel_map.dtype != torch.int32 or \
+            voxel_points_count.dtype != torch.int32:
+        raise RuntimeError('scatter_reduce: point2voxel_map must be an int32 tensor with one entry per point and '
+                           'voxel_points_count int32 (as scatter_index returns them)')
+    order, seg = grouping if grouping is not None else group_points(point2voxel_map, voxel_points_count)
+    return _lib.load_node().scatter_reduce(feats, point2voxel_map.contiguous(), voxel_points_count.contiguous(), REDUCE[reduce_type],
+                                           order, seg)
 
 
 def scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce_type='max', grouping=None):
     """feats (N,C) -> (M,C): max | mean | sum of the rows that share a voxel (reference signature + optional
     precomputed `grouping` = group_points(...))."""
     assert reduce_type in REDUCE, f'do not support reduce type {reduce_type}'
-    return _ScatterReduce.apply(feats, point2voxel_map, voxel_points_count, reduce_type, grouping)
+    return _scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce_type, grouping)
 
 
 class Scatter(object):
