@@ -307,7 +307,7 @@ std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tens
 // Selection / gather of the positives + decode x2 + loss(es) + the gradient scattered into the NCHW head output: ONE launch
 // (gd3d_anchor_head_bbox_loss[_dyn]); the zero-filled-then-scattered gradient waits in the node and backward hands it over
 // (scaled by the upstream gradient on the device unless that is the library's unit gradient).  A second backward under
-// retain_graph launches again.  Argument meaning as in head_loss._anchor_head_launch, which this replaces.
+// retain_graph launches again.  Called from head_loss._anchor_head_fused (argument meaning documented there).
 struct AnchorHeadCall {
   Tensor bbox_pred, bbox_targets, bbox_weights, anchors, sel, avg_dev;   // sel: (P,) positives or the (M,) label map (dense)
   gd3d_params params;
