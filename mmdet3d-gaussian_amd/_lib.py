@@ -1,7 +1,8 @@
-"""ctypes binding of libgd3d.so — the only way the Python host code reaches the HIP kernels.
+"""ctypes binding of libgd3d.so — the only way the Python host code reaches the HIP kernels — and the choice of host glue
+above it (`load_node`: Python autograd.Function + ctypes, or the optional C++ node).
 
-There is NO CPU fallback: if the library cannot be loaded (or built) every op raises.  The
-signatures mirror include/gd3d.h one to one.
+Nothing substitutes for the library: if it cannot be loaded (or built) every op raises; a GPU tensor never takes a CPU
+path (CPU tensors run the library's own `_cpu` twins).  The signatures mirror include/gd3d.h one to one.
 """
 import ctypes
 import os
@@ -233,9 +234,9 @@ def _bind(path):
 
 
 def load():
-    """Load libgd3d.so, building it first when the in-tree binary is missing or older than its sources.
-    A failed compile is an error (it never falls back to an older binary); only a machine WITHOUT hipcc may run a
-    binary whose source hash no longer matches, and says so."""
+    """Load libgd3d.so, building it first when the in-tree binary is missing or does not match its sources (content hash).
+    A binary that does not match is NEVER loaded: it is rebuilt, or — on a machine without hipcc — refused (a library built
+    from other sources may disagree with this binding about arguments: the ABI version only covers the header)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -244,39 +245,42 @@ def load():
         _lib = _bind(override)
         return _lib
     if _build.is_stale():
-        if os.path.exists(_build.hipcc_path()):
-            _build.build()                  # compile or link errors propagate
-        elif os.path.isfile(_build.LIB_PATH):
-            import warnings
-            warnings.warn(f'libgd3d.so does not match its sources (source hash {_build.source_hash()[:12]}) and hipcc is '
-                          'not available to rebuild it: running the binary as it is')
-        else:
-            raise RuntimeError('libgd3d.so (HIP kernels for gfx950) is missing and hipcc is not available to build it; '
-                               'there is no CPU fallback for this package')
+        if not os.path.exists(_build.hipcc_path()):
+            what = 'does not match its sources' if os.path.isfile(_build.LIB_PATH) else 'is missing'
+            raise RuntimeError(f'libgd3d.so (HIP kernels for gfx950) {what} (source hash {_build.source_hash()[:12]}) and hipcc is '
+                               'not available to build it; a GPU tensor has no other path in this package')
+        _build.build()                  # compile or link errors propagate
     _lib = _bind(_build.LIB_PATH)
     return _lib
 
 
+# ---- host glue above the C ABI: Python (torch.autograd.Function + ctypes, _pynode.py) or C++ (csrc/torch_node.cpp) -------------
+# Both call the same extern "C" entry points with the same arguments: a choice of glue, not of arithmetic.
+#   GD3D_HOST=python  the Python glue (needs nothing beyond libgd3d.so)
+#   GD3D_HOST=cpp     the C++ node; a failure to build or load it is an error
+#   unset / auto      the C++ node when its in-tree binary matches its sources or can be rebuilt; the Python glue otherwise,
+#                     with ONE loud log line saying why
+HOST_GLUE_MODES = ('python', 'cpp')
 _node = None
+_glue = None        # the resolved mode of `_node`
+_forced = None      # set_host_glue()
+_unit_grads = {}    # device index (-1: CPU) -> address of gd_loss.unit_grad's constant; pushed into whichever glue is loaded
 
 
-def load_node():
-    """The C++ autograd node of GDLoss (csrc/torch_node.cpp -> _gd3d_node.so), bound to the loaded libgd3d.so.  Like the
-    library it is built in-tree on first use and never substituted: a failed compile or a missing compiler raises."""
-    global _node
+def register_unit_grad(device_index, address):
+    _unit_grads[int(device_index)] = int(address)
     if _node is not None:
-        return _node
-    load()
+        _node.set_unit_grad(int(device_index), int(address))
+
+
+def _load_cpp_node():
+    """_gd3d_node.so, bound to the loaded libgd3d.so.  Raises when it is missing or stale and cannot be rebuilt; never loads a
+    binary whose hash (sources + flags + torch version) differs: it would have been compiled against another libtorch."""
     if _build.node_is_stale():
-        if os.path.exists(_build.host_cxx_path()):
-            _build.build_node()
-        elif os.path.isfile(_build.NODE_PATH):
-            import warnings
-            warnings.warn('_gd3d_node.so does not match its sources and the ROCm clang++ is not available to rebuild it: '
-                          'running the binary as it is')
-        else:
-            raise RuntimeError('_gd3d_node.so (the autograd node of GDLoss) is missing and the ROCm clang++ is not available '
-                               'to build it; there is no Python substitute for it in this package')
+        if _build.host_cxx_path() is None:
+            what = 'does not match its sources / this torch' if os.path.isfile(_build.NODE_PATH) else 'is missing'
+            raise RuntimeError(f'_gd3d_node.so {what} and the ROCm clang++ is not available to build it')
+        _build.build_node()
     import importlib.util
     import torch  # noqa: F401  (libtorch must be loaded before the node is)
     spec = importlib.util.spec_from_file_location('_gd3d_node', _build.NODE_PATH)
@@ -285,8 +289,60 @@ def load_node():
     ver = mod.bind(os.environ.get('GD3D_LIB') or _build.LIB_PATH)
     if ver != ABI_VERSION:
         raise RuntimeError(f'_gd3d_node.so bound a library of ABI version {ver} != {ABI_VERSION}')
-    _node = mod
+    return mod
+
+
+def _requested_glue():
+    mode = _forced or os.environ.get('GD3D_HOST', '').strip().lower() or 'auto'
+    if mode not in HOST_GLUE_MODES + ('auto',):
+        raise RuntimeError(f"GD3D_HOST={mode!r}: expected 'python', 'cpp' or 'auto'")
+    return mode
+
+
+def load_node():
+    """The host-glue module GDLoss (reduced forms), nms_gpu (scored path), the anchor-head slice and scatter_reduce call:
+    `reduced`, `nms_scored`, `anchor_head`, `scatter_reduce`, `set_unit_grad`, `finish_calls`, `bind` — from _pynode.py or from
+    _gd3d_node.so (see the table above)."""
+    global _node, _glue
+    if _node is not None:
+        return _node
+    load()
+    mode = _requested_glue()
+    if mode == 'python':
+        from . import _pynode
+        _node, _glue = _pynode, 'python'
+    elif mode == 'cpp':
+        _node, _glue = _load_cpp_node(), 'cpp'
+    else:
+        try:
+            _node, _glue = _load_cpp_node(), 'cpp'
+        except Exception as e:   # missing compiler, torch headers this compiler rejects, an unloadable binary ...
+            import logging
+            logging.getLogger('mmdet3d_gaussian_amd').warning(
+                'host glue: the optional C++ autograd node is unavailable (%s); using the Python glue (torch.autograd.Function '
+                '+ ctypes over the same C ABI and kernels: identical results, 7-30 us more host time per training-size call). '
+                'Set GD3D_HOST=python to silence this, GD3D_HOST=cpp to make it an error.', str(e).splitlines()[0][:300])
+            from . import _pynode
+            _node, _glue = _pynode, 'python'
+    for idx, address in _unit_grads.items():
+        _node.set_unit_grad(idx, address)
     return _node
+
+
+def host_glue():
+    """'python' or 'cpp': which glue load_node() resolved to (resolves it on first use)."""
+    load_node()
+    return _glue
+
+
+def set_host_glue(mode):
+    """Select the glue for the calls that follow ('python' | 'cpp' | None = GD3D_HOST / auto again).  Nodes already attached to
+    live graphs keep working: each is self-contained."""
+    global _node, _glue, _forced
+    if mode is not None and mode not in HOST_GLUE_MODES:
+        raise RuntimeError(f"set_host_glue({mode!r}): expected 'python', 'cpp' or None")
+    _forced = mode
+    _node = _glue = None
 
 
 def check(rc, what):

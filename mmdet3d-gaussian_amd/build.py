@@ -52,10 +52,11 @@ def hipcc_path():
 
 
 def host_cxx_path():
+    """The ROCm toolchain's own clang++ (host compiler of the `_cpu` twins and of the optional C++ node), or None."""
     for c in ('/opt/rocm/lib/llvm/bin/clang++', '/opt/rocm/llvm/bin/clang++', shutil.which('amdclang++') or ''):
         if c and os.path.exists(c):
             return c
-    raise RuntimeError('the ROCm clang++ (host compiler of the _cpu twins) was not found next to hipcc')
+    return None
 
 
 NODE_SOURCE = 'torch_node.cpp'
@@ -110,10 +111,13 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         jobs.append((src, obj, [hipcc] + COMMON + flags + ['-c', path, '-o', obj]))
+    cxx = host_cxx_path()
+    if cxx is None:
+        raise RuntimeError('the ROCm clang++ (host compiler of the _cpu twins) was not found next to hipcc: cannot build libgd3d.so')
     for src, flags in HOST_SOURCES.items():
         path = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src.replace('.cpp', '.o'))
-        jobs.append((src, obj, [host_cxx_path()] + HOST_COMMON + flags + ['-c', path, '-o', obj]))
+        jobs.append((src, obj, [cxx] + HOST_COMMON + flags + ['-c', path, '-o', obj]))
 
     def compile_one(job):
         src, obj, cmd = job
@@ -141,23 +145,24 @@ def build(force=False, verbose=False):
 
 
 def node_source_hash():
-    """The node is rebuilt when its source, the C header or the torch it was compiled against change."""
+    """The node is rebuilt when its source, the C header, the flags or the torch it was compiled against change.  The
+    compiler's PATH is not part of it: a box without the compiler can still verify (and load) a matching prebuilt binary."""
     import torch
     h = hashlib.sha256()
     h.update(torch.__version__.encode())
     for d in (os.path.join(CSRC, NODE_SOURCE), os.path.join(PKG_DIR, '..', 'include', 'gd3d.h')):
         with open(d, 'rb') as f:
             h.update(f.read())
-    h.update(repr(node_command('OUT')).encode())
+    h.update(repr(node_command('OUT', cxx='CXX')).encode())
     return h.hexdigest()
 
 
-def node_command(out):
+def node_command(out, cxx=None):
     import sysconfig
     import torch
     tdir = os.path.dirname(os.path.abspath(torch.__file__))
     tlib = os.path.join(tdir, 'lib')
-    return [host_cxx_path(), '-std=c++17', '-O2', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
+    return [cxx or host_cxx_path(), '-std=c++17', '-O2', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
             '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1', '-DTORCH_EXTENSION_NAME=_gd3d_node',
             f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}',
             '-isystem', os.path.join(tdir, 'include'), '-isystem', os.path.join(tdir, 'include', 'torch', 'csrc', 'api', 'include'),
@@ -179,6 +184,8 @@ def build_node(force=False, verbose=False):
     time (`bind`), so the two are built independently."""
     if not force and not node_is_stale():
         return NODE_PATH
+    if host_cxx_path() is None:
+        raise RuntimeError('the ROCm clang++ was not found: cannot build the optional C++ node (_gd3d_node.so)')
     tmp = f'{NODE_PATH}.{os.getpid()}.tmp'
     cmd = node_command(tmp)
     if verbose:

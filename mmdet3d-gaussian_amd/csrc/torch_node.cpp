@@ -1,5 +1,7 @@
-// torch_node.cpp — host glue above the C ABI, in C++: the autograd node of GDLoss's reduced forms (reduction 'mean' / 'sum'), and
-// the allocate-launch-read-back sequence of nms_gpu's scored path (nms_scored, at the end).
+// torch_node.cpp — OPTIONAL host glue above the C ABI, in C++: the autograd node of GDLoss's reduced forms (reduction 'mean' / 'sum'),
+// of the anchor-head slice and of scatter_reduce, and the allocate-launch-read-back sequence of nms_gpu's scored path (nms_scored, at
+// the end).  The package's first-class host layer is mmdet3d-gaussian_amd/_pynode.py (torch.autograd.Function + ctypes, same function
+// surface, bit-identical results); this module is an accelerator `_lib.load_node()` prefers when it builds (GD3D_HOST=python|cpp).
 //
 // Why this exists.  A training-size GDLoss call (64-4096 positives, gd_anchor3d_head.py:137-141) is one 6 us launch; as a
 // Python torch.autograd.Function it cost 15 us in forward and 35-60 us per call under backward(), of which 3.8 / 23-41 us
@@ -461,7 +463,10 @@ Tensor anchor_head(const Tensor& bbox_pred, const Tensor& bbox_targets, const c1
 // forward: vox_scatter_reduce over the grouped points (order / seg from scatter.group_points); backward: the voxel-ordered form for
 // rows of 128 bytes and more (c % 4 == 0, 32 <= c <= 256, aligned), the map-ordered gather otherwise — the choice scatter.py made.
 struct ScatterReduceBackward : public torch::autograd::Node {
-  Tensor pmap_, count_, argmax_, order_, seg_;
+  // the index tensors as SavedVariables: an in-place edit of the map or of a cached grouping between forward and backward is
+  // detected by version (as ctx.save_for_backward does in the Python glue), and a released graph raises torch's own message
+  torch::autograd::SavedVariable pmap_, count_, argmax_, order_, seg_;
+  bool has_argmax_ = false;
   int red_ = 0;
   int64_t n_ = 0, c_ = 0, v_ = 0;
   at::ScalarType in_dtype_ = at::kFloat;
@@ -469,27 +474,37 @@ struct ScatterReduceBackward : public torch::autograd::Node {
   std::string name() const override { return "GDScatterReduceBackward"; }
   void release_variables() override {
     std::lock_guard<std::mutex> lock(mutex_);
-    pmap_.reset(); count_.reset(); argmax_.reset(); order_.reset(); seg_.reset();
+    pmap_.reset_data(); count_.reset_data(); argmax_.reset_data(); order_.reset_data(); seg_.reset_data();
   }
   variable_list apply(variable_list&& grads) override {
     std::lock_guard<std::mutex> lock(mutex_);
-    variable_list out(1);
-    if (!grads[0].defined()) return out;
-    TORCH_CHECK(order_.defined(), "Trying to backward through the graph a second time (the scatter node's index tensors were freed)");
+    const bool twice = at::GradMode::is_enabled();   // create_graph=True
     at::AutoGradMode no_grad(false);
+    variable_list out(1);
+    const Tensor pmap = pmap_.unpack(), count = count_.unpack(), order = order_.unpack(), seg = seg_.unpack();
+    const Tensor argmax = has_argmax_ ? argmax_.unpack() : Tensor();
+    if (!grads[0].defined()) return out;
     const Tensor g = grads[0].contiguous().to(at::kFloat);
     c10::DeviceGuard device_guard(g.device());
     Tensor gf = at::empty({n_, c_}, g.options());
-    const int32_t* am = argmax_.defined() ? argmax_.data_ptr<int32_t>() : nullptr;
+    const int32_t* am = argmax.defined() ? argmax.data_ptr<int32_t>() : nullptr;
     void* stream = current_stream(g);
     int rc;
     if (c_ % 4 == 0 && c_ >= 32 && c_ <= 256 && ((uintptr_t)g.data_ptr() & 15) == 0)
-      rc = abi.scatter_backward_grouped(fp(g), order_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf),
+      rc = abi.scatter_backward_grouped(fp(g), order.data_ptr<int32_t>(), seg.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf),
                                         stream);
     else
-      rc = abi.scatter_backward(fp(g), pmap_.data_ptr<int32_t>(), count_.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf), stream);
+      rc = abi.scatter_backward(fp(g), pmap.data_ptr<int32_t>(), count.data_ptr<int32_t>(), am, n_, (int32_t)c_, v_, red_, fp(gf), stream);
     fail(rc, "vox_scatter_backward");
     out[0] = in_dtype_ == at::kFloat ? gf : gf.to(in_dtype_);
+    if (twice) {   // the gradient was written by a kernel: differentiating it again raises instead of treating it as a constant
+      Tensor a = out[0].detach();
+      a.set_requires_grad(true);
+      auto err = std::make_shared<torch::autograd::DelayedError>(
+          "trying to differentiate twice a function that was marked with @once_differentiable", (int64_t)1);
+      at::AutoGradMode grad_on(true);
+      return (*err)(variable_list{a});
+    }
     return out;
   }
 };
@@ -501,7 +516,8 @@ Tensor scatter_reduce(const Tensor& feats, const Tensor& pmap, const Tensor& cou
     TORCH_CHECK(t->scalar_type() == at::kInt && t->is_contiguous() && t->device() == feats.device(),
                 "scatter_reduce: map / count / order / seg must be contiguous int32 tensors on feats' device");
   const int64_t n = feats.size(0), c = feats.size(1), v = count.numel();
-  TORCH_CHECK(pmap.numel() == n && seg.numel() == v + 1 && red >= 0 && red <= 2, "scatter_reduce: inconsistent index tensors");
+  TORCH_CHECK(pmap.numel() == n && order.numel() == n && seg.numel() == v + 1 && red >= 0 && red <= 2,
+              "scatter_reduce: inconsistent index tensors");
   const bool need_grad = at::GradMode::is_enabled() && feats.requires_grad();
   std::shared_ptr<ScatterReduceBackward> node;
   if (need_grad) {
@@ -520,7 +536,11 @@ Tensor scatter_reduce(const Tensor& feats, const Tensor& pmap, const Tensor& cou
     result = feats.scalar_type() == at::kFloat ? out : out.to(feats.scalar_type());
   }
   if (node) {
-    node->pmap_ = pmap; node->count_ = count; node->argmax_ = argmax; node->order_ = order; node->seg_ = seg;
+    using torch::autograd::SavedVariable;
+    node->pmap_ = SavedVariable(pmap, false); node->count_ = SavedVariable(count, false);
+    node->order_ = SavedVariable(order, false); node->seg_ = SavedVariable(seg, false);
+    node->has_argmax_ = argmax.defined();
+    if (argmax.defined()) node->argmax_ = SavedVariable(argmax, false);
     node->red_ = (int)red; node->n_ = n; node->c_ = c; node->v_ = v; node->in_dtype_ = feats.scalar_type();
     torch::autograd::set_history(result, node);
   }

@@ -19,9 +19,8 @@ from copy import deepcopy
 
 import torch
 from torch import nn
-from torch.autograd.function import once_differentiable
-
 from . import _lib
+from ._pynode import guard_double_backward  # noqa: F401  (head_loss / heat_loss / anchor_cls import it from here)
 from .registry import LOSSES, register_with_mmdet
 
 LOSS_TYPES = {'gwd3d': 0, 'kld3d': 1, 'bd3d': 2, 'jd3d': 3, 'kld3d_symmax': 4, 'kld3d_symmin': 5, 'kfiou3d': 6}
@@ -60,20 +59,6 @@ class DispatchTimer:
             if h:
                 self._abi.gd3d_prof_event_destroy(h)
                 setattr(self, slot, None)
-
-
-def guard_double_backward(impl):
-    """The backward functions here return gradients that ctypes kernels wrote: no autograd graph hangs off them.  Under
-    `create_graph=True` (the only case in which grad mode is ON inside a backward) take torch's once_differentiable
-    route, which raises if that result is differentiated again instead of silently treating it as a constant; the plain
-    call otherwise, without the wrapper's per-call cost."""
-    guarded = once_differentiable(impl)
-
-    def backward(ctx, *grads):
-        if torch.is_grad_enabled():
-            return guarded(ctx, *grads)
-        return impl(ctx, *grads)
-    return backward
 
 
 def make_params(loss_type, fun, tau, alpha, center_offset, kwargs):
@@ -119,18 +104,11 @@ def _library():
     return _LIB
 
 
-_NODE = None
-
-
 def _node():
-    """csrc/torch_node.cpp: the reduced forms' autograd node in C++ (a Python autograd.Function costs 4 us per forward and
-    23-41 us per backward before it does anything: profiles/r04_small_p_latency.jsonl)."""
-    global _NODE
-    if _NODE is None:
-        _NODE = _lib.load_node()
-        for idx, t in _UNIT_GRAD.items():
-            _NODE.set_unit_grad(-1 if idx == 'cpu' else idx, t.data_ptr())
-    return _NODE
+    """The host glue the reduced forms go through (`_lib.load_node()`): _pynode.py — a torch.autograd.Function over ctypes — or
+    the optional C++ node of csrc/torch_node.cpp (a Python Function costs 4 us per forward and 23-41 us per backward before it
+    does anything: profiles/r04_small_p_latency.jsonl).  Same C ABI calls either way."""
+    return _lib.load_node()
 
 
 def _rows(t):
@@ -211,7 +189,7 @@ def unit_grad(device):
     t = _UNIT_GRAD.get(idx)
     if t is None:
         t = _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=dev if idx == 'cpu' else torch.device('cuda', idx))
-        _node().set_unit_grad(-1 if idx == 'cpu' else idx, t.data_ptr())   # the C++ node knows it by address too
+        _lib.register_unit_grad(-1 if idx == 'cpu' else idx, t.data_ptr())   # the glue (either one) knows it by address
     return t
 
 
@@ -266,8 +244,8 @@ def per_pair_call(params, pred, target, row_weight, scale, want_loss, want_gp, w
 
 
 def reduced_call(params, pred, target, row_weight, scale, prologue=None, select=False, want_flag=False):
-    """scale * sum_i w_i L_i as a 0-dim tensor whose autograd node (C++, csrc/torch_node.cpp) holds the final gradients the
-    SAME launch produced.  With `select` the value and the gradient are those of the reference's early-out
+    """scale * sum_i w_i L_i as a 0-dim tensor whose autograd node (_pynode.GDLossReduced, or its C++ twin in
+    csrc/torch_node.cpp) holds the final gradients the SAME launch produced.  With `select` the value and the gradient are those of the reference's early-out
     `(pred * weight).sum()` when no weight entry is > 0; `want_flag` also returns the int32 (1,) any-positive flag.
     Backward: the gradients are handed over, scaled by the upstream gradient on the device (gd3d_grad_finish) unless that is
     `unit_grad`; a second backward under retain_graph recomputes them; differentiating them again raises."""

@@ -70,9 +70,9 @@ def anchor_head_decoded_loss(loss_module, bbox_pred, bbox_targets, bbox_weights,
 def _anchor_head_fused(bbox_pred, bbox_targets, bbox_weights, anchors, pos_or_labels, params, dw, scale, dense=False,
                        num_classes=0, sl1=None):
     """selection / gather of the positives + decode x2 + loss(es) + gradient scatter into the NCHW head output: one launch,
-    behind the C++ autograd node of csrc/torch_node.cpp (`anchor_head`: the zero-filled-then-scattered gradient waits in the
-    node; backward hands it over, scaled on the device unless the upstream gradient is gd_loss.unit_grad; a second backward
-    under retain_graph launches again; differentiating the gradient raises).  `pos_or_labels` is either the (P,) int64
+    behind the host glue's `anchor_head` node (_pynode.GDAnchorHead, or its C++ twin in csrc/torch_node.cpp:
+    `_lib.load_node()`): the zero-filled-then-scattered gradient waits in the node; backward hands it over, scaled on the device unless the upstream gradient is gd_loss.unit_grad; a second backward
+    under retain_graph launches again; differentiating the gradient raises.  `pos_or_labels` is either the (P,) int64
     positive list (dense=False) or the (M,) int64 label map (dense=True); `scale` a float or, for a device-resident
     normaliser (dense form only), the tuple (avg_dev, gd_weight, sl1_weight)."""
     avg_dev, w_gd, w_sl1 = (scale if isinstance(scale, tuple) else (None, 0.0, 0.0))

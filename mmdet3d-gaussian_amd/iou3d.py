@@ -87,7 +87,8 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
     fused_sort = n_all <= _scored_max(lib) and scores.dim() == 1 and scores.dtype in (torch.float32, torch.float16,
                                                                                      torch.bfloat16)
     if fused_sort and scores.dtype == torch.float32 and scores.is_contiguous():
-        # the usual call: allocations, launch, count read-back and cut in the C++ glue (csrc/torch_node.cpp nms_scored)
+        # the usual call: allocations, launch, count read-back and cut in the host glue (`nms_scored` of _pynode.py or of its
+        # C++ twin csrc/torch_node.cpp: _lib.load_node())
         post = int(post_max_size) if (post_max_size is not None and post_max_size >= 0 and not padded) else -1
         keep, num = _lib.load_node().nms_scored(boxes, scores, float(thresh), n, bool(normal), bool(padded), post)
         if padded:

@@ -146,11 +146,12 @@ def group_points(point2voxel_map, voxel_points_count):
 
 
 def _scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce_type='max', grouping=None):
-    """The reduce with its autograd node in the C++ glue (csrc/torch_node.cpp `scatter_reduce`: forward vox_scatter_reduce over
-    the grouped points; backward the voxel-ordered form for rows of one 128-byte line and more (c % 4 == 0, 32 <= c <= 256:
+    """The reduce with its autograd node in the host glue (`_lib.load_node()`: _pynode.GDScatterReduce — the shape of the
+    reference's own `_ScatterReduce` Function, ops/voxel/scatter.py:29-72 — or its C++ twin in csrc/torch_node.cpp): forward
+    vox_scatter_reduce over the grouped points; backward the voxel-ordered form for rows of one 128-byte line and more (c % 4 == 0, 32 <= c <= 256:
     every gradient row read once and streamed to its points), the map-ordered gather for narrower rows (c = 10: 40 us against
-    118 us, profiles/r04_scatter_kernel_time.txt)).  As a Python autograd.Function the call was host-bound at 110 us
-    forward + backward below ~0.5 M points — slower than torch's index_add for `sum`."""
+    118 us, profiles/r04_scatter_kernel_time.txt).  With the Python glue the call is host-bound at ~110 us forward + backward
+    below ~0.5 M points, with the C++ node at ~70 us."""
     if not feats.is_cuda:
         raise RuntimeError('scatter_reduce: the MI355X implementation has no CPU path '
                            '(neither has the reference: voxelization.h:46)')

@@ -20,3 +20,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(params=('cpp', 'python'))
+def host_glue(request):
+    """Run the test once per host glue above the C ABI: the optional C++ node (csrc/torch_node.cpp) and the Python
+    torch.autograd.Function + ctypes layer (_pynode.py).  Same C ABI calls, same kernels: every expectation holds for both."""
+    from mmdet3d_gaussian_amd import _lib
+    _lib.set_host_glue(request.param)
+    assert _lib.host_glue() == request.param
+    yield request.param
+    _lib.set_host_glue(None)

@@ -21,7 +21,7 @@ def amd():
 
 
 @pytest.mark.parametrize('lt,kw', CASES)
-def test_center_head_gd_loss_vs_reference_golden(amd, lt, kw):
+def test_center_head_gd_loss_vs_reference_golden(amd, host_glue, lt, kw):
     """CenterGDHead loss_gd slice: reference coder.decode + GDLoss + autograd (fp32/fp64 golden) vs one fused launch."""
     g = np.load(GOLD)
     coder = amd.CenterPointBBoxYawCoder(pc_range=g['cfg_pc_range'].tolist(), out_size_factor=int(g['cfg_out_size_factor']),
@@ -64,7 +64,7 @@ def test_center_head_gd_loss_on_extreme_head_outputs_vs_reference_golden(amd):
 
 @pytest.mark.parametrize('lt', ['gwd3d', 'kld3d', 'bd3d'])
 @pytest.mark.parametrize('P', [1, 300, 5000])
-def test_anchor_decoded_loss_vs_oracle(amd, lt, P):
+def test_anchor_decoded_loss_vs_oracle(amd, host_glue, lt, P):
     """GDAnchor3DHead decoded branch: decode(anchors, pred) / decode(anchors, target) + GDLoss with decode_weight (P,7),
     avg_factor; one launch vs the fp64 oracle (coder restated, loss pinned)."""
     rng = np.random.default_rng(P)
@@ -105,7 +105,7 @@ def test_anchor_decoded_loss_on_extreme_encodings_vs_reference_golden(amd):
 
 
 @pytest.mark.parametrize('dense', [True, False])
-def test_anchor_head_gather_fused_on_extreme_encodings_vs_reference_golden(amd, dense):
+def test_anchor_head_gather_fused_on_extreme_encodings_vs_reference_golden(amd, host_glue, dense):
     """The gather-fused anchor-head kernel (its own decode path: head_anchor_kernel) on anchor_extreme.npz: the 48 rows are
     the 48 anchors of one 8 x 6 sample and exactly ONE of them is positive per call, so the reduced loss IS that positive's
     loss (loss_weight 1, num_total_samples 1, weights 1)."""
@@ -133,7 +133,7 @@ def test_anchor_head_gather_fused_on_extreme_encodings_vs_reference_golden(amd, 
         check_extreme(f'{lt}.dense{int(dense)}', loss, grow, g, lt)
 
 
-def test_anchor_head_slice_end_to_end(amd):
+def test_anchor_head_slice_end_to_end(amd, host_glue):
     """gd_anchor3d_head.py:95-141 from raw head tensors: permute/reshape, positive gather, decode_weight, fused loss;
     compared with the same slice assembled from the torch coder mirror + the plain (unfused) GDLoss."""
     torch.manual_seed(0)
@@ -166,7 +166,7 @@ def test_anchor_head_slice_end_to_end(amd):
 
 
 @pytest.mark.parametrize('lt,red', [('kld3d', 'mean'), ('gwd3d', 'mean'), ('bd3d', 'sum')])
-def test_anchor_head_gather_fused_matches_unfused_and_oracle(amd, lt, red):
+def test_anchor_head_gather_fused_matches_unfused_and_oracle(amd, host_glue, lt, red):
     """Gather + decode + loss + gradient scatter in ONE launch straight from the NCHW head output, vs (a) the
     torch-gather + fused-decode path and (b) the fp64 oracle on numpy-gathered rows."""
     torch.manual_seed(1)
@@ -240,7 +240,7 @@ SL1_CASES = [
 
 @pytest.mark.parametrize('dense', [True, False])
 @pytest.mark.parametrize('case', range(len(SL1_CASES)))
-def test_anchor_head_bbox_loss_full_regression_term(amd, case, dense):
+def test_anchor_head_bbox_loss_full_regression_term(amd, host_glue, case, dense):
     """loss_bbox of loss_single (:95-161) = GD on decoded boxes + SmoothL1/L1 on encoded boxes (add_sin_difference,
     code_weight), one launch, vs the fp64 torch restatement with autograd (oracle/head_torch.py)."""
     from oracle import head_torch
@@ -274,7 +274,7 @@ def test_anchor_head_bbox_loss_full_regression_term(amd, case, dense):
     assert gflat[~nz.cuda()].abs().max().item() == 0.0
 
 
-def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd):
+def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd, host_glue):
     """No positive anchor -> 0 with a zero gradient (:160); the encoded-box loss may be an mmdet-style module object."""
     anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(11)
 
@@ -296,7 +296,7 @@ def test_anchor_head_bbox_loss_no_positives_and_mmdet_like_module(amd):
                                   anchors.cuda(), C, 9.0)
 
 
-def test_anchor_head_bbox_loss_dense_replays_as_a_hipgraph(amd):
+def test_anchor_head_bbox_loss_dense_replays_as_a_hipgraph(amd, host_glue):
     """The dense form (label test inside the kernel) has static shapes and no host sync, so loss_bbox fwd + bwd can be
     captured once and replayed with new head outputs / labels in the same buffers: same bits as the eager call."""
     anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(3)
@@ -522,7 +522,7 @@ def test_device_center_coder_vs_reference_golden_and_autograd(amd):
         coder.decode(torch.zeros(1, 2), torch.zeros(1, 11))           # no CPU path
 
 
-def test_head_functions_second_backward_on_a_retained_graph(amd):
+def test_head_functions_second_backward_on_a_retained_graph(amd, host_glue):
     """the head-level nodes scale their saved gradient buffers in place; a second backward through the same
     node (retain_graph=True, upstream gradient != 1, e.g. an AMP loss scale) must recompute instead of scaling twice."""
     anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(21)
@@ -557,7 +557,7 @@ def test_head_functions_second_backward_on_a_retained_graph(amd):
         assert torch.equal(v.grad, first[k]), k
 
 
-def test_anchor_head_num_total_samples_none_is_the_batch_size(amd):
+def test_anchor_head_num_total_samples_none_is_the_batch_size(amd, host_glue):
     """loss_single substitutes int(cls_score.shape[0]) — the batch size — for num_total_samples=None
     (gd_anchor3d_head.py:85-86); the empty CenterGDHead slice returns a zero that still reaches `pred`."""
     anchors, bbox_pred, bbox_targets, bbox_weights, labels, C = _head_inputs(5)
@@ -644,7 +644,7 @@ def test_device_point_coder_vs_reference_golden(amd):
     assert coder.decode(priors[:0], p7[:0], correct_yaw=False).shape == (0, 200, 7)
 
 
-def test_anchor_head_node_guards_double_backward_in_place_edits_and_released_graphs(amd):
+def test_anchor_head_node_guards_double_backward_in_place_edits_and_released_graphs(amd, host_glue):
     """The anchor-head slice's autograd node lives in the C++ glue (csrc/torch_node.cpp `anchor_head`): like the loss node it hands
     out kernel-written gradients, so differentiating them again must raise; an in-place edit of the head output between forward
     and backward is detected (the node saved it for a possible replay); a released graph says so."""

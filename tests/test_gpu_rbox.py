@@ -25,7 +25,7 @@ def amd():
 @pytest.mark.parametrize('n,thr,clutter', [(1, 0.25, True), (2, 0.25, True), (63, 0.25, True), (64, 0.01, True),
                                            (65, 0.25, True), (129, 0.5, False), (1000, 0.2, True), (4096, 0.25, True),
                                            (4096, 0.01, False), (9000, 0.7, True), (20000, 0.5, True)])
-def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
+def test_nms_keep_indices_bit_exact(amd, host_glue, n, thr, clutter):
     boxes, scores = nms_boxes(n, seed=n + int(thr * 100), clutter=clutter)
     want = oracle.nms_gpu_oracle(boxes, scores, thr)
     got = amd.nms_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr)
@@ -34,7 +34,7 @@ def test_nms_keep_indices_bit_exact(amd, n, thr, clutter):
 
 
 @pytest.mark.parametrize('n,thr', [(8448, 0.6), (8449, 0.6), (12288, 0.3), (16384, 0.7)])
-def test_nms_two_level_scan_boundaries_bit_exact(amd, n, thr):
+def test_nms_two_level_scan_boundaries_bit_exact(amd, host_glue, n, thr):
     """n > 8448 takes the two-level scan (super-blocks of 4096 boxes resolved in turn, kept rows spread to the right by a
     chip-wide kernel): the last single-level size, the first two-level size, an exact multiple of the super-block and
     the rank-path maximum, against the CPU restatement."""
@@ -102,7 +102,7 @@ def test_batched_nms_empty_group_beyond_the_single_level_size(amd, mode):
         assert torch.equal(multi[2], single(bl[2], sl[2], 0.5))
 
 
-def test_nms_randomised_sweep_bit_exact(amd):
+def test_nms_randomised_sweep_bit_exact(host_glue, amd):
     """40 seeded random problems (size, threshold, clutter, extent, pre/post cuts drawn at random): keep indices equal to
     the CPU oracle in every one — the mask compaction, the register clipping path, the score ranking and the scan are
     all exercised at sizes that are not multiples of anything."""
@@ -123,7 +123,7 @@ def test_nms_randomised_sweep_bit_exact(amd):
         assert np.array_equal(got.cpu().numpy(), want), (case, n, thr, clutter, extent, pre, post)
 
 
-def test_nms_pre_post_cuts_and_alias(amd):
+def test_nms_pre_post_cuts_and_alias(host_glue, amd):
     boxes, scores = nms_boxes(3000, seed=1)
     b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     want = oracle.nms_gpu_oracle(boxes, scores, 0.2, pre_max_size=1000, post_max_size=83)   # nuScenes test_cfg
@@ -133,7 +133,7 @@ def test_nms_pre_post_cuts_and_alias(amd):
     np.testing.assert_array_equal(got2.cpu().numpy(), want)
 
 
-def test_nms_empty_and_identical_boxes(amd):
+def test_nms_empty_and_identical_boxes(host_glue, amd):
     e = amd.nms_gpu(torch.zeros(0, 5).cuda(), torch.zeros(0).cuda(), 0.5)
     assert e.shape == (0,) and e.dtype == torch.int64
     b = torch.tensor([[0, 0, 2, 1, 0.3]]).repeat(200, 1).cuda()
@@ -199,7 +199,7 @@ def _mask_words(amd, bs, thr):
     (833, 0.6, 'clutter'),      # ragged last block, just above the switch-over
     (767, 0.6, 'clutter'),      # ... and the largest set the one-kernel form still takes
 ])
-def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
+def test_nms_compacted_mask_paths_bit_exact(amd, host_glue, n, thr, kind):
     """The rotated mask kernels pack the pairs that survive the bounding-circle test densely before clipping them — inside one
     wave below 768 boxes (nms_mask_compact_kernel), through a queue in HBM between two kernels above: queue overflow / carry,
     8-64 rows per wave, the overflow list, and the thresholds for which a far-apart pair is NOT a non-hit must all give the
@@ -222,7 +222,7 @@ def test_nms_compacted_mask_paths_bit_exact(amd, n, thr, kind):
 @pytest.mark.parametrize('n,pre,normal', [(1, None, False), (63, None, False), (64, 10, False), (65, None, True), (1000, 500, False),
                                           (2049, None, False), (4096, None, False), (4096, 1000, True), (3000, 0, False),
                                           (9000, 4096, False), (16384, 2000, False), (16385, 2000, False)])
-def test_nms_fused_score_sort_equals_torch_sort_path(amd, n, pre, normal):
+def test_nms_fused_score_sort_equals_torch_sort_path(amd, host_glue, n, pre, normal):
     """Up to 16384 candidates the library orders the scores itself (rank by counting, prep scattered to the rank): the kept
     indices must equal those of the torch.sort(descending, stable) + rnms_*_ordered path, for ties, +-0, infinities and
     NaN scores too; one box more takes the torch.sort path inside nms_gpu."""
@@ -266,7 +266,7 @@ def test_nms_float64_scores_keep_torch_sort(amd):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
-def test_nms_normal(amd):
+def test_nms_normal(host_glue, amd):
     boxes, scores = nms_boxes(2000, seed=4)
     want = oracle.nms_gpu_oracle(boxes, scores, 0.3, normal=True)
     got = amd.nms_normal_gpu(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.3)
@@ -298,7 +298,7 @@ def test_eval_iou_large_matches_oracle(amd):
     assert amd.iou_bev(torch.zeros(0, 7).cuda(), torch.from_numpy(g).cuda()).shape == (0, 500)
 
 
-def test_nms_degenerate_geometry_bit_exact(amd):
+def test_nms_degenerate_geometry_bit_exact(host_glue, amd):
     """Zero-area, identical, shared-edge, nested, axis-aligned, huge and NaN boxes: no hang, no fault, and the same keep
     list as the oracle (the fp32 operation sequence is the same on both sides, also for garbage)."""
     rng = np.random.default_rng(3)
@@ -485,7 +485,7 @@ def test_box3d_multiclass_nms_matches_the_restated_loop(amd):
         assert gl.dtype == torch.int64 and np.array_equal(gl.cpu().numpy(), wl) and np.array_equal(gd.cpu().numpy(), wd)
 
 
-def test_nms_gpu_padded_is_sync_free_and_replays_as_a_hipgraph(amd):
+def test_nms_gpu_padded_is_sync_free_and_replays_as_a_hipgraph(host_glue, amd):
     """nms_gpu(..., padded=True): kept indices padded to the candidate count + a device count, no read-back: equal to the plain
     call, also from inside a captured graph on new boxes in the same buffers"""
     b0, s0 = nms_boxes(1500, seed=31)
@@ -612,7 +612,7 @@ def test_pairwise_matrix_offsets_beyond_2_31(amd):
     torch.cuda.empty_cache()
 
 
-def test_nms_at_the_maximum_size_closed_form(amd):
+def test_nms_at_the_maximum_size_closed_form(host_glue, amd):
     """n = 65 536 (RNMS_MAX_N): 32 768 separated sites on a 256 x 128 unit grid with two identical axis-aligned boxes each
     (all coordinates exact in fp32 and below 256).  Whatever the order, exactly the higher-scored box of every site
     survives, in descending score order.  One box more is refused, not truncated.
@@ -656,7 +656,7 @@ def test_nms_at_the_maximum_size_closed_form(amd):
 
 
 @pytest.mark.parametrize('n', [300, 5000, 20000])
-def test_nms_nan_and_infinite_scores_order_as_torch_sort(amd, n):
+def test_nms_nan_and_infinite_scores_order_as_torch_sort(amd, host_glue, n):
     """mmdet3d's nms_gpu orders with `scores.sort(0, descending=True)`: NaN first, then +inf ... -inf.  The library's own
     score ordering (n <= 16 384) and the torch.sort path above it do the same (stable among equals)."""
     b, s = nms_boxes(n, seed=4)
@@ -736,7 +736,7 @@ import nms_ref  # noqa: E402
 
 
 @pytest.mark.parametrize('name', nms_ref.SETS)
-def test_nms_keep_list_against_the_reference_derived_one(amd, name):
+def test_nms_keep_list_against_the_reference_derived_one(amd, host_glue, name):
     """nms_gpu against the greedy list that the reference's own compiled iou_bev implies (ops/eval/affinity.cpp:51-81 over
     rbox_utils.hpp:280-302; call site gd_centerpoint_head.py:336-345) on the box sets of the call sites: configs[4] 3 x 4096
     thr 0.25, nuScenes 1000 / 83 thr 0.2, PV-RCNN shapes thr 0.7 / 0.8.  Boxes whose decision (or a decision upstream of

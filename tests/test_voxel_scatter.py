@@ -107,7 +107,7 @@ def test_gpu_index_build_equals_the_aten_statement_and_the_oracle(n, ndim, dtype
 @pytest.mark.parametrize('n,c', [(1, 4), (257, 9), (5000, 10), (20000, 64), (3000, 130), (9000, 16), (7000, 128), (4000, 12), (60000, 3), (30000, 33),
                                  (5000, 127), (2000, 129), (1, 3)])
 @pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
-def test_gpu_scatter_reduce_forward_backward(n, c, red):
+def test_gpu_scatter_reduce_forward_backward(host_glue, n, c, red):
     import mmdet3d_gaussian_amd as amd  # noqa: F401
     from mmdet3d_gaussian_amd.scatter import Scatter
     coors, feats = _cloud(n, n + c, c=c)
@@ -137,7 +137,7 @@ def test_gpu_scatter_reduce_forward_backward(n, c, red):
 
 
 @pytest.mark.gpu
-def test_gpu_scatter_batched_coors_and_determinism():
+def test_gpu_scatter_batched_coors_and_determinism(host_glue):
     from mmdet3d_gaussian_amd.scatter import Scatter
     rng = np.random.default_rng(0)
     n = 8000
@@ -231,7 +231,7 @@ def test_gpu_scatter_feature_offsets_beyond_2_31(red):
 
 
 @pytest.mark.gpu
-def test_gpu_scatter_all_points_outside_and_single_voxel():
+def test_gpu_scatter_all_points_outside_and_single_voxel(host_glue):
     """Edge clouds: every point invalid (no voxel at all), and every point in ONE voxel (the longest possible segment)."""
     from mmdet3d_gaussian_amd.scatter import Scatter
     n, c = 5000, 16
@@ -262,7 +262,7 @@ def test_gpu_scatter_all_points_outside_and_single_voxel():
 @pytest.mark.gpu
 @pytest.mark.parametrize('c', [3, 10, 16])
 @pytest.mark.parametrize('red', ['sum', 'mean', 'max'])
-def test_gpu_narrow_rows_long_runs_and_same_bits_as_the_vector_kernels(c, red):
+def test_gpu_narrow_rows_long_runs_and_same_bits_as_the_vector_kernels(host_glue, c, red):
     """Rows that are not whole 16-byte vectors, and narrow rows, on a skewed cloud: three voxels hold 40 % of the points (runs of
     thousands of points; in the voxel-ordered backward several LDS tiles per workgroup), the rest are singletons and small
     voxels.  Every kernel visits a voxel's points in ascending point id: the c channels embedded in the first columns of a
@@ -312,7 +312,7 @@ def test_gpu_index_reports_key_overflow_and_out_of_range_coordinates():
 
 
 @pytest.mark.gpu
-def test_gpu_backward_with_its_zero_fill_replays_in_a_hipgraph():
+def test_gpu_backward_with_its_zero_fill_replays_in_a_hipgraph(host_glue):
     """The arg-max backward at narrow rows clears grad_feats and then routes the voxel gradients: the clear is a KERNEL of the
     library, not a hipMemsetAsync — a memset node of a captured graph was found not to be reliably ordered against the kernels
     around it on this ROCm (round 4, rotated NMS).  Five replays on a poisoned output buffer must equal the eager result; the
