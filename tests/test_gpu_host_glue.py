@@ -108,12 +108,11 @@ def test_nms_scored_is_bit_equal_between_the_glues(amd, n, thr, normal):
     c = rng.uniform(-40, 40, (n, 2)); wl = rng.uniform(0.8, 4.5, (n, 2))
     boxes = torch.from_numpy(np.concatenate([c - wl / 2, c + wl / 2, rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)).cuda()
     scores = torch.from_numpy(rng.uniform(0, 1, n).astype(np.float32)).cuda()
-    fn = amd.nms_normal_gpu if normal else amd.nms_gpu
 
     def run():
         from mmdet3d_gaussian_amd.iou3d import _nms
-        keep = fn(boxes, scores, thr)
-        cut = fn(boxes, scores, thr, pre_max_size=max(1, n // 2), post_max_size=5)
+        keep = amd.nms_normal_gpu(boxes, scores, thr) if normal else amd.nms_gpu(boxes, scores, thr)
+        cut = _nms(boxes, scores, thr, max(1, n // 2), 5, normal)
         pk, pn = _nms(boxes, scores, thr, None, 50, normal, padded=True)
         k = int(pn.item())
         return [keep, cut, pk[:k], pn]
