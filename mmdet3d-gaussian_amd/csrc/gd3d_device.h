@@ -436,10 +436,23 @@ GD_DEV float kl_fwd(const Box& q, const Box& r, float dX, float dY, float dZ, fl
   return fmaf(0.5f * ia2, xyz2, (fa + fb) + (fe + T));
 }
 
+// g (rho^2 - 1) of an extent ratio rho = r / q, from the accurately formed d = rho - 1.
+// Test hooks (defined by tools/build_variants.py only, never in the product build; profiles/r05_gate_bites.txt shows the parity
+// gates failing on them): GD_TEST_NAIVE_RATIO forms rho^2 - 1 the textbook way, which cancels on late-training (near-identical)
+// boxes; GD_TEST_PERTURB_KL_BWD=<eps> scales everything kl_bwd accumulates by (1 + eps).
+#ifdef GD_TEST_NAIVE_RATIO
+#define GD_RATIO_TERM(g, d, r, iq) ((g) * (((r) * (iq)) * ((r) * (iq)) - 1.0f))
+#else
+#define GD_RATIO_TERM(g, d, r, iq) ((g) * (d) * (2.0f + (d)))
+#endif
+
 // accumulates into gq (if GQ) and gr (if GR) with upstream g; c = cos(yaw_q - yaw_r)
 template <bool GQ, bool GR>
 GD_DEV void kl_bwd(const Box& q, const Box& r, float cq, float sq, float s, float c, float ia2, const KlI& k, float g,
                    Adj& gq, Adj& gr) {
+#ifdef GD_TEST_PERTURB_KL_BWD
+  g *= 1.0f + (float)(GD_TEST_PERTURB_KL_BWD);
+#endif
   const float gx = g * ia2;
   const float gu = gx * k.U * k.iaq, gv = gx * k.V * k.ibq;      // d/du, d/dv
   const float gDX = fmaf(cq, gu, -sq * gv), gDY = fmaf(sq, gu, cq * gv), gDZ = gx * k.W * k.ieq;
@@ -451,9 +464,9 @@ GD_DEV void kl_bwd(const Box& q, const Box& r, float cq, float sq, float s, floa
     gq.gZ += gDZ;
     gq.gr += fmaf(gu, k.v, fmaf(-gv, k.u, gsc));                  // u' = v, v' = -u under a turn of q
     const float t2 = g * s2 * k.dAr;                              // d T / d aq = s^2 (Ar-Br) / (Aq aq), d T / d bq = -(...)/(Bq bq)
-    gq.ga += k.iaq * (fmaf(t2, k.iaq * k.iaq, -g * k.da * (2.0f + k.da)) - gx * k.U * k.U);
-    gq.gb += k.ibq * (fmaf(-t2, k.ibq * k.ibq, -g * k.db * (2.0f + k.db)) - gx * k.V * k.V);
-    gq.ge += k.ieq * (-g * k.de * (2.0f + k.de) - gx * k.W * k.W);
+    gq.ga += k.iaq * (fmaf(t2, k.iaq * k.iaq, GD_RATIO_TERM(-g, k.da, r.a, k.iaq)) - gx * k.U * k.U);
+    gq.gb += k.ibq * (fmaf(-t2, k.ibq * k.ibq, GD_RATIO_TERM(-g, k.db, r.b, k.ibq)) - gx * k.V * k.V);
+    gq.ge += k.ieq * (GD_RATIO_TERM(-g, k.de, r.e, k.ieq) - gx * k.W * k.W);
   }
   if (GR) {
     gr.gX -= gDX;
@@ -461,9 +474,9 @@ GD_DEV void kl_bwd(const Box& q, const Box& r, float cq, float sq, float s, floa
     gr.gZ -= gDZ;
     gr.gr -= gsc;
     const float t3 = g * s2 * k.dAq * k.iAB2;                     // d T / d ar = s^2 ar (Aq-Bq)/(Aq Bq)
-    gr.ga += fmaf(g * k.da * (2.0f + k.da), frcp(r.a), t3 * r.a);  // d f / d ar = (rho^2 - 1) / ar
-    gr.gb += fmaf(g * k.db * (2.0f + k.db), frcp(r.b), -t3 * r.b);
-    gr.ge += g * k.de * (2.0f + k.de) * frcp(r.e);
+    gr.ga += fmaf(GD_RATIO_TERM(g, k.da, r.a, k.iaq), frcp(r.a), t3 * r.a);  // d f / d ar = (rho^2 - 1) / ar
+    gr.gb += fmaf(GD_RATIO_TERM(g, k.db, r.b, k.ibq), frcp(r.b), -t3 * r.b);
+    gr.ge += GD_RATIO_TERM(g, k.de, r.e, k.ieq) * frcp(r.e);
   }
 }
 

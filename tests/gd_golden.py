@@ -43,21 +43,33 @@ def families(with_ident=True):
     return f if with_ident else [x for x in f if x != 'ident']
 
 
-# ---------------------------------------------------------------- tolerance policy
-# north_star: "outputs match the reference within 1e-5 fp32".  The reference's own fp32
-# result differs from its fp64 result by up to ~2e-4 (loss) / O(0.1) (grad) on near-identical
-# boxes (catastrophic cancellation in whlr_distance, then sqrt), so a fixed 1e-5
-# is only meaningful where the reference itself is that accurate.  Policy, per element i of one
-# (case, input family):
-#     |ours_i - ref64_i| <= (TOL + YARD * max_j relerr_ref32_j) * (1 + scale_i)
-# with scale_i = |ref64_i| for losses and the row's max |grad| for gradients, and
-# relerr_ref32_j = |ref32_j - ref64_j| / (1 + scale_j) the reference's OWN fp32 error on that
-# family.  I.e. 1e-5 relative wherever the reference's fp32 is trustworthy (kitti / large / delta
-# families: max relerr_ref32 ~1e-6), and never asked to be more than YARD x closer to the truth
-# than the reference's own worst fp32 evaluation on the same inputs (near-identical family).
+# ---------------------------------------------------------------- tolerance
+# north_star: "outputs match the reference within 1e-5 fp32".
+#
+# THE PRODUCT (HIP kernels, their `_cpu` twins, the host build of the device math) is held to a FLAT bound against the
+# reference's fp64 run, on every input family of the golden vectors and on every seeded comfortable-regime comparison:
+#     |ours_i - ref64_i| <= FLAT * (1 + scale_i),   FLAT = 1e-5
+# with scale_i = |ref64_i| for losses and the row's max |grad64| for gradients.  Measured worst over the 422 golden
+# comparisons: 4.1e-6 (profiles/r04_accuracy_report.txt), so the gate sits 2.4x above what the kernels achieve — a
+# regression of the late-training accuracy (near-identical boxes: kl_bwd / bd<> cancellations) by 1e-4 relative fails
+# (profiles/r05_gate_bites.txt).  No sampling allowance anywhere except the loss VALUE on the `ident` family (identical
+# boxes: the value is sqrt(cancellation noise), the reference's own fp32 gives 0 .. ~1e-3 there).
+#
+# Exceptions, by name (REF32_EXCEPTIONS): comparisons where the reference's formula itself is ill-conditioned in fp32 on
+# the family, so that "the reference's fp64" is not what an fp32 evaluation of the reference's arithmetic can reach; there
+# the product must reproduce the reference's FP32 result to 1e-6 instead (kfiou3d with fun='nlog' on encoded-delta-like
+# boxes: -log(1 - d + 1e-7) at d -> 1; both the reference's fp32 and this kernel sit 1.5e-2 from fp64 and 2e-7 .. 8e-7 from
+# each other).
+#
+# THE OLD POLICY — (TOL + 3 x the reference's own worst fp32 error on the family) x (1 + scale) — remains for what is NOT the
+# product: the fp32 build of the C oracle (a plain fp32 port, as noisy as the reference's fp32), and as the ceiling of the
+# stress families (tests/gd_stress.py), whose inputs are ill-conditioned by construction.
+FLAT = 1e-5
 LOSS_TOL = 1e-5
 GRAD_TOL = 1e-5
 YARD = 3.0
+REF32_TOL = 1e-6
+REF32_EXCEPTIONS = frozenset({'kfiou3d.1.delta.loss', 'kfiou3d.1.delta.gp', 'kfiou3d.1.delta.gt'})
 
 
 def _scale(ref64, rowwise):
@@ -65,7 +77,7 @@ def _scale(ref64, rowwise):
     return a.max(axis=-1, keepdims=True) if rowwise else a
 
 
-def _bound(ref64, ref32, tol, rowwise):
+def _policy(ref64, ref32, tol, rowwise):
     ref64 = np.asarray(ref64, np.float64)
     ref32 = np.asarray(ref32, np.float64)
     sc = 1 + _scale(ref64, rowwise)
@@ -76,21 +88,38 @@ def _bound(ref64, ref32, tol, rowwise):
     return (tol + YARD * yard) * sc * np.ones_like(ref64)
 
 
-def loss_bound(l64, l32, tol=LOSS_TOL):
-    return _bound(l64, l32, tol, rowwise=False)
+def policy_loss_bound(l64, l32, tol=LOSS_TOL):
+    """1e-5 + 3 x the reference's own fp32 noise on the family: the fp32 ORACLE's gate (not the product's)."""
+    return _policy(l64, l32, tol, rowwise=False)
 
 
-def grad_bound(g64, g32, tol=GRAD_TOL):
-    return _bound(g64, g32, tol, rowwise=True)
+def policy_grad_bound(g64, g32, tol=GRAD_TOL):
+    return _policy(g64, g32, tol, rowwise=True)
 
 
-# Sampling allowance, ONLY where the reference's own fp32 evaluation is not trustworthy (the near-identical and identical
-# families: catastrophic cancellation, the yardstick there is a maximum over 128 noisy rows): up to FRAC_OUT of the
-# elements may lie between bound and HARD x bound; none beyond.  Everywhere else (kitti / large / delta families, seeded
-# oracle comparisons, head slices) the bound is strict: no element may exceed it.
+def _flat(ref64, rowwise, flat=FLAT, unit=1.0):
+    """flat x (unit + scale): `unit` is the loss_weight the compared quantities were multiplied by (the 1e-5 is stated for the
+    reference's per-pair output at loss_weight 1; a value near 0 computed at loss_weight 5 carries 5x the absolute rounding)."""
+    ref64 = np.asarray(ref64, np.float64)
+    return flat * (unit + _scale(ref64, rowwise)) * np.ones_like(ref64)
+
+
+def loss_bound(l64, l32=None):
+    """The product's gate: flat 1e-5 x (1 + |ref64|).  (`l32` is accepted for call-site symmetry and not used: the bound does
+    not widen with the reference's fp32 noise any more.)"""
+    return _flat(l64, rowwise=False)
+
+
+def grad_bound(g64, g32=None):
+    """The product's gate for gradients: flat 1e-5 x (1 + row max |grad64|)."""
+    return _flat(g64, rowwise=True)
+
+
+# Sampling allowance: ONLY for the loss value on the `ident` family (see above): up to FRAC_OUT of the elements may lie between
+# bound and HARD x bound; none beyond.
 FRAC_OUT = 0.002
 HARD = 4.0
-NOISY_FAMILIES = ('near', 'ident')
+NOISY_FAMILIES = ('ident',)
 
 # (name, max |ours - ref64| / (1 + scale), max |ours - ref32| / (1 + scale), max |ref32 - ref64| / (1 + scale)) rows
 # collected by check_close(..., report=...); tests/test_gpu_gd_loss.py writes them out as the accuracy report
@@ -128,12 +157,57 @@ def check_close(name, ours, ref64, bound, noisy=False, report=None):
                              f'bound={bound.flat[k]:.3e}')
 
 
+def check_golden(name, ours, ref64, ref32, rowwise, report=False):
+    """One golden comparison of the PRODUCT under the policy above: flat 1e-5 against the reference's fp64 — or, for the named
+    exceptions, 1e-6 against the reference's fp32."""
+    if name in REF32_EXCEPTIONS:
+        ref32 = np.asarray(ref32, np.float64)
+        if report:
+            REPORT.append((name, _relerr(ours, ref64, ref64, rowwise), _relerr(ours, ref32, ref64, rowwise),
+                           _relerr(ref32, ref64, ref64, rowwise)))
+        check_close(name + '[vs ref32]', ours, ref32, _flat(ref32, rowwise, REF32_TOL))
+        return
+    check_close(name, ours, ref64, _flat(ref64, rowwise), report=(ref32, rowwise) if report else None)
+
+
 def oracle32_bounds(pred, target, prm, ref64, scale):
-    """Tolerance for seeded inputs that have no reference-fp32 run: the fp32 build of the oracle (pinned to be as
-    accurate as the reference's fp32, test_oracle_gd.py) plays the yardstick role of ref32."""
-    import oracle
-    r32 = oracle.gd_loss(pred, target, prm, scale=scale, dtype=np.float32)
-    return (loss_bound(ref64['loss'], r32['loss']), grad_bound(ref64['grad_pred'], r32['grad_pred']))
+    """Bounds for seeded comfortable-regime inputs against the fp64 oracle: the product's flat gate.  (The name is historical:
+    the fp32 oracle used to widen them.)"""
+    unit = max(1.0, float(scale))
+    return _flat(ref64['loss'], False, FLAT, unit), _flat(ref64['grad_pred'], True, FLAT, unit)
+
+
+# Ceilings of the stress families (tests/gd_stress.py) whose inputs are ill-conditioned BY CONSTRUCTION (dims over 12 decades, or
+# clamped to 1e-7 thickness: the fp32 rounding of the inputs' own products already moves the fp64 answer by more than 1e-5 on
+# isolated rows, for ANY fp32 evaluation — the fp32 oracle measures 3e-4 .. 8e-3 there).  Bound = CAP x (1 + scale), strict (no
+# sampling allowance), CAP per (family: loss, grad) = ~3 x the worst the product measures over all loss types, both sizes the
+# suites use, HIP + `_cpu` twin + host build (profiles/r05_stress_accuracy.txt).  Families absent from the table — aspect, bigyaw,
+# farcentre, fardist, square, yaw90: worst 6e-6 — are held to the flat gate.
+STRESS_CAPS = {'hugedim': (1.5e-3, 5e-2), 'tinydim': (1e-4, 2e-2), 'negdim': (1e-4, 1e-4)}
+
+
+def stress_bounds(kind, pred, target, prm, ref64, scale):
+    cap = STRESS_CAPS.get(kind, (FLAT, FLAT))
+    return _flat(ref64['loss'], False, cap[0]), _flat(ref64['grad_pred'], True, cap[1])
+
+
+STRESS_REPORT = {}   # (who, kind) -> [worst loss relerr, worst grad relerr] over all loss types of the family
+
+
+def stress_report(who, kind, lt, fun, loss, grad, ref64):
+    e = STRESS_REPORT.setdefault((who, kind), [0.0, 0.0, '', ''])
+    el, eg = _relerr(loss, ref64['loss'], ref64['loss'], False), _relerr(grad, ref64['grad_pred'], ref64['grad_pred'], True)
+    if el > e[0]:
+        e[0], e[2] = el, f'{lt}.{fun}'
+    if eg > e[1]:
+        e[1], e[3] = eg, f'{lt}.{fun}'
+    path = os.environ.get('GD3D_STRESS_REPORT')
+    if path:
+        with open(path, 'w') as f:
+            f.write('# worst |ours - oracle64| / (1 + scale) per stress family (tests/gd_stress.py), over all loss types\n')
+            f.write(f'{"who":10s} {"family":10s} {"loss":>10s} {"at":22s} {"grad":>10s} {"at":22s} cap(loss, grad)\n')
+            for (w, k), v in sorted(STRESS_REPORT.items()):
+                f.write(f'{w:10s} {k:10s} {v[0]:10.2e} {v[2]:22s} {v[1]:10.2e} {v[3]:22s} {STRESS_CAPS.get(k, (FLAT, FLAT))}\n')
 
 
 # ---------------------------------------------------------------- non-finite / degenerate rows (gd_nonfinite.npz)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import oracle
-from gd_golden import (LOSS_TOL, NOISY_FAMILIES, NONFINITE_CASES, check_close, check_nonfinite, check_nonfinite_grad_rows, families,
+from gd_golden import (LOSS_TOL, NONFINITE_CASES, check_close, check_golden, check_nonfinite, check_nonfinite_grad_rows, families,
                        grad_bound, index, loss_bound, module, nonfinite, oracle32_bounds, pair_case_names, pairs)
 
 import mmdet3d_gaussian_amd as amd
@@ -47,14 +47,13 @@ def test_pairs_against_reference_golden(case):
             loss = mod(pred, tgt)
         key = f'{case}.{fam}'
         l64, l32 = g[key + '.loss64'], g[key + '.loss32']
-        noisy = fam in NOISY_FAMILIES
         if fam == 'ident':
             check_close(key + '.loss', loss.detach().numpy(), l64, np.maximum(loss_bound(l64, l32), 2e-3), noisy=True)
             continue
         loss.sum().backward()
-        check_close(key + '.loss', loss.detach().numpy(), l64, loss_bound(l64, l32), noisy)
-        check_close(key + '.gp', pred.grad.numpy(), g[key + '.gp64'], grad_bound(g[key + '.gp64'], g[key + '.gp32']), noisy)
-        check_close(key + '.gt', tgt.grad.numpy(), g[key + '.gt64'], grad_bound(g[key + '.gt64'], g[key + '.gt32']), noisy)
+        check_golden(key + '.loss', loss.detach().numpy(), l64, l32, False)
+        check_golden(key + '.gp', pred.grad.numpy(), g[key + '.gp64'], g[key + '.gp32'], True)
+        check_golden(key + '.gt', tgt.grad.numpy(), g[key + '.gt64'], g[key + '.gt32'], True)
 
 
 @pytest.mark.parametrize('case', sorted(index()['module']))
@@ -112,20 +111,21 @@ def test_against_fp64_oracle_ragged_sizes(lt, n):
 
 @pytest.mark.parametrize('kind', __import__('gd_stress').FAMILIES)
 def test_stress_families_against_fp64_oracle(kind):
-    from gd_stress import ILL_CONDITIONED, stress_pairs
+    from gd_golden import stress_bounds, stress_report
+    from gd_stress import stress_pairs
     p_np, t_np = stress_pairs(2048, kind, seed=1)
-    noisy = kind in ILL_CONDITIONED
     for lt in ALL_LOSSES:
         for fun, tau in ((('none', 0.0), ('expm1', 0.0)) if lt == 'kfiou3d' else (('log1p', 1.0), ('none', 0.0))):
             prm = oracle.make_params(lt, fun=fun, tau=tau)
             with np.errstate(all='ignore'):
                 ref = oracle.gd_loss(p_np, t_np, prm, scale=1.0)
-                lb, gb = oracle32_bounds(p_np, t_np, prm, ref, 1.0)
+                lb, gb = stress_bounds(kind, p_np, t_np, prm, ref, 1.0)
             p = _t(p_np).requires_grad_(True)
             out = amd.GDLoss(lt, fun=fun, tau=tau, reduction='none', loss_weight=1.0)(p, _t(t_np))
             out.sum().backward()
-            check_close(f'{kind}.{lt}.{fun}.loss', out.detach().numpy(), ref['loss'], lb, noisy)
-            check_close(f'{kind}.{lt}.{fun}.gp', p.grad.numpy(), ref['grad_pred'], gb, noisy)
+            stress_report('cpu_twin', kind, lt, fun, out.detach().numpy(), p.grad.numpy(), ref)
+            check_close(f'{kind}.{lt}.{fun}.loss', out.detach().numpy(), ref['loss'], lb)
+            check_close(f'{kind}.{lt}.{fun}.gp', p.grad.numpy(), ref['grad_pred'], gb)
 
 
 def test_nonfinite_and_degenerate_rows_vs_real_reference():
