@@ -19,8 +19,8 @@ VARIANTS = {'perturb': '-DGD_TEST_PERTURB_KL_BWD=1e-4', 'naive': '-DGD_TEST_NAIV
 SELECT = 'test_pairs_against_reference_golden and (kld3d or jd3d)'   # every loss that goes through kl_bwd
 
 
-def run(lib):
-    env = dict(os.environ, GD3D_HOST='python')
+def run(lib, report):
+    env = dict(os.environ, GD3D_HOST='python', GD3D_ACCURACY_REPORT=report)   # the child's report must not replace the suite's
     if lib:
         env['GD3D_LIB'] = lib
     else:
@@ -41,7 +41,7 @@ def main():
              '# against the product build and two deliberately damaged builds.  The damaged builds MUST fail.']
     ok = True
     for name, lib in [('product', None)] + [(k, os.path.join(ROOT, 'tools', 'variants', f'libgd3d_{k}.so')) for k in VARIANTS]:
-        rc, tail, fails = run(lib)
+        rc, tail, fails = run(lib, f'{out}.{name}.accuracy.txt')
         lines.append(f'{name:8s} ({VARIANTS.get(name, "as shipped")}): pytest rc={rc}: {tail}')
         fam = {}
         for key, nbad, ntot, err, bound in fails:
