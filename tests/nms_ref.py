@@ -137,3 +137,23 @@ def compare_keep(g, keep_idx, band=BAND):
     _, _, unc = uncertain(m, g['nz_i'], g['nz_j'], g['nz_iou'], g['thr'], band)
     dis = got != ref
     return int(unc.sum()), int((dis & ~unc).sum()), int(dis.sum())
+
+
+# The residue, pinned by identity (profiles/r04_nms_ref_crosscheck.txt): over all eight sets the keep list differs from the
+# reference-derived one in exactly ONE box — waymo2, score-order position 1617 (original index 1599), which this package DROPS
+# and the reference-derived list keeps: its pair (774, 1617) has reference IoU 0.24999867 <= 0.25 < 0.2500009 (ours); the fp64
+# clipping of the same fp32 boxes says 0.2500012, i.e. dropped.
+RESIDUE = {'waymo2': [(1617, 1599, False)]}   # set -> [(position in score order, original index, kept by this package)]
+
+
+def disagreements(g, keep_idx):
+    """[(position in score order, original index, kept by `keep_idx`)] of every box whose keep state differs from keep_ref."""
+    order = g['order']
+    m = len(order)
+    pos = np.full(len(g['scores']), -1, np.int64)
+    pos[order] = np.arange(m)
+    got = np.zeros(m, bool)
+    got[pos[np.asarray(keep_idx, np.int64)]] = True
+    ref = np.zeros(m, bool)
+    ref[g['keep_ref']] = True
+    return [(int(p), int(order[p]), bool(got[p])) for p in np.flatnonzero(got != ref)]
