@@ -31,9 +31,12 @@ profiles/r03_rccl_rehearsal_*.json: 425 us per step replayed, 432 us eager, agai
 collective).  HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the per-kernel durations
 come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says which),
 followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph` override.
-The step: three GDLoss forwards, then ONE torch.autograd.backward over the three losses whose upstream gradients are the
-library's unit-gradient constant (gd_loss.unit_grad): backward then launches nothing, because the fused forward launch
-already wrote the final gradients (a plain `loss.backward()` costs a ones-fill plus one early-exit launch per loss).
+The step (round 5): three GDLoss forwards, then a plain `(l0 + l1 + l2).backward()` — the form every caller of the reference
+runs (tools/train.py:213-220 -> mmcv's OptimizerHook: `loss.backward()`): torch adds the losses, fills a ones tensor, and each
+loss's node launches one early-exit `grad_finish` (the fused forward launch already wrote the final gradients).  `value` times
+THIS step.  Rounds 3-4 headlined the cheaper form beside it (`--unit-grad`, reported as `value_unit_grad`: one
+torch.autograd.backward over the three losses whose upstream gradients are the library's unit-gradient constant,
+gd_loss.unit_grad, recognised by address: backward launches nothing; ~10 us per step less).
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
 (python -m torch.distributed.run, 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank failed.
 
@@ -43,10 +46,11 @@ tensors through GDLoss's `_cpu` twins (tests/test_bench_rehearsal.py); the line 
 carries no roofline claim.
 
 The JSON line also carries
-  value_plain_backward, roofline.frac_step_plain_backward : the same step ending in a plain `(l0 + l1 + l2).backward()` (what
-                 every reference caller does: mmcv's OptimizerHook calls loss.backward()), timed over a second, shorter region
-                 right after the main one (N = 1, eager).  The headline step hands the library's unit gradient to
-                 torch.autograd.backward instead, which saves a ones-fill and three early-exit launches (~10 us per step).
+  value_form   : which step `value` times (plain backward unless --unit-grad) and how the inputs are allocated.
+  value_unit_grad, roofline.frac_step_unit_grad : the step handing the library's unit gradient to torch.autograd.backward
+                 (no ones-fill, no early-exit launches), timed over a second, shorter region right after the main one (eager).
+  value_plain_backward, roofline.frac_step_plain_backward : the plain-backward figures under their round-4 names (= `value` /
+                 `roofline.frac_step` unless --unit-grad swapped the regions).
   value_separate_inputs : the headline step again on inputs that are one torch allocation EACH (third region, N = 1, eager). The
                  main region's four input arrays are row ranges of ONE allocation: two read streams from separate allocations
                  collide in the memory system on some draws of their physical placement (5-8 % of the kernel time).
@@ -55,7 +59,10 @@ The JSON line also carries
                  every fused dispatch, on the stream it is launched on.  `frac` is that kernel alone;
                  `frac_step` prices the WHOLE timed step the same way (3 x 88 B x pairs / ms_per_step / peak:
                  SURVEY.md §8d's protocol, reduce launches and the backward call included).
-  cpu_baseline : the fp32 CPU oracle ("port") timed on this host's cores on a bounded sample.
+  cpu_baseline : the fp32 C oracle ("port") timed on this host's cores on a bounded sample; beside it `torch_chain` = the
+                 reference's OWN PyTorch-CPU op chain restated op for op (its time is the reference's time on this host; 1 k / 1 M /
+                 10 M pairs, 1 thread and all granted cores), `torch_chain_lean` = an entry-form rewrite 2.2-2.6x faster than
+                 that (not the reference's shape), `product_cpu` = this package's own CPU path (the `_cpu` twins).
 """
 import argparse
 import json
@@ -154,7 +161,10 @@ def cpu_baseline(sample_pairs, seed):
            'sample': f'{reps} pass(es) over {sample_pairs} pairs x 3 losses fwd+grad, fp32 C oracle '
                      f'(oracle/gd_oracle.c), OpenMP {cores} threads, {dt:.2f} s wall; single thread: {n1} pairs x 3 '
                      f'losses in {dt1:.2f} s'}
-    out['torch_chain'] = torch_chain_baseline(min(sample_pairs, 1_000_000), seed, cores)
+    # the reference's CPU path as PyTorch runs it: the literal op chain (= the reference's time), then the lean rewrite
+    big = [n for n in (10_000_000,) if sample_pairs >= 4_000_000]     # rehearsals with a small --cpu-sample stay small
+    out['torch_chain'] = torch_chain_baseline(seed, cores, True, [1000, min(sample_pairs, 1_000_000)] + big)
+    out['torch_chain_lean'] = torch_chain_baseline(seed, cores, False, [min(sample_pairs, 1_000_000)], budget_s=10.0)
     out['product_cpu'] = product_cpu_baseline(min(sample_pairs, 4_000_000), seed, cores)
     return out
 
@@ -203,30 +213,60 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def torch_chain_baseline(sample_pairs, seed, cores):
-    """SURVEY.md §8d CPU baseline (2): the op-for-op PyTorch-CPU statement of a1-a9 (oracle/gd_torch.py, checked against
-    the reference's golden vectors in tests/test_oracle_torch.py), forward + autograd backward, fp32, on this host with
-    torch.set_num_threads(1) and (all granted cores).  This is the shape of the reference's own CPU path: ~110-145 ATen
-    ops per loss call plus autograd."""
+def torch_chain_baseline(seed, cores, literal, sizes, budget_s=45.0):
+    """SURVEY.md §8d CPU baseline (2): the reference's CPU path as an eager PyTorch op chain with autograd, fp32, on this host with
+    torch.set_num_threads(1) and (all granted cores), forward + backward of the three losses.
+
+    literal=True : oracle/gd_torch.py `literal_gd_loss` — the reference's OWN chain op for op (stack / diag_embed / bmm on
+                   (N,2,2), the weighted_loss wrapper: 103 / 110 / 140 top-level ATen ops forward, the same count as the
+                   reference module; reproduces the reference's fp32 golden values bit for bit, tests/test_oracle_torch.py).
+                   Its time IS the reference's time on this host.  -> cpu_baseline.torch_chain
+    literal=False: `gd_loss` — an entry-form rewrite without (N,2,2) matrices or bmm: 2.2-2.6x faster than the reference's
+                   chain, NOT its shape; kept for continuity with earlier rounds.  -> cpu_baseline.torch_chain_lean
+    sizes: pairs per pass, ascending (1 k, 1 M, 10 M).  Small sizes repeat until ~0.3 s.  Bounded: a (size,
+    threads) cell is skipped (recorded as null with the reason) once the chain's share of the budget is spent."""
     from oracle import gd_torch
-    pred, tgt = synthetic_pairs(sample_pairs, seed, torch.device('cpu'))
-    res = {}
+    fn = gd_torch.literal_gd_loss if literal else gd_torch.gd_loss
+    res = {'unit': 'M box-pairs/s'}
     keep = torch.get_num_threads()
+    spent, skipped = 0.0, []
     try:
-        for label, nt in (('threads_1', 1), (f'threads_{cores}', cores)):
-            torch.set_num_threads(nt)
-            p = pred.clone().requires_grad_(True)
-            for lt in LOSSES:   # untimed warm pass on a slice
-                gd_torch.gd_loss(p[:50_000], tgt[:50_000], lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
-            t0 = time.perf_counter()
-            for lt in LOSSES:
-                p.grad = None
-                gd_torch.gd_loss(p, tgt, lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
-            res[label] = round(3 * sample_pairs / (time.perf_counter() - t0) / 1e6, 3)
+        for n in sizes:
+            pred, tgt = synthetic_pairs(n, seed, torch.device('cpu'))
+            cell = {}
+            for label, nt in ((f'threads_{cores}', cores), ('threads_1', 1)):
+                if spent >= budget_s:
+                    cell[label] = None
+                    skipped.append(f'{n} pairs {label}')
+                    continue
+                torch.set_num_threads(nt)
+                p = pred.clone().requires_grad_(True)
+                m = min(n, 50_000)
+                for lt in LOSSES:   # untimed warm pass on a slice
+                    fn(p[:m], tgt[:m], lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
+                reps, t0 = 0, time.perf_counter()
+                while True:
+                    for lt in LOSSES:
+                        p.grad = None
+                        fn(p, tgt, lt, fun='log1p', tau=1.0, loss_weight=5.0).backward()
+                    reps += 1
+                    dt = time.perf_counter() - t0
+                    if dt >= 0.3 or reps >= 200:
+                        break
+                spent += dt
+                cell[label] = round(3 * n * reps / dt / 1e6, 3)
+            res[f'pairs_{n}'] = cell
+            del pred, tgt
     finally:
         torch.set_num_threads(keep)
-    res['unit'] = 'M box-pairs/s'
-    res['sample'] = f'{sample_pairs} pairs x 3 losses, forward + autograd backward, fp32, eager PyTorch-CPU op chain (oracle/gd_torch.py)'
+    which = ('the reference\'s own op chain restated op for op (oracle/gd_torch.py literal_gd_loss: (N,2,2) stack / diag_embed / bmm + '
+             'weighted_loss wrapper)' if literal else 'entry-form rewrite without bmm (oracle/gd_torch.py gd_loss), 2.2-2.6x faster than '
+             'the reference\'s chain')
+    res['sample'] = (f'{" / ".join(str(n) for n in sizes)} pairs x 3 losses, forward + autograd backward, fp32, eager PyTorch-CPU: {which}; '
+                     f'{spent:.1f} s' + (f'; skipped (time bound): {", ".join(skipped)}' if skipped else ''))
+    if literal:
+        res['top_level_aten_ops_forward'] = {'gwd3d': 103, 'kld3d': 110, 'bd3d': 140, 'reference_module_same_count': [103, 110, 140],
+                                             'survey_8a': [106, 113, 143]}
     return res
 
 
@@ -377,8 +417,10 @@ def main():
     ap.add_argument('--separate-inputs', action='store_true',
                     help='one torch allocation per input array (target + one prediction leaf per loss) instead of row ranges of '
                          'ONE allocation: exposes the placement lottery of DESIGN.md 5.3')
-    ap.add_argument('--sum-backward', action='store_true',
-                    help="round 2's step: (l0 + l1 + l2).backward() instead of one autograd.backward with unit gradients")
+    ap.add_argument('--unit-grad', action='store_true',
+                    help="main region = rounds 3-4's step: one torch.autograd.backward over the three losses with the library's unit "
+                         'gradient (gd_loss.unit_grad) instead of the plain (l0 + l1 + l2).backward() every reference caller runs')
+    ap.add_argument('--sum-backward', action='store_true', help=argparse.SUPPRESS)   # the default since round 5
     ap.add_argument('--event-every', type=int, default=5,
                     help='eager launches: bind a HIP event pair to the fused dispatches of every N-th step of the timed region '
                          '(1 = every step as in round 2, which costs ~5 us of GPU time per timed launch; 0 = none in the '
@@ -436,8 +478,9 @@ def main():
             torch.cuda.synchronize(dev)
 
     import mmdet3d_gaussian_amd as amd
-    from mmdet3d_gaussian_amd import gd_loss as gdl
+    from mmdet3d_gaussian_amd import _lib as amd_lib, gd_loss as gdl
     amd.load_library()
+    host_glue = amd_lib.host_glue()
 
     _, n = shard_rows(args.pairs, rank, world, args.strong)
     pred0, tgt = synthetic_pairs(n, seed=rank, device=dev)
@@ -469,24 +512,33 @@ def main():
     last = {}
 
     unit = [gdl.unit_grad(dev)] * len(LOSSES)
+    rank_id = torch.full((), float(rank), dtype=torch.float32, device=dev)
 
-    def compute(record, plain=False):
+    main_plain = not args.unit_grad
+
+    def compute(record, plain=None):
         """gwd3d, kld3d, bd3d: GDLoss forward each, then ONE autograd backward over the three losses (every loss's fused
-        kernel has already produced its gradient; with the library's unit gradient as upstream gradient backward launches
-        nothing).  `plain`: end in `(l0 + l1 + l2).backward()` as the reference's callers do.  Returns the 3 detached loss
-        scalars (N > 1: stacked into the (3,) tensor the per-step collective sends — inside the captured graph)."""
+        kernel has already produced its gradient).  `plain` (the main region's form, round 5): end in `(l0 + l1 + l2).backward()` as
+        the reference's callers do (tools/train.py:213-220 -> mmcv's OptimizerHook): torch fills a ones tensor and each loss's
+        node launches one early-exit `grad_finish`.  Otherwise: torch.autograd.backward with the library's unit gradient as upstream
+        gradient, recognised by address — backward launches nothing.  Returns the 3 detached loss scalars (N > 1: stacked into the
+        (3,) tensor the per-step collective sends — inside the captured graph)."""
+        if plain is None:
+            plain = main_plain
         losses_ = []
         for lt in LOSSES:
             gdl.PROFILE_EVENTS = events[lt] if (record and on_gpu) else None
             preds[lt].grad = None
             losses_.append(mods[lt](preds[lt], cur['tgt']))
         gdl.PROFILE_EVENTS = None
-        if args.sum_backward or plain:
+        if plain:
             (losses_[0] + losses_[1] + losses_[2]).backward()
         else:
             torch.autograd.backward(losses_, grad_tensors=unit)
         outs = [l.detach() for l in losses_]
-        return torch.stack(outs) if use_dist else outs
+        # N > 1: the per-step payload is (4,): the three shard losses and THIS RANK'S ID — so that what the collective returns
+        # names the ranks that took part (`config.ranks_seen` is read from the last step's gather, not from WORLD_SIZE)
+        return torch.stack(outs + [rank_id]) if use_dist else outs
 
     graph = None
     graph_note = None
@@ -514,7 +566,7 @@ def main():
                 graph = None
                 graph_note = 'hipGraph capture failed on another rank; eager launches'
 
-    def step(record, plain=False):
+    def step(record, plain=None):
         if graph is None:
             outs = compute(record, plain)
         else:
@@ -645,14 +697,14 @@ def main():
     # (mmcv's OptimizerHook, set up from tools/train.py:213-220).  Eager launches only (a captured graph would need its own
     # capture of the other backward); same barrier + synchronize brackets and MAX over ranks as the main region.
     plain_steps = args.plain_steps if args.plain_steps >= 0 else max(10, args.steps // 2)
-    plain_elapsed = None
-    if graph is None and plain_steps > 0 and not args.sum_backward:
+    plain_elapsed = None      # elapsed time of the second region, which runs the OTHER backward form than the main region
+    if graph is None and plain_steps > 0:
         for _ in range(5):
-            step(False, plain=True)
+            step(False, plain=not main_plain)
         sync_all()
         tp = time.perf_counter()
         for _ in range(plain_steps):
-            step(False, plain=True)
+            step(False, plain=not main_plain)
         device_sync()
         if use_dist and not on_gpu:
             last['pending'].result()
@@ -662,7 +714,7 @@ def main():
     # rounds 1-3 and of a caller who does not carve its arrays from one allocation.  Its value moves with the physical placement
     # the process draws (70-74 G pairs/s); reported beside `value`, never as it.
     sep_elapsed = None
-    if graph is None and not use_dist and on_gpu and plain_steps > 0 and not args.separate_inputs and not args.sum_backward:
+    if graph is None and not use_dist and on_gpu and plain_steps > 0 and not args.separate_inputs:
         held = (cur['tgt'], dict(preds))
         cur['tgt'] = held[0].clone()
         for lt in LOSSES:
@@ -683,12 +735,29 @@ def main():
         step(False)
         device_sync()
 
+    first_row, _ = shard_rows(args.pairs, rank, world, args.strong)
+    mine = torch.tensor([float(rank), float(first_row), float(n)] + [kern_ms[lt] for lt in LOSSES], dtype=torch.float64, device=dev)
     if use_dist:
-        total, per_rank = last['pending'].result()   # (3,), (world, 3)
-        vals = (total / world).tolist()               # mean over ranks of per-rank means (equal shard sizes)
+        total, per_rank = last['pending'].result()   # (4,), (world, 4): the last timed-path step's gather
+        per_rank = per_rank.double().cpu()
+        vals = (total[:3] / world).tolist()           # mean over ranks of per-rank means (equal shard sizes)
+        ranks_seen = sorted(int(round(r)) for r in per_rank[:, 3].tolist())
+        per_rank_loss = [[round(v, 6) for v in row[:3]] for row in per_rank.tolist()]
+        # one more call of the SAME collective routine, after the timed regions: every rank's id, row range and fused-kernel means
+        facts = amd.sharded.gather_shard_losses(mine, async_op=False).result()[1].cpu()
     else:
         vals = [v.item() for v in last['outs']]
+        ranks_seen, per_rank_loss, facts = [0], [[round(v, 6) for v in vals]], mine.reshape(1, -1).cpu()
     losses = dict(zip(LOSSES, vals))
+    facts = facts[facts[:, 0].argsort()]
+    rank_rows = [[int(r[1]), int(r[1]) + int(r[2])] for r in facts.tolist()]      # [first, end) in the global numbering
+    kern_by_rank = facts[:, 3:]
+    rccl_version = None
+    if on_gpu and use_dist and backend == 'nccl':
+        try:
+            rccl_version = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rccl_version = f'unavailable ({type(e).__name__})'
 
     # The box's own ceiling for this access mix, measured in this process right after the timed region: z = x + y with
     # nontemporal 16-byte accesses over the fused kernel's OWN buffers (pred and target read, the gradient written:
@@ -738,15 +807,29 @@ def main():
                 except Exception:  # noqa: BLE001
                     traffic = None
             traffic_note = f'static: PMC passes of an earlier run of this command (profiles/traffic.json); {why}'
+        # the two backward forms: the main region ran one (`value`), the second region the other
+        other_value = round(job_value(args.pairs, world, args.strong, plain_steps, plain_elapsed), 2) if plain_elapsed else None
+        other_ms = round(plain_elapsed / plain_steps * 1e3, 4) if plain_elapsed else None
+        other_frac = (round(BYTES_PER_PAIR * n * len(LOSSES) / (plain_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
+                      if plain_elapsed else None)
+        main_ms, main_frac = round(elapsed / args.steps * 1e3, 4), round(step_gbps / HBM_PEAK_GBPS, 4)
+        by_form = {'plain': (round(value, 2), main_ms, main_frac, args.steps), 'unit': (other_value, other_ms, other_frac, plain_steps if plain_elapsed else 0)}
+        if not main_plain:
+            by_form = {'plain': by_form['unit'], 'unit': by_form['plain']}
         line = {
             'metric': 'M box-pairs/sec (fwd+bwd) for GWD/KLD/BCD @10M pairs',
+            # which step `value` times (round 5: the reference caller's form; rounds 3-4 headlined the unit-gradient form)
+            'value_form': ('plain (l0 + l1 + l2).backward(), as every reference caller runs it (tools/train.py:213-220 -> mmcv OptimizerHook)'
+                           if main_plain else 'torch.autograd.backward([l0, l1, l2], grad_tensors=[gd_loss.unit_grad] * 3)')
+                          + ('; inputs are row ranges of one allocation' if not args.separate_inputs else '; one allocation per input array'),
             'value': round(value, 2), 'unit': 'M box-pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             # the same step ending in a plain (l0 + l1 + l2).backward(), second region of `plain_backward_steps` steps
-            'value_plain_backward': round(job_value(args.pairs, world, args.strong, plain_steps, plain_elapsed), 2) if plain_elapsed else None,
-            'ms_per_step_plain_backward': round(plain_elapsed / plain_steps * 1e3, 4) if plain_elapsed else None,
-            'plain_backward_steps': plain_steps if plain_elapsed else 0,
+            'value_plain_backward': by_form['plain'][0], 'ms_per_step_plain_backward': by_form['plain'][1],
+            'plain_backward_steps': by_form['plain'][3],
+            # the same step with the library's unit gradient handed to torch.autograd.backward (backward launches nothing)
+            'value_unit_grad': by_form['unit'][0], 'ms_per_step_unit_grad': by_form['unit'][1], 'unit_grad_steps': by_form['unit'][3],
             # the unit-gradient step again on inputs that are one torch allocation each (third region, N = 1): placement lottery
             'value_separate_inputs': round(job_value(args.pairs, world, args.strong, plain_steps, sep_elapsed), 2) if sep_elapsed else None,
             'ms_per_step_separate_inputs': round(sep_elapsed / plain_steps * 1e3, 4) if sep_elapsed else None,
@@ -754,24 +837,33 @@ def main():
                                     if args.strong else
                                     f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
                                    'step = gwd3d + kld3d + bd3d, each GDLoss forward + backward over the whole batch '
-                                   + ('(one autograd backward() of the summed losses' if args.sum_backward else
+                                   + ('(one plain backward() of the summed losses' if main_plain else
                                       '(one torch.autograd.backward over the three losses, upstream gradients = gd_loss.unit_grad')
                                    + '; fun=log1p, tau=1, reduction=mean, loss_weight=5)',
                        'pairs_per_gpu': n, 'losses': list(LOSSES), 'parallelism': f'pair-sharded x{world}',
+                       # which host glue above the C ABI made the calls (mmdet3d-gaussian_amd/_lib.py: Python autograd.Function +
+                       # ctypes, or the optional C++ node; GD3D_HOST=python|cpp)
+                       'host_glue': host_glue,
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'prewarm_s': round(sum(prewarm_blocks), 2),
                        'input_allocation': 'one torch allocation per array' if args.separate_inputs else
                                            'target and the three prediction leaves are row ranges of one allocation',
                        'device': 'MI355X (HIP kernels)' if on_gpu else f'cpu (rehearsal: GDLoss _cpu twins, {torch.get_num_threads()} threads per rank; not the metric)',
-                       'collective': (f'all_gather of (3,) shard losses per step over {"RCCL" if backend == "nccl" else backend}, async') if use_dist else None,
+                       'collective': (f'all_gather of (4,) = 3 shard losses + the rank id per step over {"RCCL" if backend == "nccl" else backend}, async') if use_dist else None,
+                       # evidence that N ranks ran, from what the collective RETURNED (not from WORLD_SIZE): the rank ids and the per-rank
+                       # losses of the last step's gather; per-rank fused-kernel means and row ranges from one more gather after the regions
+                       'ranks_seen': ranks_seen, 'per_rank_loss': per_rank_loss,
+                       'per_rank_kernel_ms': {'max': {lt: round(float(kern_by_rank[:, k].max()), 4) for k, lt in enumerate(LOSSES)},
+                                              'min': {lt: round(float(kern_by_rank[:, k].min()), 4) for k, lt in enumerate(LOSSES)}},
+                       'per_rank_rows': rank_rows if (args.strong or world > 1) else None,
+                       'rccl_version': rccl_version,
                        'host_enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 4),
                        'graph_replay_ms_per_step': round(replay_ms, 4) if replay_ms is not None else None},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4),
                          # the whole timed step priced like the kernel (reduce launches and backward included)
                          'achieved_step': round(step_gbps, 1), 'frac_step': round(step_gbps / HBM_PEAK_GBPS, 4),
-                         'frac_step_plain_backward': (round(BYTES_PER_PAIR * n * len(LOSSES) / (plain_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
-                                                      if plain_elapsed else None),
+                         'frac_step_plain_backward': by_form['plain'][2], 'frac_step_unit_grad': by_form['unit'][2],
                          'traffic': traffic,
                          'traffic_source': traffic_note, 'traffic_by_loss': traffic_by_loss or None,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,

@@ -75,10 +75,23 @@ def test_two_ranks_under_the_drivers_launcher_weak_scaling():
     assert 'gloo' in d['config']['collective'] and d['config']['device'].startswith('cpu')
     # whole-job value: 3 losses x 20 000 pairs x 2 ranks x 4 steps over the max-over-ranks time
     assert abs(d['value'] - 3 * 20000 * 2 * 4 / (d['ms_per_step'] * 4e-3) / 1e6) <= 0.02 * d['value']
-    assert d['plain_backward_steps'] == 3 and d['value_plain_backward'] > 0
+    # round 5: `value` times the reference caller's step (plain backward); the unit-gradient form is the second region
+    assert d['value_form'].startswith('plain (l0 + l1 + l2).backward()')
+    assert d['plain_backward_steps'] == 4 and d['value_plain_backward'] == d['value']
+    assert d['unit_grad_steps'] == 3 and d['value_unit_grad'] > 0
+    assert d['config']['host_glue'] in ('python', 'cpp')
     want = _expected_losses(2, lambda rank: 20000)
     got = np.array([d['loss_values'][k] for k in ('gwd3d', 'kld3d', 'bd3d')])
     assert np.all(np.abs(got - want) <= 1e-5 * (1 + np.abs(want))), (got, want)
+    # the line proves its ranks from what the collective RETURNED: the rank ids travel in the per-step
+    # payload, the per-rank losses are the last step's (world, 3) stack
+    c = d['config']
+    assert c['ranks_seen'] == [0, 1] and c['rccl_version'] is None and 'rank id' in c['collective']
+    per = np.array(c['per_rank_loss'])
+    assert per.shape == (2, 3)
+    assert np.allclose(per.mean(0), want, rtol=1e-5) and not np.allclose(per[0], per[1])   # rank r's pairs are seeded with r
+    assert c['per_rank_rows'] == [[0, 20000], [20000, 40000]]
+    assert set(c['per_rank_kernel_ms']) == {'max', 'min'}
 
 
 def test_three_ranks_strong_scaling_contiguous_row_ranges():
@@ -88,6 +101,8 @@ def test_three_ranks_strong_scaling_contiguous_row_ranges():
     assert len(lines) == 1
     d = lines[0]
     assert d['scaling'] == 'strong' and d['n_gpus'] == 3 and d['config']['pairs_per_gpu'] == 30001 * 1 // 3
+    assert d['config']['ranks_seen'] == [0, 1, 2] and np.array(d['config']['per_rank_loss']).shape == (3, 3)
+    assert d['config']['per_rank_rows'] == [[0, 10000], [10000, 20000], [20000, 30001]]     # contiguous ranges [r N/G, (r+1) N/G)
     assert abs(d['value'] - 3 * 30001 * 4 / (d['ms_per_step'] * 4e-3) / 1e6) <= 0.02 * d['value']
 
 

@@ -122,3 +122,32 @@ def test_graph_replayed_step_with_async_gather(rccl_group):
         for lt in lts:
             assert torch.equal(ggrads[lt], wgrads[lt]), (rep, lt)
     torch.cuda.synchronize()
+
+
+def test_bench_line_proves_its_ranks_over_rccl():
+    """bench.py under the driver's launcher with ONE rank over RCCL (a child process; the card allows it next to this one):
+    the line's `config` carries what the collective RETURNED — rank ids that travelled in the per-step payload, the per-rank
+    loss stack, per-rank fused-kernel means — and the RCCL version; at N ranks the same fields are what proves N ranks ran
+    (tests/test_bench_rehearsal.py asserts them for 2 and 3 gloo ranks).  Launcher as /root/reference/tools/dist_train.sh:8-9."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--pairs', '1000000', '--steps', '5', '--warmup', '2',
+           '--prewarm', '0.2', '--cpu-sample', '0', '--no-traffic']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.lstrip().startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1
+    d, c = lines[0], lines[0]['config']
+    assert d['n_gpus'] == 1 and c['launch'] == 'hipGraph replay' and 'RCCL' in c['collective']
+    assert c['ranks_seen'] == [0] and len(c['per_rank_loss']) == 1 and len(c['per_rank_loss'][0]) == 3
+    assert all(abs(a - d['loss_values'][k]) <= 1e-5 for a, k in zip(c['per_rank_loss'][0], ('gwd3d', 'kld3d', 'bd3d')))
+    assert c['rccl_version'] and c['rccl_version'][0].isdigit() and '.' in c['rccl_version']
+    assert c['per_rank_kernel_ms']['max'] == c['per_rank_kernel_ms']['min'] and c['per_rank_kernel_ms']['max']['kld3d'] > 0
+    assert c['host_glue'] in ('python', 'cpp') and d['value_form'].startswith('plain')
