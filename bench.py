@@ -601,6 +601,14 @@ def main():
         tick[0] += 1
         return every > 0 and tick[0] % every == 0
 
+    # No cyclic garbage collection between here and the end of the timed regions: a generation-2 pass of the Python collector
+    # falling into a region stalls the host for ~0.14 s (measured, round 5: tools/scratch note in profiles/r05_step_variants.jsonl),
+    # the GPU idles, its clocks drop, and the steps that follow run 5-20 % slow for tens of steps — round 5's first runs caught one
+    # in the second region (0.485 ms per step instead of 0.406).  Collect NOW (before the pre-warm ramps the clocks), then keep the
+    # collector off until the regions are done; reference counting still frees every tensor at once.
+    import gc
+    gc.collect()
+    gc.disable()
     prewarm_blocks = []
     if args.prewarm > 0:
         # at least `--prewarm` seconds; on the GPU then on until two consecutive 20-step blocks agree to 1.5 % (at most 5 x as
@@ -737,6 +745,7 @@ def main():
 
     first_row, _ = shard_rows(args.pairs, rank, world, args.strong)
     mine = torch.tensor([float(rank), float(first_row), float(n)] + [kern_ms[lt] for lt in LOSSES], dtype=torch.float64, device=dev)
+    gc.enable()
     if use_dist:
         total, per_rank = last['pending'].result()   # (4,), (world, 4): the last timed-path step's gather
         per_rank = per_rank.double().cpu()

@@ -139,7 +139,7 @@ def test_bench_line_proves_its_ranks_over_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--pairs', '1000000', '--steps', '5', '--warmup', '2',
-           '--prewarm', '0.2', '--cpu-sample', '0', '--no-traffic']
+           '--prewarm', '0.2', '--cpu-sample', '0', '--no-traffic', '--graph']     # --graph: the launch mode of N > 1 ranks
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.lstrip().startswith('{') and '"metric"' in ln]

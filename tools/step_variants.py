@@ -7,6 +7,12 @@ moves every number of a process by up to 5 %, DESIGN.md §5.3, so only same-proc
   *_defer     : the reduce stage of every loss on a side stream (a `deferred_sums` context that existed in gd_loss.py for
                 this measurement only: 25-60 us per step SLOWER eagerly and as a graph, removed; profiles/r03_step_variants.jsonl)
   eager / graph : launched per step / one hipGraph replay per step
+  round 5, what the three early-exit grad_finish launches of the plain step cost, under the PYTHON glue so that
+  the launch can be intercepted (MEASUREMENT ONLY: both hacks return wrong gradients whenever the upstream gradient is not 1):
+  sum_bwd_py            : the plain step through the Python glue (the like-for-like base of the next two)
+  sum_bwd_py_no_finish  : every 0-dim upstream gradient treated as the unit gradient -> no grad_finish launch at all: the UPPER
+                          BOUND of what any coalescing of the three launches could save
+  sum_bwd_py_one_finish : only the first node of each backward launches grad_finish: the launch count a coalesced form would have
 
 Prints one JSON line per variant: us per step (wall, 60 steps after 10 warm-ups) and the loss values (must agree)."""
 import json
@@ -54,6 +60,26 @@ def main():
         return [l.detach() for l in ls]
 
     variants = [('sum_bwd', lambda: step_sum()), ('unit_bwd', lambda: step_unit())]
+    from mmdet3d_gaussian_amd import _lib, _pynode
+    real_is_unit = _pynode._is_unit_grad
+
+    def with_python_glue(fn, hack):
+        def run():
+            _lib.set_host_glue('python')
+            calls = [0]
+
+            def one(g):
+                calls[0] += 1
+                return real_is_unit(g) or calls[0] % 3 != 1
+            _pynode._is_unit_grad = {'none': real_is_unit, 'no_finish': lambda g: True, 'one_finish': one}[hack]
+            try:
+                return fn()
+            finally:
+                _pynode._is_unit_grad = real_is_unit
+                _lib.set_host_glue(None)
+        return run
+    variants += [('sum_bwd_py', with_python_glue(step_sum, 'none')), ('sum_bwd_py_no_finish', with_python_glue(step_sum, 'no_finish')),
+                 ('sum_bwd_py_one_finish', with_python_glue(step_sum, 'one_finish')), ('unit_bwd_py', with_python_glue(step_unit, 'none'))]
     if hasattr(gdl, 'deferred_sums'):
         variants += [('sum_bwd_defer', lambda: step_sum(True)), ('unit_bwd_defer', lambda: step_unit(True))]
 
@@ -80,7 +106,7 @@ def main():
             us, host, outs = timed(fn)
             print(json.dumps({'variant': name, 'launch': 'eager', 'rep': rep, 'us_per_step': round(us, 1),
                               'host_us': round(host, 1), 'losses': [round(o.item(), 6) for o in outs]}), flush=True)
-        for name, fn in variants:
+        for name, fn in variants[:2]:
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
