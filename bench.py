@@ -609,6 +609,16 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # Both backward forms once, BEFORE the clocks are ramped: the first torch.autograd.backward(..., grad_tensors=...) of a process
+    # spends ~0.14 s of host time in one-time work inside torch (measured, round 5); left to happen in the second region's warm-up
+    # steps it idles the GPU, the clocks drop, and that region and the next run 10-20 % slow (0.46-0.49 ms per step instead of 0.41).
+    if graph is None:
+        for form in (not main_plain, main_plain):
+            for _ in range(2):
+                step(False, plain=form)
+        device_sync()
+        if use_dist and not on_gpu:
+            last['pending'].result()
     prewarm_blocks = []
     if args.prewarm > 0:
         # at least `--prewarm` seconds; on the GPU then on until two consecutive 20-step blocks agree to 1.5 % (at most 5 x as
