@@ -147,7 +147,10 @@ __global__ __launch_bounds__(T) void cls_dir_kernel(const Args a) {
         const float d0 = a.dir[o0], d1 = a.dir[o1];
         const long long k = a.dir_t[n];
         const float dw = a.dir_w[n];
-        const float z = k == 0 ? d1 - d0 : d0 - d1;              // logit of the wrong bin minus logit of the right one
+        // a direction target outside [0, 2) on a positive anchor: F.cross_entropy raises in the reference (a device-side assert on
+        // the GPU); the sync-free analogue here is a NaN direction loss and NaN direction gradients for that anchor — loud in
+        // the first step instead of a silently finite "bin 1" 
+        const float z = (k == 0 ? d1 - d0 : d0 - d1) + ((k == 0 || k == 1) ? 0.0f : __builtin_nanf(""));   // wrong bin minus right bin
         const float e = expf(-fabsf(z));
         ld += (fmaxf(z, 0.0f) + log1pf(e)) * dw;                 // logsumexp(d) - d[k] = softplus(z)
         const float r = 1.0f / (1.0f + e);

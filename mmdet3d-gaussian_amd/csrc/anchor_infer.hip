@@ -6,8 +6,9 @@
 // (third party, absent; restated from the published 0.x text by the test infrastructure): per sample ~100 framework
 // launches and two host syncs per class around `nms_gpu` (BASELINE configs[4]: Waymo PointPillars, 3 x 4096 boxes).
 // Here, for all samples of the batch:
-//   anchor_score_kernel   best class logit of every anchor, in the reference's anchor order (h, w, a): sigmoid is monotonic,
-//                         so the nms_pre selection needs no sigmoid and the class maps are never permuted or copied;
+//   anchor_score_kernel   fp32 sigmoid of the best class logit of every anchor, in the reference's anchor order (h, w, a): the
+//                         nms_pre selection ranks what the reference ranks (saturated scores tie, ties go by index); the class
+//                         maps are never permuted or copied;
 //   center_infer_select   (center_infer.hip) the nms_pre best anchors per sample and level;
 //   anchor_gather_kernel  per selected anchor: its C class scores (sigmoid), direction bin, the 7 deltas and its anchor ->
 //                         DeltaXYZWLHR decode in the reference's fp32 operation order, the BEV box for the NMS, and the
@@ -45,7 +46,11 @@ __global__ __launch_bounds__(T) void anchor_score_kernel(const ScoreArgs a) {
       const float v = base[(size_t)(an * a.C + c) * a.HW];
       m = (v > m || v != v) ? v : m;      // torch.max propagates NaN
     }
-    o[an] = m;
+    // ranked on the fp32 SIGMOID of the best logit, as the reference's `scores.max(dim=1)` is (anchor3d_head get_bboxes_single):
+    // logits that saturate to the same fp32 score (x > ~17, or strongly negative) are TIES there, and the selection breaks ties
+    // by index — ranking on the raw logit would order them strictly and move the nms_pre boundary.  Same expression
+    // as the gather kernel's class scores below; a rounded monotone function of m, so unsaturated logits keep their order.
+    o[an] = (m != m) ? m : 1.0f / (1.0f + expf(-m));
   }
 }
 

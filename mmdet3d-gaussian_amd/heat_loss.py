@@ -36,13 +36,12 @@ def _tasks(logits, targets, grads):
 
 class _HeatFocal(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, targets, *logits):
+    def _launch(cfg, xs, targets, need):
+        """One gd3d_heat_focal_loss launch set -> (per-task gradient maps | None, out (3, T): losses, factors, num_pos)."""
         lib = _lib.load()
         alpha, gamma, weight = cfg
-        T = len(logits)
-        dev = logits[0].device
-        need = [bool(ctx.needs_input_grad[2 + t]) for t in range(T)]
-        xs = [x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous() for x in logits]
+        T = len(xs)
+        dev = xs[0].device
         with torch.cuda.device(dev):
             grads = [torch.empty_like(x) if nd else None for x, nd in zip(xs, need)]
             arr = _tasks(xs, targets, grads)
@@ -51,7 +50,14 @@ class _HeatFocal(torch.autograd.Function):
             _lib.check(lib.gd3d_heat_focal_loss(arr, T, alpha, gamma, CLIP_EPS, LOG_EPS, weight, out[0].data_ptr(), out[1].data_ptr(),
                                                 out[2].data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
                        'gd3d_heat_focal_loss')
-        ctx.state = (xs, targets, grads, out, [x.dtype for x in logits], [x.shape for x in logits])
+        return grads, out
+
+    @staticmethod
+    def forward(ctx, cfg, targets, *logits):
+        need = [bool(ctx.needs_input_grad[2 + t]) for t in range(len(logits))]
+        xs = [x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous() for x in logits]
+        grads, out = _HeatFocal._launch(cfg, xs, targets, need)
+        ctx.state = (cfg, xs, targets, grads, out, need, [x.dtype for x in logits], [x.shape for x in logits])
         ctx.used = False
         losses, num_pos = out[0], out[2]
         ctx.mark_non_differentiable(num_pos)
@@ -61,10 +67,11 @@ class _HeatFocal(torch.autograd.Function):
     @guard_double_backward
     def backward(ctx, grad_losses, _grad_num_pos):
         lib = _lib.load()
-        xs, targets, grads, out, dtypes, shapes = ctx.state
-        if ctx.used:
-            raise RuntimeError('center_head_heatmap_loss: the gradient maps were scaled in place by the first backward; '
-                               'call the loss again instead of retain_graph')
+        cfg, xs, targets, grads, out, need, dtypes, shapes = ctx.state
+        if ctx.used:   # retain_graph replay: the maps of the first backward were scaled in place and handed over: launch again,
+            grads, out = _HeatFocal._launch(cfg, xs, targets, need)   # as the loss / anchor-head / centre-head nodes do
+        else:
+            ctx.state = (cfg, xs, targets, None, None, need, dtypes, shapes)
         ctx.used = True
         T = len(xs)
         with torch.cuda.device(xs[0].device):

@@ -46,7 +46,7 @@ def main():
 
         def ours():
             cls.grad = dirs.grad = None
-            a, b = amd.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, C, avg)
+            a, b = amd.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, C, avg)
             (a + b).backward()
             return a, b
 
@@ -64,7 +64,7 @@ def main():
         assert (gd - dirs.grad).abs().max().item() <= 1e-4 * dirs.grad.abs().max().item() + 1e-9
         t_ours, t_eager = timeit(ours, 50), timeit(eager, 10)
         with torch.no_grad():
-            t_fwd = timeit(lambda: amd.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, C, avg), 50)
+            t_fwd = timeit(lambda: amd.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, C, avg), 50)
         n = B * H * W * A
         algo = n * C * 8 + n * 2 * 4 + n * 12           # class logits in + gradients out, direction gradients out, label + weight
         print(json.dumps(dict(geometry=name, batch=B, anchors_per_sample=H * W * A, classes=C, ours_fwd_bwd_us=round(t_ours, 1),
@@ -89,7 +89,7 @@ def whole():
         t.requires_grad_(True)
 
     def fn(cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors):
-        return amd.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors, avg)
+        return amd.extras.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors, avg)
     args = (cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors)
 
     def ours():

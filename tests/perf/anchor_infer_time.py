@@ -69,14 +69,14 @@ def main():
             ('KITTI 248x216x6, nms_pre 4096, max_num 100', (4, 248, 216), dict(use_rotate_nms=True, nms_pre=4096, nms_thr=0.01, score_thr=0.05, max_num=100), 0.0, 1.0),
             ('Waymo 468x468x6, nms_pre 4096, max_num 500', (1, 468, 468), dict(use_rotate_nms=True, nms_pre=4096, nms_thr=0.25, score_thr=0.1, max_num=500), 0.7854, 0.0)):
         cls, bbox, dirs, anchors = [t.to(dev) for t in head_outputs(g, B, 6, 3, H, W, scene=150.0)]
-        ours = amd.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim)
+        ours = amd.extras.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim)
         ref = [eager_single(cls[b], bbox[b], dirs[b], anchors, cfg, 3, doff, dlim) for b in range(B)]
         for o, r in zip(ours, ref):
             assert o[0].shape == r[0].shape, (o[0].shape, r[0].shape)
             torch.testing.assert_close(o[0], r[0], rtol=1e-5, atol=1e-5)
             assert torch.equal(o[2], r[2])
-        us_a = timeit(lambda: amd.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim), 50)
-        us_p = timeit(lambda: amd.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim, padded=True), 100)
+        us_a = timeit(lambda: amd.extras.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim), 50)
+        us_p = timeit(lambda: amd.extras.anchor_head_get_bboxes([cls], [bbox], [dirs], [anchors], cfg, 3, doff, dlim, padded=True), 100)
         us_b = timeit(lambda: [eager_single(cls[b], bbox[b], dirs[b], anchors, cfg, 3, doff, dlim) for b in range(B)], 5, warm=1)
         print(json.dumps(dict(what=f'anchor head get_bboxes, {name}, batch {B}', detections=[int(o[0].shape[0]) for o in ours],
                               ours_us=round(us_a, 1), ours_padded_no_readback_us=round(us_p, 1), eager_us=round(us_b, 1))), flush=True)

@@ -43,12 +43,12 @@ def main():
     anchors = kitti_anchors(H, W).to(dev)
     pairs = [random_gt(G, seed=100 + i, with_ignored=False) for i in range(B)]
     gts, labels = [p[0].to(dev) for p in pairs], [p[1].to(dev) for p in pairs]
-    ours = lambda: amd.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3)          # noqa: E731
+    ours = lambda: amd.extras.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3)          # noqa: E731
     eager = lambda: ORA.anchor_target_3d(anchors, gts, labels, KITTI_ASSIGNERS, 3)                # noqa: E731
     a, e = ours(), eager()
     assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and a[6] == e[6] and a[7] == e[7]
     t_o, t_e = timeit(ours, 30), timeit(eager, 3, warm=1)
-    t_p = timeit(lambda: amd.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3, padded=True), 30)
+    t_p = timeit(lambda: amd.extras.anchor_head_get_targets(anchors, gts, labels, KITTI_ASSIGNERS, 3, padded=True), 30)
     print(json.dumps(dict(step='anchor_target_3d', geometry='kitti', batch=B, anchors_per_sample=H * W * 6, boxes_per_sample=G, positives=a[6],
                           ours_us=round(t_o, 1), ours_no_readback_us=round(t_p, 1), reference_ops_on_gpu_us=round(t_e, 1),
                           speedup=round(t_e / t_o, 1))), flush=True)
@@ -58,7 +58,7 @@ def main():
     gt_t, gl_t = torch.stack(gts), torch.stack(labels)
 
     def fn(cls, bbox, dirs, gt, gl, static=True):
-        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), static=static)
+        r = amd.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), static=static)
         return r['loss_cls'][0], r['loss_bbox'][0], r['loss_dir'][0]
 
     def run(static):
@@ -102,7 +102,7 @@ def waymo():
         box = torch.cat([torch.rand(G, 2, generator=g) * 140 - 70, torch.zeros(G, 1), sz, (torch.rand(G, 1, generator=g) * 2 - 1) * 3.14159], dim=-1)
         gts.append(box.to(dev))
         labels.append(lab.to(dev))
-    ours = lambda: amd.anchor_head_get_targets(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)          # noqa: E731
+    ours = lambda: amd.extras.anchor_head_get_targets(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)          # noqa: E731
     eager = lambda: ORA.anchor_target_3d(anchors, gts, labels, cfgs, 3, assign_per_class=False, dir_offset=0.7854)                # noqa: E731
     a, e = ours(), eager()
     assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and torch.equal(a[4], e[4]) and a[6] == e[6] and a[7] == e[7]
@@ -117,7 +117,7 @@ def waymo():
     gt_t, gl_t = torch.stack(gts), torch.stack(labels)
 
     def fn(cls, bbox, dirs, gt, gl, static=True):
-        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), assign_per_class=False,
+        r = amd.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), assign_per_class=False,
                                     dir_offset=0.7854, static=static)
         return r['loss_cls'][0], r['loss_bbox'][0], r['loss_dir'][0]
 

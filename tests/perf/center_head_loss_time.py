@@ -48,7 +48,7 @@ def main():
     chans = (('heatmap', None), ('reg', 2), ('height', 1), ('dim', 3), ('yaw', 1), ('dir', 2), ('vel', 2))
     pds = [{k: (torch.randn(B, c if c else len(names), 128, 128, generator=g) * 0.5 - (2.0 if c is None else 0.0)).to(dev).requires_grad_(True)
             for k, c in chans} for names in TASKS]
-    hm, an, pi = amd.center_head_get_targets(gb, gl, TASKS, cfg)
+    hm, an, pi = amd.extras.center_head_get_targets(gb, gl, TASKS, cfg)
 
     def zero():
         for p in pds:
@@ -57,7 +57,7 @@ def main():
 
     def heat_ours():
         zero()
-        l, _ = amd.center_head_heatmap_loss(cls, [p['heatmap'] for p in pds], hm)
+        l, _ = amd.extras.center_head_heatmap_loss(cls, [p['heatmap'] for p in pds], hm)
         l.sum().backward()
 
     def heat_eager():
@@ -77,11 +77,11 @@ def main():
     big_t = [torch.rand(64, len(names), 128, 128, generator=g).to(dev) ** 6 for names in TASKS]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        amd.center_head_heatmap_loss(cls, big_x, big_t)
+        amd.extras.center_head_heatmap_loss(cls, big_x, big_t)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(20):
-        amd.center_head_heatmap_loss(cls, big_x, big_t)
+        amd.extras.center_head_heatmap_loss(cls, big_x, big_t)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
@@ -91,7 +91,7 @@ def main():
 
     def full_ours():
         zero()
-        out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds)
+        out = amd.extras.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds)
         sum(out.values()).backward()
 
     def full_eager():
@@ -111,14 +111,14 @@ def main():
     # static form: nothing is read back (row offsets and num_pos stay on the device), so the whole method can be captured
     def full_static():
         zero()
-        out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds, static=True)
+        out = amd.extras.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, gb, gl, pds, static=True)
         sum(out.values()).backward()
     us_s = timeit(full_static, 30)
     keys = ('heatmap', 'reg', 'height', 'dim', 'yaw', 'dir', 'vel')
 
     def fn(*args):
         bx, lb, flat = args[:B], args[B:2 * B], args[2 * B:]
-        out = amd.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, list(bx), list(lb),
+        out = amd.extras.center_gd_head_loss(cls, l1, gd, coder, TASKS, cfg, list(bx), list(lb),
                                       [dict(zip(keys, flat[7 * t:7 * t + 7])) for t in range(len(TASKS))], static=True)
         return [out[k] for k in sorted(out)]
     step = amd.GraphedStep(fn, gb + gl + [p[k] for p in pds for k in keys])

@@ -12,13 +12,13 @@ g = torch.Generator().manual_seed(3)
 classes = [1, 2, 2, 1, 2, 2]
 tasks = [{k: v.to(dev) for k, v in pd.items()} for pd in make_tasks(g, 1, 128, 128, classes, 'yaw')]
 coder = amd.CenterPointBBoxYawCoder(**NUS)
-for _ in range(50): amd.center_head_get_bboxes(tasks, coder, NUS_TEST, classes)
+for _ in range(50): amd.extras.center_head_get_bboxes(tasks, coder, NUS_TEST, classes)
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
-for _ in range(500): amd.center_head_get_bboxes(tasks, coder, NUS_TEST, classes)
+for _ in range(500): amd.extras.center_head_get_bboxes(tasks, coder, NUS_TEST, classes)
 pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(14)
 import time
 t=time.perf_counter()
-for _ in range(500): amd.center_head_get_bboxes(tasks, coder, NUS_TEST, classes, padded=True)
+for _ in range(500): amd.extras.center_head_get_bboxes(tasks, coder, NUS_TEST, classes, padded=True)
 torch.cuda.synchronize(); print('padded us/call', (time.perf_counter()-t)/500*1e6)

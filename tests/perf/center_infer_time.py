@@ -90,21 +90,21 @@ def main():
         for name, thr in (('config threshold 0.1 (every candidate passes)', NUS_TEST['score_threshold']),
                           ('threshold at the 40 % quantile of the candidates', midgap(cpu, 500, 0.4))):
             cfg = dict(NUS_TEST, score_threshold=thr)
-            a = amd.center_head_get_bboxes(tasks, coder, cfg, classes)
+            a = amd.extras.center_head_get_bboxes(tasks, coder, cfg, classes)
             b = eager(tasks, NUS, cfg, classes, False)
             c = eager(tasks, NUS, cfg, classes, True)
             for x, y, z in zip(a, b, c):
                 assert x[0].shape == y[0].shape == z[0].shape, (x[0].shape, y[0].shape, z[0].shape)
                 torch.testing.assert_close(x[0], y[0], rtol=1e-5, atol=1e-5)
                 assert torch.equal(x[2], y[2]) and torch.equal(y[0], z[0])
-            us_a = timeit(lambda: amd.center_head_get_bboxes(tasks, coder, cfg, classes), 50)
+            us_a = timeit(lambda: amd.extras.center_head_get_bboxes(tasks, coder, cfg, classes), 50)
             us_b = timeit(lambda: eager(tasks, NUS, cfg, classes, False), 10, warm=2)
             us_c = timeit(lambda: eager(tasks, NUS, cfg, classes, True), 10, warm=2)
             # nothing read back (padded=True): the call pipelines, and the slice replays as a hipGraph
-            us_p = timeit(lambda: amd.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True), 100)
+            us_p = timeit(lambda: amd.extras.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True), 100)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                amd.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True)
+                amd.extras.center_head_get_bboxes(tasks, coder, cfg, classes, padded=True)
             us_g = timeit(graph.replay, 200)
             print(json.dumps(dict(what=f'get_bboxes, 6 tasks x batch {B}, 128x128, K=500; {name}', detections=[int(x[0].shape[0]) for x in a],
                                   ours_us=round(us_a, 1), ours_padded_no_readback_us=round(us_p, 1), ours_padded_as_a_hipgraph_us=round(us_g, 1),
@@ -114,10 +114,10 @@ def main():
         g = torch.Generator().manual_seed(4)
         heat = torch.rand(shape, generator=g).to(dev)
         pred = torch.randn(shape[0], 11, shape[2], shape[3], generator=g).to(dev)
-        s1 = amd.select_best(heat, pred, K)
+        s1 = amd.extras.select_best(heat, pred, K)
         s2 = cit.select_best(heat, pred, K)
         assert torch.equal(s1[0], s2[0])
-        us_a = timeit(lambda: amd.select_best(heat, pred, K), 50)
+        us_a = timeit(lambda: amd.extras.select_best(heat, pred, K), 50)
         us_b = timeit(lambda: cit.select_best(heat, pred, K), 20)
         print(json.dumps(dict(what=f'select_best {shape}, K={K}', ours_us=round(us_a, 1), torch_ops_us=round(us_b, 1))), flush=True)
 

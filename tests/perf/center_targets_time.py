@@ -26,16 +26,16 @@ def main():
         data = [scene(g, n) for _ in range(B)]
         boxes, labels = [d[0] for d in data], [d[1] for d in data]
         gb, gl = [b.cuda() for b in boxes], [l.cuda() for l in labels]
-        got = amd.center_head_get_targets(gb, gl, TASKS, NUS)
+        got = amd.extras.center_head_get_targets(gb, gl, TASKS, NUS)
         want = ct.get_targets(boxes, labels, counts, NUS)
         for t in range(len(TASKS)):
             assert torch.equal(got[0][t].cpu(), want[0][t]) and torch.equal(got[1][t].cpu(), want[1][t]) and torch.equal(got[2][t].cpu(), want[2][t])
         for _ in range(10):
-            amd.center_head_get_targets(gb, gl, TASKS, NUS)
+            amd.extras.center_head_get_targets(gb, gl, TASKS, NUS)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(100):
-            amd.center_head_get_targets(gb, gl, TASKS, NUS)
+            amd.extras.center_head_get_targets(gb, gl, TASKS, NUS)
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 100 * 1e6
         t0 = time.perf_counter()

@@ -35,17 +35,17 @@ kld = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
 
 def once():
     tasks = [{k: v.to(dev) + 0.0 for k, v in pd.items()} for pd in cpu_tasks]          # fresh tensors: new addresses
-    amd.center_head_get_bboxes(tasks, coder, cfg, classes)
-    hm, an, pi = amd.center_head_get_targets([boxes.to(dev)], [labels.to(dev)], TASKS, tcfg)
+    amd.extras.center_head_get_bboxes(tasks, coder, cfg, classes)
+    hm, an, pi = amd.extras.center_head_get_targets([boxes.to(dev)], [labels.to(dev)], TASKS, tcfg)
     pds = [{k: v.requires_grad_(True) for k, v in t.items()} for t in tasks]
-    out = amd.center_gd_head_loss(dict(type='GaussianFocalLoss'), dict(type='L1Loss', loss_weight=0.25), gd, coder, TASKS, tcfg,
+    out = amd.extras.center_gd_head_loss(dict(type='GaussianFocalLoss'), dict(type='L1Loss', loss_weight=0.25), gd, coder, TASKS, tcfg,
                                   [boxes.to(dev)], [labels.to(dev)], pds, static=True)
     sum(out.values()).backward()
     an = a_anchors.to(dev) + 0.0
     o = [t.to(dev).requires_grad_(True) for t in a_outs]
-    res = amd.gd_anchor_head_loss(FOCAL, SL1, CE, kld, TRAIN_CFG, 3, an, [o[0]], [o[1]], [o[2]], [b.to(dev) for b, _ in a_gt], [l.to(dev) for _, l in a_gt])
+    res = amd.extras.gd_anchor_head_loss(FOCAL, SL1, CE, kld, TRAIN_CFG, 3, an, [o[0]], [o[1]], [o[2]], [b.to(dev) for b, _ in a_gt], [l.to(dev) for _, l in a_gt])
     (res['loss_cls'][0] + res['loss_bbox'][0] + res['loss_dir'][0]).backward()
-    amd.anchor_head_get_bboxes([o[0].detach()], [o[1].detach()], [o[2].detach()], [an.reshape(-1, 7)], a_infer_cfg, 3, 0.0, 1.0)
+    amd.extras.anchor_head_get_bboxes([o[0].detach()], [o[1].detach()], [o[2].detach()], [an.reshape(-1, 7)], a_infer_cfg, 3, 0.0, 1.0)
 
 
 for _ in range(200):

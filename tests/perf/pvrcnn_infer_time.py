@@ -61,7 +61,7 @@ def main():
         rois, cls_score, bbox_pred, class_labels, class_pred = make(4, R, 3, seed=R, shuffle=False)
         rois, cls_score, bbox_pred = rois.to(dev), cls_score.to(dev), bbox_pred.to(dev)
         class_labels, class_pred = [l.to(dev) for l in class_labels], [p.to(dev) for p in class_pred]
-        ours = lambda: amd.pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred, CFG)      # noqa: E731
+        ours = lambda: amd.extras.pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred, CFG)      # noqa: E731
         ref = lambda: eager(rois, cls_score, bbox_pred, class_labels, class_pred)                                  # noqa: E731
         a, e = ours(), ref()
         for (ab, as_, al), (eb, es, el) in zip(a, e):

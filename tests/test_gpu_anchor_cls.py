@@ -39,7 +39,7 @@ def run_both(case, C, avg, focal=FOCAL, ce=CE, up=(1.0, 1.0)):
     (up[0] * lc + up[1] * ld).backward()
     dev = torch.device('cuda:0')
     cg, dg = cls.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
-    gc, gd = pkg.anchor_head_cls_dir_loss(focal, ce, cg, dg, labels.to(dev), lw.to(dev), dt.to(dev), dw.to(dev), C, avg)
+    gc, gd = pkg.extras.anchor_head_cls_dir_loss(focal, ce, cg, dg, labels.to(dev), lw.to(dev), dt.to(dev), dw.to(dev), C, avg)
     (up[0] * gc + up[1] * gd).backward()
     return (lc, ld, c64.grad, d64.grad), (gc, gd, cg.grad, dg.grad)
 
@@ -101,7 +101,7 @@ def test_negative_labels_are_not_positives():
     dw[0, :50] = 1.0              # must not enter the direction term
     dev = torch.device('cuda:0')
     cg, dg = cls.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
-    gc, gd = pkg.anchor_head_cls_dir_loss(FOCAL, CE, cg, dg, labels.to(dev), lw.to(dev), dt.to(dev), dw.to(dev), 3, 9.0)
+    gc, gd = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cg, dg, labels.to(dev), lw.to(dev), dt.to(dev), dw.to(dev), 3, 9.0)
     (gc + gd).backward()
     lab2 = labels.clone()
     lab2[0, :50] = 3
@@ -115,7 +115,7 @@ def test_without_direction_classifier_and_default_avg():
     cls, dirs, labels, lw, dt, dw = make(3, 2, 3, 9, 11, seed=8, pos_frac=0.05)
     dev = torch.device('cuda:0')
     cg = cls.to(dev).requires_grad_(True)
-    gc, gd = pkg.anchor_head_cls_dir_loss(FOCAL, None, cg, None, labels.to(dev), lw.to(dev), None, None, 3)
+    gc, gd = pkg.extras.anchor_head_cls_dir_loss(FOCAL, None, cg, None, labels.to(dev), lw.to(dev), None, None, 3)
     assert gd is None
     gc.backward()
     c64 = cls.double().requires_grad_(True)
@@ -129,8 +129,8 @@ def test_deterministic_and_no_grad():
     case = make(2, 6, 3, 32, 32, seed=12, pos_frac=0.03)
     dev = torch.device('cuda:0')
     args = [t.to(dev) for t in case]
-    a = pkg.anchor_head_cls_dir_loss(FOCAL, CE, args[0], args[1], args[2], args[3], args[4], args[5], 3, 21.0)
-    b = pkg.anchor_head_cls_dir_loss(FOCAL, CE, args[0], args[1], args[2], args[3], args[4], args[5], 3, 21.0)
+    a = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, args[0], args[1], args[2], args[3], args[4], args[5], 3, 21.0)
+    b = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, args[0], args[1], args[2], args[3], args[4], args[5], 3, 21.0)
     assert a[0].item() == b[0].item() and a[1].item() == b[1].item()
     assert not a[0].requires_grad
 
@@ -139,15 +139,15 @@ def test_argument_checks():
     dev = torch.device('cuda:0')
     cls, dirs, labels, lw, dt, dw = [t.to(dev) for t in make(1, 2, 3, 4, 4, seed=1)]
     with pytest.raises(RuntimeError, match='no CPU path'):
-        pkg.anchor_head_cls_dir_loss(FOCAL, CE, cls.cpu(), dirs.cpu(), labels.cpu(), lw.cpu(), dt.cpu(), dw.cpu(), 3, 1.0)
+        pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls.cpu(), dirs.cpu(), labels.cpu(), lw.cpu(), dt.cpu(), dw.cpu(), 3, 1.0)
     with pytest.raises(RuntimeError, match='is not'):
-        pkg.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, 4, 1.0)
+        pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, 4, 1.0)
     with pytest.raises(RuntimeError, match='entries'):
-        pkg.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels[:, :-1], lw, dt, dw, 3, 1.0)
+        pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels[:, :-1], lw, dt, dw, 3, 1.0)
     with pytest.raises(RuntimeError, match='FocalLoss'):
-        pkg.anchor_head_cls_dir_loss(dict(type='GaussianFocalLoss'), CE, cls, dirs, labels, lw, dt, dw, 3, 1.0)
+        pkg.extras.anchor_head_cls_dir_loss(dict(type='GaussianFocalLoss'), CE, cls, dirs, labels, lw, dt, dw, 3, 1.0)
     with pytest.raises(RuntimeError, match='num_total_samples'):
-        pkg.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, 3, 0)
+        pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls, dirs, labels, lw, dt, dw, 3, 0)
 
 
 # ---- GDAnchor3DHead.loss_single end to end (gd_anchor3d_head.py:62-161) -------------------------------------------------
@@ -183,7 +183,7 @@ def test_loss_single_end_to_end(lt, kw):
     for k in ('cls', 'bbox', 'dirs'):
         g[k].requires_grad_(True)
     mod = pkg.GDLoss(lt, loss_weight=5.0, **kw)
-    out = pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'],
+    out = pkg.extras.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'],
                                          g['bw'], g['dt'], g['dw'], g['anchors'], avg)
     (out[0] + out[1] + out[2]).backward()
     gd_cfg = dict(loss_type=lt, loss_weight=5.0, **kw)
@@ -208,7 +208,7 @@ def test_loss_single_replays_as_a_hipgraph():
     order = ('cls', 'bbox', 'dirs', 'labels', 'lw', 'bt', 'bw', 'dt', 'dw', 'anchors')
 
     def fn(cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors):
-        return pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors, 23.0)
+        return pkg.extras.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, cls, bbox, dirs, labels, lw, bt, bw, dt, dw, anchors, 23.0)
     step = pkg.GraphedStep(fn, tuple(g[k] for k in order))
     c2, _ = head_case(7)
     g2 = {k: v.to(dev) for k, v in c2.items()}
@@ -231,9 +231,9 @@ def test_loss_single_without_direction_classifier():
     dev = torch.device('cuda:0')
     g = {k: v.to(dev) for k, v in c.items()}
     mod = pkg.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
-    a = pkg.gd_anchor_head_loss_single(FOCAL, SL1, None, mod, None, C, g['cls'], g['bbox'], None, g['labels'], g['lw'], g['bt'], g['bw'], None, None,
+    a = pkg.extras.gd_anchor_head_loss_single(FOCAL, SL1, None, mod, None, C, g['cls'], g['bbox'], None, g['labels'], g['lw'], g['bt'], g['bw'], None, None,
                                        g['anchors'], 5.0, use_direction_classifier=False)
-    b = pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, None, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'], g['bw'], g['dt'], g['dw'],
+    b = pkg.extras.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, None, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'], g['bw'], g['dt'], g['dw'],
                                        g['anchors'], 5.0)
     assert a[2] is None and a[0].item() == b[0].item() and a[1].item() == b[1].item()
 
@@ -250,7 +250,7 @@ def test_unit_gradient_constant_is_recognised_by_address():
         g = {k: v.to(dev) for k, v in c.items()}
         for k in ('cls', 'bbox', 'dirs'):
             g[k].requires_grad_(True)
-        out = pkg.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'],
+        out = pkg.extras.gd_anchor_head_loss_single(FOCAL, SL1, CE, mod, TRAIN_CFG, C, g['cls'], g['bbox'], g['dirs'], g['labels'], g['lw'], g['bt'],
                                              g['bw'], g['dt'], g['dw'], g['anchors'], 13.0)
         if unit:
             torch.autograd.backward(list(out), [gd_loss.unit_grad(dev)] * 3)
@@ -259,3 +259,34 @@ def test_unit_gradient_constant_is_recognised_by_address():
         res.append([g[k].grad.clone() for k in ('cls', 'bbox', 'dirs')])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_direction_target_outside_its_two_bins_poisons_the_direction_loss():
+    """a dir target outside [0, 2) on a positive anchor makes F.cross_entropy raise in the reference; here — no host
+    sync to raise from — the direction loss and that anchor's direction gradients are NaN (loud in the first step) instead of a
+    silently finite "bin 1"; the classification term and every other anchor's gradient are untouched."""
+    cls, dirs, labels, lw, dt, dw = make(2, 2, 3, 9, 11, seed=5, pos_frac=0.2)
+    dev = torch.device('cuda:0')
+    args = lambda d: (labels.to(dev), lw.to(dev), d.to(dev), dw.to(dev), 3, 11.0)
+    cg, dg = cls.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
+    lc0, ld0 = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cg, dg, *args(dt))
+    (lc0 + ld0).backward()
+    good_c, good_d = cg.grad.clone(), dg.grad.clone()
+    assert torch.isfinite(ld0)
+    pos = (labels < 3).nonzero()
+    bad = dt.clone()
+    b, n = int(pos[0, 0]), int(pos[0, 1])
+    for wrong in (2, -1, 7):
+        bad[b, n] = wrong
+        c2, d2 = cls.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
+        lc, ld = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, c2, d2, *args(bad))
+        (lc + ld).backward()
+        assert torch.isnan(ld) and torch.equal(lc, lc0) and torch.equal(c2.grad, good_c)
+        nan = torch.isnan(d2.grad)
+        assert int(nan.sum()) == 2 and torch.equal(d2.grad[~nan], good_d[~nan])      # that anchor's two direction logits only
+    # a bad target on a NON-positive anchor is never read (the reference gathers the positives first, :143-146)
+    neg = (labels >= 3).nonzero()
+    bad = dt.clone()
+    bad[int(neg[0, 0]), int(neg[0, 1])] = 5
+    _, ld = pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, cls.to(dev), dirs.to(dev), *args(bad))
+    assert torch.equal(ld, ld0)

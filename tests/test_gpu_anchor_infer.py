@@ -51,7 +51,7 @@ def run_and_check(levels, cfg, C, dir_offset, dir_limit_offset):
     """levels: list of (cls, bbox, dirs, anchors) CPU tensors"""
     B = levels[0][0].shape[0]
     gpu = [[t.cuda() for t in lv] for lv in levels]
-    out, cands = amd.anchor_head_get_bboxes([lv[0] for lv in gpu], [lv[1] for lv in gpu], [lv[2] for lv in gpu], [lv[3] for lv in gpu],
+    out, cands = amd.extras.anchor_head_get_bboxes([lv[0] for lv in gpu], [lv[1] for lv in gpu], [lv[2] for lv in gpu], [lv[3] for lv in gpu],
                                             cfg, C, dir_offset, dir_limit_offset, return_candidates=True)
     assert len(out) == B
     from oracle import nms_gpu_oracle
@@ -123,7 +123,7 @@ def test_anchor_head_get_bboxes_padded_replays_as_a_hipgraph_and_errors():
     b = head_outputs(g, 2, 6, 3, 62, 54)
     cfg = dict(use_rotate_nms=True, nms_pre=1000, nms_thr=0.1, score_thr=0.05, max_num=80)
     static = [t.cuda().clone() for t in a]
-    call = lambda: amd.anchor_head_get_bboxes([static[0]], [static[1]], [static[2]], [static[3]], cfg, 3, 0.7854, 0.0, padded=True)  # noqa: E731
+    call = lambda: amd.extras.anchor_head_get_bboxes([static[0]], [static[1]], [static[2]], [static[3]], cfg, 3, 0.7854, 0.0, padded=True)  # noqa: E731
     call()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -134,17 +134,17 @@ def test_anchor_head_get_bboxes_padded_replays_as_a_hipgraph_and_errors():
             s.copy_(t)
         graph.replay()
         torch.cuda.synchronize()
-        want = amd.anchor_head_get_bboxes([src[0].cuda()], [src[1].cuda()], [src[2].cuda()], [src[3].cuda()], cfg, 3, 0.7854, 0.0)
+        want = amd.extras.anchor_head_get_bboxes([src[0].cuda()], [src[1].cuda()], [src[2].cuda()], [src[3].cuda()], cfg, 3, 0.7854, 0.0)
         n = out['counts'].tolist()
         for i in range(2):
             assert n[i] == want[i][0].shape[0] > 0 and torch.equal(out['bboxes'][i, :n[i]], want[i][0])
             assert torch.equal(out['scores'][i, :n[i]], want[i][1]) and torch.equal(out['labels'][i, :n[i]], want[i][2])
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.anchor_head_get_bboxes([a[0]], [a[1]], [a[2]], [a[3]], cfg, 3)
+        amd.extras.anchor_head_get_bboxes([a[0]], [a[1]], [a[2]], [a[3]], cfg, 3)
     with pytest.raises(RuntimeError, match='unsupported configuration'):
-        amd.anchor_head_get_bboxes([static[0]], [static[1]], [static[2]], [static[3]], dict(cfg, nms_pre=-1), 3)     # 20 088 anchors into the NMS
+        amd.extras.anchor_head_get_bboxes([static[0]], [static[1]], [static[2]], [static[3]], dict(cfg, nms_pre=-1), 3)     # 20 088 anchors into the NMS
     with pytest.raises(RuntimeError, match='do not describe'):
-        amd.anchor_head_get_bboxes([static[0]], [static[1][:, :35]], [static[2]], [static[3]], cfg, 3)
+        amd.extras.anchor_head_get_bboxes([static[0]], [static[1][:, :35]], [static[2]], [static[3]], cfg, 3)
 
 
 def test_anchor_head_get_bboxes_random_configurations():
@@ -159,3 +159,28 @@ def test_anchor_head_get_bboxes_random_configurations():
         cfg = dict(use_rotate_nms=bool(it % 3), nms_pre=nms_pre, nms_thr=float(rng.choice([0.01, 0.2, 0.5])),
                    score_thr=midgap_scores([lv[0]], C, float(rng.uniform(0.9, 0.999))), max_num=int(rng.integers(1, 300)))
         run_and_check([lv], cfg, C, float(rng.choice([0.0, 0.7854])), float(rng.choice([0.0, 0.5, 1.0])))
+
+
+def test_saturated_scores_tie_and_the_nms_pre_cut_goes_by_index():
+    """the nms_pre selection ranks the fp32 SIGMOID of the best class logit, as the reference does (`scores.max(dim=1)`
+    then topk): logits beyond the saturation point (x > ~17 -> 1.0f) are ties there, and ties go by index.  Here 300 anchors carry
+    saturated logits of DIFFERENT sizes (20 .. 60, shuffled); with nms_pre = 100 the candidates must be the 100 saturated anchors of
+    lowest index — ranking on the raw logit would have picked the 100 largest logits instead."""
+    g = torch.Generator().manual_seed(7)
+    B, A, C, H, W = 1, 2, 1, 20, 25
+    cls, bbox, dirs, anchors = head_outputs(g, B, A, C, H, W)
+    N = H * W * A
+    flat = torch.full((N,), -4.0)                                   # (cell, a) order, as the reference flattens the maps
+    sat = torch.randperm(N, generator=g)[:300]
+    flat[sat] = 20.0 + 40.0 * torch.rand(300, generator=g)
+    assert bool((torch.sigmoid(flat[sat]) == 1.0).all())
+    cls = flat.view(H, W, A).permute(2, 0, 1).reshape(1, A * C, H, W).contiguous()
+    cfg = dict(use_rotate_nms=True, nms_pre=100, nms_thr=0.01, score_thr=0.1, max_num=100)
+    _, cands = amd.extras.anchor_head_get_bboxes([cls.cuda()], [bbox.cuda()], [dirs.cuda()], [anchors.cuda()], cfg, C, 0.0, 1.0, return_candidates=True)
+    want = torch.sort(sat)[0][:100]
+    dec = ait.delta_decode(anchors[want], bbox[0].permute(1, 2, 0).reshape(-1, 7)[want])
+    got_boxes = cands['boxes'][0].cpu()
+    assert got_boxes.shape[0] == 100 and bool((cands['scores'][0].cpu() == 1.0).all())
+    torch.testing.assert_close(got_boxes, dec.float(), rtol=3e-6, atol=3e-6)            # the 100 lowest-index saturated anchors, in index order
+    by_logit = sat[torch.sort(flat[sat], descending=True)[1][:100]]
+    assert set(by_logit.tolist()) != set(want.tolist())                                 # the two rankings really differ on this input

@@ -42,7 +42,7 @@ def random_gt(n, seed, num_classes=3, x=(0, 69), y=(-39, 39), with_ignored=True)
 def run_both(anchors, gts, labels, assigners, num_classes=3, **kw):
     ref = ORA.anchor_target_3d(anchors, gts, labels, assigners, num_classes, **kw)
     dev = torch.device('cuda:0')
-    got = pkg.anchor_head_get_targets(anchors.to(dev), [g.to(dev) for g in gts], [l.to(dev) for l in labels], assigners, num_classes, **kw)
+    got = pkg.extras.anchor_head_get_targets(anchors.to(dev), [g.to(dev) for g in gts], [l.to(dev) for l in labels], assigners, num_classes, **kw)
     return ref, got
 
 
@@ -128,7 +128,7 @@ def test_no_boxes_at_all_and_padded_form():
     assert got[6] == 2 and got[7] == 2 * anchors.numel() // 7                   # max(0, 1) per sample; every anchor a negative
     dev = torch.device('cuda:0')
     b, l = random_gt(9, seed=2)
-    res = pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev), empty[0].to(dev)], [l.to(dev), empty[1].to(dev)], KITTI_ASSIGNERS, 3, padded=True)
+    res = pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev), empty[0].to(dev)], [l.to(dev), empty[1].to(dev)], KITTI_ASSIGNERS, 3, padded=True)
     ref = ORA.anchor_target_3d(anchors, [b, empty[0]], [l, empty[1]], KITTI_ASSIGNERS, 3)
     counts = res[6].cpu()
     assert counts.dtype == torch.int32 and counts.shape == (2, 2)
@@ -151,18 +151,18 @@ def test_deterministic_and_argument_checks():
     anchors = kitti_anchors(30, 30)
     dev = torch.device('cuda:0')
     b, l = random_gt(40, seed=8)
-    a = pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev)] * 3, [l.to(dev)] * 3, KITTI_ASSIGNERS, 3)
-    c = pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev)] * 3, [l.to(dev)] * 3, KITTI_ASSIGNERS, 3)
+    a = pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev)] * 3, [l.to(dev)] * 3, KITTI_ASSIGNERS, 3)
+    c = pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev)] * 3, [l.to(dev)] * 3, KITTI_ASSIGNERS, 3)
     assert all(torch.equal(x, y) for x, y in zip(a[:6], c[:6])) and a[6:] == c[6:]
     assert torch.equal(a[0][0], a[0][2]) and torch.equal(a[2][0], a[2][1])
     with pytest.raises(RuntimeError, match='assigners for'):
-        pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l.to(dev)], KITTI_ASSIGNERS[:2], 3)
+        pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l.to(dev)], KITTI_ASSIGNERS[:2], 3)
     with pytest.raises(RuntimeError, match='MaxIoUAssigner'):
-        pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l.to(dev)], dict(type='ATSSAssigner'), 3)
+        pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l.to(dev)], dict(type='ATSSAssigner'), 3)
     with pytest.raises(RuntimeError, match='one label each'):
-        pkg.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l[:-1].to(dev)], KITTI_ASSIGNERS, 3)
+        pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.to(dev)], [l[:-1].to(dev)], KITTI_ASSIGNERS, 3)
     with pytest.raises(RuntimeError, match='boxes in a sample'):
-        pkg.anchor_head_get_targets(anchors.to(dev), [b.repeat(30, 1).to(dev)], [l.repeat(30).to(dev)], KITTI_ASSIGNERS, 3)
+        pkg.extras.anchor_head_get_targets(anchors.to(dev), [b.repeat(30, 1).to(dev)], [l.repeat(30).to(dev)], KITTI_ASSIGNERS, 3)
 
 
 # ---- GDAnchor3DHead.loss end to end (gd_anchor3d_head.py:167-240) ---------------------------------------------------------
@@ -201,7 +201,7 @@ def test_head_loss_end_to_end(static):
     dev = torch.device('cuda:0')
     g = [o.to(dev).requires_grad_(True) for o in outs]
     mod = pkg.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
-    res = pkg.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors.to(dev), [g[0]], [g[1]], [g[2]], [b.to(dev) for b in gts],
+    res = pkg.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors.to(dev), [g[0]], [g[1]], [g[2]], [b.to(dev) for b in gts],
                                   [l.to(dev) for l in labels], static=static)
     assert sorted(res) == ['loss_bbox', 'loss_cls', 'loss_dir'] and all(len(v) == 1 for v in res.values())
     (res['loss_cls'][0] + res['loss_bbox'][0] + res['loss_dir'][0]).backward()
@@ -235,7 +235,7 @@ def test_head_loss_static_form_replays_as_a_hipgraph():
     an = anchors.to(dev)
 
     def fn(cls, bbox, dirs, gt, gl):
-        r = pkg.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, an, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), static=True)
+        r = pkg.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, an, cls, bbox, dirs, list(gt.unbind(0)), list(gl.unbind(0)), static=True)
         return r['loss_cls'][0], r['loss_bbox'][0], r['loss_dir'][0]
     o1 = [o.to(dev).requires_grad_(True) for o in head_outputs(2, H, W, seed=3)]
     gt1, gl1 = padded_batch(60, (10, 4))
@@ -294,7 +294,7 @@ def test_random_configurations(seed):
     kw = dict(assign_per_class=(mode == 0), dir_offset=rf(-1, 1), pos_weight=-1 if seed % 2 else 1.5)
     ref = ORA.anchor_target_3d(anchors, gts, labels, assigner, S, **kw)
     dev = torch.device('cuda:0')
-    got = pkg.anchor_head_get_targets(anchors.to(dev), [g.to(dev) for g in gts], [l.to(dev) for l in labels], assigner, S, **kw)
+    got = pkg.extras.anchor_head_get_targets(anchors.to(dev), [g.to(dev) for g in gts], [l.to(dev) for l in labels], assigner, S, **kw)
     for k in (0, 1, 3, 4, 5):
         assert torch.equal(got[k].cpu(), ref[k]), k
     assert torch.equal(got[2].cpu()[..., [2, 6]], ref[2][..., [2, 6]])
@@ -315,14 +315,14 @@ def test_static_form_equals_the_eager_one_bit_for_bit():
     res = []
     for static in (False, True):
         g = [o.to(dev).requires_grad_(True) for o in outs]
-        r = pkg.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors.to(dev), g[0], g[1], g[2], [p[0].to(dev) for p in pairs],
+        r = pkg.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors.to(dev), g[0], g[1], g[2], [p[0].to(dev) for p in pairs],
                                     [p[1].to(dev) for p in pairs], static=static)
         (r['loss_cls'][0] + r['loss_bbox'][0] + r['loss_dir'][0]).backward()
         res.append(([r[k][0].detach().clone() for k in ('loss_cls', 'loss_bbox', 'loss_dir')], [t.grad.clone() for t in g]))
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match='one value'):
-        pkg.anchor_head_cls_dir_loss(FOCAL, CE, g[0], g[2], torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev),
+        pkg.extras.anchor_head_cls_dir_loss(FOCAL, CE, g[0], g[2], torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev),
                                      torch.zeros(3, H * W * 6, dtype=torch.long, device=dev), torch.ones(3, H * W * 6, device=dev), 3, torch.ones(2, device=dev))
 
 
@@ -342,7 +342,7 @@ def test_car_only_config_flat_anchors_single_assigner():
     ref = ORA.anchor_target_3d(grid, boxes, labels, one, 1)
     dev = torch.device('cuda:0')
     for an in (flat, grid):
-        got = pkg.anchor_head_get_targets(an.to(dev), [b.to(dev) for b in boxes], [l.to(dev) for l in labels], one, 1)
+        got = pkg.extras.anchor_head_get_targets(an.to(dev), [b.to(dev) for b in boxes], [l.to(dev) for l in labels], one, 1)
         for k in (0, 1, 3, 4, 5):
             assert torch.equal(got[k].cpu(), ref[k])
         assert torch.allclose(got[2].cpu(), ref[2], rtol=2e-6, atol=2e-7) and got[6] == ref[6] and got[7] == ref[7]

@@ -44,7 +44,7 @@ def test_train_a_toy_center_head_then_detect():
     history = []
     for it in range(60):
         opt.zero_grad()
-        loss_dict = amd.center_gd_head_loss(loss_cls, loss_l1, loss_gd, coder, tasks, train_cfg, gt_boxes, gt_labels,
+        loss_dict = amd.extras.center_gd_head_loss(loss_cls, loss_l1, loss_gd, coder, tasks, train_cfg, gt_boxes, gt_labels,
                                             tuple([p] for p in forward()), static=bool(it % 2))
         total = sum(loss_dict.values())
         assert torch.isfinite(total)
@@ -53,7 +53,7 @@ def test_train_a_toy_center_head_then_detect():
         history.append(total.item())
     assert history[-1] < 0.35 * history[0], (history[0], history[-1])
     with torch.no_grad():
-        dets = amd.center_head_get_bboxes(tuple([p] for p in forward()), coder, test_cfg, [len(t) for t in tasks])
+        dets = amd.extras.center_head_get_bboxes(tuple([p] for p in forward()), coder, test_cfg, [len(t) for t in tasks])
     assert len(dets) == B
     found = 0
     for b, (boxes, scores, labels) in enumerate(dets):

@@ -64,7 +64,7 @@ def test_select_best_with_equal_scores_takes_the_lowest_indices():
     sig = d['heat'].sigmoid()
     pred = cit.reconstruct({k: d[k] for k in ('reg', 'height', 'dim', 'yaw', 'dir', 'vel')}, 'yaw')
     K = int(d['K'])
-    s, c, xy, p = amd.select_best(sig.to(dev()), pred.to(dev()), K)
+    s, c, xy, p = amd.extras.select_best(sig.to(dev()), pred.to(dev()), K)
     assert torch.equal(s.cpu(), d['scores'])              # the score VALUES are unique whatever the tie order
     B, C, H, W = sig.shape
     idx = torch.from_numpy(lex_topk(sig, K))
@@ -94,7 +94,7 @@ def test_select_best_degenerate_maps(shape, K):
     flat[torch.randint(0, flat.numel(), (9,), generator=g)] = 0.0
     maps.append(wild)
     for m in maps:
-        s, c, xy, p = amd.select_best(m.to(dev()), pred.to(dev()), K)
+        s, c, xy, p = amd.extras.select_best(m.to(dev()), pred.to(dev()), K)
         idx = torch.from_numpy(lex_topk(m, K))
         cell = idx % (H * W)
         assert torch.equal(c.cpu(), idx // (H * W))
@@ -114,7 +114,7 @@ def test_select_best_wide_maps(shape, K):
         m = torch.randn(shape, generator=g) if kind == 'normal' else torch.rand(shape, generator=g)
         if kind == 'quantised':
             m = (m * 16).floor() / 16
-        s, c, xy, p = amd.select_best(m.to(dev()), pred.to(dev()), K)
+        s, c, xy, p = amd.extras.select_best(m.to(dev()), pred.to(dev()), K)
         idx = torch.from_numpy(lex_topk(m, K))
         cell = idx % (H * W)
         assert torch.equal(c.cpu(), idx // (H * W)), kind
@@ -173,7 +173,7 @@ def run_and_check(tasks, kind, cfg, test_cfg, classes, wrap=False):
     coder = (amd.CenterPointBBoxCoderRev if kind == 'rev' else amd.CenterPointBBoxYawCoder)(**cfg)
     gpu = [{k: v.to(dev()) for k, v in pd.items()} for pd in tasks]
     arg = tuple([pd] for pd in gpu) if wrap else gpu
-    out, cands = amd.center_head_get_bboxes(arg, coder, test_cfg, classes, return_candidates=True)
+    out, cands = amd.extras.center_head_get_bboxes(arg, coder, test_cfg, classes, return_candidates=True)
     stage = {}
     cit.get_bboxes(tasks, kind, cfg, test_cfg, classes, stage=stage)
     B = tasks[0]['heatmap'].shape[0]
@@ -290,15 +290,15 @@ def test_errors():
     tasks = make_tasks(g, 1, 16, 16, [1], 'yaw')
     coder = amd.CenterPointBBoxYawCoder(**NUS)
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.center_head_get_bboxes(tasks, coder, NUS_TEST, [1])
+        amd.extras.center_head_get_bboxes(tasks, coder, NUS_TEST, [1])
     gpu = [{k: v.to(dev()) for k, v in tasks[0].items()}]
     with pytest.raises(RuntimeError, match='out of range'):
-        amd.center_head_get_bboxes(gpu, coder, NUS_TEST, [1])          # 500 > 16 * 16: torch.topk raises in the reference
+        amd.extras.center_head_get_bboxes(gpu, coder, NUS_TEST, [1])          # 500 > 16 * 16: torch.topk raises in the reference
     with pytest.raises(AssertionError):
-        amd.center_head_get_bboxes(gpu, coder, dict(NUS_TEST, max_per_img=50, nms_type='soft'), [1])
+        amd.extras.center_head_get_bboxes(gpu, coder, dict(NUS_TEST, max_per_img=50, nms_type='soft'), [1])
     del gpu[0]['dir']
     with pytest.raises(RuntimeError, match='dir'):
-        amd.center_head_get_bboxes(gpu, coder, dict(NUS_TEST, max_per_img=50), [1])
+        amd.extras.center_head_get_bboxes(gpu, coder, dict(NUS_TEST, max_per_img=50), [1])
 
 
 def test_get_bboxes_replays_as_a_hipgraph():
@@ -311,18 +311,18 @@ def test_get_bboxes_replays_as_a_hipgraph():
     second = make_tasks(g, 2, 128, 128, classes, 'yaw')
     static = [{k: v.to(dev()).clone() for k, v in pd.items()} for pd in first]
     cfg = dict(NUS_TEST, score_threshold=midgap(first + second, 500, 0.4))
-    amd.center_head_get_bboxes(static, coder, cfg, classes, padded=True)          # warm-up outside the capture
+    amd.extras.center_head_get_bboxes(static, coder, cfg, classes, padded=True)          # warm-up outside the capture
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        out = amd.center_head_get_bboxes(static, coder, cfg, classes, padded=True)
+        out = amd.extras.center_head_get_bboxes(static, coder, cfg, classes, padded=True)
     for src in (second, first):
         for pd_s, pd_n in zip(static, src):
             for k in pd_s:
                 pd_s[k].copy_(pd_n[k])
         graph.replay()
         torch.cuda.synchronize()
-        want = amd.center_head_get_bboxes([{k: v.to(dev()) for k, v in pd.items()} for pd in src], coder, cfg, classes)
+        want = amd.extras.center_head_get_bboxes([{k: v.to(dev()) for k, v in pd.items()} for pd in src], coder, cfg, classes)
         n = out['counts'].tolist()
         for b in range(2):
             assert n[b] == want[b][0].shape[0] > 0
@@ -364,7 +364,7 @@ def test_select_best_random_shapes_and_k():
         elif kind == 4:
             m = -m.abs() - 100.0                          # all negative
         pred = torch.randn(B, 2, H, W, generator=g)
-        s, c, xy, p = amd.select_best(m.to(dev()), pred.to(dev()), K)
+        s, c, xy, p = amd.extras.select_best(m.to(dev()), pred.to(dev()), K)
         idx = torch.from_numpy(lex_topk(m, K))
         cell = idx % (H * W)
         assert torch.equal(c.cpu(), idx // (H * W)), (it, B, C, H, W, K, kind)

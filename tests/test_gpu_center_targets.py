@@ -37,7 +37,7 @@ def check(boxes, labels, tasks, cfg, objects=False):
         grav = [torch.cat([b[:, :2], (b[:, 2] + b[:, 5] * 0.5).unsqueeze(1), b[:, 3:]], 1) for b in boxes]
     else:
         gpu_boxes, grav = [b.cuda() for b in boxes], boxes
-    hm, an, pi = amd.center_head_get_targets(gpu_boxes, [l.cuda() for l in labels], tasks, cfg)
+    hm, an, pi = amd.extras.center_head_get_targets(gpu_boxes, [l.cuda() for l in labels], tasks, cfg)
     hw, aw, pw = ct.get_targets(grav, labels, counts, cfg)
     assert len(hm) == len(hw) == len(tasks)
     for t in range(len(tasks)):
@@ -102,7 +102,7 @@ def test_targets_feed_the_head_losses():
     """the outputs are what center_head_losses takes: boxes (n, 9) and [batch, x, y] rows on the device"""
     g = torch.Generator().manual_seed(33)
     data = [scene(g, n, spread=50.0, ignore=0.0) for n in (50, 60)]
-    hm, an, pi = amd.center_head_get_targets([d[0].cuda() for d in data], [d[1].cuda() for d in data], TASKS, NUS)
+    hm, an, pi = amd.extras.center_head_get_targets([d[0].cuda() for d in data], [d[1].cuda() for d in data], TASKS, NUS)
     coder = amd.CenterPointBBoxYawCoder(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
     maps = [{k: (torch.randn(2, c, 128, 128, generator=g) * 0.3).cuda().requires_grad_(True)
              for k, c in (('reg', 2), ('height', 1), ('dim', 3), ('yaw', 1), ('dir', 2), ('vel', 2))} for _ in TASKS]
@@ -117,12 +117,12 @@ def test_targets_errors():
     g = torch.Generator().manual_seed(34)
     b, l = scene(g, 10)
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.center_head_get_targets([b], [l], TASKS, NUS)
+        amd.extras.center_head_get_targets([b], [l], TASKS, NUS)
     with pytest.raises(RuntimeError, match='one label each'):
-        amd.center_head_get_targets([b.cuda()], [l[:5].cuda()], TASKS, NUS)
+        amd.extras.center_head_get_targets([b.cuda()], [l[:5].cuda()], TASKS, NUS)
     big = scene(g, 9000)
     with pytest.raises(RuntimeError, match='sorts at most'):
-        amd.center_head_get_targets([big[0].cuda()], [big[1].cuda()], TASKS, NUS)
+        amd.extras.center_head_get_targets([big[0].cuda()], [big[1].cuda()], TASKS, NUS)
 
 
 def test_targets_random_batches():

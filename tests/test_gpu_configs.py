@@ -388,7 +388,7 @@ def test_anchor_head_loss_at_the_configs_real_geometry(amd, name):
     dev = torch.device('cuda:0')
     if name == 'kitti':
         B, H, W, per_class, dir_offset = 2, 248, 216, True, 0.0
-        anchors = amd.anchor3d_range_anchors((H, W), KITTI_RANGES, KITTI_SIZES, [0, 1.57], dev)[0]
+        anchors = amd.extras.anchor3d_range_anchors((H, W), KITTI_RANGES, KITTI_SIZES, [0, 1.57], dev)[0]
         assigners, sizes = KITTI_ASSIGNERS, KITTI_SIZES
         gts = [random_gt(18 + 5 * b, seed=200 + b, with_ignored=False) for b in range(B)]
         mod = amd.GDLoss('kld3d', fun='log1p', tau=1.0, loss_weight=5.0)
@@ -396,7 +396,7 @@ def test_anchor_head_loss_at_the_configs_real_geometry(amd, name):
         B, H, W, per_class, dir_offset = 1, 468, 468, False, 0.7854
         rng = [[-74.88, -74.88, -0.0345, 74.88, 74.88, -0.0345], [-74.88, -74.88, -0.1188, 74.88, 74.88, -0.1188], [-74.88, -74.88, 0.0, 74.88, 74.88, 0.0]]
         sizes = [[4.73, 2.08, 1.77], [1.81, 0.84, 1.77], [0.91, 0.84, 1.74]]
-        anchors = amd.anchor3d_range_anchors((H, W), rng, sizes, [0, 1.57], dev, aligned=True)[0]
+        anchors = amd.extras.anchor3d_range_anchors((H, W), rng, sizes, [0, 1.57], dev, aligned=True)[0]
         assigners = [dict(type='MaxIoUAssigner', iou_calculator=dict(type='BboxOverlapsNearest3D'), pos_iou_thr=p, neg_iou_thr=n, min_pos_iou=n, ignore_iof_thr=-1)
                      for p, n in ((0.55, 0.4), (0.5, 0.3), (0.5, 0.3))]
         g = torch.Generator().manual_seed(9)
@@ -407,14 +407,14 @@ def test_anchor_head_loss_at_the_configs_real_geometry(amd, name):
         mod = amd.GDLoss('gwd3d', fun='log1p', tau=0.0, loss_weight=5.0)
     tcfg = dict(assigner=assigners, allowed_border=0, code_weight=[1.0] * 7, pos_weight=-1, debug=False)
     boxes, labels = [p[0].to(dev) for p in gts], [p[1].to(dev) for p in gts]
-    tg = amd.anchor_head_get_targets(anchors, boxes, labels, assigners, 3, assign_per_class=per_class, dir_offset=dir_offset)
+    tg = amd.extras.anchor_head_get_targets(anchors, boxes, labels, assigners, 3, assign_per_class=per_class, dir_offset=dir_offset)
     ref = ORA.anchor_target_3d_single(anchors.cpu(), gts[0][0], gts[0][1], assigners, 3, assign_per_class=per_class, dir_offset=dir_offset)
     assert torch.equal(tg[0][0].cpu(), ref[0]) and torch.equal(tg[4][0].cpu(), ref[4]) and int((ref[0] < 3).sum()) >= len(gts[0][1])
     outs = head_outputs(B, H, W, seed=3)
     res = []
     for static in (False, True):
         g3 = [o.to(dev).requires_grad_(True) for o in outs]
-        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, g3[0], g3[1], g3[2], boxes, labels, assign_per_class=per_class,
+        r = amd.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, tcfg, 3, anchors, g3[0], g3[1], g3[2], boxes, labels, assign_per_class=per_class,
                                     dir_offset=dir_offset, static=static)
         losses = [r[k][0] for k in ('loss_cls', 'loss_bbox', 'loss_dir')]
         (losses[0] + losses[1] + losses[2]).backward()

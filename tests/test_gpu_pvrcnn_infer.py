@@ -40,7 +40,7 @@ def test_get_bboxes_stagewise(B, R, C, clockwise):
     rois, cls_score, bbox_pred, class_labels, class_pred = make(B, R, C, seed=B * 10 + C)
     dev = torch.device('cuda:0')
     cfg = dict(CFG, score_thr=[0.3, 0.5, 0.2][:C] if C > 1 else 0.4, nms_thr=[0.1, 0.2, 0.05][:C] if C > 1 else 0.1)
-    got, (boxes, bev) = pkg.pvrcnn_head_get_bboxes(rois.to(dev), cls_score.to(dev), bbox_pred.to(dev), [l.to(dev) for l in class_labels],
+    got, (boxes, bev) = pkg.extras.pvrcnn_head_get_bboxes(rois.to(dev), cls_score.to(dev), bbox_pred.to(dev), [l.to(dev) for l in class_labels],
                                                    [p.to(dev) for p in class_pred], cfg, clockwise=clockwise, return_decoded=True)
     want_boxes = ORA.decode_rois(rois, bbox_pred, clockwise)
     assert torch.allclose(boxes.cpu(), want_boxes, rtol=2e-6, atol=2e-5)
@@ -64,7 +64,7 @@ def test_rotation_sense_and_a_sample_that_keeps_nothing():
     probs = [torch.tensor([[0.9]]), torch.tensor([[0.01]])]
     labels = [torch.tensor([1]), torch.tensor([1])]
     for cw, sgn in ((False, 1.0), (True, -1.0)):
-        out = pkg.pvrcnn_head_get_bboxes(rois.to(dev), torch.tensor([[0.7], [0.6]]).to(dev), pred.to(dev), [l.to(dev) for l in labels],
+        out = pkg.extras.pvrcnn_head_get_bboxes(rois.to(dev), torch.tensor([[0.7], [0.6]]).to(dev), pred.to(dev), [l.to(dev) for l in labels],
                                          [p.to(dev) for p in probs], CFG, clockwise=cw)
         b0 = out[0][0].cpu()
         assert b0.shape == (1, 7) and abs(b0[0, 0].item() - 5.0 * math.cos(0.5)) < 1e-5 and abs(b0[0, 1].item() - sgn * 5.0 * math.sin(0.5)) < 1e-5
@@ -76,8 +76,8 @@ def test_argument_checks():
     dev = torch.device('cuda:0')
     rois, cls_score, bbox_pred, class_labels, class_pred = make(2, 10, 3, seed=1)
     with pytest.raises(RuntimeError, match='no CPU path'):
-        pkg.pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred, CFG)
+        pkg.extras.pvrcnn_head_get_bboxes(rois, cls_score, bbox_pred, class_labels, class_pred, CFG)
     with pytest.raises(RuntimeError, match='are not'):
-        pkg.pvrcnn_head_get_bboxes(rois[:, :7].to(dev), cls_score.to(dev), bbox_pred.to(dev), class_labels, class_pred, CFG)
+        pkg.extras.pvrcnn_head_get_bboxes(rois[:, :7].to(dev), cls_score.to(dev), bbox_pred.to(dev), class_labels, class_pred, CFG)
     with pytest.raises(RuntimeError, match='samples but'):
-        pkg.pvrcnn_head_get_bboxes(rois.to(dev), cls_score.to(dev), bbox_pred.to(dev), class_labels[:1], class_pred, CFG)
+        pkg.extras.pvrcnn_head_get_bboxes(rois.to(dev), cls_score.to(dev), bbox_pred.to(dev), class_labels[:1], class_pred, CFG)

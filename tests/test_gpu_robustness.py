@@ -191,7 +191,7 @@ def test_anchor_head_entry_points_take_half_precision_and_strided_inputs(amd):
 
     def run(maps, boxes, labels):
         maps = [m.clone().requires_grad_(True) for m in maps]
-        r = amd.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, maps[0], maps[1], maps[2], boxes, labels)
+        r = amd.extras.gd_anchor_head_loss(FOCAL, SL1, CE, mod, TRAIN_CFG, 3, anchors, maps[0], maps[1], maps[2], boxes, labels)
         tot = r['loss_cls'][0] + r['loss_bbox'][0] + r['loss_dir'][0]
         tot.backward()
         return [r[k][0].detach().float() for k in ('loss_cls', 'loss_bbox', 'loss_dir')], [m.grad for m in maps]
@@ -212,7 +212,7 @@ def test_anchor_head_entry_points_take_half_precision_and_strided_inputs(amd):
     cfg = dict(use_rotate_nms=True, nms_pre=256, nms_thr=0.01, score_thr=0.05, max_num=50)
     flat = anchors.reshape(-1, 7)
     wide = [o.to(torch.bfloat16).float() for o in outs]
-    a = amd.anchor_head_get_bboxes([outs[0].to(torch.bfloat16)], [outs[1].to(torch.bfloat16)], [outs[2].to(torch.bfloat16)], [flat], cfg, 3, 0.0, 1.0)
-    c = amd.anchor_head_get_bboxes([wide[0]], [wide[1]], [wide[2]], [flat], cfg, 3, 0.0, 1.0)
+    a = amd.extras.anchor_head_get_bboxes([outs[0].to(torch.bfloat16)], [outs[1].to(torch.bfloat16)], [outs[2].to(torch.bfloat16)], [flat], cfg, 3, 0.0, 1.0)
+    c = amd.extras.anchor_head_get_bboxes([wide[0]], [wide[1]], [wide[2]], [flat], cfg, 3, 0.0, 1.0)
     for x, y in zip(a, c):
         assert x[0].shape == y[0].shape and torch.allclose(x[0].float(), y[0], rtol=1e-2, atol=1e-2) and torch.equal(x[2], y[2])

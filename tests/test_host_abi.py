@@ -222,7 +222,7 @@ def test_center_infer_queries_and_argument_checks_without_gpu():
     d.num_channels = 17
     assert lib.center_infer_select(ctypes.byref(d), 256, 256, 256, 256, 256, None) == 10001
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.select_best(torch.zeros(1, 1, 8, 8), torch.zeros(1, 4, 8, 8), 4)
+        amd.extras.select_best(torch.zeros(1, 1, 8, 8), torch.zeros(1, 4, 8, 8), 4)
     with pytest.raises(RuntimeError, match='no CPU path'):
         amd.CenterPointBBoxCoderRev([0, 0], 4, [0.2, 0.2]).decode(torch.zeros(1, 4, 2), torch.zeros(1, 4, 10))
 
@@ -297,8 +297,8 @@ def test_anchor_targets_struct_layout_and_argument_checks():
     d.gt_start[1] = -1
     assert lib.anchor_targets_build(ctypes.byref(d), *args, None) == 10001
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
+        amd.extras.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
                                     [dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45)], 1)
     with pytest.raises(RuntimeError, match='sampling=True'):
-        amd.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
+        amd.extras.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
                                     dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45), 1, sampling=True)

@@ -22,18 +22,18 @@ def test_new_entry_points_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match='GPU tensors'):
         amd.GraphedStep(lambda x: x.sum(), (torch.zeros(3),))
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.center_head_heatmap_loss(dict(type='GaussianFocalLoss'), [torch.zeros(1, 1, 4, 4)], [torch.zeros(1, 1, 4, 4)])
+        amd.extras.center_head_heatmap_loss(dict(type='GaussianFocalLoss'), [torch.zeros(1, 1, 4, 4)], [torch.zeros(1, 1, 4, 4)])
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.center_head_get_targets([torch.zeros(2, 9)], [torch.zeros(2, dtype=torch.long)], [['a']],
+        amd.extras.center_head_get_targets([torch.zeros(2, 9)], [torch.zeros(2, dtype=torch.long)], [['a']],
                                     dict(grid_size=[8, 8, 1], point_cloud_range=[0, 0, 0, 8, 8, 1], voxel_size=[1, 1, 1],
                                          out_size_factor=1, gaussian_overlap=0.1, min_radius=2))
     coder = amd.CenterPointBBoxYawCoder([0, 0], 1, [1, 1])
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.center_head_get_bboxes([dict(heatmap=torch.zeros(1, 1, 4, 4), height=torch.zeros(1, 1, 4, 4), dim=torch.zeros(1, 3, 4, 4),
+        amd.extras.center_head_get_bboxes([dict(heatmap=torch.zeros(1, 1, 4, 4), height=torch.zeros(1, 1, 4, 4), dim=torch.zeros(1, 3, 4, 4),
                                          yaw=torch.zeros(1, 1, 4, 4), dir=torch.zeros(1, 2, 4, 4))], coder,
                                    dict(nms_type='rotate', max_per_img=4, nms_thr=0.2, pre_max_size=10, post_max_size=5), [1])
     with pytest.raises(RuntimeError, match='label sets'):
-        amd.center_head_get_targets([], [], [['a']], {})
+        amd.extras.center_head_get_targets([], [], [['a']], {})
 
 
 def test_heatmap_loss_config_parsing():
@@ -66,7 +66,7 @@ def test_anchor_cls_config_parsing_and_cpu_refusal():
     with pytest.raises(RuntimeError, match='activated'):
         anchor_cls._focal_cfg(dict(type='FocalLoss', activated=True))
     with pytest.raises(RuntimeError, match='no CPU path'):
-        amd.anchor_head_cls_dir_loss(dict(type='FocalLoss'), dict(type='CrossEntropyLoss'), torch.zeros(1, 2, 3, 3), torch.zeros(1, 4, 3, 3),
+        amd.extras.anchor_head_cls_dir_loss(dict(type='FocalLoss'), dict(type='CrossEntropyLoss'), torch.zeros(1, 2, 3, 3), torch.zeros(1, 4, 3, 3),
                                      torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), torch.zeros(1, 18, dtype=torch.long), torch.ones(1, 18), 1, 1.0)
 
 

@@ -134,9 +134,9 @@ def test_product_anchor_grid_equals_the_restatement_and_aligned_form_sits_on_cel
     import mmdet3d_gaussian_amd as amd
     R = [[0.08, -39.60, -0.6, 68.88, 39.44, -0.6]] * 2 + [[0.08, -39.60, -1.78, 68.88, 39.44, -1.78]]
     S = [[0.8, 0.6, 1.73], [1.76, 0.6, 1.73], [3.9, 1.6, 1.56]]
-    a = amd.anchor3d_range_anchors((20, 18), R, S, [0, 1.57], 'cpu')
+    a = amd.extras.anchor3d_range_anchors((20, 18), R, S, [0, 1.57], 'cpu')
     assert a.shape == (1, 20, 18, 3, 2, 7) and torch.equal(a, ORA.range_anchors((20, 18), R, S, [0, 1.57]))
-    w = amd.anchor3d_range_anchors((4, 8), [[-8., -4., 0.5, 8., 4., 0.5]], [[1., 2., 3.], [2., 2., 2.]], [0., 1.57], 'cpu', aligned=True)
+    w = amd.extras.anchor3d_range_anchors((4, 8), [[-8., -4., 0.5, 8., 4., 0.5]], [[1., 2., 3.], [2., 2., 2.]], [0., 1.57], 'cpu', aligned=True)
     assert w.shape == (1, 4, 8, 2, 2, 7)
     assert w[0, :, 0, 0, 0, 1].tolist() == [-3.0, -1.0, 1.0, 3.0] and w[0, 0, :, 1, 1, 0].tolist() == [-7.0, -5.0, -3.0, -1.0, 1.0, 3.0, 5.0, 7.0]
     assert w[0, 2, 3, 1, 1, :6].tolist() == [-1.0, 1.0, 0.5, 2.0, 2.0, 2.0] and abs(w[0, 2, 3, 1, 1, 6].item() - 1.57) < 1e-6
