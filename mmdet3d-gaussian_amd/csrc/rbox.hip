@@ -618,24 +618,39 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
   return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-  return ((unsigned long long)wave_or_u32((unsigned int)(v >> 32)) << 32) | wave_or_u32((unsigned int)v);
+  // the two halves interleaved: every DPP step has to wait for the VALU result before it (two wait states); with two independent
+  // chains one half's step fills the other's wait
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+  lo = dpp_or<0x111, 0xf>(lo); hi = dpp_or<0x111, 0xf>(hi);
+  lo = dpp_or<0x112, 0xf>(lo); hi = dpp_or<0x112, 0xf>(hi);
+  lo = dpp_or<0x114, 0xf>(lo); hi = dpp_or<0x114, 0xf>(hi);
+  lo = dpp_or<0x118, 0xf>(lo); hi = dpp_or<0x118, 0xf>(hi);
+  lo = dpp_or<0x142, 0xa>(lo); hi = dpp_or<0x142, 0xa>(hi);
+  lo = dpp_or<0x143, 0xc>(lo); hi = dpp_or<0x143, 0xc>(hi);
+  return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, 63) << 32) |
+         (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)lo, 63);
 }
 // ---- greedy scan: one workgroup, phase-shifted waves, one LDS-only barrier per 64-box block ("interval") -------------
 // Measured with the cycle-stamp build (tools/scan_profile.py): a global-memory round trip from this CU is ~2700 cycles,
 // a resolved block ~1200.  So no wave may load and use a value inside one interval:
-//   wave 0 (resolver) reads everything it needs for block t — colm[64t+l], the three "urgent" words
-//     mask[64t+l][t+1..t+3] and the box id — from an LDS ring that other waves filled one interval earlier.  It solves
-//     the block wave-parallel (kept = alive; kept' = alive & ~ballot(col & kept) until stable: the unique solution of the
-//     triangular system the greedy order defines), OR-reduces the kept lanes' urgent words on the DPP network into
-//     remv[t+1..t+3], stores the kept ids and publishes the kept word.
-//   waves 1.. (3 groups x SCAN_GW, group j phase-shifted by j intervals) run super-iterations of three intervals:
-//     interval t0      ISSUE  : loads of the mask rows kept in block t0-1 (words >= t0+3; the group's waves split the
-//                               rows) and, rank 0 only, of the resolver's inputs for block t0+3;
+//   wave 0 (resolver) reads what the NEXT block waits for — colm[64t+l] and the first "urgent" word mask[64t+l][t+1] — from an
+//     LDS ring that other waves filled one interval earlier.  It solves the block wave-parallel (kept = alive; kept' = alive &
+//     ~ballot(col & kept) until stable: the unique solution of the triangular system the greedy order defines), publishes the
+//     kept word and the compacted lane list, and carries the OR of the kept lanes' first urgent word to the next block in
+//     registers (a full DPP reduction; round 5).
+//   field waves (3, one per phase) fetch the resolver's inputs for block t0+3 (five fields per box), and in the interval in which
+//     their loads fly run the SCRIBE step of block t0: kept ids to `keep`, urgent words 2 and 3 OR-ed into remv[t0+2], remv[t0+3],
+//     the running count (round 5: until then all of that sat on the resolver's critical path).
+//   waves 1..12 (3 groups x SCAN_GW row waves, group j phase-shifted by j intervals) run super-iterations of three intervals:
+//     interval t0      ISSUE  : loads of the mask rows kept in block t0-1 (words >= t0+3; the group's waves split the rows);
 //     interval t0+1    nothing (the loads are in flight across two barriers; straight-line code inside ONE loop
 //                               iteration, so the compiler waits for them only at their first use);
-//     interval t0+2    CONSUME: OR the rows into remv (ds_or_b64), write the resolver's inputs into the ring.
+//     interval t0+2    CONSUME: OR the rows into remv (ds_or_b64).
 //   Block b's rows therefore reach remv[w >= b+4] during interval b+3, one barrier before block b+4 is resolved; words
 //   b+1..b+3 are covered by the urgent words.  Every wave executes exactly cb barriers.
+//   What bounds it (profiles/r05_nms_pmc.txt): a wave issues one instruction per ~10 cycles here (4 waves per SIMD, dependent
+//   scalar/vector chains), and an interval lasts as long as its longest instruction stream: the row waves' ISSUE (~90
+//   instructions for 4 rows), then the resolver (~60) and the CONSUME (~50).
 // History: one scalar readlane step per kept box + load->use inside the interval: 1.2-3.8 us per block.
 constexpr int SCAN_GW = 4;                          // row waves per propagate group
 constexpr int SCAN_U = 16;                          // rows in flight per row wave: SCAN_GW x SCAN_U = 64 = every box of a block
@@ -680,6 +695,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
                                                           long long* __restrict__ dbg, const ScanWindow win) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
   __shared__ unsigned long long skept[4];
+  __shared__ int scount;        // boxes kept before the block the next scribe step handles (handed from field wave to field wave)
   __shared__ int klist[4][64];  // lane indices of the boxes kept in a block, compacted (k-th kept box -> lane)
   __shared__ unsigned long long rin[SCAN_RING][2 + SCAN_NU][64];  // [slot][col, urgent 1..3, id][lane]
   const int g = blockIdx.x;  // one workgroup per group
@@ -707,6 +723,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   if (windowed && c_begin == 0)   // the first super-block opens the global removed-set for everything right of it
     for (int w = cb + tid; w < cb_all; w += SCAN_T) gremv[w] = 0ull;
   if (tid < 4) skept[tid] = 0ull;
+  if (tid == 0) scount = (windowed && c_begin > 0) ? (int)num_keep[g] : 0;
   lds_barrier();
   const int NB = cb - c_begin;  // intervals = barriers every wave executes in the main phase
 
@@ -727,17 +744,21 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 #pragma unroll
       for (int f = 0; f < 2 + SCAN_NU; ++f) rin[B & (SCAN_RING - 1)][f][lane] = load_field(B, f);
     }
-    int count = (windowed && c_begin > 0) ? (int)num_keep[g] : 0;
+    // Round 5: the resolver keeps ONLY what the next block waits for.  Per block: the column word and the FIRST urgent word from
+    // the ring, remv[c] from LDS, the fixed point, the kept word + compacted lane list published for the row waves, and the OR
+    // of the kept lanes' first urgent word carried to the next block IN REGISTERS (a full DPP reduction: no LDS atomic and no
+    // LDS round trip between two blocks).  Everything else a kept block owes — the kept ids to `keep`, the urgent words 2 and 3
+    // into remv[c+2], remv[c+3], the running count — is done ONE INTERVAL LATER by the field wave that idles in that interval
+    // (`scribe` below): off the critical path.  Until then the resolver's own stream was the scan's critical path at clustered
+    // scenes (stamps, profiles/r05_nms_pmc.txt: lds 180 | solve 176 | ids + urgent ORs + lists 580 | barrier 116 of 1052 cycles).
+    unsigned long long carry = 0ull;   // kept boxes of the previous block -> removed lanes of this one
     for (int c = c_begin; c < cb; ++c) {
       SCAN_STAMP(0);
       const int slot = c & (SCAN_RING - 1);
       const unsigned long long col = rin[slot][0][lane];
-      unsigned long long urg[SCAN_NU];
-#pragma unroll
-      for (int k = 0; k < SCAN_NU; ++k) urg[k] = rin[slot][1 + k][lane];
-      const long long id = (long long)rin[slot][1 + SCAN_NU][lane];
+      unsigned long long urg1 = rin[slot][1][lane];
       const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
-      unsigned long long cur = uniform_u64(remv[c]);
+      unsigned long long cur = uniform_u64(remv[c]) | carry;
       const int nvalid = min(64, n - c * 64);
       if (nvalid < 64) cur |= ~0ull << nvalid;
       const unsigned long long alive = ~cur;
@@ -751,50 +772,15 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       }
       SCAN_STAMP(2);
       const bool mine = (kept >> lane) & 1ull;
-      if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
-        keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
-      // the kept lanes' urgent words: OR-reduced inside every QUAD of lanes on the DPP network (two steps for all six dwords
-      // together), then lanes 3, 7, ... 63 OR their quad's totals into remv[c+1..c+3] with ds_or_b64 — 16 same-address LDS
-      // atomics per word, which the LDS works off while the wave goes on (they are only waited for before the barrier).
-      // History: three full wave reductions one after the other, results through SGPRs: ~130 instructions (round 3); one
-      // interleaved full reduction with lane 63 storing: ~60 (round 4, -62 cycles); this form: ~25.  A ds_or_b64 from EVERY kept
-      // lane needs no reduction at all but serialises up to 64 atomics per word on a sparse scene.
-#pragma unroll
-      for (int k = 0; k < SCAN_NU; ++k) urg[k] = mine ? urg[k] : 0ull;
-      {
-        unsigned int h[2 * SCAN_NU];
-#pragma unroll
-        for (int k = 0; k < SCAN_NU; ++k) {
-          h[2 * k] = (unsigned int)urg[k];
-          h[2 * k + 1] = (unsigned int)(urg[k] >> 32);
-        }
-#pragma unroll
-        for (int k = 0; k < 2 * SCAN_NU; ++k) h[k] = dpp_or<0x111, 0xf>(h[k]);   // row_shr:1
-#pragma unroll
-        for (int k = 0; k < 2 * SCAN_NU; ++k) h[k] = dpp_or<0x112, 0xf>(h[k]);   // row_shr:2 -> lane 4q+3 holds quad q
-#pragma unroll
-        for (int k = 0; k < SCAN_NU; ++k) urg[k] = ((unsigned long long)h[2 * k + 1] << 32) | h[2 * k];
-      }
-      if ((lane & 3) == 3) {
-        // ds_or_b64 written out: an atomicOr() here is rewritten by the compiler's wave-level atomic optimisation into a
-        // readlane loop over the active lanes plus a scalar round trip — the very cost this form removes
-#pragma unroll
-        for (int k = 0; k < SCAN_NU; ++k)
-          if (c + 1 + k < cb)   // (uniform bound)
-            asm volatile("ds_or_b64 %0, %1" ::"v"(lds_offset(&remv[c + 1 + k])), "v"(urg[k]) : "memory");
-      }   // (they are waited for right before the barrier below, behind the rest of the block's bookkeeping)
       if (mine) klist[c & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = lane;
-      count += __builtin_popcountll(kept);
-      if (lane == 0) {
-        skept[c & 3] = kept;
-        if (windowed) gkept[c] = kept;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lane 63's ds_or_b64 above are inline asm: the compiler does not count them
+      if (lane == 0) skept[c & 3] = kept;
+      urg1 = mine ? urg1 : 0ull;
+      carry = (c + 1 < cb) ? wave_or_u64(urg1) : 0ull;   // (uniform bound)
       SCAN_STAMP(3);
       lds_barrier();
       SCAN_STAMP(5);
     }
-    if (lane == 0) num_keep[g] = count;
+    if (NB == 0 && lane == 0) num_keep[g] = 0;   // an empty group: no block, no scribe step (a windowed launch returned above)
   } else {
     // ---------------------------------------------------------------- propagate / loader groups
     // Round 4: the resolver's inputs (five fields per box of block t + 3) are fetched by three FIELD waves of their own, one
@@ -809,6 +795,54 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
     const int trail = NB - lead - 3 * S;
     for (int q = 0; q < lead; ++q) lds_barrier();
     if (field_wave) {
+      // scribe: what block c owes beyond the resolver's critical path (see there), run by a field wave during the interval AFTER
+      // block c was resolved — the one of its three intervals in which it used to wait for its loads.  The ring still holds the
+      // block's fields (slot c & 3 is rewritten three intervals later), skept / klist are the resolver's, the count of boxes
+      // kept so far travels from scribe to scribe through `scount`.
+      auto scribe = [&](int c) {
+        const int slot = c & (SCAN_RING - 1);
+        const unsigned long long kept = uniform_u64(skept[c & 3]);
+        unsigned long long urg[SCAN_NU - 1];
+#pragma unroll
+        for (int k = 0; k < SCAN_NU - 1; ++k) urg[k] = rin[slot][2 + k][lane];
+        const long long id = (long long)rin[slot][1 + SCAN_NU][lane];
+        const int count = __builtin_amdgcn_readfirstlane(scount);
+        const bool mine = (kept >> lane) & 1ull;
+        if (mine)  // with `order` the kept indices come out already mapped to the caller's box numbering
+          keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+        // the kept lanes' urgent words 2.. : OR-reduced inside every QUAD of lanes on the DPP network, then lanes 3, 7, ... 63 OR
+        // their quad's totals into remv[c+2..] with ds_or_b64 (16 same-address LDS atomics per word; written out because an
+        // atomicOr() here is rewritten into a readlane loop over the active lanes plus a scalar round trip)
+#pragma unroll
+        for (int k = 0; k < SCAN_NU - 1; ++k) urg[k] = mine ? urg[k] : 0ull;
+        {
+          unsigned int h[2 * (SCAN_NU - 1)];
+#pragma unroll
+          for (int k = 0; k < SCAN_NU - 1; ++k) {
+            h[2 * k] = (unsigned int)urg[k];
+            h[2 * k + 1] = (unsigned int)(urg[k] >> 32);
+          }
+#pragma unroll
+          for (int k = 0; k < 2 * (SCAN_NU - 1); ++k) h[k] = dpp_or<0x111, 0xf>(h[k]);   // row_shr:1
+#pragma unroll
+          for (int k = 0; k < 2 * (SCAN_NU - 1); ++k) h[k] = dpp_or<0x112, 0xf>(h[k]);   // row_shr:2 -> lane 4q+3 holds quad q
+#pragma unroll
+          for (int k = 0; k < SCAN_NU - 1; ++k) urg[k] = ((unsigned long long)h[2 * k + 1] << 32) | h[2 * k];
+        }
+        if ((lane & 3) == 3) {
+#pragma unroll
+          for (int k = 0; k < SCAN_NU - 1; ++k)
+            if (c + 2 + k < cb)   // (uniform bound)
+              asm volatile("ds_or_b64 %0, %1" ::"v"(lds_offset(&remv[c + 2 + k])), "v"(urg[k]) : "memory");
+        }
+        if (lane == 0) {
+          const int total = count + __builtin_popcountll(kept);
+          scount = total;
+          if (windowed) gkept[c] = kept;
+          if (c == cb - 1) num_keep[g] = total;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ds_or_b64 above are inline asm: the compiler does not count them
+      };
       for (int s2 = 0; s2 < S; ++s2) {
         const int t0 = c_begin + grp + 3 * s2;
         // ---- interval t0: issue the loads of block t0 + 3's inputs (constant field ids: a run-time id cost ~430 cycles per field)
@@ -816,7 +850,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 #pragma unroll
         for (int f = 0; f < 2 + SCAN_NU; ++f) in[f] = load_field(t0 + 3, f);
         lds_barrier();
-        // ---- interval t0+1: the loads fly
+        // ---- interval t0+1: the loads fly; block t0 was resolved in the interval before: its scribe step
+        scribe(t0);
         lds_barrier();
         // ---- interval t0+2: into the ring (first USE of the loaded registers pinned here, see the row waves)
 #pragma unroll
@@ -828,9 +863,18 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
         }
         lds_barrier();
       }
-      for (int q = 0; q < trail; ++q) lds_barrier();
+      // the trailing intervals of this wave (no block left to fetch): interval tq = lead + 3 S + q; its scribe step falls on q == 1
+      const int tq = c_begin + lead + 3 * S;
+      for (int q = 0; q < trail; ++q) {
+        if (q == 1) scribe(tq);
+        lds_barrier();
+      }
+      // the LAST block was resolved in the last interval: its scribe step comes after the last barrier, from the field wave
+      // whose turn it would be (block cb - 1 belongs to the phase of group (NB - 1) % 3)
+      if (NB > 0 && grp == (NB - 1) % 3) scribe(cb - 1);
       return;
     }
+
     for (int s2 = 0; s2 < S; ++s2) {
       const int t0 = c_begin + grp + 3 * s2;
       [[maybe_unused]] const int c = t0;  // (SCAN_STAMP index)
@@ -838,16 +882,25 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       // ---- interval t0: issue
       const int bk = t0 - 1;             // block whose kept rows this group spreads
       const int first = t0 + SCAN_NU;    // = bk + 1 + SCAN_NU: first word not covered by the urgent words
-      unsigned long long kb = 0ull;
-      if (bk >= c_begin && first < cb) kb = uniform_u64(skept[bk & 3]);
+      // both LDS reads of the interval issued together, unconditionally (one round trip instead of two back to back: the kept
+      // word used to be read under the bounds test and waited for before the lane list was even requested; ~120 of the issue
+      // interval's ~650 cycles).  bk & 3 is a valid slot even for bk = c_begin - 1; its stale content is masked right below.
+      // (written out: left to the compiler the first read is waited for — its value feeds scalar code — before the second is issued)
+      unsigned long long kbv;
+      int myl;
+      asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(kbv), "=&v"(myl)
+                   : "v"(lds_offset(&skept[bk & 3])), "v"(lds_offset(&klist[bk & 3][(rank + SCAN_GW * lane) & 63]))
+                   : "memory");
+      unsigned long long kb = uniform_u64(kbv);
+      if (!(bk >= c_begin && first < cb)) kb = 0ull;   // (uniform)
       // this wave's share: every SCAN_GW-th kept box, read from the compacted list the resolver left in LDS: lane u
       // fetches the row of slot u, the slots then cost a v_readlane + multiply + load each (a lone wave pays ~5 cycles
       // per instruction: walking the kept bits with ffbl / and / compare cost more than the memory round trip)
       const int cnt = __builtin_popcountll(kb);
       const int m = cnt > rank ? (cnt - rank + SCAN_GW - 1) / SCAN_GW : 0;  // rows of this wave (uniform)
-      // (unconditional: a lane beyond m reads a stale or foreign slot that no readlane below ever selects; predicating the read
-      //  on lane < m made it wait for the kept word's own LDS round trip first)
-      const int myl = klist[bk & 3][(rank + SCAN_GW * lane) & 63];
+      // (the lane-list read above is unconditional: a lane beyond m reads a stale or foreign slot that no readlane below ever
+      //  selects; predicating the read on lane < m made it wait for the kept word's own LDS round trip first)
       if (wave == 1) SCAN_STAMP_SYNC(13);
       const unsigned long long* blk = mask + (size_t)(max(bk, c_begin) * 64) * cbs;
       // Loads are unconditional per lane: the word index is clamped into the row (w < cb is the same for every row of a
@@ -861,17 +914,23 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
       for (int ch = 0; ch < CH; ++ch) wcl[ch] = (unsigned int)min(first + ch * 64 + lane, cb - 1);
       static_assert(U % 2 == 0 && U * SCAN_GW >= 64, "rows are issued in pairs; a group's waves cover a whole block");
       const int mlast = max(m - 1, 0);
+      const unsigned int myrow = (unsigned int)myl * (unsigned int)cbs;   // word offset of this lane's row inside the block (< 64 * 1024)
 #pragma unroll
-      for (int u = 0; u < U; u += 2) {  // pairs: half the uniform branches; an odd tail re-loads its last row (OR is idempotent)
+      for (int u = 0; u < U; u += 2) {  // pairs: half the uniform branches; an odd tail re-loads its last row (OR is idempotent).
+        // (Fours were tried in round 5: n = 4096 clustered 52.4 -> 51.6 us, but the dense scenes lose more — 64.4 -> 65.6 us,
+        //  n = 9000 147.0 -> 149.9 us: three clamped row indices per group instead of one per pair.)
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) v[u][ch] = v[u + 1][ch] = 0ull;
         if (u < m) {  // uniform
-          const unsigned int off0 = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;  // < 64 * 1024
-          const unsigned int off1 = (unsigned int)__builtin_amdgcn_readlane(myl, min(u + 1, mlast)) * (unsigned int)cbs;
+          // row base as a UNIFORM pointer (scalar registers) + the lane's word as the vector offset: one readlane, one 64-bit
+          // shift-add and the load per row (the row offset is multiplied out once per lane above, not once per row on the scalar
+          // unit; adding it to the lane's word first made the whole address vector arithmetic: three VALU instructions per row)
+          const unsigned long long* const r0 = blk + (unsigned int)__builtin_amdgcn_readlane((int)myrow, u);
+          const unsigned long long* const r1 = blk + (unsigned int)__builtin_amdgcn_readlane((int)myrow, min(u + 1, mlast));
 #pragma unroll
           for (int ch = 0; ch < CH; ++ch) {
-            v[u][ch] = blk[off0 + wcl[ch]];
-            v[u + 1][ch] = blk[off1 + wcl[ch]];
+            v[u][ch] = r0[wcl[ch]];
+            v[u + 1][ch] = r1[wcl[ch]];
           }
         }
       }
@@ -882,7 +941,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
           const int w = w0 + lane;
           unsigned long long acc = 0ull;
           for (int u = (w0 - first) < 64 * CH ? U : 0; u < m; ++u) {
-            const unsigned int off = (unsigned int)__builtin_amdgcn_readlane(myl, u) * (unsigned int)cbs;
+            const unsigned int off = (unsigned int)__builtin_amdgcn_readlane((int)myrow, u);
             if (w < cb) acc |= blk[off + (unsigned int)w];
           }
           if (acc) atomicOr(&remv[w], acc);
