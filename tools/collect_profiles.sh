@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence for the round into gpurun_out/<round>/.
-#   tools/collect_profiles.sh r04
+#   tools/collect_profiles.sh r05
 # Hot path only; the frozen extras (DESIGN_EXTRAS.md) are not measured any more.
 # kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
 # and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -40,7 +40,14 @@ python3 tools/step_variants.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_step_varian
 tools/pmc_issue_mix.sh $OUT/${R}_pmc_issue_mix.txt > /dev/null 2>&1
 python3 tests/perf/eval_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_eval_time.jsonl
 python3 tools/scatter_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_time.jsonl
-python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time_collection.txt
+python3 tools/scatter_kernel_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scatter_kernel_time.txt
+# the NMS scan's cycle stamps (profiling build) and the proof that the parity gates bite (damaged builds must fail)
+python3 tools/build_variants.py prof="-DSCAN_PROFILE=1" > /dev/null 2>&1
+GD3D_LIB=tools/variants/libgd3d_prof.so GD3D_HOST=python python3 tools/scan_profile.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_scan_stamps.txt
+python3 tools/gate_bites.py $OUT/${R}_gate_bites.txt > /dev/null 2>&1
+# host glue A/B at training sizes: the Python autograd.Function + ctypes layer against the optional C++ node, same box
+GD3D_HOST=python python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_python_glue.jsonl
+GD3D_HOST=cpp python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency_cpp_glue.jsonl
 # accuracy report of THIS build: the test module deletes any older file of that name before it runs and writes it only from
 # the rows it really compared; a failed or empty run leaves no report and is said so loudly
 rm -f $OUT/${R}_accuracy_report.txt
