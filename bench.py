@@ -25,12 +25,13 @@ marker packets): the kernel durations behind `roofline` are measured INSIDE the 
 dispatch with events bound to it costs ~5 us of GPU time more than a plain one (profiles/r03_event_every_ab.txt: the step
 runs 28.7 us over the sum of its three fused kernels with events on every launch, 14-16 us over it with every fifth step or
 none timed; round 2 timed every launch and so taxed its own `value` by 3.5 %).
-N > 1 replays a hipGraph of the step (torch.cuda.CUDAGraph; host ~40 us/step with the collective call): with the per-step
-collective in the loop the replayed step is the faster one (one rank under torch.distributed.run, RCCL all_gather per step,
-profiles/r03_rccl_rehearsal_*.json: 425 us per step replayed, 432 us eager, against 406 us for the N = 1 step without a
-collective).  HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the per-kernel durations
-come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says which),
-followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).  `--graph` / `--no-graph` override.
+N > 1 launches eagerly too since round 5: with the plain-backward step and the per-step collective in the loop the eager step is
+the faster one (one rank under torch.distributed.run, RCCL all_gather per step, profiles/r05_rccl_rehearsal_*.json: 439.6 us per
+step eager, 443.6 / 444.9 us as a hipGraph replay, against 416.5 us for the N = 1 step without a collective; rounds 3-4, whose
+step handed over the unit gradient, measured the replay ahead: 425 vs 432 us).  `--graph` replays a hipGraph of the step
+(torch.cuda.CUDAGraph; host ~10 us/step): HIP events cannot be bound to a dispatch inside a captured graph on ROCm, so there the
+per-kernel durations come from an eager pass run right after the timed region, same stream, same process (`roofline.timing` says
+which), followed by a bracketed run of bare replays (`config.graph_replay_ms_per_step`).
 The step (round 5): three GDLoss forwards, then a plain `(l0 + l1 + l2).backward()` — the form every caller of the reference
 runs (tools/train.py:213-220 -> mmcv's OptimizerHook: `loss.backward()`): torch adds the losses, fills a ones tensor, and each
 loss's node launches one early-exit `grad_finish` (the fused forward launch already wrote the final gradients).  `value` times
@@ -412,8 +413,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=10_000_000, help='pairs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--prewarm', type=float, default=1.0,
                     help='seconds of untimed steps before the W warmup steps (clock ramp of a cold GPU; 0 = off)')
-    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (default for N > 1; at N = 1 it is 5 us per step slower than eager launches)')
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (default for N = 1)')
+    ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (4-20 us per step slower than eager launches for the plain-backward step, with or without the collective)')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly (the default)')
     ap.add_argument('--separate-inputs', action='store_true',
                     help='one torch allocation per input array (target + one prediction leaf per loss) instead of row ranges of '
                          'ONE allocation: exposes the placement lottery of DESIGN.md 5.3')
@@ -470,7 +471,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    use_graph = on_gpu and (args.graph or world > 1) and not args.no_graph
+    use_graph = on_gpu and args.graph and not args.no_graph
     fail_rank = int(os.environ.get('GD3D_BENCH_FAIL_RANK', '-1'))   # tests: this rank dies after the warmup steps
 
     def device_sync():
