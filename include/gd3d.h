@@ -37,6 +37,7 @@ extern "C" {
 /* error codes outside the hipError_t range */
 #define GD3D_E_BADARG 10001   /* null pointer / negative size / unknown enum */
 #define GD3D_E_TOOLARGE 10002 /* n exceeds what the launch geometry supports */
+#define GD3D_E_HOST 10003     /* `_cpu` twins only: a worker thread failed (out of host memory); outputs are not to be used */
 
 /* loss_type: keys of GDLoss.BAG_GD_LOSS (gaussian_distance_loss.py:253-259) */
 enum {

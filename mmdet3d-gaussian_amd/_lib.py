@@ -220,12 +220,45 @@ def lib_path():
 ABI_VERSION = 6
 
 
+def host_simd_ok():
+    """The `_cpu` twins are compiled for x86-64-v3 (AVX2 + FMA: the per-pair math is written in explicit fmaf(), build.py); on a
+    host CPU without them a twin would die of SIGILL.  Read once from /proc/cpuinfo; unknown platforms are given the benefit of
+    the doubt (the HIP entry points need none of this)."""
+    global _simd_ok
+    if _simd_ok is None:
+        _simd_ok = True
+        try:
+            with open('/proc/cpuinfo') as f:
+                for line in f:
+                    if line.startswith('flags'):
+                        flags = set(line.split(':', 1)[1].split())
+                        _simd_ok = {'avx2', 'fma'} <= flags
+                        break
+        except OSError:
+            pass
+    return _simd_ok
+
+
+_simd_ok = None
+
+
+def _unsupported_cpu_twin(name):
+    def raiser(*_a, **_k):
+        raise RuntimeError(f'{name}: the CPU twins of libgd3d.so are built for x86-64-v3 (AVX2 + FMA) and this host CPU lacks them; '
+                           'move the tensors to the GPU (the HIP entry points are unaffected)')
+    return raiser
+
+
 def _bind(path):
     L = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
+    if not host_simd_ok():   # a clear error instead of SIGILL (the C++ node checks for itself: it resolves its own pointers)
+        for name in SYMBOLS:
+            if name.endswith('_cpu'):
+                setattr(L, name, _unsupported_cpu_twin(name))
     arch = ctypes.c_char_p()
     ver = L.gd3d_abi_version(ctypes.byref(arch))
     if ver != ABI_VERSION:
@@ -347,4 +380,5 @@ def set_host_glue(mode):
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError(f'{what} failed with code {rc}' + (' (bad argument)' if rc == 10001 else ''))
+        raise RuntimeError(f'{what} failed with code {rc}' + {10001: ' (bad argument)', 10002: ' (too large)',
+                                                               10003: ' (a host worker thread failed: out of memory?)'}.get(rc, ''))

@@ -163,7 +163,7 @@ int gd3d_loss_fused_cpu(const gd3d_params* p, const float* pred, const float* ta
   j.tau = p->tau;
   for (int k = 0; k < 3; ++k) j.c[k] = p->center_offset[k];
   const TileFn fn = pick(p, grad_target != nullptr);
-  parallel_ranges(tiles, team_size(nthreads, tiles), [&](int64_t a, int64_t b) { fn(j, a, b); });
+  if (!parallel_ranges(tiles, team_size(nthreads, tiles), [&](int64_t a, int64_t b) { fn(j, a, b); })) return GD3D_E_HOST;
   if (loss_sum != nullptr) *loss_sum = (float)sum_partials(j.partials, tiles);
   return 0;
 }
@@ -178,14 +178,14 @@ int gd3d_scale_rows_cpu(float* grad, const float* g, int per_row, int64_t n, int
   if (n < 0 || g == nullptr || (n > 0 && grad == nullptr)) return GD3D_E_BADARG;
   if (!per_row && g[0] == 1.0f) return 0;   // loss.backward(): nothing to scale (what the device kernel's early exit does)
   const int64_t tiles = (n + TILE - 1) / TILE;
-  parallel_ranges(tiles, team_size(nthreads, tiles), [&](int64_t a, int64_t b) {
+  const bool ok = parallel_ranges(tiles, team_size(nthreads, tiles), [&](int64_t a, int64_t b) {
     const int64_t hi = std::min(n, b * TILE);
     for (int64_t i = a * TILE; i < hi; ++i) {
       const float s = per_row ? g[i] : g[0];
       for (int k = 0; k < 7; ++k) grad[i * 7 + k] *= s;
     }
   });
-  return 0;
+  return ok ? 0 : GD3D_E_HOST;
 }
 
 }  // extern "C"

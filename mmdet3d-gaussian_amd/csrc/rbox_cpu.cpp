@@ -30,7 +30,7 @@ int eval_iou_rows(const float* det, int64_t nd, const float* gt, int64_t ng, flo
   if (nd < 0 || ng < 0) return GD3D_E_BADARG;
   if (nd == 0 || ng == 0) return 0;
   if (det == nullptr || gt == nullptr || iou == nullptr) return GD3D_E_BADARG;
-  parallel_ranges(nd, rows_team(nthreads, nd, ng), [&](int64_t a, int64_t b) {
+  const bool team_ok = parallel_ranges(nd, rows_team(nthreads, nd, ng), [&](int64_t a, int64_t b) {
     HullScratch<1> hs;
     for (int64_t i = a; i < b; ++i)
       for (int64_t j = 0; j < ng; ++j) {
@@ -42,7 +42,7 @@ int eval_iou_rows(const float* det, int64_t nd, const float* gt, int64_t ng, flo
         iou[i * ng + j] = eval_iou<IS3D, 1>(d, g, z_offset, hs, 0);
       }
   });
-  return 0;
+  return team_ok ? 0 : GD3D_E_HOST;
 }
 
 }  // namespace
@@ -53,7 +53,7 @@ int riou_bev_xyxyr_cpu(const float* a, int64_t na, const float* b, int64_t nb, f
   if (na < 0 || nb < 0) return GD3D_E_BADARG;
   if (na == 0 || nb == 0) return 0;
   if (a == nullptr || b == nullptr || iou == nullptr) return GD3D_E_BADARG;
-  parallel_ranges(na, rows_team(nthreads, na, nb), [&](int64_t r0, int64_t r1) {
+  const bool team_ok = parallel_ranges(na, rows_team(nthreads, na, nb), [&](int64_t r0, int64_t r1) {
     VertexScratch<1> vs;
     for (int64_t i = r0; i < r1; ++i) {
       OBox A;
@@ -65,7 +65,7 @@ int riou_bev_xyxyr_cpu(const float* a, int64_t na, const float* b, int64_t nb, f
       }
     }
   });
-  return 0;
+  return team_ok ? 0 : GD3D_E_HOST;
 }
 
 int riou_eval_bev_cpu(const float* det, int64_t nd, const float* gt, int64_t ng, float* iou, int32_t nthreads) {
@@ -81,14 +81,14 @@ int riou_eval_trans_bev_cpu(const float* det, int64_t nd, int32_t det_cols, cons
   if (nd < 0 || ng < 0 || det_cols < 2 || gt_cols < 2) return GD3D_E_BADARG;
   if (nd == 0 || ng == 0) return 0;
   if (det == nullptr || gt == nullptr || dist == nullptr) return GD3D_E_BADARG;
-  parallel_ranges(nd, rows_team(nthreads, nd, ng * 16), [&](int64_t a, int64_t b) {
+  const bool team_ok = parallel_ranges(nd, rows_team(nthreads, nd, ng * 16), [&](int64_t a, int64_t b) {
     for (int64_t i = a; i < b; ++i)
       for (int64_t j = 0; j < ng; ++j) {
         const float dx = det[i * det_cols] - gt[j * gt_cols], dy = det[i * det_cols + 1] - gt[j * gt_cols + 1];
         dist[i * ng + j] = std::sqrt(dx * dx + dy * dy);   // affinity.cpp:98-100 in fp32, correctly rounded
       }
   });
-  return 0;
+  return team_ok ? 0 : GD3D_E_HOST;
 }
 
 // match_coco on the host: the matcher kernel's own statement of matcher.cpp:8-74 (csrc/eval_match.hip) — per threshold the
@@ -109,7 +109,7 @@ int eval_match_coco_cpu(const float* cost, const float* cost_thrs, const uint8_t
     std::memcpy(&u, &v, 4);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   };
-  parallel_ranges(nt, gd3d_host::team_size(nthreads, nt, 1, nd * ng < 65536 ? (int64_t)1 << 40 : 2), [&](int64_t t0, int64_t t1) {
+  const bool team_ok = parallel_ranges(nt, gd3d_host::team_size(nthreads, nt, 1, nd * ng < 65536 ? (int64_t)1 << 40 : 2), [&](int64_t t0, int64_t t1) {
     std::vector<unsigned char> taken((size_t)ng);
     for (int64_t t = t0; t < t1; ++t) {
       std::fill(taken.begin(), taken.end(), (unsigned char)0);
@@ -132,7 +132,7 @@ int eval_match_coco_cpu(const float* cost, const float* cost_thrs, const uint8_t
       }
     }
   });
-  return 0;
+  return team_ok ? 0 : GD3D_E_HOST;
 }
 
 // greedy NMS on score-sorted boxes: box i suppresses a later box j iff iou(box_i, box_j) > thresh (argument order i, j) — the

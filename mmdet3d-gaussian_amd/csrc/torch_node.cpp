@@ -98,8 +98,15 @@ std::atomic<int64_t> g_finish_calls{0};   // gd3d_grad_finish launches made so f
 constexpr int MAX_DEVICES = 64;
 const void* g_unit_grad[MAX_DEVICES + 1] = {};   // [MAX_DEVICES] = the CPU's
 
+// the `_cpu` twins are built for x86-64-v3 (build.py): a clear error instead of SIGILL on a host without AVX2 / FMA
+void require_cpu_twins() {
+  static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  TORCH_CHECK(ok, "GDLoss on CPU tensors: the CPU twins of libgd3d.so are built for x86-64-v3 (AVX2 + FMA) and this host CPU lacks them");
+}
+
 void fail(int rc, const char* what) {
-  TORCH_CHECK(rc == 0, what, " failed with code ", rc, rc == GD3D_E_BADARG ? " (bad argument)" : "");
+  TORCH_CHECK(rc == 0, what, " failed with code ", rc,
+              rc == GD3D_E_BADARG ? " (bad argument)" : rc == GD3D_E_HOST ? " (a host worker thread failed: out of memory?)" : "");
 }
 
 inline float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
@@ -223,6 +230,7 @@ std::tuple<Tensor, c10::optional<Tensor>> reduced(const Tensor& pred, const Tens
                   target.device() == pred.device(),
               "gd3d node: pred / target must be contiguous fp32 (N, 7) tensors on one device");
   TORCH_CHECK(pred.is_cuda() || pred.is_cpu(), "gd3d node: no implementation for device ", pred.device());
+  if (pred.is_cpu()) require_cpu_twins();
   TORCH_CHECK(abi.bound, "gd3d node: bind(path of libgd3d.so) has not been called");
   const int64_t n = pred.size(0);
   Tensor w;

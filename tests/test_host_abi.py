@@ -302,3 +302,62 @@ def test_anchor_targets_struct_layout_and_argument_checks():
     with pytest.raises(RuntimeError, match='sampling=True'):
         amd.extras.anchor_head_get_targets(torch.zeros(2, 2, 1, 2, 7), [torch.zeros(1, 7)], [torch.zeros(1, dtype=torch.long)],
                                     dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45), 1, sampling=True)
+
+
+def test_cpu_twins_refuse_a_host_without_avx2_fma_instead_of_sigill():
+    """the `_cpu` twins are compiled for x86-64-v3; on a host CPU without AVX2 / FMA the binding replaces every
+    `*_cpu` entry by a callable that raises a clear RuntimeError (a fresh process: the check is made once, at bind time)."""
+    import subprocess
+    import sys
+    code = f'''
+import sys
+sys.path.insert(0, {ROOT!r})
+import torch
+from mmdet3d_gaussian_amd import _lib
+_lib._simd_ok = False                      # what host_simd_ok() finds on such a host
+import mmdet3d_gaussian_amd as amd
+t = torch.rand(8, 7) + 0.5
+try:
+    amd.GDLoss('gwd3d', reduction='none')(t, t)
+except RuntimeError as e:
+    print('REFUSED', e)
+try:
+    amd.nms_gpu(torch.rand(4, 5), torch.rand(4), 0.5)
+except RuntimeError as e:
+    print('REFUSED', e)
+'''
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.stdout.count('REFUSED') == 2 and 'AVX2' in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_host_thread_team_reports_a_throwing_worker(tmp_path):
+    """ADVICE r04: a worker body that throws (std::bad_alloc in a scratch vector) must not escape a std::thread (std::terminate):
+    parallel_ranges catches it, the other ranges finish, and the entry point returns GD3D_E_HOST."""
+    import shutil
+    import subprocess
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        pytest.skip('no host C++ compiler')
+    src = tmp_path / 't.cpp'
+    src.write_text('''
+#include <cstdio>
+#include <new>
+#include "%s/mmdet3d-gaussian_amd/csrc/host_threads.h"
+int main() {
+  std::atomic<long> done{0};
+  const bool ok = gd3d_host::parallel_ranges(1000, 4, [&](int64_t a, int64_t b) {
+    if (a == 250) throw std::bad_alloc();
+    done += b - a;
+  });
+  const bool ok1 = gd3d_host::parallel_ranges(10, 1, [&](int64_t, int64_t) { throw 1; });
+  const bool ok2 = gd3d_host::parallel_ranges(100, 3, [&](int64_t a, int64_t b) { done += b - a; });
+  std::printf("%%d %%d %%d %%ld\\n", (int)ok, (int)ok1, (int)ok2, done.load());
+  return 0;
+}
+''' % ROOT)
+    exe = tmp_path / 't'
+    subprocess.run([cxx, '-std=c++17', '-O1', '-pthread', str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.split()
+    assert out == ['0', '0', '1', '850'], out          # 750 from the three healthy ranges of the first team + 100
+    hdr = open(os.path.join(ROOT, 'include', 'gd3d.h')).read()
+    assert '#define GD3D_E_HOST 10003' in hdr
