@@ -6,7 +6,7 @@ nothing but `hipcc`'s output: no torch headers, no pybind11, no libtorch link.  
 OPTIONAL accelerator with the same function surface (a C++ node saves 7-30 us of Python per training-size call,
 profiles/r04_node_ab.txt); `_lib.load_node()` picks one of the two (`GD3D_HOST=python|cpp`).  Both are glue: the same
 `extern "C"` entry points with the same arguments, so values and gradients are bit-identical between them
-(tests/test_host_glue.py, and the GPU suites parametrised over both).
+(tests/test_autograd_node.py, tests/test_gpu_host_glue.py, and the GPU suites parametrised over both).
 
 Surface (argument for argument that of csrc/torch_node.cpp):
   reduced(...)        GDLoss's reduced forms ('mean' / 'sum'): one fused launch writes the loss sum AND the final gradients; they
