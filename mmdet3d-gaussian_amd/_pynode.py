@@ -122,8 +122,11 @@ def _weights(w):
 class GDLossReduced(torch.autograd.Function):
     """scale * sum_i w_i L_i with the final gradients produced by the SAME launch (see module docstring)."""
 
+    # (the non-tensor arguments travel as ONE tuple: Function.apply walks its argument list several times per call — functorch
+    #  unwrapping, needs_input_grad — and thirteen arguments cost ~3 us more than four)
     @staticmethod
-    def forward(ctx, pred, target, weight, params, prologue, aux, scale, select, ticket, ev0, ev1, ws_floats, flag_box):
+    def forward(ctx, pred, target, weight, call):
+        params, prologue, aux, scale, select, ticket, ev0, ev1, ws_floats, flag_box = call
         need_gp, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gp, gt, buf = _reduced_launch(pred, target, weight, params, prologue, scale, select, ticket, ev0, ev1, ws_floats,
                                       need_gp, need_gt, True)
@@ -171,7 +174,7 @@ class GDLossReduced(torch.autograd.Function):
                                               prologue if select else None, stream)
                 if rc != 0:
                     _lib.check(rc, 'gd3d_grad_finish')
-        return (gp, gt) + (None,) * 11
+        return gp, gt, None, None
 
 
 def _reduced_launch(pred, target, weight, params, prologue, scale, select, ticket, ev0, ev1, ws_floats, need_gp, need_gt,
@@ -237,9 +240,16 @@ def reduced(pred, target, weight, params, prologue, aux, scale, select, ticket, 
         raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue) are GPU-only')
     p = _copy_struct(_lib.Params, params)
     pro = _copy_struct(_lib.Prologue, prologue) if prologue else None
+    return reduced_trusted(pred, target, weight, p, pro, aux, float(scale), bool(select), int(ticket), int(ev_start), int(ev_stop),
+                           int(ws_floats), want_flag)
+
+
+def reduced_trusted(pred, target, weight, params, prologue, aux, scale, select, ticket, ev_start, ev_stop, ws_floats, want_flag):
+    """`reduced` for a caller that has validated its operands itself and hands over ctypes STRUCTS it never rewrites
+    (GDLoss.forward: `_rows`, the weight normalisation and `make_params`, which builds a new struct whenever a hyper-parameter
+    changes): no checks, no copies — the Python glue's per-call cost is what separates it from the C++ node."""
     box = [] if want_flag else None
-    total = GDLossReduced.apply(pred, target, weight, p, pro, aux, float(scale), bool(select), int(ticket), int(ev_start),
-                                int(ev_stop), int(ws_floats), box)
+    total = GDLossReduced.apply(pred, target, weight, (params, prologue, aux, scale, select, ticket, ev_start, ev_stop, ws_floats, box))
     return total, (box[0] if want_flag else None)
 
 
@@ -272,7 +282,7 @@ def _anchor_head_launch(bbox_pred, bbox_targets, bbox_weights, anchors, sel, par
 
 class GDAnchorHead(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bbox_pred, *args):
+    def forward(ctx, bbox_pred, args):
         loss, grad = _anchor_head_launch(bbox_pred, *args, ctx.needs_input_grad[0])
         ctx.save_for_backward(bbox_pred)
         ctx.grad, ctx.used, ctx.args = grad, False, args
@@ -292,7 +302,7 @@ class GDAnchorHead(torch.autograd.Function):
                 rc = _lib.load().gd3d_scale_rows(g.data_ptr(), go.data_ptr(), 0, g.numel() // 7, stream)
             if rc != 0:
                 _lib.check(rc, 'gd3d_scale_rows')
-        return (g,) + (None,) * 13
+        return g, None
 
 
 def anchor_head(bbox_pred, bbox_targets, bbox_weights, anchors, sel, params, sl1, decode_weight, dense, num_classes, scale,
@@ -318,8 +328,8 @@ def anchor_head(bbox_pred, bbox_targets, bbox_weights, anchors, sel, params, sl1
     p = _copy_struct(_lib.Params, params)
     s = _copy_struct(_lib.SmoothL1, sl1) if sl1 else None
     dw = None if decode_weight is None else [float(x) for x in decode_weight]
-    return GDAnchorHead.apply(bbox_pred, bbox_targets, bbox_weights, anchors, sel, p, s, dw, bool(dense), int(num_classes),
-                              float(scale), avg_dev, float(w_gd), float(w_sl1))
+    return GDAnchorHead.apply(bbox_pred, (bbox_targets, bbox_weights, anchors, sel, p, s, dw, bool(dense), int(num_classes),
+                                          float(scale), avg_dev, float(w_gd), float(w_sl1)))
 
 
 # ---- dynamic scatter-reduce -----------------------------------------------------------------------------------------------------------

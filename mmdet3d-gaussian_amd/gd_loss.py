@@ -262,9 +262,12 @@ def reduced_call(params, pred, target, row_weight, scale, prologue=None, select=
             # training-size call: ONE launch, the last workgroup finishes the sum (per-stream arrival ticket, zeroed once)
             idx = pred.device.index
             ticket = _ticket(idx, _raw_stream(idx)) or 0
+    aux = None if prologue is None else getattr(prologue, "_keepalive", None)
+    trusted = getattr(node, 'reduced_trusted', None)
+    if trusted is not None:   # the Python glue: operands were validated by GDLoss.forward, the structs are never rewritten
+        return trusted(pred, target, row_weight, params, prologue, aux, scale, select, ticket, ev0, ev1, _ws_floats(n), want_flag)
     return node.reduced(pred, target, row_weight, ctypes.addressof(params), 0 if prologue is None else ctypes.addressof(prologue),
-                        None if prologue is None else getattr(prologue, "_keepalive", None), scale, select, ticket, ev0, ev1, _ws_floats(n),
-                        want_flag)
+                        aux, scale, select, ticket, ev0, ev1, _ws_floats(n), want_flag)
 
 
 class _GDPerPair(torch.autograd.Function):
@@ -363,6 +366,8 @@ class GDLoss(nn.Module):
             raise RuntimeError(f'pred {tuple(pred.shape)} and target {tuple(target.shape)} disagree')
         if p.device != t.device:
             raise RuntimeError(f'pred is on {p.device} and target on {t.device}')
+        if not p.is_cuda and p.device.type != 'cpu':
+            raise RuntimeError(f'GDLoss: no implementation for device {p.device}')
         if prologue is not None and not p.is_cuda:
             raise RuntimeError('GDLoss: the head-level fusions (bbox-coder prologue) are GPU-only')
         n = p.shape[0]
