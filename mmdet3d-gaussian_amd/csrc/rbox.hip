@@ -448,11 +448,18 @@ constexpr unsigned QUEUE_SENTINEL = 0xffffffffu;   // (65535, 65535): never a qu
 constexpr unsigned QUEUE_SHARDS = 64;
 constexpr unsigned CTL_STRIDE = 32;                                  // words: one 128-byte line per counter
 constexpr unsigned CTL_WORDS = (QUEUE_SHARDS + 1) * CTL_STRIDE;      // per group: shard counters, then the overflow counter
+// Suppressor lists of the PULL scan (round 5; one group, a threshold >= 0.5: nms_pull_scan_kernel below): per box j up to
+// PULL_LCAP ids of boxes of EARLIER 64-blocks whose IoU with j exceeds the threshold, in any order; unused slots hold PULL_NONE.
+constexpr int PULL_LCAP = 16;
+constexpr unsigned short PULL_NONE = 0xffffu;   // points at bit 63 of kept word 1023, which no launch that takes this path ever sets
 struct QueueArgs {
   unsigned* queue;   // (G, QUEUE_SHARDS, scap)
   unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
   unsigned* ovl;     // (G, npairs) overflowed block pair ids
   unsigned scap, npairs;   // scap: entries per shard
+  unsigned short* lists;   // (cap, PULL_LCAP) or nullptr: no lists wanted
+  unsigned* lcnt;          // (cap) entries appended per box (may exceed PULL_LCAP: the list is then incomplete)
+  unsigned* lfail;         // (1) set when the lists cannot be used: a full list, or block pairs that went to the overflow list
 };
 
 __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
@@ -486,8 +493,16 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     rcy = R.cy;
     rext = fabsf(R.x2 - R.x1) + fabsf(R.y2 - R.y1);
     mask[(size_t)(i0 + lane) * a.cbs + c] = 0ull;                 // the clip kernel ORs into these
-    if (rb == c) colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
+    if (rb == c) {
+      colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
+      if (q.lists != nullptr) {   // the pull scan's suppressor list of this box: empty (the clip kernel appends)
+        q.lcnt[i0 + lane] = 0u;
+        uint4* const l4 = reinterpret_cast<uint4*>(q.lists + (size_t)(i0 + lane) * PULL_LCAP);
+        l4[0] = l4[1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      }
+    }
   }
+  if (q.lists != nullptr && pair == 0 && lane == 0) *q.lfail = 0u;
   // circle tests, straight-line as in compact_pair: lane l (column box j) against the 64 row boxes; bit r of `cand` = the
   // pair (row i0 + r, column j) survives.  On the diagonal block only the pairs with the column box AFTER the row box.
   unsigned long long cand = 0ull;
@@ -575,12 +590,19 @@ __global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, con
       const OBox B = ob[j];
       if (iou_bev<64>(A, B, L.vs, lane) > thresh) {
         atomicOr(&mask[(size_t)i * a.cbs + (j >> 6)], 1ull << (j & 63));
-        if ((i >> 6) == (j >> 6)) atomicOr(&colm[j], 1ull << (i & 63));
+        if ((i >> 6) == (j >> 6)) {
+          atomicOr(&colm[j], 1ull << (i & 63));
+        } else if (q.lists != nullptr) {   // i suppresses j from an earlier block: one more entry of j's list
+          const unsigned pos = atomicAdd(&q.lcnt[j], 1u);
+          if (pos < (unsigned)PULL_LCAP) q.lists[(size_t)j * PULL_LCAP + pos] = (unsigned short)i;
+          else *q.lfail = 1u;              // the list is incomplete: the pull scan must not run (the classic scan does)
+        }
       }
     }
   }
   unsigned novf = __hip_atomic_load(&ctl[QUEUE_SHARDS * CTL_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (novf == 0u) return;
+  if (q.lists != nullptr && lane == 0) *q.lfail = 1u;   // pairs served by compact_pair() below write mask words only: no lists
   const int cb = (n + 63) >> 6;
   const unsigned npairs_now = (unsigned)(cb * (cb + 1) / 2);
   novf = novf < npairs_now ? novf : npairs_now;
@@ -685,6 +707,7 @@ struct ScanWindow {
   int c_begin, c_end;               // blocks; c_end is clamped to the group's block count
   unsigned long long* gremv;        // (G, cbs) global removed-set, nullptr = single-level scan over all blocks
   unsigned long long* gkept;        // (G, cbs) kept word per block
+  const unsigned* pull_fail;        // nullptr, or the pull scan's failure word: this (classic) scan runs only if it is set
 };
 constexpr int SCAN_SB = 64;         // blocks per super-block (4096 boxes): rows inside it fit the one-chunk scan variant
 
@@ -698,6 +721,8 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   __shared__ int scount;        // boxes kept before the block the next scribe step handles (handed from field wave to field wave)
   __shared__ int klist[4][64];  // lane indices of the boxes kept in a block, compacted (k-th kept box -> lane)
   __shared__ unsigned long long rin[SCAN_RING][2 + SCAN_NU][64];  // [slot][col, urgent 1..3, id][lane]
+  // launched behind nms_pull_scan_kernel as its fallback: nothing to do when that one ran (uniform)
+  if (win.pull_fail != nullptr && __hip_atomic_load(win.pull_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   const int g = blockIdx.x;  // one workgroup per group
   const int n = group_n(a, g);
   const int cb_all = (n + 63) >> 6;
@@ -974,6 +999,155 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   }
 }
 
+// ---- PULL scan (round 5): the greedy scan for high thresholds (>= 0.5), where a box has few suppressor candidates ---------------------
+// The classic scan above PUSHES: every kept box's mask row is fetched and OR-ed into the removed-set by twelve row waves — work that
+// grows with the number of KEPT boxes (n = 9000 at thr 0.7: 72 % kept, 46 rows per block: the row waves' issue stream sets a
+// ~1500-cycle interval, and above 8448 boxes three scan launches and two propagate launches are needed).  At a high threshold few
+// pairs overlap that much: the clip kernel therefore also appends, for every pair (i, j) it finds above the threshold with i in an
+// EARLIER 64-block, the id i to box j's SUPPRESSOR LIST (<= PULL_LCAP entries, any order: the test below is an OR).  Box j is then
+// removed iff a KEPT box of its list, or (colm, as before) a kept earlier box of its own block, suppresses it: the resolver wave reads
+// the kept words of all earlier blocks from LDS — it wrote them itself, in order — so no row propagation, no urgent words, one level
+// for any n <= 16384; its instruction stream per block is the interval.  Three field waves prefetch (column word, id, list) three
+// blocks ahead into an LDS ring and run the scribe step (kept ids, count) in their idle interval, exactly as in the classic scan.
+// Same greedy decisions by construction (the lists hold every earlier-block candidate, kept or not).  A full list or an overflowed
+// block pair sets *lfail in the clip kernel: this kernel then leaves at once and the classic scan launched behind it runs.
+constexpr int PULL_T = 256;   // resolver + three field waves
+constexpr int PULL_RING = 4;
+
+__global__ __launch_bounds__(PULL_T) void nms_pull_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ colm,
+                                                               const unsigned short* __restrict__ lists,
+                                                               const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
+                                                               long long* __restrict__ keep, long long* __restrict__ num_keep) {
+  if (__hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform: the classic scan takes over
+  __shared__ unsigned long long keptw[1024];                 // kept word per block; words >= cb stay 0 (PULL_NONE points at word 1023)
+  __shared__ uint4 rlist[PULL_RING][2][64];                  // [slot][half][lane]: the box's 16 list entries
+  __shared__ unsigned long long rcol[PULL_RING][64], rid[PULL_RING][64];
+  __shared__ int rchunks[PULL_RING];                         // 4-entry chunks the resolver has to look at for the slot's block (uniform)
+  __shared__ unsigned long long skept[4];
+  __shared__ int scount;
+  const int n = a.n;
+  const int cb = (n + 63) >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long* order = a.order;
+  for (int w = tid; w < 1024; w += PULL_T) keptw[w] = 0ull;
+  if (tid == 0) scount = 0;
+  lds_barrier();
+  const int NB = cb;
+
+  struct Fields {
+    unsigned long long col, id;
+    uint4 l0, l1;
+    int chunks;
+  };
+  auto load_fields = [&](int B) -> Fields {
+    Fields f;
+    const int j = B * 64 + lane;
+    const bool ok = B < cb && j < n;
+    f.col = ok ? colm[j] : 0ull;
+    f.id = (unsigned long long)((ok && order != nullptr) ? order[j] : (long long)j);
+    const uint4 none = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    const uint4* const l4 = reinterpret_cast<const uint4*>(lists + (size_t)(ok ? j : 0) * PULL_LCAP);
+    f.l0 = ok ? l4[0] : none;
+    f.l1 = ok ? l4[1] : none;
+    const unsigned c = ok ? lcnt[j] : 0u;
+    f.chunks = (int)((min(c, (unsigned)PULL_LCAP) + 3u) >> 2);
+    return f;
+  };
+  auto store_fields = [&](int B, const Fields& f) {   // whole wave; the chunk count of the block is the maximum over its boxes
+    const int slot = B & (PULL_RING - 1);
+    rcol[slot][lane] = f.col;
+    rid[slot][lane] = f.id;
+    rlist[slot][0][lane] = f.l0;
+    rlist[slot][1][lane] = f.l1;
+    int m = f.chunks;
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, true));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
+    if (lane == 63) rchunks[slot] = m;
+  };
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------- resolver
+    for (int B = 0; B < 3; ++B) store_fields(B, load_fields(B));   // the first three blocks: nobody runs ahead of them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int c = 0; c < cb; ++c) {
+      const int slot = c & (PULL_RING - 1);
+      const unsigned long long col = rcol[slot][lane];
+      const uint4 l0 = rlist[slot][0][lane], l1 = rlist[slot][1][lane];
+      const int chunks = __builtin_amdgcn_readfirstlane(rchunks[slot]);
+      const unsigned int e32[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+      unsigned int dead = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < chunks) {   // uniform
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned int e = (k & 1) ? (e32[2 * q + (k >> 1)] >> 16) : (e32[2 * q + (k >> 1)] & 0xffffu);
+            const unsigned long long w = keptw[e >> 6];          // LDS gather: kept word of the entry's (earlier) block
+            dead |= (unsigned int)(w >> (e & 63u)) & 1u;
+          }
+        }
+      }
+      unsigned long long cur = __ballot(dead != 0u);
+      const int nvalid = min(64, n - c * 64);
+      if (nvalid < 64) cur |= ~0ull << nvalid;
+      const unsigned long long alive = ~cur;
+      const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
+      unsigned long long kept = alive;
+      for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
+        const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
+        const unsigned long long nk = alive & ~__ballot(sup);
+        if (nk == kept) break;
+        kept = nk;
+      }
+      if (lane == 0) {
+        keptw[c] = kept;          // read back by THIS wave for later blocks: LDS executes a wave's accesses in order
+        skept[c & 3] = kept;
+      }
+      lds_barrier();
+    }
+    if (NB == 0 && lane == 0) num_keep[0] = 0;
+    return;
+  }
+  // ------------------------------------------------------------------ field waves (one per phase), with the scribe step
+  const int grp = wave - 1;
+  const int lead = min(grp, NB);
+  const int S = (NB - lead) / 3;
+  const int trail = NB - lead - 3 * S;
+  auto scribe = [&](int c) {
+    const unsigned long long kept = uniform_u64(skept[c & 3]);
+    const long long id = (long long)rid[c & (PULL_RING - 1)][lane];
+    const int count = __builtin_amdgcn_readfirstlane(scount);
+    if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+    if (lane == 0) {
+      const int total = count + __builtin_popcountll(kept);
+      scount = total;
+      if (c == cb - 1) num_keep[0] = total;
+    }
+  };
+  for (int q = 0; q < lead; ++q) lds_barrier();
+  for (int s2 = 0; s2 < S; ++s2) {
+    const int t0 = grp + 3 * s2;
+    Fields f = load_fields(t0 + 3);   // ---- interval t0: issue the loads of block t0 + 3
+    lds_barrier();
+    scribe(t0);                       // ---- interval t0 + 1: the loads fly; block t0 was resolved in the interval before
+    lds_barrier();
+    asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.chunks));   // ---- interval t0 + 2: first use pinned here; into the ring
+    if (t0 + 3 < cb) store_fields(t0 + 3, f);
+    lds_barrier();
+  }
+  const int tq = lead + 3 * S;
+  for (int q = 0; q < trail; ++q) {
+    if (q == 1) scribe(tq);
+    lds_barrier();
+  }
+  if (NB > 0 && grp == (NB - 1) % 3) scribe(cb - 1);
+}
+
 // Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
 // boxes further right; those mask rows are OR-ed into the global removed-set by the whole chip instead of by the one scan
 // workgroup.  One wave per (64-box row block of the super-block, 64-word chunk right of it): lane = word, the wave walks
@@ -1097,7 +1271,7 @@ extern "C" {
 //   candidate queue of the queued mask form (QUEUE_PER_BOX entries per box) | its control words | overflowed block pairs
 constexpr size_t QUEUE_PER_BOX = 128;
 struct WsLayout {
-  size_t mask, colm, gremv, queue, qctl, ovl, total;
+  size_t mask, colm, gremv, queue, qctl, ovl, lists, lcnt, lfail, total;
   unsigned scap, npairs;
 };
 static WsLayout ws_layout(size_t G, size_t cap) {
@@ -1111,7 +1285,11 @@ static WsLayout ws_layout(size_t G, size_t cap) {
   L.npairs = (unsigned)(cb * (cb + 1) / 2);
   L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
   L.ovl = L.qctl + align_up(G * CTL_WORDS * sizeof(unsigned), 256);
-  L.total = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
+  // suppressor lists of the pull scan (single-group calls only): ids, counts, the failure word
+  L.lists = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
+  L.lcnt = L.lists + align_up(G == 1 ? cap * PULL_LCAP * sizeof(unsigned short) : 0, 256);
+  L.lfail = L.lcnt + align_up(G == 1 ? cap * sizeof(unsigned) : 0, 256);
+  L.total = L.lfail + 256;
   return L;
 }
 
@@ -1167,6 +1345,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     return e != nullptr ? atoll(e) : (long long)QUEUE_MIN_N;
   }();
   const bool queued = mode == MODE_ROT && cap >= queue_min_n && pairs <= 0x7fffffffLL && (thresh_dev != nullptr || thresh >= 0.0f);   // (per-group device thresholds are checked in the kernel)
+  bool use_pull = false;
   if (mode == MODE_ROT && queued) {
     QueueArgs q;
     q.queue = (unsigned*)((char*)workspace + W.queue);
@@ -1174,6 +1353,16 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     q.ovl = (unsigned*)((char*)workspace + W.ovl);
     q.scap = W.scap;
     q.npairs = W.npairs;
+    // pull scan (suppressor lists instead of row propagation): one group of known size, one host-side threshold >= 0.5 — where few
+    // pairs overlap that much; a full list or an overflowed block pair falls back to the classic scan on the device
+    static const float pull_min_thr = [] {
+      const char* e = getenv("RNMS_PULL_MIN_THR");   // measurement / test override (a value > 1 switches the pull scan off)
+      return e != nullptr ? (float)atof(e) : 0.5f;
+    }();
+    use_pull = G == 1 && counts == nullptr && thresh_dev == nullptr && thresh >= pull_min_thr && cap <= 16384;
+    q.lists = use_pull ? (unsigned short*)((char*)workspace + W.lists) : nullptr;
+    q.lcnt = use_pull ? (unsigned*)((char*)workspace + W.lcnt) : nullptr;
+    q.lfail = use_pull ? (unsigned*)((char*)workspace + W.lfail) : nullptr;
     // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_place_kernel:
     // `ctl_zeroed`); only a caller that prepared the records itself pays a fill in the stream (4.4 us in the trace)
     const int zero_n = (int)CTL_WORDS;   // per group
@@ -1204,6 +1393,23 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   win.c_begin = 0;
   win.c_end = a.cbs;
   win.gremv = win.gkept = nullptr;
+  win.pull_fail = nullptr;
+  if (use_pull) {   // the pull scan first; the classic launches below run only if it declined (a device-side decision)
+    const unsigned* const lfail = (const unsigned*)((char*)workspace + W.lfail);
+    hipLaunchKernelGGL(nms_pull_scan_kernel, dim3(1), dim3(PULL_T), 0, s, a, (const unsigned long long*)colm,
+                       (const unsigned short*)((char*)workspace + W.lists), (const unsigned*)((char*)workspace + W.lcnt), lfail,
+                       (long long*)keep, (long long*)num_keep);
+    win.pull_fail = lfail;
+    // its fallback: ONE single-level classic launch whatever n (beyond two chunks per row the <.., 2> kernel ORs the rest in
+    // synchronously: correct, slower than the two-level form — which would cost five launches of which four do nothing here)
+    if (a.cbs <= 64 + 1 + SCAN_NU)
+      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+    else
+      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+    return (int)hipGetLastError();
+  }
   // n <= 8448: one launch resolves everything.  Beyond that the single workgroup's row propagation (three 64-word chunks
   // per kept row, one CU's miss bandwidth) dominates and the two-level form wins: r02, kernels of rnms_bev, single ->
   // two-level: n = 9000 339 -> 237 us (72 % kept), 208 -> 207 (25 % kept), 400 -> 237 (79 % kept); n = 16384 1052 -> 476 us;

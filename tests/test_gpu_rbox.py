@@ -845,3 +845,57 @@ def test_batched_scored_sets_replay_in_a_hipgraph_with_a_persistent_workspace(am
         torch.cuda.synchronize()
         for g in range(G):
             assert int(num[g]) == int(n2[g]) > 0 and torch.equal(keep[g, :int(num[g])], k2[g, :int(n2[g])]), (seed, g, num.tolist(), n2.tolist())
+
+
+# ---- the pull scan (thresholds >= 0.5: suppressor lists instead of row propagation) and its device-side fallback ----
+@pytest.mark.parametrize('n,thr', [(768, 0.5), (1000, 0.7), (4096, 0.5), (8448, 0.6), (9000, 0.7), (9000, 0.8), (12288, 0.55), (16384, 0.7)])
+def test_pull_scan_keep_indices_bit_exact(amd, n, thr):
+    """High-threshold calls take nms_pull_scan_kernel (one group, thr >= 0.5, n <= 16384): same greedy keep list as the CPU oracle,
+    through nms_gpu (score ranking inside the library) and through the pre-sorted C ABI entry."""
+    boxes, scores = nms_boxes(n, seed=n + 5, clutter=True)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    want = oracle.nms_gpu_oracle(boxes, scores, thr)
+    assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), want)
+    lib = amd.load_library()
+    order = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[order].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+    for _ in range(2):   # the second call reuses the workspace (lists, counts and the failure word are reset by the call itself)
+        assert lib.rnms_bev(sb.data_ptr(), n, thr, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+        k = int(num.item())
+        assert np.array_equal(order[keep[:k]].cpu().numpy(), want)
+
+
+def test_pull_scan_falls_back_when_a_suppressor_list_overflows(amd):
+    """Forty near-duplicates of one box spread over many 64-blocks: the last ones have > 16 earlier-block suppressor candidates, the
+    clip kernel sets the failure word, the pull scan leaves and the classic scan launched behind it produces the list."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    boxes, scores = nms_boxes(n, seed=77, clutter=False)
+    dup = rng.choice(n, 40, replace=False)
+    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (40, 5)).astype(np.float32)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    for thr in (0.5, 0.9):
+        want = oracle.nms_gpu_oracle(boxes, scores, thr)
+        assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), want)
+    lib = amd.load_library()
+    from mmdet3d_gaussian_amd import _lib  # noqa: F401
+    order = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[order].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    assert lib.rnms_bev(sb.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 1          # the failure word (last 256 bytes of the workspace)
+    # and a call on the same workspace whose lists fit clears it again
+    b2, s2 = nms_boxes(n, seed=78, clutter=False)
+    o2 = torch.sort(torch.from_numpy(s2).cuda(), dim=0, descending=True, stable=True)[1]
+    sb2 = torch.from_numpy(b2).cuda()[o2].contiguous()
+    assert lib.rnms_bev(sb2.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
+    assert np.array_equal(o2[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(b2, s2, 0.5))
