@@ -707,22 +707,19 @@ struct ScanWindow {
   int c_begin, c_end;               // blocks; c_end is clamped to the group's block count
   unsigned long long* gremv;        // (G, cbs) global removed-set, nullptr = single-level scan over all blocks
   unsigned long long* gkept;        // (G, cbs) kept word per block
-  const unsigned* pull_fail;        // nullptr, or the pull scan's failure word: this (classic) scan runs only if it is set
 };
 constexpr int SCAN_SB = 64;         // blocks per super-block (4096 boxes): rows inside it fit the one-chunk scan variant
 
 template <int U, int CH>
-__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
-                                                          const unsigned long long* __restrict__ colm_,
-                                                          long long* __restrict__ keep_, long long* __restrict__ num_keep,
-                                                          long long* __restrict__ dbg, const ScanWindow win) {
+__device__ __forceinline__ void nms_scan_body(const NmsArgs& a, const unsigned long long* __restrict__ mask_,
+                                              const unsigned long long* __restrict__ colm_,
+                                              long long* __restrict__ keep_, long long* __restrict__ num_keep,
+                                              long long* __restrict__ dbg, const ScanWindow& win) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // cbs words
   __shared__ unsigned long long skept[4];
   __shared__ int scount;        // boxes kept before the block the next scribe step handles (handed from field wave to field wave)
   __shared__ int klist[4][64];  // lane indices of the boxes kept in a block, compacted (k-th kept box -> lane)
   __shared__ unsigned long long rin[SCAN_RING][2 + SCAN_NU][64];  // [slot][col, urgent 1..3, id][lane]
-  // launched behind nms_pull_scan_kernel as its fallback: nothing to do when that one ran (uniform)
-  if (win.pull_fail != nullptr && __hip_atomic_load(win.pull_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   const int g = blockIdx.x;  // one workgroup per group
   const int n = group_n(a, g);
   const int cb_all = (n + 63) >> 6;
@@ -999,6 +996,15 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   }
 }
 
+// the classic scan as a kernel of its own (single-level, or one super-block of the two-level form)
+template <int U, int CH>
+__global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask_,
+                                                          const unsigned long long* __restrict__ colm_,
+                                                          long long* __restrict__ keep_, long long* __restrict__ num_keep,
+                                                          long long* __restrict__ dbg, const ScanWindow win) {
+  nms_scan_body<U, CH>(a, mask_, colm_, keep_, num_keep, dbg, win);
+}
+
 // ---- PULL scan (round 5): the greedy scan for high thresholds (>= 0.5), where a box has few suppressor candidates ---------------------
 // The classic scan above PUSHES: every kept box's mask row is fetched and OR-ed into the removed-set by twelve row waves — work that
 // grows with the number of KEPT boxes (n = 9000 at thr 0.7: 72 % kept, 46 rows per block: the row waves' issue stream sets a
@@ -1007,60 +1013,66 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 // EARLIER 64-block, the id i to box j's SUPPRESSOR LIST (<= PULL_LCAP entries, any order: the test below is an OR).  Box j is then
 // removed iff a KEPT box of its list, or (colm, as before) a kept earlier box of its own block, suppresses it: the resolver wave reads
 // the kept words of all earlier blocks from LDS — it wrote them itself, in order — so no row propagation, no urgent words, one level
-// for any n <= 16384; its instruction stream per block is the interval.  Three field waves prefetch (column word, id, list) three
-// blocks ahead into an LDS ring and run the scribe step (kept ids, count) in their idle interval, exactly as in the classic scan.
+// for any n <= 16384; its instruction stream per block is the interval.  Three field waves prefetch (column word, id, list) FOUR
+// blocks ahead into an LDS ring — so that the resolver can fetch block c + 1's fields from the ring while it works on block c: the
+// LDS round trip of the ring is off its critical path, only the gather of the kept words is on it — and run the scribe step (kept
+// ids, count) in their idle interval, exactly as in the classic scan.
 // Same greedy decisions by construction (the lists hold every earlier-block candidate, kept or not).  A full list or an overflowed
-// block pair sets *lfail in the clip kernel: this kernel then leaves at once and the classic scan launched behind it runs.
-constexpr int PULL_T = 256;   // resolver + three field waves
-constexpr int PULL_RING = 4;
+// block pair sets *lfail in the clip kernel: the workgroup then runs the CLASSIC scan instead (same launch: no second kernel).
+constexpr int PULL_RING = 8;
+constexpr int PULL_FW = 3;      // field waves = intervals of a field wave's cycle (6 — a five-interval flight of the loads — measured no faster: the resolver is the interval)
 
-__global__ __launch_bounds__(PULL_T) void nms_pull_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ colm,
-                                                               const unsigned short* __restrict__ lists,
-                                                               const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
-                                                               long long* __restrict__ keep, long long* __restrict__ num_keep) {
-  if (__hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform: the classic scan takes over
+struct PullFields {
+  unsigned long long col;
+  long long id;
+  uint4 l0, l1;
+  unsigned cnt;
+};
+
+__device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned long long* __restrict__ colm,
+                                              const unsigned short* __restrict__ lists, const unsigned* __restrict__ lcnt,
+                                              long long* __restrict__ keep, long long* __restrict__ num_keep,
+                                              [[maybe_unused]] long long* __restrict__ dbg) {
   __shared__ unsigned long long keptw[1024];                 // kept word per block; words >= cb stay 0 (PULL_NONE points at word 1023)
   __shared__ uint4 rlist[PULL_RING][2][64];                  // [slot][half][lane]: the box's 16 list entries
   __shared__ unsigned long long rcol[PULL_RING][64], rid[PULL_RING][64];
   __shared__ int rchunks[PULL_RING];                         // 4-entry chunks the resolver has to look at for the slot's block (uniform)
-  __shared__ unsigned long long skept[4];
-  __shared__ int scount;
-  const int n = a.n;
-  const int cb = (n + 63) >> 6;
+  __shared__ unsigned long long pkept[4];
+  __shared__ int pcount;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave > PULL_FW) return;                                 // resolver + six field waves; terminated waves leave the barriers
+  const int n = a.n;
+  const int cb = (n + 63) >> 6;
   const long long* order = a.order;
-  for (int w = tid; w < 1024; w += PULL_T) keptw[w] = 0ull;
-  if (tid == 0) scount = 0;
+  for (int w = tid; w < 1024; w += 64 * (PULL_FW + 1)) keptw[w] = 0ull;
+  if (tid == 0) pcount = 0;
   lds_barrier();
   const int NB = cb;
 
-  struct Fields {
-    unsigned long long col, id;
-    uint4 l0, l1;
-    int chunks;
-  };
-  auto load_fields = [&](int B) -> Fields {
-    Fields f;
-    const int j = B * 64 + lane;
-    const bool ok = B < cb && j < n;
-    f.col = ok ? colm[j] : 0ull;
-    f.id = (unsigned long long)((ok && order != nullptr) ? order[j] : (long long)j);
-    const uint4 none = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    const uint4* const l4 = reinterpret_cast<const uint4*>(lists + (size_t)(ok ? j : 0) * PULL_LCAP);
-    f.l0 = ok ? l4[0] : none;
-    f.l1 = ok ? l4[1] : none;
-    const unsigned c = ok ? lcnt[j] : 0u;
-    f.chunks = (int)((min(c, (unsigned)PULL_LCAP) + 3u) >> 2);
+  // The loads of a block's fields are issued in one interval and USED two barriers later (a global-memory round trip is longer
+  // than an interval): nothing may touch a loaded value before store_fields — not even a select on `ok`: the rows are read from a
+  // clamped index and masked at store time.
+  auto load_fields = [&](int B) -> PullFields {
+    PullFields f;
+    const int j = min(B * 64 + lane, n - 1);   // n >= 1 here
+    f.col = colm[j];
+    f.id = order != nullptr ? order[j] : (long long)j;
+    const uint4* const l4 = reinterpret_cast<const uint4*>(lists + (size_t)j * PULL_LCAP);
+    f.l0 = l4[0];
+    f.l1 = l4[1];
+    f.cnt = lcnt[j];
     return f;
   };
-  auto store_fields = [&](int B, const Fields& f) {   // whole wave; the chunk count of the block is the maximum over its boxes
+  auto store_fields = [&](int B, const PullFields& f) {   // whole wave; the chunk count of the block is the maximum over its boxes
     const int slot = B & (PULL_RING - 1);
-    rcol[slot][lane] = f.col;
-    rid[slot][lane] = f.id;
-    rlist[slot][0][lane] = f.l0;
-    rlist[slot][1][lane] = f.l1;
-    int m = f.chunks;
+    const bool ok = B * 64 + lane < n;           // (B < cb is the caller's business)
+    const uint4 none = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    rcol[slot][lane] = ok ? f.col : 0ull;
+    rid[slot][lane] = (unsigned long long)f.id;
+    rlist[slot][0][lane] = ok ? f.l0 : none;
+    rlist[slot][1][lane] = ok ? f.l1 : none;
+    int m = ok ? (int)((min(f.cnt, (unsigned)PULL_LCAP) + 3u) >> 2) : 0;
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
@@ -1072,43 +1084,61 @@ __global__ __launch_bounds__(PULL_T) void nms_pull_scan_kernel(const NmsArgs a, 
 
   if (wave == 0) {
     // ---------------------------------------------------------------- resolver
-    for (int B = 0; B < 3; ++B) store_fields(B, load_fields(B));   // the first three blocks: nobody runs ahead of them
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int B = 0; B <= PULL_FW; ++B)
+      if (B < cb) store_fields(B, load_fields(B));   // the first seven blocks: nobody runs ahead of them
+    // fields of the block about to be resolved, held in registers one block ahead of their use.  They are re-read from the ring
+    // INTO THE SAME registers as soon as their last use is past (the list after the gather, the column word after the fixed point):
+    // no copies, and the LDS round trip overlaps the rest of the interval.
+    unsigned long long col = rcol[0][lane];
+    uint4 l0 = rlist[0][0][lane], l1 = rlist[0][1][lane];
+    int chunks = __builtin_amdgcn_readfirstlane(rchunks[0]);
+    const unsigned int* const kept32 = reinterpret_cast<const unsigned int*>(keptw);
+    // entry e -> bit (e & 31) of DWORD (e >> 5) of the kept words: 32-bit reads and one v_bfe per entry; two entries per list dword
+    auto test2 = [&](unsigned int pair) -> unsigned int {
+      const unsigned int w0 = kept32[(pair >> 5) & 0x7ffu];     // (the low entry's dword index: bits 5..15)
+      const unsigned int w1 = kept32[pair >> 21];                // (the high entry's: bits 21..31)
+      return __builtin_amdgcn_ubfe(w0, pair, 1u) | __builtin_amdgcn_ubfe(w1, pair >> 16, 1u);   // v_bfe_u32 takes offset mod 32
+    };
     for (int c = 0; c < cb; ++c) {
-      const int slot = c & (PULL_RING - 1);
-      const unsigned long long col = rcol[slot][lane];
-      const uint4 l0 = rlist[slot][0][lane], l1 = rlist[slot][1][lane];
-      const int chunks = __builtin_amdgcn_readfirstlane(rchunks[slot]);
-      const unsigned int e32[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+      SCAN_STAMP(0);
+      const int nslot = (c + 1) & (PULL_RING - 1);   // block c + 1: in the ring since the barrier before this interval
+      // four entries per uniform step: at these thresholds the longest list of a block mostly has <= 4 entries, often none
       unsigned int dead = 0u;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < chunks) {   // uniform
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const unsigned int e = (k & 1) ? (e32[2 * q + (k >> 1)] >> 16) : (e32[2 * q + (k >> 1)] & 0xffffu);
-            const unsigned long long w = keptw[e >> 6];          // LDS gather: kept word of the entry's (earlier) block
-            dead |= (unsigned int)(w >> (e & 63u)) & 1u;
-          }
-        }
+      if (chunks > 0) {
+        dead = test2(l0.x) | test2(l0.y);
+        if (chunks > 1) dead |= test2(l0.z) | test2(l0.w);
+        if (chunks > 2) dead |= test2(l1.x) | test2(l1.y);
+        if (chunks > 3) dead |= test2(l1.z) | test2(l1.w);
       }
+      l0 = rlist[nslot][0][lane];
+      l1 = rlist[nslot][1][lane];
+      const int nchunks_v = rchunks[nslot];
       unsigned long long cur = __ballot(dead != 0u);
+      SCAN_STAMP(1);
       const int nvalid = min(64, n - c * 64);
       if (nvalid < 64) cur |= ~0ull << nvalid;
       const unsigned long long alive = ~cur;
       const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
       unsigned long long kept = alive;
-      for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
-        const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
-        const unsigned long long nk = alive & ~__ballot(sup);
-        if (nk == kept) break;
-        kept = nk;
+      // (no alive box is suppressed by an alive earlier box of its own block — the usual case here: the fixed point is `alive`)
+      if (__ballot(((clo & (unsigned int)alive) | (chi & (unsigned int)(alive >> 32))) != 0u) != 0ull) {
+        for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
+          const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
+          const unsigned long long nk = alive & ~__ballot(sup);
+          if (nk == kept) break;
+          kept = nk;
+        }
       }
+      col = rcol[nslot][lane];
+      SCAN_STAMP(2);
       if (lane == 0) {
         keptw[c] = kept;          // read back by THIS wave for later blocks: LDS executes a wave's accesses in order
-        skept[c & 3] = kept;
+        pkept[c & 3] = kept;
       }
+      chunks = __builtin_amdgcn_readfirstlane(nchunks_v);
+      SCAN_STAMP(3);
       lds_barrier();
+      SCAN_STAMP(5);
     }
     if (NB == 0 && lane == 0) num_keep[0] = 0;
     return;
@@ -1116,36 +1146,58 @@ __global__ __launch_bounds__(PULL_T) void nms_pull_scan_kernel(const NmsArgs a, 
   // ------------------------------------------------------------------ field waves (one per phase), with the scribe step
   const int grp = wave - 1;
   const int lead = min(grp, NB);
-  const int S = (NB - lead) / 3;
-  const int trail = NB - lead - 3 * S;
+  const int S = (NB - lead) / PULL_FW;
+  const int trail = NB - lead - PULL_FW * S;
   auto scribe = [&](int c) {
-    const unsigned long long kept = uniform_u64(skept[c & 3]);
+    const unsigned long long kept = uniform_u64(pkept[c & 3]);
     const long long id = (long long)rid[c & (PULL_RING - 1)][lane];
-    const int count = __builtin_amdgcn_readfirstlane(scount);
+    const int count = __builtin_amdgcn_readfirstlane(pcount);
     if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
     if (lane == 0) {
       const int total = count + __builtin_popcountll(kept);
-      scount = total;
+      pcount = total;
       if (c == cb - 1) num_keep[0] = total;
     }
   };
+  // A block's fields are loaded FIVE intervals before they enter the ring: SIX field waves, each with a six-interval cycle (issue,
+  // scribe, three idle intervals, store) and ONE register set — no rotation of register sets, whose copies are uses that make the
+  // compiler wait for the load in front of them.  This scan's interval (~0.2 us of resolver work) is far shorter than a
+  // global-memory round trip (1.1-1.6 us from this CU); with the classic scan's two-interval flight the store step waited for its
+  // loads and the interval became half a memory latency (0.47 us per block: 66 us at n = 9000).
   for (int q = 0; q < lead; ++q) lds_barrier();
   for (int s2 = 0; s2 < S; ++s2) {
-    const int t0 = grp + 3 * s2;
-    Fields f = load_fields(t0 + 3);   // ---- interval t0: issue the loads of block t0 + 3
+    const int t0 = grp + PULL_FW * s2;
+    PullFields f = load_fields(t0 + PULL_FW + 1);   // ---- interval t0: issue the loads of block t0 + 7
     lds_barrier();
-    scribe(t0);                       // ---- interval t0 + 1: the loads fly; block t0 was resolved in the interval before
+    scribe(t0);                                     // ---- interval t0 + 1: block t0 was resolved in the interval before
     lds_barrier();
-    asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.chunks));   // ---- interval t0 + 2: first use pinned here; into the ring
-    if (t0 + 3 < cb) store_fields(t0 + 3, f);
+    for (int q = 2; q < PULL_FW - 1; ++q) lds_barrier();   // ---- intervals t0 + 2 .. t0 + 4: the loads fly
+    asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.cnt));   // ---- interval t0 + 5: first use pinned here; into the ring (the
+    if (t0 + PULL_FW + 1 < cb) store_fields(t0 + PULL_FW + 1, f);   // resolver fetches block t0 + 7 during interval t0 + 6)
     lds_barrier();
   }
-  const int tq = lead + 3 * S;
+  const int tq = lead + PULL_FW * S;
   for (int q = 0; q < trail; ++q) {
     if (q == 1) scribe(tq);
     lds_barrier();
   }
-  if (NB > 0 && grp == (NB - 1) % 3) scribe(cb - 1);
+  if (NB > 0 && grp == (NB - 1) % PULL_FW) scribe(cb - 1);
+}
+
+// ONE launch for a call that may take the pull scan: the failure word the clip kernel left decides (uniform) between the pull scan
+// (four waves; the other twelve leave at once) and the classic single-level scan — beyond two chunks per row its <.., 2> form ORs the
+// rest in synchronously: correct, slower than the two-level form, and only ever run as a fallback here.
+template <int CH>
+__global__ __launch_bounds__(SCAN_T) void nms_pull_or_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask,
+                                                                  const unsigned long long* __restrict__ colm,
+                                                                  const unsigned short* __restrict__ lists,
+                                                                  const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
+                                                                  long long* __restrict__ keep, long long* __restrict__ num_keep,
+                                                                  long long* __restrict__ dbg, const ScanWindow win) {
+  if (__hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
+  else
+    nms_pull_body(a, colm, lists, lcnt, keep, num_keep, dbg);
 }
 
 // Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
@@ -1393,21 +1445,16 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   win.c_begin = 0;
   win.c_end = a.cbs;
   win.gremv = win.gkept = nullptr;
-  win.pull_fail = nullptr;
-  if (use_pull) {   // the pull scan first; the classic launches below run only if it declined (a device-side decision)
+  if (use_pull) {   // ONE launch: pull scan, or — decided on the device from the clip kernel's failure word — the classic one
     const unsigned* const lfail = (const unsigned*)((char*)workspace + W.lfail);
-    hipLaunchKernelGGL(nms_pull_scan_kernel, dim3(1), dim3(PULL_T), 0, s, a, (const unsigned long long*)colm,
-                       (const unsigned short*)((char*)workspace + W.lists), (const unsigned*)((char*)workspace + W.lcnt), lfail,
-                       (long long*)keep, (long long*)num_keep);
-    win.pull_fail = lfail;
-    // its fallback: ONE single-level classic launch whatever n (beyond two chunks per row the <.., 2> kernel ORs the rest in
-    // synchronously: correct, slower than the two-level form — which would cost five launches of which four do nothing here)
+    const unsigned short* const lists = (const unsigned short*)((char*)workspace + W.lists);
+    const unsigned* const lcnt = (const unsigned*)((char*)workspace + W.lcnt);
     if (a.cbs <= 64 + 1 + SCAN_NU)
-      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+      hipLaunchKernelGGL((nms_pull_or_scan_kernel<1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     else
-      hipLaunchKernelGGL((nms_scan_kernel<SCAN_U, 2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                         (const unsigned long long*)colm, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+      hipLaunchKernelGGL((nms_pull_or_scan_kernel<2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+                         (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     return (int)hipGetLastError();
   }
   // n <= 8448: one launch resolves everything.  Beyond that the single workgroup's row propagation (three 64-word chunks
