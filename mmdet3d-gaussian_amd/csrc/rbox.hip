@@ -1020,7 +1020,10 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 // Same greedy decisions by construction (the lists hold every earlier-block candidate, kept or not).  A full list or an overflowed
 // block pair sets *lfail in the clip kernel: the workgroup then runs the CLASSIC scan instead (same launch: no second kernel).
 constexpr int PULL_RING = 8;
-constexpr int PULL_FW = 3;      // field waves = intervals of a field wave's cycle (6 — a five-interval flight of the loads — measured no faster: the resolver is the interval)
+#ifndef PULL_FW_N
+#define PULL_FW_N 3
+#endif
+constexpr int PULL_FW = PULL_FW_N;      // field waves = intervals of a field wave's cycle (6 — a five-interval flight of the loads — measured no faster: the resolver is the interval)
 
 struct PullFields {
   unsigned long long col;
@@ -1064,14 +1067,17 @@ __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned l
     f.cnt = lcnt[j];
     return f;
   };
-  auto store_fields = [&](int B, const PullFields& f) {   // whole wave; the chunk count of the block is the maximum over its boxes
+  auto store_fields = [&](int B, const PullFields f) {   // whole wave; the chunk count of the block is the maximum over its boxes
     const int slot = B & (PULL_RING - 1);
     const bool ok = B * 64 + lane < n;           // (B < cb is the caller's business)
-    const uint4 none = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    // component-wise selects: a select between two uint4 OBJECTS made the compiler keep `f` in scratch memory, and the store
+    // to scratch waited for the loads in the interval that issued them (the whole scan then ran at one memory latency per
+    // three intervals: 0.47 us per block)
+    const unsigned int none = 0xffffffffu;
     rcol[slot][lane] = ok ? f.col : 0ull;
     rid[slot][lane] = (unsigned long long)f.id;
-    rlist[slot][0][lane] = ok ? f.l0 : none;
-    rlist[slot][1][lane] = ok ? f.l1 : none;
+    rlist[slot][0][lane] = make_uint4(ok ? f.l0.x : none, ok ? f.l0.y : none, ok ? f.l0.z : none, ok ? f.l0.w : none);
+    rlist[slot][1][lane] = make_uint4(ok ? f.l1.x : none, ok ? f.l1.y : none, ok ? f.l1.z : none, ok ? f.l1.w : none);
     int m = ok ? (int)((min(f.cnt, (unsigned)PULL_LCAP) + 3u) >> 2) : 0;
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
