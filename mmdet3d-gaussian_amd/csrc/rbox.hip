@@ -15,6 +15,7 @@
 //      each 64-box diagonal block wave-parallel from an LDS ring, three phase-shifted groups of loader waves OR the
 //      mask rows of the boxes just kept into the removed-set (LDS); one LDS-only barrier per block.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/gd3d.h"
@@ -451,7 +452,9 @@ constexpr unsigned CTL_WORDS = (QUEUE_SHARDS + 1) * CTL_STRIDE;      // per grou
 // Suppressor lists of the PULL scan (round 5; one group, a threshold >= 0.5: nms_pull_scan_kernel below): per box j up to
 // PULL_LCAP ids of boxes of EARLIER 64-blocks whose IoU with j exceeds the threshold, in any order; unused slots hold PULL_NONE.
 constexpr int PULL_LCAP = 16;
-constexpr unsigned short PULL_NONE = 0xffffu;   // points at bit 63 of kept word 1023, which no launch that takes this path ever sets
+constexpr unsigned PULL_MAX_N = 16384;          // the pull scan's kept BYTES: one per box + the two constants below
+constexpr unsigned short PULL_NONE = 0x4000u;   // "no entry": index of a kept byte that is always 0
+constexpr unsigned short PULL_ONE = 0x4001u;    // index of a kept byte that is always 1 (boxes past the end of the last block)
 struct QueueArgs {
   unsigned* queue;   // (G, QUEUE_SHARDS, scap)
   unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
@@ -498,7 +501,8 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
       if (q.lists != nullptr) {   // the pull scan's suppressor list of this box: empty (the clip kernel appends)
         q.lcnt[i0 + lane] = 0u;
         uint4* const l4 = reinterpret_cast<uint4*>(q.lists + (size_t)(i0 + lane) * PULL_LCAP);
-        l4[0] = l4[1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        const unsigned int none2 = (unsigned int)PULL_NONE * 0x10001u;
+        l4[0] = l4[1] = make_uint4(none2, none2, none2, none2);
       }
     }
   }
@@ -1011,19 +1015,40 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
 // ~1500-cycle interval, and above 8448 boxes three scan launches and two propagate launches are needed).  At a high threshold few
 // pairs overlap that much: the clip kernel therefore also appends, for every pair (i, j) it finds above the threshold with i in an
 // EARLIER 64-block, the id i to box j's SUPPRESSOR LIST (<= PULL_LCAP entries, any order: the test below is an OR).  Box j is then
-// removed iff a KEPT box of its list, or (colm, as before) a kept earlier box of its own block, suppresses it: the resolver wave reads
-// the kept words of all earlier blocks from LDS — it wrote them itself, in order — so no row propagation, no urgent words, one level
-// for any n <= 16384; its instruction stream per block is the interval.  Three field waves prefetch (column word, id, list) FOUR
-// blocks ahead into an LDS ring — so that the resolver can fetch block c + 1's fields from the ring while it works on block c: the
-// LDS round trip of the ring is off its critical path, only the gather of the kept words is on it — and run the scribe step (kept
-// ids, count) in their idle interval, exactly as in the classic scan.
+// removed iff a KEPT box of its list, or (colm, as before) a kept earlier box of its own block, suppresses it.  No row propagation,
+// no urgent words, one level for any n <= 16384.
+// What bounds it is the RESOLVER's instruction stream (one wave; ~4.5 ns per instruction at the clock a one-workgroup kernel gets):
+// every instruction it does not execute is time, so everything that can be prepared is prepared by the field waves:
+//   * kept BYTES in LDS, one per box (keptb[]): a list entry IS the LDS address of its kept byte — one ds_read_u8 per entry, no
+//     shift / mask / bit extract; unused entries point at a byte that is always 0 (PULL_NONE), the lanes past the end of the last
+//     block at one that is always 1 (PULL_ONE): no bounds logic in the loop.  The resolver's own lane writes its kept byte;
+//   * the ring holds the entries as dwords, four per ds_read_b128; the first eight of block c + 1 are fetched while block c is
+//     worked on, entries 8-15 (rare) on demand;
+//   * rflag[slot] = (block + 1) << 8 | (any column word non-zero) << 7 | 4-entry chunks to look at: the in-block step (the usual
+//     fixed point over colm) is skipped with one scalar branch where no box of the block has an in-block candidate.
+// No barrier in the loop.  The workgroup synchronises through LDS words (one CU's LDS executes every wave's accesses in issue
+// order, so "data, then flag" by the writer and "flag, then data" by the reader is enough; compiler fences keep the statements in
+// that order):
+//   rflag[slot]  written by a field wave AFTER the slot's fields; the resolver reads it with block c + 1's fields while it works on
+//                block c and re-reads only if the block is not there yet (never in steady state: the ring is 16 blocks deep);
+//   pdone[c]     = (kept boxes before block c) << 1 | 1, written by the resolver after the block's kept bytes; field wave g polls
+//                it (s_sleep) before its scribe step of block t (kept ids to `keep`).
+// Nine field waves (the waves that do not share the resolver's SIMD), wave g serving blocks t = g, g + 9, ...: issue the loads of
+// block t + 16, wait for block t to be resolved, read its kept bytes / base / ids, store block t + 16's fields into the ring slot
+// block t just vacated (same wave, same iteration: no other ordering needed), write the kept ids.  Nine blocks of resolver time
+// cover a global-memory round trip; the prologue fills the ring with all sixteen waves in one round trip.  Every polling loop is
+// bounded (a bug must not hang the GPU): a wave that gives up returns, and the resolver then reports num_keep = -1.
+// History (n = 9000 thr 0.7, this kernel): kept BITS + barrier per block + the field waves' loaded fields in SCRATCH memory (a
+// select between two uint4 objects; they waited for their loads in the interval that issued them) 66.8 us; without the scratch
+// 44.4 us; kept bytes and no barrier: see profiles/r05_nms_pmc.txt.
 // Same greedy decisions by construction (the lists hold every earlier-block candidate, kept or not).  A full list or an overflowed
 // block pair sets *lfail in the clip kernel: the workgroup then runs the CLASSIC scan instead (same launch: no second kernel).
-constexpr int PULL_RING = 8;
-#ifndef PULL_FW_N
-#define PULL_FW_N 3
+constexpr int PULL_RING = 16;
+constexpr int PULL_FW = 9;
+constexpr int PULL_SPIN_MAX = 1 << 22;
+#ifndef PULL_POLL_SLEEP
+#define PULL_POLL_SLEEP 4
 #endif
-constexpr int PULL_FW = PULL_FW_N;      // field waves = intervals of a field wave's cycle (6 — a five-interval flight of the loads — measured no faster: the resolver is the interval)
 
 struct PullFields {
   unsigned long long col;
@@ -1032,30 +1057,42 @@ struct PullFields {
   unsigned cnt;
 };
 
+// volatile accesses that stay LDS instructions (a volatile access through a generic pointer becomes a flat_load / flat_store with an
+// immediate wait)
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// the byte at an LDS ADDRESS held in a register (ds_read_u8 v, vaddr: no base to add — the instruction's 16-bit offset field cannot
+// reach an array the compiler placed beyond 64 KB)
+__device__ __forceinline__ unsigned int lds_byte_at(unsigned int addr) { return *(const lds_u8*)(size_t)addr; }
+__device__ __forceinline__ unsigned int lds_peek(const unsigned int* p) { return *(const volatile lds_u32*)p; }
+__device__ __forceinline__ void lds_poke(unsigned int* p, unsigned int v) { *(volatile lds_u32*)p = v; }
+#define COMPILER_FENCE() asm volatile("" ::: "memory")
+
 __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned long long* __restrict__ colm,
                                               const unsigned short* __restrict__ lists, const unsigned* __restrict__ lcnt,
                                               long long* __restrict__ keep, long long* __restrict__ num_keep,
                                               [[maybe_unused]] long long* __restrict__ dbg) {
-  __shared__ unsigned long long keptw[1024];                 // kept word per block; words >= cb stay 0 (PULL_NONE points at word 1023)
-  __shared__ uint4 rlist[PULL_RING][2][64];                  // [slot][half][lane]: the box's 16 list entries
+  constexpr int KB = (int)PULL_MAX_N + 64;
+  __shared__ __attribute__((aligned(16))) unsigned char keptb[KB];   // kept byte per box, then PULL_NONE's 0 and PULL_ONE's 1
+  __shared__ uint4 rent[PULL_RING][4][64];                   // [slot][chunk][lane]: the box's 16 list entries as kept-byte indices
   __shared__ unsigned long long rcol[PULL_RING][64], rid[PULL_RING][64];
-  __shared__ int rchunks[PULL_RING];                         // 4-entry chunks the resolver has to look at for the slot's block (uniform)
-  __shared__ unsigned long long pkept[4];
-  __shared__ int pcount;
+  __shared__ unsigned int rflag[PULL_RING];
+  __shared__ unsigned int failed;                            // a polling loop gave up: the result is void (num_keep = -1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave > PULL_FW) return;                                 // resolver + six field waves; terminated waves leave the barriers
   const int n = a.n;
   const int cb = (n + 63) >> 6;
   const long long* order = a.order;
-  for (int w = tid; w < 1024; w += 64 * (PULL_FW + 1)) keptw[w] = 0ull;
-  if (tid == 0) pcount = 0;
-  lds_barrier();
-  const int NB = cb;
+  const unsigned int kb0 = (unsigned int)(size_t)(lds_u8*)keptb;   // LDS address of keptb[0]: the ring holds ADDRESSES of kept bytes
+  for (int w = tid; w < KB / 4; w += SCAN_T) reinterpret_cast<unsigned int*>(keptb)[w] = 0u;
+  if (tid < PULL_RING) rflag[tid] = 0u;
+  if (tid == 0) failed = 0u;
+  // The resolver works in groups of four blocks (exit checks cost instructions): blocks cb .. cbp - 1 are PADDING, entered into the
+  // ring like real ones with every lane "past the end" (dead on arrival); their kept bytes land behind box n - 1, inside keptb.
+  const int cbp = (cb + 3) & ~3;
 
-  // The loads of a block's fields are issued in one interval and USED two barriers later (a global-memory round trip is longer
-  // than an interval): nothing may touch a loaded value before store_fields — not even a select on `ok`: the rows are read from a
-  // clamped index and masked at store time.
+  // nothing may touch a loaded value before store_fields — not even a select on `ok`: the rows are read from a clamped index and
+  // masked at store time (a use makes the compiler wait for the load where the use stands)
   auto load_fields = [&](int B) -> PullFields {
     PullFields f;
     const int j = min(B * 64 + lane, n - 1);   // n >= 1 here
@@ -1067,131 +1104,172 @@ __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned l
     f.cnt = lcnt[j];
     return f;
   };
-  auto store_fields = [&](int B, const PullFields f) {   // whole wave; the chunk count of the block is the maximum over its boxes
+  auto store_fields = [&](int B, const PullFields f) {   // whole wave; (B < cb is the caller's business)
     const int slot = B & (PULL_RING - 1);
-    const bool ok = B * 64 + lane < n;           // (B < cb is the caller's business)
-    // component-wise selects: a select between two uint4 OBJECTS made the compiler keep `f` in scratch memory, and the store
-    // to scratch waited for the loads in the interval that issued them (the whole scan then ran at one memory latency per
-    // three intervals: 0.47 us per block)
-    const unsigned int none = 0xffffffffu;
-    rcol[slot][lane] = ok ? f.col : 0ull;
+    const bool ok = B * 64 + lane < n;
+    // (component-wise: a select between two uint4 OBJECTS made the compiler keep `f` in scratch memory)
+    const unsigned int none = PULL_NONE;
+    auto lo = [&](unsigned int pair) { return kb0 + (ok ? (pair & 0xffffu) : none); };
+    auto hi = [&](unsigned int pair) { return kb0 + (ok ? (pair >> 16) : none); };
+    rent[slot][0][lane] = make_uint4(kb0 + (ok ? (f.l0.x & 0xffffu) : (unsigned int)PULL_ONE), hi(f.l0.x), lo(f.l0.y), hi(f.l0.y));
+    rent[slot][1][lane] = make_uint4(lo(f.l0.z), hi(f.l0.z), lo(f.l0.w), hi(f.l0.w));
+    rent[slot][2][lane] = make_uint4(lo(f.l1.x), hi(f.l1.x), lo(f.l1.y), hi(f.l1.y));
+    rent[slot][3][lane] = make_uint4(lo(f.l1.z), hi(f.l1.z), lo(f.l1.w), hi(f.l1.w));
+    const unsigned long long col = ok ? f.col : 0ull;
+    rcol[slot][lane] = col;
     rid[slot][lane] = (unsigned long long)f.id;
-    rlist[slot][0][lane] = make_uint4(ok ? f.l0.x : none, ok ? f.l0.y : none, ok ? f.l0.z : none, ok ? f.l0.w : none);
-    rlist[slot][1][lane] = make_uint4(ok ? f.l1.x : none, ok ? f.l1.y : none, ok ? f.l1.z : none, ok ? f.l1.w : none);
-    int m = ok ? (int)((min(f.cnt, (unsigned)PULL_LCAP) + 3u) >> 2) : 0;
+    int m = ok ? (int)((min(f.cnt, (unsigned)PULL_LCAP) + 3u) >> 2) : 0;   // the chunk count of the block: the maximum over its boxes
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, true));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
-    if (lane == 63) rchunks[slot] = m;
+    const unsigned int hascol = __ballot(col != 0ull) != 0ull ? 0x80u : 0u;
+    COMPILER_FENCE();                            // the flag goes last
+    if (lane == 63) lds_poke(&rflag[slot], ((unsigned int)((B >> 4) + 1) << 8) | hascol | (unsigned int)m);   // (ring generation + 1) << 8 | ...
   };
+
+  lds_barrier();                                 // (the zero fill above, before the first flags)
+  if (tid == 0) keptb[PULL_ONE] = 0x80;
+  if (wave < cbp) store_fields(wave, load_fields(wave));   // prologue: sixteen waves, sixteen blocks, one memory round trip
+  lds_barrier();                                 // the only barriers of this scan
+  if (cb == 0) {
+    if (tid == 0) num_keep[0] = 0;
+    return;
+  }
 
   if (wave == 0) {
     // ---------------------------------------------------------------- resolver
-    for (int B = 0; B <= PULL_FW; ++B)
-      if (B < cb) store_fields(B, load_fields(B));   // the first seven blocks: nobody runs ahead of them
-    // fields of the block about to be resolved, held in registers one block ahead of their use.  They are re-read from the ring
-    // INTO THE SAME registers as soon as their last use is past (the list after the gather, the column word after the fixed point):
-    // no copies, and the LDS round trip overlaps the rest of the interval.
-    unsigned long long col = rcol[0][lane];
-    uint4 l0 = rlist[0][0][lane], l1 = rlist[0][1][lane];
-    int chunks = __builtin_amdgcn_readfirstlane(rchunks[0]);
-    const unsigned int* const kept32 = reinterpret_cast<const unsigned int*>(keptw);
-    // entry e -> bit (e & 31) of DWORD (e >> 5) of the kept words: 32-bit reads and one v_bfe per entry; two entries per list dword
-    auto test2 = [&](unsigned int pair) -> unsigned int {
-      const unsigned int w0 = kept32[(pair >> 5) & 0x7ffu];     // (the low entry's dword index: bits 5..15)
-      const unsigned int w1 = kept32[pair >> 21];                // (the high entry's: bits 21..31)
-      return __builtin_amdgcn_ubfe(w0, pair, 1u) | __builtin_amdgcn_ubfe(w1, pair >> 16, 1u);   // v_bfe_u32 takes offset mod 32
-    };
-    for (int c = 0; c < cb; ++c) {
-      SCAN_STAMP(0);
-      const int nslot = (c + 1) & (PULL_RING - 1);   // block c + 1: in the ring since the barrier before this interval
-      // four entries per uniform step: at these thresholds the longest list of a block mostly has <= 4 entries, often none
-      unsigned int dead = 0u;
-      if (chunks > 0) {
-        dead = test2(l0.x) | test2(l0.y);
-        if (chunks > 1) dead |= test2(l0.z) | test2(l0.w);
-        if (chunks > 2) dead |= test2(l1.x) | test2(l1.y);
-        if (chunks > 3) dead |= test2(l1.z) | test2(l1.w);
-      }
-      l0 = rlist[nslot][0][lane];
-      l1 = rlist[nslot][1][lane];
-      const int nchunks_v = rchunks[nslot];
-      unsigned long long cur = __ballot(dead != 0u);
-      SCAN_STAMP(1);
-      const int nvalid = min(64, n - c * 64);
-      if (nvalid < 64) cur |= ~0ull << nvalid;
-      const unsigned long long alive = ~cur;
-      const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
-      unsigned long long kept = alive;
-      // (no alive box is suppressed by an alive earlier box of its own block — the usual case here: the fixed point is `alive`)
-      if (__ballot(((clo & (unsigned int)alive) | (chi & (unsigned int)(alive >> 32))) != 0u) != 0ull) {
-        for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
-          const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
-          const unsigned long long nk = alive & ~__ballot(sup);
-          if (nk == kept) break;
-          kept = nk;
+    // Unrolled over the ring (slot = block & 15 is a constant in every copy: all ring addresses are instruction offsets off three
+    // per-lane registers).  The fields of the block about to be resolved are in registers one block ahead of their use and are
+    // re-read from the ring INTO THE SAME registers as soon as their last use is past.  Per block, usual path (<= 4 entries per
+    // list, no in-block candidate): ~30 instructions, one LDS round trip (the kept bytes) on the dependent chain.
+    const uint4* const rl = &rent[0][0][lane];
+    const unsigned long long* const rc = &rcol[0][lane];
+    // two register sets, blocks of even / odd index: block c's fields are fetched while block c - 2 is worked on, so that neither
+    // the flag nor the entries are waited for (with one set the ring read and the kept-byte read were two LDS round trips in a row)
+    unsigned long long colA = rc[0], colB = rc[64];
+    uint4 l0A = rl[0], l1A = rl[64], l0B = rl[256], l1B = rl[256 + 64];
+    unsigned int nflagA = rflag[0], nflagB = rflag[1];   // (cbp >= 4 here: blocks 0 and 1 are in the ring since the prologue)
+    for (int c0 = 0; c0 < cbp; c0 += PULL_RING) {
+      unsigned char* const kw = keptb + c0 * 64 + lane;
+      const int rem = cbp - c0;                                 // blocks left, this group included: a multiple of four
+      const unsigned int gen1 = (unsigned int)(c0 >> 4) + 1u;   // what the flag of every block of this group carries
+      // one block; true = stop (no blocks left).  Instantiated sixteen times below (the compiler refuses to unroll a loop with
+      // this body)
+      auto block = [&](auto U) -> bool {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u % 4 == 0 && u > 0)
+          if (rem <= u) return true;
+        [[maybe_unused]] const int c = c0 + u;
+        SCAN_STAMP(0);
+        constexpr int fslot = (u + 2) & (PULL_RING - 1);   // the slot fetched in this block: block c + 2
+        uint4& l0 = (u & 1) ? l0B : l0A;
+        uint4& l1 = (u & 1) ? l1B : l1A;
+        unsigned long long& col = (u & 1) ? colB : colA;
+        unsigned int& nflag = (u & 1) ? nflagB : nflagA;
+        unsigned int flag = (unsigned int)__builtin_amdgcn_readfirstlane((int)nflag);
+        if (__builtin_expect((flag >> 8) != gen1, 0)) {
+          // the block is not in the ring yet (never in steady state): re-read flag and fields.  Gives up after PULL_SPIN_MAX polls
+          // — a bug must not hang the GPU —, marks the scan failed and goes on with a harmless flag; once failed, no more waiting.
+          flag = gen1 << 8;
+          bool got = false;
+          for (int spins = 0; spins < PULL_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            COMPILER_FENCE();
+            const unsigned int fl = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_peek(&rflag[u]));
+            COMPILER_FENCE();
+            l0 = rl[u * 256];
+            l1 = rl[u * 256 + 64];
+            col = rc[u * 64];
+            if ((fl >> 8) == gen1) {
+              flag = fl;
+              got = true;
+              break;
+            }
+          }
+          if (!got) lds_poke(&failed, 1u);
         }
-      }
-      col = rcol[nslot][lane];
-      SCAN_STAMP(2);
-      if (lane == 0) {
-        keptw[c] = kept;          // read back by THIS wave for later blocks: LDS executes a wave's accesses in order
-        pkept[c & 3] = kept;
-      }
-      chunks = __builtin_amdgcn_readfirstlane(nchunks_v);
-      SCAN_STAMP(3);
-      lds_barrier();
-      SCAN_STAMP(5);
+        unsigned int dead = lds_byte_at(l0.x) | lds_byte_at(l0.y) | lds_byte_at(l0.z) | lds_byte_at(l0.w);   // always: empty entries read a 0
+        if (__builtin_expect((flag & 6u) != 0u, 0)) {   // more than one 4-entry chunk (the count is 0..4)
+          dead |= lds_byte_at(l1.x) | lds_byte_at(l1.y) | lds_byte_at(l1.z) | lds_byte_at(l1.w);
+          if ((flag & 0x7fu) > 2u) {   // rare: the block's own slot still holds them
+            const uint4 l2 = rl[u * 256 + 128], l3 = rl[u * 256 + 192];
+            dead |= lds_byte_at(l2.x) | lds_byte_at(l2.y) | lds_byte_at(l2.z) | lds_byte_at(l2.w);
+            dead |= lds_byte_at(l3.x) | lds_byte_at(l3.y) | lds_byte_at(l3.z) | lds_byte_at(l3.w);
+          }
+        }
+        COMPILER_FENCE();
+        nflag = lds_peek(&rflag[fslot]);   // flag first, then the fields it vouches for
+        COMPILER_FENCE();
+        l0 = rl[fslot * 256];
+        l1 = rl[fslot * 256 + 64];
+        unsigned long long kept = __ballot(dead < 0x80u);   // no KEPT (0x80) byte among the entries
+        SCAN_STAMP(1);
+        if (__builtin_expect((flag & 0x80u) != 0u, 0)) {   // some box of the block has an earlier box of the block on its column word
+          const unsigned long long alive = kept;
+          const unsigned int clo = (unsigned int)col, chi = (unsigned int)(col >> 32);
+          if (__ballot(((clo & (unsigned int)alive) | (chi & (unsigned int)(alive >> 32))) != 0u) != 0ull) {
+            for (;;) {  // <= 65 rounds; the fixed point is the greedy keep set of the block
+              const bool sup = ((clo & (unsigned int)kept) | (chi & (unsigned int)(kept >> 32))) != 0u;
+              const unsigned long long nk = alive & ~__ballot(sup);
+              if (nk == kept) break;
+              kept = nk;
+            }
+          }
+        }
+        col = rc[fslot * 64];
+        SCAN_STAMP(2);
+        // one byte per box: 0x80 kept, 0x01 resolved and not kept (0 = not resolved yet: what the field waves poll).  Read back by
+        // THIS wave for later blocks: LDS runs a wave's accesses in order.
+        kw[u * 64] = __builtin_amdgcn_inverse_ballot_w64(kept) ? 0x80 : 0x01;
+        COMPILER_FENCE();
+        SCAN_STAMP(3);
+        return false;
+      };
+#define PULL_BLOCK(u) if (block(std::integral_constant<int, u>{})) break;
+      PULL_BLOCK(0) PULL_BLOCK(1) PULL_BLOCK(2) PULL_BLOCK(3) PULL_BLOCK(4) PULL_BLOCK(5) PULL_BLOCK(6) PULL_BLOCK(7)
+      PULL_BLOCK(8) PULL_BLOCK(9) PULL_BLOCK(10) PULL_BLOCK(11) PULL_BLOCK(12) PULL_BLOCK(13) PULL_BLOCK(14) PULL_BLOCK(15)
+#undef PULL_BLOCK
+      static_assert(PULL_RING == 16, "the resolver is unrolled over the ring");
     }
-    if (NB == 0 && lane == 0) num_keep[0] = 0;
+    if (lds_peek(&failed) != 0u && lane == 0) num_keep[0] = -1;
     return;
   }
-  // ------------------------------------------------------------------ field waves (one per phase), with the scribe step
-  const int grp = wave - 1;
-  const int lead = min(grp, NB);
-  const int S = (NB - lead) / PULL_FW;
-  const int trail = NB - lead - PULL_FW * S;
-  auto scribe = [&](int c) {
-    const unsigned long long kept = uniform_u64(pkept[c & 3]);
-    const long long id = (long long)rid[c & (PULL_RING - 1)][lane];
-    const int count = __builtin_amdgcn_readfirstlane(pcount);
-    if ((kept >> lane) & 1ull) keep[count + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
-    if (lane == 0) {
-      const int total = count + __builtin_popcountll(kept);
-      pcount = total;
-      if (c == cb - 1) num_keep[0] = total;
+  // ------------------------------------------------------------------ field waves: waves 1-3, 5-7, 9-11 (not on the resolver's SIMD)
+  if ((wave & 3) == 0 || wave > 11) return;
+  const int g = wave - 1 - (wave >> 2);
+  int base = 0;                                   // kept boxes before block t: the running count is this wave's own business
+  auto kept_word = [&](int blk) -> unsigned long long { return __ballot(keptb[blk * 64 + lane] >= 0x80); };
+  for (int t = g; t < cb; t += PULL_FW) {
+    const bool more = t + PULL_RING < cbp;
+    PullFields f = {};
+    if (more) f = load_fields(t + PULL_RING);     // in flight while the resolver works through the ~nine blocks up to t
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u8*)(size_t)(kb0 + (unsigned int)t * 64u)) == 0) {
+      if (++spins > PULL_SPIN_MAX) return;
+      __builtin_amdgcn_s_sleep(PULL_POLL_SLEEP);
     }
-  };
-  // A block's fields are loaded FIVE intervals before they enter the ring: SIX field waves, each with a six-interval cycle (issue,
-  // scribe, three idle intervals, store) and ONE register set — no rotation of register sets, whose copies are uses that make the
-  // compiler wait for the load in front of them.  This scan's interval (~0.2 us of resolver work) is far shorter than a
-  // global-memory round trip (1.1-1.6 us from this CU); with the classic scan's two-interval flight the store step waited for its
-  // loads and the interval became half a memory latency (0.47 us per block: 66 us at n = 9000).
-  for (int q = 0; q < lead; ++q) lds_barrier();
-  for (int s2 = 0; s2 < S; ++s2) {
-    const int t0 = grp + PULL_FW * s2;
-    PullFields f = load_fields(t0 + PULL_FW + 1);   // ---- interval t0: issue the loads of block t0 + 7
-    lds_barrier();
-    scribe(t0);                                     // ---- interval t0 + 1: block t0 was resolved in the interval before
-    lds_barrier();
-    for (int q = 2; q < PULL_FW - 1; ++q) lds_barrier();   // ---- intervals t0 + 2 .. t0 + 4: the loads fly
-    asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.cnt));   // ---- interval t0 + 5: first use pinned here; into the ring (the
-    if (t0 + PULL_FW + 1 < cb) store_fields(t0 + PULL_FW + 1, f);   // resolver fetches block t0 + 7 during interval t0 + 6)
-    lds_barrier();
+    COMPILER_FENCE();
+    // scribe step of block t; its global store goes last (loads and stores share one in-order counter)
+    for (int blk = max(t - PULL_FW + 1, 0); blk < t; ++blk) base += __builtin_popcountll(kept_word(blk));   // the blocks since this wave's last one: all resolved before t
+    const unsigned long long kept = kept_word(t);
+    const long long id = (long long)rid[t & (PULL_RING - 1)][lane];
+    if (more) {
+      COMPILER_FENCE();                           // (the id above is read before the slot is overwritten)
+      asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.cnt));   // first use of the loaded fields pinned here
+      store_fields(t + PULL_RING, f);
+      COMPILER_FENCE();
+    }
+    if ((kept >> lane) & 1ull) keep[base + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+    base += __builtin_popcountll(kept);
+    if (t == cb - 1 && lane == 0 && lds_peek(&failed) == 0u) num_keep[0] = base;
   }
-  const int tq = lead + PULL_FW * S;
-  for (int q = 0; q < trail; ++q) {
-    if (q == 1) scribe(tq);
-    lds_barrier();
-  }
-  if (NB > 0 && grp == (NB - 1) % PULL_FW) scribe(cb - 1);
 }
 
 // ONE launch for a call that may take the pull scan: the failure word the clip kernel left decides (uniform) between the pull scan
-// (four waves; the other twelve leave at once) and the classic single-level scan — beyond two chunks per row its <.., 2> form ORs the
+// (ten waves; the others leave after the prologue) and the classic single-level scan — beyond two chunks per row its <.., 2> form ORs the
 // rest in synchronously: correct, slower than the two-level form, and only ever run as a fallback here.
 template <int CH>
 __global__ __launch_bounds__(SCAN_T) void nms_pull_or_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask,

@@ -17,4 +17,4 @@ for n, thr in ((9000, 0.7), (4096, 0.5)):
     st = ws[:cb * 16 * 8 + 16 * 8].view(torch.int64).cpu().numpy().reshape(-1, 16)[:cb].astype(np.float64)
     iv = np.diff(st[:, 0])
     d = lambda a, b: np.median(st[8:-2, b] - st[8:-2, a])
-    print(f'n={n} thr={thr} kept={int(num)} blocks={cb}: interval median {np.median(iv):.0f} (min {iv.min():.0f} max {iv.max():.0f}) cyc | gather {d(0,1):.0f} fixedpoint {d(1,2):.0f} publish {d(2,3):.0f} barrier {d(3,5):.0f}')
+    print(f'n={n} thr={thr} kept={int(num)} blocks={cb}: interval median {np.median(iv):.0f} (min {iv.min():.0f} max {iv.max():.0f}) cyc | gather {d(0,1):.0f} fixedpoint {d(1,2):.0f} publish {d(2,3):.0f} ringwait {d(3,4):.0f} | spins total {st[:, 6].sum():.0f} blocks with spins {(st[:, 6] > 0).sum()}')
