@@ -449,19 +449,23 @@ constexpr unsigned QUEUE_SENTINEL = 0xffffffffu;   // (65535, 65535): never a qu
 constexpr unsigned QUEUE_SHARDS = 64;
 constexpr unsigned CTL_STRIDE = 32;                                  // words: one 128-byte line per counter
 constexpr unsigned CTL_WORDS = (QUEUE_SHARDS + 1) * CTL_STRIDE;      // per group: shard counters, then the overflow counter
-// Suppressor lists of the PULL scan (round 5; one group, a threshold >= 0.5: nms_pull_scan_kernel below): per box j up to
-// PULL_LCAP ids of boxes of EARLIER 64-blocks whose IoU with j exceeds the threshold, in any order; unused slots hold PULL_NONE.
-constexpr int PULL_LCAP = 16;
-constexpr unsigned PULL_MAX_N = 16384;          // the pull scan's kept BYTES: one per box + the two constants below
-constexpr unsigned short PULL_NONE = 0x4000u;   // "no entry": index of a kept byte that is always 0
-constexpr unsigned short PULL_ONE = 0x4001u;    // index of a kept byte that is always 1 (boxes past the end of the last block)
+// Victim lists of the LIST scan (round 5; one group of known size, n <= LIST_MAX_N: nms_list_body below).  Per box i two lists of
+// 16-bit ids of boxes of LATER 64-blocks whose IoU with i exceeds the threshold, in any order, with a counter each (nothing is
+// initialised but the counters; readers mask by the count):
+//   near list: victims in the next LIST_K blocks (<= LIST_NEAR entries): marked by the scan's resolver wave itself;
+//   far list : victims beyond (<= LIST_FAR entries): marked by helper waves.
+constexpr int LIST_K = 8;
+constexpr int LIST_NEAR = 16;
+constexpr int LIST_FAR = 64;
+constexpr unsigned LIST_MAX_N = 16384;          // the list scan keeps one state BYTE per box in LDS
+constexpr unsigned short LIST_DUMMY = 0x4040u;  // first of 64 scratch state bytes (never boxes), four bytes apart, one per lane
 struct QueueArgs {
   unsigned* queue;   // (G, QUEUE_SHARDS, scap)
   unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
   unsigned* ovl;     // (G, npairs) overflowed block pair ids
   unsigned scap, npairs;   // scap: entries per shard
-  unsigned short* lists;   // (cap, PULL_LCAP) or nullptr: no lists wanted
-  unsigned* lcnt;          // (cap) entries appended per box (may exceed PULL_LCAP: the list is then incomplete)
+  unsigned short* lists;   // (cap, LIST_NEAR) near lists, then (cap, LIST_FAR) far lists — or nullptr: no lists wanted
+  unsigned* lcnt;          // (cap, 2) entries appended per box to its near / far list (may exceed the capacity: the list is then incomplete)
   unsigned* lfail;         // (1) set when the lists cannot be used: a full list, or block pairs that went to the overflow list
 };
 
@@ -498,12 +502,8 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     mask[(size_t)(i0 + lane) * a.cbs + c] = 0ull;                 // the clip kernel ORs into these
     if (rb == c) {
       colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
-      if (q.lists != nullptr) {   // the pull scan's suppressor list of this box: empty (the clip kernel appends)
-        q.lcnt[i0 + lane] = 0u;
-        uint4* const l4 = reinterpret_cast<uint4*>(q.lists + (size_t)(i0 + lane) * PULL_LCAP);
-        const unsigned int none2 = (unsigned int)PULL_NONE * 0x10001u;
-        l4[0] = l4[1] = make_uint4(none2, none2, none2, none2);
-      }
+      if (q.lists != nullptr)   // the list scan's victim lists of this box: empty (the clip kernel appends)
+        reinterpret_cast<uint2*>(q.lcnt)[i0 + lane] = make_uint2(0u, 0u);
     }
   }
   if (q.lists != nullptr && pair == 0 && lane == 0) *q.lfail = 0u;
@@ -596,10 +596,16 @@ __global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, con
         atomicOr(&mask[(size_t)i * a.cbs + (j >> 6)], 1ull << (j & 63));
         if ((i >> 6) == (j >> 6)) {
           atomicOr(&colm[j], 1ull << (i & 63));
-        } else if (q.lists != nullptr) {   // i suppresses j from an earlier block: one more entry of j's list
-          const unsigned pos = atomicAdd(&q.lcnt[j], 1u);
-          if (pos < (unsigned)PULL_LCAP) q.lists[(size_t)j * PULL_LCAP + pos] = (unsigned short)i;
-          else *q.lfail = 1u;              // the list is incomplete: the pull scan must not run (the classic scan does)
+        } else if (q.lists != nullptr) {   // i suppresses j of a later block: one more entry of i's near or far victim list
+          const bool far = (j >> 6) - (i >> 6) > LIST_K;
+          const unsigned pos = atomicAdd(&q.lcnt[2 * i + (far ? 1 : 0)], 1u);
+          if (far) {
+            if (pos < (unsigned)LIST_FAR) q.lists[(size_t)a.cap * LIST_NEAR + (size_t)i * LIST_FAR + pos] = (unsigned short)j;
+            else *q.lfail = 1u;            // the list is incomplete: the list scan must not run (the classic scan does)
+          } else {
+            if (pos < (unsigned)LIST_NEAR) q.lists[(size_t)i * LIST_NEAR + pos] = (unsigned short)j;
+            else *q.lfail = 1u;
+          }
         }
       }
     }
@@ -1009,130 +1015,147 @@ __global__ __launch_bounds__(SCAN_T) void nms_scan_kernel(const NmsArgs a, const
   nms_scan_body<U, CH>(a, mask_, colm_, keep_, num_keep, dbg, win);
 }
 
-// ---- PULL scan (round 5): the greedy scan for high thresholds (>= 0.5), where a box has few suppressor candidates ---------------------
-// The classic scan above PUSHES: every kept box's mask row is fetched and OR-ed into the removed-set by twelve row waves — work that
-// grows with the number of KEPT boxes (n = 9000 at thr 0.7: 72 % kept, 46 rows per block: the row waves' issue stream sets a
-// ~1500-cycle interval, and above 8448 boxes three scan launches and two propagate launches are needed).  At a high threshold few
-// pairs overlap that much: the clip kernel therefore also appends, for every pair (i, j) it finds above the threshold with i in an
-// EARLIER 64-block, the id i to box j's SUPPRESSOR LIST (<= PULL_LCAP entries, any order: the test below is an OR).  Box j is then
-// removed iff a KEPT box of its list, or (colm, as before) a kept earlier box of its own block, suppresses it.  No row propagation,
-// no urgent words, one level for any n <= 16384.
-// What bounds it is the RESOLVER's instruction stream (one wave; ~4.5 ns per instruction at the clock a one-workgroup kernel gets):
-// every instruction it does not execute is time, so everything that can be prepared is prepared by the field waves:
-//   * kept BYTES in LDS, one per box (keptb[]): a list entry IS the LDS address of its kept byte — one ds_read_u8 per entry, no
-//     shift / mask / bit extract; unused entries point at a byte that is always 0 (PULL_NONE), the lanes past the end of the last
-//     block at one that is always 1 (PULL_ONE): no bounds logic in the loop.  The resolver's own lane writes its kept byte;
-//   * the ring holds the entries as dwords, four per ds_read_b128; the first eight of block c + 1 are fetched while block c is
-//     worked on, entries 8-15 (rare) on demand;
-//   * rflag[slot] = (block + 1) << 8 | (any column word non-zero) << 7 | 4-entry chunks to look at: the in-block step (the usual
-//     fixed point over colm) is skipped with one scalar branch where no box of the block has an in-block candidate.
-// No barrier in the loop.  The workgroup synchronises through LDS words (one CU's LDS executes every wave's accesses in issue
-// order, so "data, then flag" by the writer and "flag, then data" by the reader is enough; compiler fences keep the statements in
-// that order):
-//   rflag[slot]  written by a field wave AFTER the slot's fields; the resolver reads it with block c + 1's fields while it works on
-//                block c and re-reads only if the block is not there yet (never in steady state: the ring is 16 blocks deep);
-//   pdone[c]     = (kept boxes before block c) << 1 | 1, written by the resolver after the block's kept bytes; field wave g polls
-//                it (s_sleep) before its scribe step of block t (kept ids to `keep`).
-// Nine field waves (the waves that do not share the resolver's SIMD), wave g serving blocks t = g, g + 9, ...: issue the loads of
-// block t + 16, wait for block t to be resolved, read its kept bytes / base / ids, store block t + 16's fields into the ring slot
-// block t just vacated (same wave, same iteration: no other ordering needed), write the kept ids.  Nine blocks of resolver time
-// cover a global-memory round trip; the prologue fills the ring with all sixteen waves in one round trip.  Every polling loop is
-// bounded (a bug must not hang the GPU): a wave that gives up returns, and the resolver then reports num_keep = -1.
-// History (n = 9000 thr 0.7, this kernel): kept BITS + barrier per block + the field waves' loaded fields in SCRATCH memory (a
-// select between two uint4 objects; they waited for their loads in the interval that issued them) 66.8 us; without the scratch
-// 44.4 us; kept bytes and no barrier: see profiles/r05_nms_pmc.txt.
-// Same greedy decisions by construction (the lists hold every earlier-block candidate, kept or not).  A full list or an overflowed
-// block pair sets *lfail in the clip kernel: the workgroup then runs the CLASSIC scan instead (same launch: no second kernel).
-constexpr int PULL_RING = 16;
-constexpr int PULL_FW = 9;
-constexpr int PULL_SPIN_MAX = 1 << 22;
-#ifndef PULL_POLL_SLEEP
-#define PULL_POLL_SLEEP 4
+// ---- LIST scan (round 5): the greedy scan on per-box VICTIM LISTS and one state BYTE per box in LDS ----------------------------------
+// The classic scan above keeps the removed-set as bit words and PUSHES whole 512-byte mask rows of every kept box through twelve row
+// waves; its interval is an instruction stream of ~90 (row waves) / ~60 (resolver) instructions, and a wave issues one instruction
+// per ~8 cycles.  Here the clip kernel, which finds every pair (i < j, IoU > thr) anyway, also appends j to box i's near or far
+// VICTIM LIST when j lies in a later 64-block (in-block pairs stay in colm), and the scan is:
+//   state byte of box j (stb[j], LDS): 0 alive so far | 0x01 a kept earlier box suppresses it | after its block was resolved:
+//                                      0x80 kept, 0x02 not kept;
+//   block c, resolver wave:  alive = (stb == 0) per lane -> in-block fixed point over colm (skipped when no box of the block has an
+//                            in-block candidate) -> kept; own byte := 0x80 / 0x02; kept lanes write 0x01 to their NEAR victims
+//                            (blocks c + 1 .. c + LIST_K) — the LDS addresses of those bytes sit in a ring that helper waves filled
+//                            long before, four per instruction pair;
+//   helper wave of block c:  after the block is resolved, writes 0x01 to the FAR victims (blocks > c + LIST_K) of its kept boxes and
+//                            sets fdone[c]; the resolver looks at fdone[c - LIST_K - 1] before it reads block c's bytes.
+// What bounds it is the RESOLVER's instruction stream (~30 instructions per block on the usual path, one LDS round trip — its own
+// state bytes — on the dependent chain), so everything that can be prepared is prepared by the helpers.  The resolver works in
+// groups of four blocks, the body instantiated four times with the slot offsets as instruction offsets, and with two register sets
+// (block c + 2's fields are fetched while block c is worked on).  No barrier in the loop: the workgroup synchronises through LDS
+// words (one CU's LDS executes every wave's accesses in issue order, so "data, then flag" by the writer and "flag, then data" by the
+// reader is enough; compiler fences keep the statements in that order):
+//   rflag[slot] = (ring generation + 1) << 8 | (some column word non-zero) << 7 | near chunks (0..4),
+//                 written by a helper AFTER the slot's fields; re-read by the resolver only if the block is not there yet;
+//   stb[64 t]     polled by helper waves (s_sleep) for "block t resolved";   fdone[]  as above.
+// Twelve helper waves (those that do not share the resolver's SIMD: waves w, w + 4, w + 8, w + 12 sit on one SIMD — HW_ID), wave g
+// serving blocks t = g, g + 12, ...: issue the loads of block t's far list (as many uint4 as the block's longest far list needs: the
+// counts were loaded one iteration earlier) and of block t + 16's near list / column word / id, wait for block t, far victims,
+// fdone, count the kept boxes since its last block (the running count is the helper's own business), put block t + 16 into the
+// ring slot block t just vacated (same wave, same iteration: no other ordering needed), write block t's kept ids.  The prologue
+// fills the ring with all sixteen waves in one memory round trip.  Every polling loop is bounded (a bug must not hang the GPU): the
+// scan is then marked failed and num_keep = -1.
+// Two things this kernel is sensitive to, both measured (profiles/r05_nms_pmc.txt): (a) CODE SIZE — every launch starts with a cold
+// instruction cache; a first build (resolver unrolled over all 16 slots, list loops unrolled: 61 KB) spent 2000-4000 cycles per
+// block in its first pass; (b) the BYTES the helpers load — with one 128-byte list per box loaded twice per block the resolver ran at
+// half speed although it never waited for a helper: hence near / far lists split by the clip kernel and far loads sized by count.
+// Same greedy decisions by construction.  A full list or an overflowed block pair sets *lfail in the clip kernel: the workgroup then
+// runs the CLASSIC scan instead (same launch: no second kernel).
+// History (n = 9000, thr 0.7, scan kernels only): classic two-level ~100 us; pull formulation (suppressor lists, kept bits gathered)
+// 66.8 us, 44.4 us once its field waves no longer kept loaded fields in SCRATCH memory (a select between two uint4 objects), 23.5 us
+// with kept bytes, no barrier and an unrolled resolver — for thresholds >= 0.5 only; this push formulation serves every threshold.
+constexpr int LIST_RING = 16;
+constexpr int LIST_HW = 12;
+constexpr int LIST_SPIN_MAX = 1 << 22;
+#ifndef LIST_POLL_SLEEP
+#define LIST_POLL_SLEEP 2
 #endif
-
-struct PullFields {
-  unsigned long long col;
-  long long id;
-  uint4 l0, l1;
-  unsigned cnt;
-};
 
 // volatile accesses that stay LDS instructions (a volatile access through a generic pointer becomes a flat_load / flat_store with an
 // immediate wait)
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
-// the byte at an LDS ADDRESS held in a register (ds_read_u8 v, vaddr: no base to add — the instruction's 16-bit offset field cannot
-// reach an array the compiler placed beyond 64 KB)
-__device__ __forceinline__ unsigned int lds_byte_at(unsigned int addr) { return *(const lds_u8*)(size_t)addr; }
 __device__ __forceinline__ unsigned int lds_peek(const unsigned int* p) { return *(const volatile lds_u32*)p; }
 __device__ __forceinline__ void lds_poke(unsigned int* p, unsigned int v) { *(volatile lds_u32*)p = v; }
+// the byte at an LDS ADDRESS held in a register (ds_write_b8 vaddr, v: no base to add — the instruction's 16-bit offset field cannot
+// reach an array the compiler placed beyond 64 KB)
+__device__ __forceinline__ void lds_mark_at(unsigned int addr) { *(lds_u8*)(size_t)addr = 1; }
 #define COMPILER_FENCE() asm volatile("" ::: "memory")
+__device__ __forceinline__ int wave_max_i32(int m) {   // uniform result
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, true));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(m, 63);
+}
 
-__device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned long long* __restrict__ colm,
+struct RingFields {      // what a ring slot is made of, as loaded
+  uint4 n0, n1;          // the near list: sixteen 16-bit ids
+  uint2 cnt;             // near / far count
+  unsigned long long col;
+  long long id;
+};
+
+__device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned long long* __restrict__ colm,
                                               const unsigned short* __restrict__ lists, const unsigned* __restrict__ lcnt,
                                               long long* __restrict__ keep, long long* __restrict__ num_keep,
                                               [[maybe_unused]] long long* __restrict__ dbg) {
-  constexpr int KB = (int)PULL_MAX_N + 64;
-  __shared__ __attribute__((aligned(16))) unsigned char keptb[KB];   // kept byte per box, then PULL_NONE's 0 and PULL_ONE's 1
-  __shared__ uint4 rent[PULL_RING][4][64];                   // [slot][chunk][lane]: the box's 16 list entries as kept-byte indices
-  __shared__ unsigned long long rcol[PULL_RING][64], rid[PULL_RING][64];
-  __shared__ unsigned int rflag[PULL_RING];
+  constexpr int SB = (int)LIST_MAX_N + 384;
+  __shared__ __attribute__((aligned(16))) unsigned char stb[SB];   // state byte per box; [LIST_DUMMY + 4 lane] are scratch
+  __shared__ unsigned int rent[LIST_RING][LIST_NEAR][64];    // [slot][k][lane]: LDS address of the state byte of the lane's k-th near victim
+  __shared__ unsigned long long rcol[LIST_RING][64], rid[LIST_RING][64];
+  __shared__ unsigned int rflag[LIST_RING];
+  __shared__ unsigned int fdone[256 + LIST_K + 1 + 7];       // [b + LIST_K + 1] != 0: the far victims of block b's kept boxes are marked
   __shared__ unsigned int failed;                            // a polling loop gave up: the result is void (num_keep = -1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n;
   const int cb = (n + 63) >> 6;
   const long long* order = a.order;
-  const unsigned int kb0 = (unsigned int)(size_t)(lds_u8*)keptb;   // LDS address of keptb[0]: the ring holds ADDRESSES of kept bytes
-  for (int w = tid; w < KB / 4; w += SCAN_T) reinterpret_cast<unsigned int*>(keptb)[w] = 0u;
-  if (tid < PULL_RING) rflag[tid] = 0u;
+  const unsigned short* const flists = lists + (size_t)a.cap * LIST_NEAR;
+  const uint2* const cnt2 = reinterpret_cast<const uint2*>(lcnt);
+  const unsigned int sb0 = (unsigned int)(size_t)(lds_u8*)stb;   // LDS address of stb[0]: the ring holds ADDRESSES of state bytes
+  const unsigned int mydummy = (unsigned int)LIST_DUMMY + 4u * (unsigned int)lane;   // (same-address byte writes of many lanes would be serialised)
+  for (int w = tid; w < SB / 4; w += SCAN_T) reinterpret_cast<unsigned int*>(stb)[w] = 0u;
+  if (tid < LIST_RING) rflag[tid] = 0u;
+  if (tid < 256 + LIST_K + 1) fdone[tid] = tid <= LIST_K ? 1u : 0u;   // (nothing to wait for before block LIST_K + 1)
   if (tid == 0) failed = 0u;
-  // The resolver works in groups of four blocks (exit checks cost instructions): blocks cb .. cbp - 1 are PADDING, entered into the
-  // ring like real ones with every lane "past the end" (dead on arrival); their kept bytes land behind box n - 1, inside keptb.
+  // The resolver works in groups of four blocks: blocks cb .. cbp - 1 are PADDING, entered into the ring like real ones; the state
+  // bytes of everything past box n - 1 start as "suppressed".
   const int cbp = (cb + 3) & ~3;
 
-  // nothing may touch a loaded value before store_fields — not even a select on `ok`: the rows are read from a clamped index and
-  // masked at store time (a use makes the compiler wait for the load where the use stands)
-  auto load_fields = [&](int B) -> PullFields {
-    PullFields f;
+  // ---- helper-side pieces.  Nothing may touch a loaded value before its consumer — not even a select: a use makes the compiler wait
+  // for the load where the use stands (rows are read from a clamped index and masked where they are consumed).
+  auto load_ring = [&](int B) -> RingFields {
+    RingFields f;
     const int j = min(B * 64 + lane, n - 1);   // n >= 1 here
+    const uint4* const l4 = reinterpret_cast<const uint4*>(lists + (size_t)j * LIST_NEAR);
+    f.n0 = l4[0];
+    f.n1 = l4[1];
+    f.cnt = cnt2[j];
     f.col = colm[j];
     f.id = order != nullptr ? order[j] : (long long)j;
-    const uint4* const l4 = reinterpret_cast<const uint4*>(lists + (size_t)j * PULL_LCAP);
-    f.l0 = l4[0];
-    f.l1 = l4[1];
-    f.cnt = lcnt[j];
     return f;
   };
-  auto store_fields = [&](int B, const PullFields f) {   // whole wave; (B < cb is the caller's business)
-    const int slot = B & (PULL_RING - 1);
+  auto store_ring = [&](int B, const RingFields f) {   // whole wave; (B < cbp is the caller's business)
+    const int slot = B & (LIST_RING - 1);
     const bool ok = B * 64 + lane < n;
-    // (component-wise: a select between two uint4 OBJECTS made the compiler keep `f` in scratch memory)
-    const unsigned int none = PULL_NONE;
-    auto lo = [&](unsigned int pair) { return kb0 + (ok ? (pair & 0xffffu) : none); };
-    auto hi = [&](unsigned int pair) { return kb0 + (ok ? (pair >> 16) : none); };
-    rent[slot][0][lane] = make_uint4(kb0 + (ok ? (f.l0.x & 0xffffu) : (unsigned int)PULL_ONE), hi(f.l0.x), lo(f.l0.y), hi(f.l0.y));
-    rent[slot][1][lane] = make_uint4(lo(f.l0.z), hi(f.l0.z), lo(f.l0.w), hi(f.l0.w));
-    rent[slot][2][lane] = make_uint4(lo(f.l1.x), hi(f.l1.x), lo(f.l1.y), hi(f.l1.y));
-    rent[slot][3][lane] = make_uint4(lo(f.l1.z), hi(f.l1.z), lo(f.l1.w), hi(f.l1.w));
+    const int cnt = ok ? (int)min(f.cnt.x, (unsigned)LIST_NEAR) : 0;
+    unsigned int* const row0 = &rent[slot][0][lane];
+    const unsigned int dummy = sb0 + mydummy;
+    const int chunks = (wave_max_i32(cnt) + 3) >> 2;        // rows the resolver will look at
+    auto put = [&](int k, unsigned int e) { row0[k * 64] = k < cnt ? sb0 + e : dummy; };
+    auto put8 = [&](int k, const uint4 q) {
+      put(k + 0, q.x & 0xffffu); put(k + 1, q.x >> 16); put(k + 2, q.y & 0xffffu); put(k + 3, q.y >> 16);
+      put(k + 4, q.z & 0xffffu); put(k + 5, q.z >> 16); put(k + 6, q.w & 0xffffu); put(k + 7, q.w >> 16);
+    };
+    if (chunks > 0) put8(0, f.n0);
+    if (chunks > 2) put8(8, f.n1);
     const unsigned long long col = ok ? f.col : 0ull;
     rcol[slot][lane] = col;
     rid[slot][lane] = (unsigned long long)f.id;
-    int m = ok ? (int)((min(f.cnt, (unsigned)PULL_LCAP) + 3u) >> 2) : 0;   // the chunk count of the block: the maximum over its boxes
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, true));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));
-    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));
     const unsigned int hascol = __ballot(col != 0ull) != 0ull ? 0x80u : 0u;
     COMPILER_FENCE();                            // the flag goes last
-    if (lane == 63) lds_poke(&rflag[slot], ((unsigned int)((B >> 4) + 1) << 8) | hascol | (unsigned int)m);   // (ring generation + 1) << 8 | ...
+    if (lane == 63) lds_poke(&rflag[slot], ((unsigned int)((B >> 4) + 1) << 8) | hascol | (unsigned int)chunks);
   };
 
-  lds_barrier();                                 // (the zero fill above, before the first flags)
-  if (tid == 0) keptb[PULL_ONE] = 0x80;
-  if (wave < cbp) store_fields(wave, load_fields(wave));   // prologue: sixteen waves, sixteen blocks, one memory round trip
+  lds_barrier();                                 // (the zero fill above, before anything else is written)
+#ifdef SCAN_PROFILE
+  if (lane == 0) dbg[(size_t)(2 * cb + 16) * 16 + wave] = __builtin_amdgcn_s_getreg(63492);   // HW_ID of every wave
+#endif
+  for (int j = n + tid; j < cbp * 64; j += SCAN_T) stb[j] = 1;   // boxes past the end: suppressed from the start
+  if (wave < cbp) store_ring(wave, load_ring(wave));   // prologue: sixteen waves, sixteen blocks, one memory round trip
   lds_barrier();                                 // the only barriers of this scan
   if (cb == 0) {
     if (tid == 0) num_keep[0] = 0;
@@ -1141,48 +1164,55 @@ __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned l
 
   if (wave == 0) {
     // ---------------------------------------------------------------- resolver
-    // Unrolled over the ring (slot = block & 15 is a constant in every copy: all ring addresses are instruction offsets off three
-    // per-lane registers).  The fields of the block about to be resolved are in registers one block ahead of their use and are
-    // re-read from the ring INTO THE SAME registers as soon as their last use is past.  Per block, usual path (<= 4 entries per
-    // list, no in-block candidate): ~30 instructions, one LDS round trip (the kept bytes) on the dependent chain.
-    const uint4* const rl = &rent[0][0][lane];
+    const unsigned int* const rl = &rent[0][0][lane];
     const unsigned long long* const rc = &rcol[0][lane];
+    struct Near { unsigned int x, y, z, w; };
+    // entries 4 chunk .. 4 chunk + 3 of the lane's near list in the slot at `r` (rows 256 bytes apart)
+    auto ring4 = [&](const unsigned int* r, int chunk) -> Near { return Near{r[chunk * 256], r[chunk * 256 + 64], r[chunk * 256 + 128], r[chunk * 256 + 192]}; };
+    auto mark4 = [&](const Near& e) { lds_mark_at(e.x); lds_mark_at(e.y); lds_mark_at(e.z); lds_mark_at(e.w); };
+    constexpr int SLOT_DW = LIST_NEAR * 64;   // dwords per ring slot
     // two register sets, blocks of even / odd index: block c's fields are fetched while block c - 2 is worked on, so that neither
-    // the flag nor the entries are waited for (with one set the ring read and the kept-byte read were two LDS round trips in a row)
+    // the flag nor the entries are waited for
     unsigned long long colA = rc[0], colB = rc[64];
-    uint4 l0A = rl[0], l1A = rl[64], l0B = rl[256], l1B = rl[256 + 64];
+    Near l0A = ring4(rl, 0), l1A = ring4(rl, 1), l0B = ring4(rl + SLOT_DW, 0), l1B = ring4(rl + SLOT_DW, 1);
     unsigned int nflagA = rflag[0], nflagB = rflag[1];   // (cbp >= 4 here: blocks 0 and 1 are in the ring since the prologue)
-    for (int c0 = 0; c0 < cbp; c0 += PULL_RING) {
-      unsigned char* const kw = keptb + c0 * 64 + lane;
-      const int rem = cbp - c0;                                 // blocks left, this group included: a multiple of four
+    unsigned int fdA = 1u, fdB = 1u;                     // (blocks 0 and 1 wait for nobody)
+    for (int c0 = 0; c0 < cbp; c0 += 4) {
+      unsigned char* const kw = stb + c0 * 64 + lane;
+      const unsigned int* const fdp = fdone + c0;
+      const int s0 = c0 & (LIST_RING - 1), s4 = (c0 + 4) & (LIST_RING - 1);   // slots of blocks c0 and c0 + 4
       const unsigned int gen1 = (unsigned int)(c0 >> 4) + 1u;   // what the flag of every block of this group carries
-      // one block; true = stop (no blocks left).  Instantiated sixteen times below (the compiler refuses to unroll a loop with
-      // this body)
-      auto block = [&](auto U) -> bool {
+      auto block = [&](auto U) {
         constexpr int u = decltype(U)::value;
-        if constexpr (u % 4 == 0 && u > 0)
-          if (rem <= u) return true;
         [[maybe_unused]] const int c = c0 + u;
         SCAN_STAMP(0);
-        constexpr int fslot = (u + 2) & (PULL_RING - 1);   // the slot fetched in this block: block c + 2
-        uint4& l0 = (u & 1) ? l0B : l0A;
-        uint4& l1 = (u & 1) ? l1B : l1A;
+#ifdef SCAN_PROFILE
+        if (lane == 0) dbg[(size_t)c * 16 + 6] = dbg[(size_t)c * 16 + 7] = 0;
+#endif
+        const int cslot = s0 + u;                                   // this block's slot
+        const int fslot = u < 2 ? s0 + u + 2 : s4 + u - 2;          // the slot fetched in this block: block c + 2
+        Near& l0 = (u & 1) ? l0B : l0A;
+        Near& l1 = (u & 1) ? l1B : l1A;
         unsigned long long& col = (u & 1) ? colB : colA;
         unsigned int& nflag = (u & 1) ? nflagB : nflagA;
+        unsigned int& fd = (u & 1) ? fdB : fdA;
         unsigned int flag = (unsigned int)__builtin_amdgcn_readfirstlane((int)nflag);
         if (__builtin_expect((flag >> 8) != gen1, 0)) {
-          // the block is not in the ring yet (never in steady state): re-read flag and fields.  Gives up after PULL_SPIN_MAX polls
-          // — a bug must not hang the GPU —, marks the scan failed and goes on with a harmless flag; once failed, no more waiting.
+          // the block is not in the ring yet (never in steady state): re-read flag and fields.  Gives up after LIST_SPIN_MAX polls,
+          // marks the scan failed and goes on with a harmless flag; once failed, no more waiting.
           flag = gen1 << 8;
           bool got = false;
-          for (int spins = 0; spins < PULL_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
+          for (int spins = 0; spins < LIST_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
             __builtin_amdgcn_s_sleep(1);
             COMPILER_FENCE();
-            const unsigned int fl = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_peek(&rflag[u]));
+#ifdef SCAN_PROFILE
+            if (lane == 0) dbg[(size_t)c * 16 + 6] = spins + 1;
+#endif
+            const unsigned int fl = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_peek(&rflag[cslot]));
             COMPILER_FENCE();
-            l0 = rl[u * 256];
-            l1 = rl[u * 256 + 64];
-            col = rc[u * 64];
+            l0 = ring4(rl + cslot * SLOT_DW, 0);
+            l1 = ring4(rl + cslot * SLOT_DW, 1);
+            col = rc[cslot * 64];
             if ((fl >> 8) == gen1) {
               flag = fl;
               got = true;
@@ -1191,21 +1221,22 @@ __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned l
           }
           if (!got) lds_poke(&failed, 1u);
         }
-        unsigned int dead = lds_byte_at(l0.x) | lds_byte_at(l0.y) | lds_byte_at(l0.z) | lds_byte_at(l0.w);   // always: empty entries read a 0
-        if (__builtin_expect((flag & 6u) != 0u, 0)) {   // more than one 4-entry chunk (the count is 0..4)
-          dead |= lds_byte_at(l1.x) | lds_byte_at(l1.y) | lds_byte_at(l1.z) | lds_byte_at(l1.w);
-          if ((flag & 0x7fu) > 2u) {   // rare: the block's own slot still holds them
-            const uint4 l2 = rl[u * 256 + 128], l3 = rl[u * 256 + 192];
-            dead |= lds_byte_at(l2.x) | lds_byte_at(l2.y) | lds_byte_at(l2.z) | lds_byte_at(l2.w);
-            dead |= lds_byte_at(l3.x) | lds_byte_at(l3.y) | lds_byte_at(l3.z) | lds_byte_at(l3.w);
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)fd) == 0, 0)) {   // the far victims of block c - LIST_K - 1 are still being marked
+          bool got = false;
+          for (int spins = 0; spins < LIST_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+#ifdef SCAN_PROFILE
+            if (lane == 0) dbg[(size_t)c * 16 + 7] = spins + 1;
+#endif
+            if (__builtin_amdgcn_readfirstlane((int)lds_peek(&fdp[u])) != 0) {
+              got = true;
+              break;
+            }
           }
+          if (!got) lds_poke(&failed, 1u);
         }
         COMPILER_FENCE();
-        nflag = lds_peek(&rflag[fslot]);   // flag first, then the fields it vouches for
-        COMPILER_FENCE();
-        l0 = rl[fslot * 256];
-        l1 = rl[fslot * 256 + 64];
-        unsigned long long kept = __ballot(dead < 0x80u);   // no KEPT (0x80) byte among the entries
+        unsigned long long kept = __ballot(kw[u * 64] == 0);   // nobody kept so far suppresses the lane's box
         SCAN_STAMP(1);
         if (__builtin_expect((flag & 0x80u) != 0u, 0)) {   // some box of the block has an earlier box of the block on its column word
           const unsigned long long alive = kept;
@@ -1219,60 +1250,114 @@ __device__ __forceinline__ void nms_pull_body(const NmsArgs& a, const unsigned l
             }
           }
         }
-        col = rc[fslot * 64];
         SCAN_STAMP(2);
-        // one byte per box: 0x80 kept, 0x01 resolved and not kept (0 = not resolved yet: what the field waves poll).  Read back by
-        // THIS wave for later blocks: LDS runs a wave's accesses in order.
-        kw[u * 64] = __builtin_amdgcn_inverse_ballot_w64(kept) ? 0x80 : 0x01;
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(kept);
+        kw[u * 64] = mine ? 0x80 : 0x02;   // (also what the helper waves poll)
+        if ((flag & 7u) != 0u && mine) {   // near victims: read back by THIS wave for later blocks — LDS runs a wave's accesses in order
+          mark4(l0);
+          if ((flag & 6u) != 0u) {         // more than one 4-entry chunk (the count is 0..4)
+            mark4(l1);
+            if ((flag & 7u) > 2u) {        // rare: the block's own slot still holds them
+              mark4(ring4(rl + cslot * SLOT_DW, 2));
+              if ((flag & 7u) > 3u) mark4(ring4(rl + cslot * SLOT_DW, 3));
+            }
+          }
+        }
+        COMPILER_FENCE();
+        nflag = lds_peek(&rflag[fslot]);   // flag first, then the fields it vouches for
+        COMPILER_FENCE();
+        l0 = ring4(rl + fslot * SLOT_DW, 0);
+        l1 = ring4(rl + fslot * SLOT_DW, 1);
+        col = rc[fslot * 64];
+        fd = lds_peek(&fdp[u + 2]);
         COMPILER_FENCE();
         SCAN_STAMP(3);
-        return false;
       };
-#define PULL_BLOCK(u) if (block(std::integral_constant<int, u>{})) break;
-      PULL_BLOCK(0) PULL_BLOCK(1) PULL_BLOCK(2) PULL_BLOCK(3) PULL_BLOCK(4) PULL_BLOCK(5) PULL_BLOCK(6) PULL_BLOCK(7)
-      PULL_BLOCK(8) PULL_BLOCK(9) PULL_BLOCK(10) PULL_BLOCK(11) PULL_BLOCK(12) PULL_BLOCK(13) PULL_BLOCK(14) PULL_BLOCK(15)
-#undef PULL_BLOCK
-      static_assert(PULL_RING == 16, "the resolver is unrolled over the ring");
+      block(std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 1>{});
+      block(std::integral_constant<int, 2>{});
+      block(std::integral_constant<int, 3>{});
     }
     if (lds_peek(&failed) != 0u && lane == 0) num_keep[0] = -1;
     return;
   }
-  // ------------------------------------------------------------------ field waves: waves 1-3, 5-7, 9-11 (not on the resolver's SIMD)
-  if ((wave & 3) == 0 || wave > 11) return;
+  // ------------------------------------------------------------------ helper waves: every wave that is not on the resolver's SIMD
+  if ((wave & 3) == 0) return;
   const int g = wave - 1 - (wave >> 2);
-  int base = 0;                                   // kept boxes before block t: the running count is this wave's own business
-  auto kept_word = [&](int blk) -> unsigned long long { return __ballot(keptb[blk * 64 + lane] >= 0x80); };
-  for (int t = g; t < cb; t += PULL_FW) {
-    const bool more = t + PULL_RING < cbp;
-    PullFields f = {};
-    if (more) f = load_fields(t + PULL_RING);     // in flight while the resolver works through the ~nine blocks up to t
+  int base = 0;                                   // kept boxes before block t
+  auto kept_word = [&](int blk) -> unsigned long long { return __ballot(stb[blk * 64 + lane] == 0x80); };
+  unsigned int fcnt_next = g < cb ? cnt2[min(g * 64 + lane, n - 1)].y : 0u;   // far count of this wave's next block, one iteration ahead
+  for (int t = g; t < cb; t += LIST_HW) {
+#ifdef SCAN_PROFILE
+#define HSTAMP(k) do { if (lane == 0) dbg[(size_t)(cb + 8 + t) * 16 + (k)] = clock64(); } while (0)
+#else
+#define HSTAMP(k) do { } while (0)
+#endif
+    HSTAMP(0);
+    const bool more = t + LIST_RING < cbp;
+    // block t's far lists: as many uint4 as its longest one needs (the counts were loaded an iteration ago; lanes past the end have
+    // a clamped index and are never kept)
+    const int fcnt = (int)min(fcnt_next, (unsigned)LIST_FAR);
+    const int nq = (wave_max_i32(fcnt) + 7) >> 3;
+    uint4 q[LIST_FAR / 8];
+    {
+      const uint4* const l4 = reinterpret_cast<const uint4*>(flists + (size_t)min(t * 64 + lane, n - 1) * LIST_FAR);
+#pragma unroll
+      for (int k = 0; k < LIST_FAR / 8; ++k) q[k] = k < nq ? l4[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    RingFields fr = {};                           // block t + 16's fields (ring), in flight while the resolver works up to t
+    if (more) fr = load_ring(t + LIST_RING);
+    if (t + LIST_HW < cb) fcnt_next = cnt2[min((t + LIST_HW) * 64 + lane, n - 1)].y;
     int spins = 0;
-    while (__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u8*)(size_t)(kb0 + (unsigned int)t * 64u)) == 0) {
-      if (++spins > PULL_SPIN_MAX) return;
-      __builtin_amdgcn_s_sleep(PULL_POLL_SLEEP);
+    while ((__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u8*)(size_t)(sb0 + (unsigned int)t * 64u)) & 0x82) == 0) {
+      if (++spins > LIST_SPIN_MAX) return;
+      __builtin_amdgcn_s_sleep(LIST_POLL_SLEEP);
     }
     COMPILER_FENCE();
-    // scribe step of block t; its global store goes last (loads and stores share one in-order counter)
-    for (int blk = max(t - PULL_FW + 1, 0); blk < t; ++blk) base += __builtin_popcountll(kept_word(blk));   // the blocks since this wave's last one: all resolved before t
+    HSTAMP(1);
     const unsigned long long kept = kept_word(t);
-    const long long id = (long long)rid[t & (PULL_RING - 1)][lane];
-    if (more) {
-      COMPILER_FENCE();                           // (the id above is read before the slot is overwritten)
-      asm volatile("" : "+v"(f.col), "+v"(f.id), "+v"(f.cnt));   // first use of the loaded fields pinned here
-      store_fields(t + PULL_RING, f);
+    const bool mine = (kept >> lane) & 1ull;
+    {   // far victims of the kept boxes: due before the resolver reaches block t + LIST_K + 1.  ROLLED, the list rotating through
+        // q[0] (register arrays cannot be indexed): code size matters here (see the header)
+      if (mine) {
+#pragma unroll 1
+        for (int k = 0; k < nq; ++k) {
+          const uint4 v = q[0];
+          const int kb = k * 8;
+          auto mark = [&](int i, unsigned int e) { stb[kb + i < fcnt ? e : mydummy] = 1; };
+          mark(0, v.x & 0xffffu); mark(1, v.x >> 16); mark(2, v.y & 0xffffu); mark(3, v.y >> 16);
+          mark(4, v.z & 0xffffu); mark(5, v.z >> 16); mark(6, v.w & 0xffffu); mark(7, v.w >> 16);
+#pragma unroll
+          for (int r = 0; r + 1 < LIST_FAR / 8; ++r) q[r] = q[r + 1];
+        }
+      }
+      COMPILER_FENCE();
+      if (lane == 0) lds_poke(&fdone[t + LIST_K + 1], 1u);
       COMPILER_FENCE();
     }
-    if ((kept >> lane) & 1ull) keep[base + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
+    // scribe step of block t; its global store goes last (loads and stores share one in-order counter)
+    HSTAMP(2);
+    for (int blk = max(t - LIST_HW + 1, 0); blk < t; ++blk) base += __builtin_popcountll(kept_word(blk));   // since this wave's last block
+    const long long id = (long long)rid[t & (LIST_RING - 1)][lane];
+    HSTAMP(3);
+    if (more) {
+      COMPILER_FENCE();                           // (the id above is read before the slot is overwritten)
+      asm volatile("" : "+v"(fr.col), "+v"(fr.id));   // first use of the loaded fields pinned here
+      store_ring(t + LIST_RING, fr);
+      COMPILER_FENCE();
+    }
+    HSTAMP(4);
+    if (mine) keep[base + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = id;
     base += __builtin_popcountll(kept);
     if (t == cb - 1 && lane == 0 && lds_peek(&failed) == 0u) num_keep[0] = base;
   }
 }
 
-// ONE launch for a call that may take the pull scan: the failure word the clip kernel left decides (uniform) between the pull scan
-// (ten waves; the others leave after the prologue) and the classic single-level scan — beyond two chunks per row its <.., 2> form ORs the
+// ONE launch for a call that may take the list scan: the failure word the clip kernel left decides (uniform) between the list scan
+// (thirteen waves; the others leave after the prologue) and the classic single-level scan — beyond two chunks per row its <.., 2> form ORs the
 // rest in synchronously: correct, slower than the two-level form, and only ever run as a fallback here.
 template <int CH>
-__global__ __launch_bounds__(SCAN_T) void nms_pull_or_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask,
+__global__ __launch_bounds__(SCAN_T) void nms_list_or_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask,
                                                                   const unsigned long long* __restrict__ colm,
                                                                   const unsigned short* __restrict__ lists,
                                                                   const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
@@ -1281,7 +1366,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_pull_or_scan_kernel(const NmsArgs 
   if (__hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
     nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
   else
-    nms_pull_body(a, colm, lists, lcnt, keep, num_keep, dbg);
+    nms_list_body(a, colm, lists, lcnt, keep, num_keep, dbg);
 }
 
 // Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
@@ -1421,10 +1506,11 @@ static WsLayout ws_layout(size_t G, size_t cap) {
   L.npairs = (unsigned)(cb * (cb + 1) / 2);
   L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
   L.ovl = L.qctl + align_up(G * CTL_WORDS * sizeof(unsigned), 256);
-  // suppressor lists of the pull scan (single-group calls only): ids, counts, the failure word
+  // victim lists of the list scan (single-group calls of at most LIST_MAX_N boxes only): ids, counts, the failure word
+  const size_t lboxes = (G == 1 && cap <= LIST_MAX_N) ? cap : 0;
   L.lists = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
-  L.lcnt = L.lists + align_up(G == 1 ? cap * PULL_LCAP * sizeof(unsigned short) : 0, 256);
-  L.lfail = L.lcnt + align_up(G == 1 ? cap * sizeof(unsigned) : 0, 256);
+  L.lcnt = L.lists + align_up(lboxes * (LIST_NEAR + LIST_FAR) * sizeof(unsigned short), 256);
+  L.lfail = L.lcnt + align_up(lboxes * 2 * sizeof(unsigned), 256);
   L.total = L.lfail + 256;
   return L;
 }
@@ -1481,7 +1567,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     return e != nullptr ? atoll(e) : (long long)QUEUE_MIN_N;
   }();
   const bool queued = mode == MODE_ROT && cap >= queue_min_n && pairs <= 0x7fffffffLL && (thresh_dev != nullptr || thresh >= 0.0f);   // (per-group device thresholds are checked in the kernel)
-  bool use_pull = false;
+  bool use_lists = false;
   if (mode == MODE_ROT && queued) {
     QueueArgs q;
     q.queue = (unsigned*)((char*)workspace + W.queue);
@@ -1489,16 +1575,16 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     q.ovl = (unsigned*)((char*)workspace + W.ovl);
     q.scap = W.scap;
     q.npairs = W.npairs;
-    // pull scan (suppressor lists instead of row propagation): one group of known size, one host-side threshold >= 0.5 — where few
-    // pairs overlap that much; a full list or an overflowed block pair falls back to the classic scan on the device
-    static const float pull_min_thr = [] {
-      const char* e = getenv("RNMS_PULL_MIN_THR");   // measurement / test override (a value > 1 switches the pull scan off)
-      return e != nullptr ? (float)atof(e) : 0.5f;
+    // list scan (victim lists and state bytes instead of mask-row propagation): one group of known size, one host-side threshold;
+    // a full list or an overflowed block pair falls back to the classic scan on the device
+    static const float list_min_thr = [] {
+      const char* e = getenv("RNMS_LIST_MIN_THR");   // measurement / test override (a value > 1 switches the list scan off)
+      return e != nullptr ? (float)atof(e) : 0.0f;
     }();
-    use_pull = G == 1 && counts == nullptr && thresh_dev == nullptr && thresh >= pull_min_thr && cap <= 16384;
-    q.lists = use_pull ? (unsigned short*)((char*)workspace + W.lists) : nullptr;
-    q.lcnt = use_pull ? (unsigned*)((char*)workspace + W.lcnt) : nullptr;
-    q.lfail = use_pull ? (unsigned*)((char*)workspace + W.lfail) : nullptr;
+    use_lists = G == 1 && counts == nullptr && thresh_dev == nullptr && thresh >= list_min_thr && cap <= (int64_t)LIST_MAX_N;
+    q.lists = use_lists ? (unsigned short*)((char*)workspace + W.lists) : nullptr;
+    q.lcnt = use_lists ? (unsigned*)((char*)workspace + W.lcnt) : nullptr;
+    q.lfail = use_lists ? (unsigned*)((char*)workspace + W.lfail) : nullptr;
     // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_place_kernel:
     // `ctl_zeroed`); only a caller that prepared the records itself pays a fill in the stream (4.4 us in the trace)
     const int zero_n = (int)CTL_WORDS;   // per group
@@ -1529,15 +1615,15 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   win.c_begin = 0;
   win.c_end = a.cbs;
   win.gremv = win.gkept = nullptr;
-  if (use_pull) {   // ONE launch: pull scan, or — decided on the device from the clip kernel's failure word — the classic one
+  if (use_lists) {   // ONE launch: list scan, or — decided on the device from the clip kernel's failure word — the classic one
     const unsigned* const lfail = (const unsigned*)((char*)workspace + W.lfail);
     const unsigned short* const lists = (const unsigned short*)((char*)workspace + W.lists);
     const unsigned* const lcnt = (const unsigned*)((char*)workspace + W.lcnt);
     if (a.cbs <= 64 + 1 + SCAN_NU)
-      hipLaunchKernelGGL((nms_pull_or_scan_kernel<1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+      hipLaunchKernelGGL((nms_list_or_scan_kernel<1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
                          (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     else
-      hipLaunchKernelGGL((nms_pull_or_scan_kernel<2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
+      hipLaunchKernelGGL((nms_list_or_scan_kernel<2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
                          (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     return (int)hipGetLastError();
   }

@@ -847,11 +847,12 @@ def test_batched_scored_sets_replay_in_a_hipgraph_with_a_persistent_workspace(am
             assert int(num[g]) == int(n2[g]) > 0 and torch.equal(keep[g, :int(num[g])], k2[g, :int(n2[g])]), (seed, g, num.tolist(), n2.tolist())
 
 
-# ---- the pull scan (thresholds >= 0.5: suppressor lists instead of row propagation) and its device-side fallback ----
-@pytest.mark.parametrize('n,thr', [(768, 0.5), (1000, 0.7), (4096, 0.5), (8448, 0.6), (9000, 0.7), (9000, 0.8), (12288, 0.55), (16384, 0.7)])
-def test_pull_scan_keep_indices_bit_exact(amd, n, thr):
-    """High-threshold calls take nms_pull_scan_kernel (one group, thr >= 0.5, n <= 16384): same greedy keep list as the CPU oracle,
-    through nms_gpu (score ranking inside the library) and through the pre-sorted C ABI entry."""
+# ---- the list scan (victim lists + one state byte per box in LDS; one group, n <= 16384) and its device-side fallback ----
+@pytest.mark.parametrize('n,thr', [(768, 0.5), (1000, 0.7), (1000, 0.2), (4096, 0.5), (4096, 0.25), (4096, 0.1), (8448, 0.6), (9000, 0.7),
+                                   (9000, 0.8), (9000, 0.3), (12288, 0.55), (16384, 0.7), (16384, 0.3), (16321, 0.45)])
+def test_list_scan_keep_indices_bit_exact(amd, n, thr):
+    """Single-group calls of 768..16384 boxes take nms_list_or_scan_kernel: same greedy keep list as the CPU oracle, through nms_gpu
+    (score ranking inside the library) and through the pre-sorted C ABI entry."""
     boxes, scores = nms_boxes(n, seed=n + 5, clutter=True)
     b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     want = oracle.nms_gpu_oracle(boxes, scores, thr)
@@ -861,27 +862,94 @@ def test_pull_scan_keep_indices_bit_exact(amd, n, thr):
     sb = b[order].contiguous()
     keep = torch.empty(n, dtype=torch.int64, device='cuda')
     num = torch.zeros(1, dtype=torch.int64, device='cuda')
-    ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     for _ in range(2):   # the second call reuses the workspace (lists, counts and the failure word are reset by the call itself)
         assert lib.rnms_bev(sb.data_ptr(), n, thr, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
         k = int(num.item())
         assert np.array_equal(order[keep[:k]].cpu().numpy(), want)
+    if thr >= 0.25:   # the list scan itself ran (no fallback); at lower thresholds these clustered scenes may overflow a victim list
+        assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
 
 
-def test_pull_scan_falls_back_when_a_suppressor_list_overflows(amd):
-    """Forty near-duplicates of one box spread over many 64-blocks: the last ones have > 16 earlier-block suppressor candidates, the
-    clip kernel sets the failure word, the pull scan leaves and the classic scan launched behind it produces the list."""
+def test_list_scan_sparse_scene_bit_exact(amd):
+    """No clutter: nearly every box is kept (dense keeps were the classic scan's worst case)."""
+    n = 4096
+    boxes, scores = nms_boxes(n, seed=4096, clutter=False)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    for thr in (0.25, 0.01):
+        assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, thr))
+
+
+def _ranked(boxes, scores):
+    order = np.argsort(-scores, kind='stable')
+    return order
+
+
+def test_list_scan_box_with_many_near_victims(amd):
+    """Forty near-duplicates at consecutive ranks 60..99: the first of them has > 16 victims inside the next blocks — more than a
+    near list holds: the failure word is set and the same launch runs the classic scan; the result is still the oracle's."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    boxes, scores = nms_boxes(n, seed=91, clutter=False)
+    order = _ranked(boxes, scores)
+    dup = order[60:100]
+    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (40, 5)).astype(np.float32)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    lib = amd.load_library()
+    for thr in (0.5, 0.2):
+        want = oracle.nms_gpu_oracle(boxes, scores, thr)
+        assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), want)
+    o = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[o].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    assert lib.rnms_bev(sb.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 1          # fallback: a near list is full (39 > 16)
+    assert np.array_equal(o[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, 0.5))
+
+
+def test_list_scan_long_far_lists(amd):
+    """Fifty near-duplicates spread over the whole ranking: the best of them has ~49 FAR victims (several uint4 of far list per
+    box, the rolled far loop runs more than once) and no list overflows."""
+    rng = np.random.default_rng(6)
+    n = 6000
+    boxes, scores = nms_boxes(n, seed=92, clutter=False)
+    order = _ranked(boxes, scores)
+    dup = order[np.arange(50) * 117 + 5]          # one per ~2 blocks: at most 5 of them inside any window of 8 blocks
+    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (50, 5)).astype(np.float32)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    lib = amd.load_library()
+    want = oracle.nms_gpu_oracle(boxes, scores, 0.5)
+    assert np.array_equal(amd.nms_gpu(b, s, 0.5).cpu().numpy(), want)
+    o = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[o].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    assert lib.rnms_bev(sb.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0          # the list scan itself ran
+    assert np.array_equal(o[keep[:int(num.item())]].cpu().numpy(), want)
+
+
+def test_list_scan_falls_back_when_a_victim_list_overflows(amd):
+    """A hundred near-duplicates of one box spread over many 64-blocks: the best of them has > 64 later-block victims, the clip kernel
+    sets the failure word, and the same launch runs the classic scan instead."""
     rng = np.random.default_rng(3)
     n = 3000
     boxes, scores = nms_boxes(n, seed=77, clutter=False)
-    dup = rng.choice(n, 40, replace=False)
-    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (40, 5)).astype(np.float32)
+    dup = rng.choice(n, 100, replace=False)
+    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (100, 5)).astype(np.float32)
     b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
     for thr in (0.5, 0.9):
         want = oracle.nms_gpu_oracle(boxes, scores, thr)
         assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), want)
     lib = amd.load_library()
-    from mmdet3d_gaussian_amd import _lib  # noqa: F401
     order = torch.sort(s, dim=0, descending=True, stable=True)[1]
     sb = b[order].contiguous()
     keep = torch.empty(n, dtype=torch.int64, device='cuda')
@@ -891,6 +959,7 @@ def test_pull_scan_falls_back_when_a_suppressor_list_overflows(amd):
     assert lib.rnms_bev(sb.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 1          # the failure word (last 256 bytes of the workspace)
+    assert np.array_equal(order[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, 0.5))
     # and a call on the same workspace whose lists fit clears it again
     b2, s2 = nms_boxes(n, seed=78, clutter=False)
     o2 = torch.sort(torch.from_numpy(s2).cuda(), dim=0, descending=True, stable=True)[1]
