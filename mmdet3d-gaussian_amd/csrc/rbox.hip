@@ -464,9 +464,9 @@ struct QueueArgs {
   unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
   unsigned* ovl;     // (G, npairs) overflowed block pair ids
   unsigned scap, npairs;   // scap: entries per shard
-  unsigned short* lists;   // (cap, LIST_NEAR) near lists, then (cap, LIST_FAR) far lists — or nullptr: no lists wanted
-  unsigned* lcnt;          // (cap, 2) entries appended per box to its near / far list (may exceed the capacity: the list is then incomplete)
-  unsigned* lfail;         // (1) set when the lists cannot be used: a full list, or block pairs that went to the overflow list
+  unsigned short* lists;   // per group: (cap, LIST_NEAR) near lists, then (cap, LIST_FAR) far lists — or nullptr: no lists wanted
+  unsigned* lcnt;          // (G, cap, 2) entries appended per box to its near / far list (may exceed the capacity: the list is then incomplete)
+  unsigned* lfail;         // (G) set when a group's lists cannot be used: a full list, or block pairs that went to the overflow list
 };
 
 __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
@@ -503,10 +503,10 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     if (rb == c) {
       colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
       if (q.lists != nullptr)   // the list scan's victim lists of this box: empty (the clip kernel appends)
-        reinterpret_cast<uint2*>(q.lcnt)[i0 + lane] = make_uint2(0u, 0u);
+        reinterpret_cast<uint2*>(q.lcnt)[(size_t)g * a.cap + i0 + lane] = make_uint2(0u, 0u);
     }
   }
-  if (q.lists != nullptr && pair == 0 && lane == 0) *q.lfail = 0u;
+  if (q.lists != nullptr && pair == 0 && lane == 0) q.lfail[g] = 0u;
   // circle tests, straight-line as in compact_pair: lane l (column box j) against the 64 row boxes; bit r of `cand` = the
   // pair (row i0 + r, column j) survives.  On the diagonal block only the pairs with the column box AFTER the row box.
   unsigned long long cand = 0ull;
@@ -598,13 +598,14 @@ __global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, con
           atomicOr(&colm[j], 1ull << (i & 63));
         } else if (q.lists != nullptr) {   // i suppresses j of a later block: one more entry of i's near or far victim list
           const bool far = (j >> 6) - (i >> 6) > LIST_K;
-          const unsigned pos = atomicAdd(&q.lcnt[2 * i + (far ? 1 : 0)], 1u);
+          unsigned short* const glists = q.lists + (size_t)g * a.cap * (LIST_NEAR + LIST_FAR);
+          const unsigned pos = atomicAdd(&q.lcnt[((size_t)g * a.cap + i) * 2 + (far ? 1 : 0)], 1u);
           if (far) {
-            if (pos < (unsigned)LIST_FAR) q.lists[(size_t)a.cap * LIST_NEAR + (size_t)i * LIST_FAR + pos] = (unsigned short)j;
-            else *q.lfail = 1u;            // the list is incomplete: the list scan must not run (the classic scan does)
+            if (pos < (unsigned)LIST_FAR) glists[(size_t)a.cap * LIST_NEAR + (size_t)i * LIST_FAR + pos] = (unsigned short)j;
+            else q.lfail[g] = 1u;          // the list is incomplete: the list scan must not run (the classic scan does)
           } else {
-            if (pos < (unsigned)LIST_NEAR) q.lists[(size_t)i * LIST_NEAR + pos] = (unsigned short)j;
-            else *q.lfail = 1u;
+            if (pos < (unsigned)LIST_NEAR) glists[(size_t)i * LIST_NEAR + pos] = (unsigned short)j;
+            else q.lfail[g] = 1u;
           }
         }
       }
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, con
   }
   unsigned novf = __hip_atomic_load(&ctl[QUEUE_SHARDS * CTL_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (novf == 0u) return;
-  if (q.lists != nullptr && lane == 0) *q.lfail = 1u;   // pairs served by compact_pair() below write mask words only: no lists
+  if (q.lists != nullptr && lane == 0) q.lfail[g] = 1u;   // pairs served by compact_pair() below write mask words only: no lists
   const int cb = (n + 63) >> 6;
   const unsigned npairs_now = (unsigned)(cb * (cb + 1) / 2);
   novf = novf < npairs_now ? novf : npairs_now;
@@ -1087,9 +1088,11 @@ struct RingFields {      // what a ring slot is made of, as loaded
   long long id;
 };
 
-__device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned long long* __restrict__ colm,
-                                              const unsigned short* __restrict__ lists, const unsigned* __restrict__ lcnt,
-                                              long long* __restrict__ keep, long long* __restrict__ num_keep,
+// returns false — before anything was written — when the clip kernel's failure word says that the lists are unusable
+__device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned long long* __restrict__ colm_,
+                                              const unsigned short* __restrict__ lists_, const unsigned* __restrict__ lcnt_,
+                                              const unsigned* __restrict__ lfail_,
+                                              long long* __restrict__ keep_, long long* __restrict__ num_keep_,
                                               [[maybe_unused]] long long* __restrict__ dbg) {
   constexpr int SB = (int)LIST_MAX_N + 384;
   __shared__ __attribute__((aligned(16))) unsigned char stb[SB];   // state byte per box; [LIST_DUMMY + 4 lane] are scratch
@@ -1100,9 +1103,16 @@ __device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned l
   __shared__ unsigned int failed;                            // a polling loop gave up: the result is void (num_keep = -1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = a.n;
+  const int g = blockIdx.x;  // one workgroup per group
+  const int n = group_n(a, g);
   const int cb = (n + 63) >> 6;
-  const long long* order = a.order;
+  const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
+  const unsigned long long* const colm = colm_ + (size_t)g * a.cap;
+  const unsigned short* const lists = lists_ + (size_t)g * a.cap * (LIST_NEAR + LIST_FAR);
+  const unsigned* const lcnt = lcnt_ + (size_t)g * a.cap * 2;
+  const unsigned* const lfail = lfail_ + g;
+  long long* const keep = keep_ + (size_t)g * a.cap;
+  long long* const num_keep = num_keep_ + g;
   const unsigned short* const flists = lists + (size_t)a.cap * LIST_NEAR;
   const uint2* const cnt2 = reinterpret_cast<const uint2*>(lcnt);
   const unsigned int sb0 = (unsigned int)(size_t)(lds_u8*)stb;   // LDS address of stb[0]: the ring holds ADDRESSES of state bytes
@@ -1150,16 +1160,22 @@ __device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned l
     if (lane == 63) lds_poke(&rflag[slot], ((unsigned int)((B >> 4) + 1) << 8) | hascol | (unsigned int)chunks);
   };
 
+  // prologue: sixteen waves, sixteen blocks, ONE memory round trip — the failure word travels with the first blocks' fields (checked
+  // after them, it cost a round trip of its own: ~2 us of a 17 us kernel)
+  const unsigned int fail = __hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  RingFields f0 = {};
+  if (wave < cbp) f0 = load_ring(wave);
   lds_barrier();                                 // (the zero fill above, before anything else is written)
+  if (fail != 0u) return false;                  // uniform over the workgroup
 #ifdef SCAN_PROFILE
   if (lane == 0) dbg[(size_t)(2 * cb + 16) * 16 + wave] = __builtin_amdgcn_s_getreg(63492);   // HW_ID of every wave
 #endif
   for (int j = n + tid; j < cbp * 64; j += SCAN_T) stb[j] = 1;   // boxes past the end: suppressed from the start
-  if (wave < cbp) store_ring(wave, load_ring(wave));   // prologue: sixteen waves, sixteen blocks, one memory round trip
+  if (wave < cbp) store_ring(wave, f0);
   lds_barrier();                                 // the only barriers of this scan
   if (cb == 0) {
     if (tid == 0) num_keep[0] = 0;
-    return;
+    return true;
   }
 
   if (wave == 0) {
@@ -1279,15 +1295,15 @@ __device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned l
       block(std::integral_constant<int, 3>{});
     }
     if (lds_peek(&failed) != 0u && lane == 0) num_keep[0] = -1;
-    return;
+    return true;
   }
   // ------------------------------------------------------------------ helper waves: every wave that is not on the resolver's SIMD
-  if ((wave & 3) == 0) return;
-  const int g = wave - 1 - (wave >> 2);
+  if ((wave & 3) == 0) return true;
+  const int hw = wave - 1 - (wave >> 2);
   int base = 0;                                   // kept boxes before block t
   auto kept_word = [&](int blk) -> unsigned long long { return __ballot(stb[blk * 64 + lane] == 0x80); };
-  unsigned int fcnt_next = g < cb ? cnt2[min(g * 64 + lane, n - 1)].y : 0u;   // far count of this wave's next block, one iteration ahead
-  for (int t = g; t < cb; t += LIST_HW) {
+  unsigned int fcnt_next = hw < cb ? cnt2[min(hw * 64 + lane, n - 1)].y : 0u;   // far count of this wave's next block, one iteration ahead
+  for (int t = hw; t < cb; t += LIST_HW) {
 #ifdef SCAN_PROFILE
 #define HSTAMP(k) do { if (lane == 0) dbg[(size_t)(cb + 8 + t) * 16 + (k)] = clock64(); } while (0)
 #else
@@ -1310,7 +1326,7 @@ __device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned l
     if (t + LIST_HW < cb) fcnt_next = cnt2[min((t + LIST_HW) * 64 + lane, n - 1)].y;
     int spins = 0;
     while ((__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u8*)(size_t)(sb0 + (unsigned int)t * 64u)) & 0x82) == 0) {
-      if (++spins > LIST_SPIN_MAX) return;
+      if (++spins > LIST_SPIN_MAX) return true;
       __builtin_amdgcn_s_sleep(LIST_POLL_SLEEP);
     }
     COMPILER_FENCE();
@@ -1351,6 +1367,7 @@ __device__ __forceinline__ void nms_list_body(const NmsArgs& a, const unsigned l
     base += __builtin_popcountll(kept);
     if (t == cb - 1 && lane == 0 && lds_peek(&failed) == 0u) num_keep[0] = base;
   }
+  return true;
 }
 
 // ONE launch for a call that may take the list scan: the failure word the clip kernel left decides (uniform) between the list scan
@@ -1363,10 +1380,7 @@ __global__ __launch_bounds__(SCAN_T) void nms_list_or_scan_kernel(const NmsArgs 
                                                                   const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
                                                                   long long* __restrict__ keep, long long* __restrict__ num_keep,
                                                                   long long* __restrict__ dbg, const ScanWindow win) {
-  if (__hip_atomic_load(lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-    nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
-  else
-    nms_list_body(a, colm, lists, lcnt, keep, num_keep, dbg);
+  if (!nms_list_body(a, colm, lists, lcnt, lfail, keep, num_keep, dbg)) nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
 }
 
 // Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
@@ -1506,12 +1520,13 @@ static WsLayout ws_layout(size_t G, size_t cap) {
   L.npairs = (unsigned)(cb * (cb + 1) / 2);
   L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
   L.ovl = L.qctl + align_up(G * CTL_WORDS * sizeof(unsigned), 256);
-  // victim lists of the list scan (single-group calls of at most LIST_MAX_N boxes only): ids, counts, the failure word
-  const size_t lboxes = (G == 1 && cap <= LIST_MAX_N) ? cap : 0;
+  // victim lists of the list scan (groups of at most LIST_MAX_N boxes only): ids, counts, one failure word per group (the LAST bytes
+  // of the workspace: tests read them)
+  const size_t lboxes = cap <= LIST_MAX_N ? G * cap : 0;
   L.lists = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
   L.lcnt = L.lists + align_up(lboxes * (LIST_NEAR + LIST_FAR) * sizeof(unsigned short), 256);
   L.lfail = L.lcnt + align_up(lboxes * 2 * sizeof(unsigned), 256);
-  L.total = L.lfail + 256;
+  L.total = L.lfail + align_up(G * sizeof(unsigned), 256);
   return L;
 }
 
@@ -1575,13 +1590,13 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     q.ovl = (unsigned*)((char*)workspace + W.ovl);
     q.scap = W.scap;
     q.npairs = W.npairs;
-    // list scan (victim lists and state bytes instead of mask-row propagation): one group of known size, one host-side threshold;
-    // a full list or an overflowed block pair falls back to the classic scan on the device
+    // list scan (victim lists and state bytes instead of mask-row propagation): groups of at most LIST_MAX_N boxes; a full list or
+    // an overflowed block pair (a negative / NaN device threshold included) falls back to the classic scan on the device, per group
     static const float list_min_thr = [] {
       const char* e = getenv("RNMS_LIST_MIN_THR");   // measurement / test override (a value > 1 switches the list scan off)
       return e != nullptr ? (float)atof(e) : 0.0f;
     }();
-    use_lists = G == 1 && counts == nullptr && thresh_dev == nullptr && thresh >= list_min_thr && cap <= (int64_t)LIST_MAX_N;
+    use_lists = list_min_thr <= 1.0f && (thresh_dev != nullptr || thresh >= list_min_thr) && cap <= (int64_t)LIST_MAX_N;
     q.lists = use_lists ? (unsigned short*)((char*)workspace + W.lists) : nullptr;
     q.lcnt = use_lists ? (unsigned*)((char*)workspace + W.lcnt) : nullptr;
     q.lfail = use_lists ? (unsigned*)((char*)workspace + W.lfail) : nullptr;
