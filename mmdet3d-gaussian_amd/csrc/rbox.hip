@@ -1353,7 +1353,14 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
     }
     // scribe step of block t; its global store goes last (loads and stores share one in-order counter)
     HSTAMP(2);
-    for (int blk = max(t - LIST_HW + 1, 0); blk < t; ++blk) base += __builtin_popcountll(kept_word(blk));   // since this wave's last block
+    // the kept boxes of the blocks since this wave's last one (all resolved before t).  Straight-line — eleven reads in flight at once,
+    // a clamped index and a masked count for the first iteration: as a loop it was eleven LDS round trips in a row (1400-1900 cycles,
+    // the longest phase of a helper and most of the kernel's tail after the resolver's last block)
+#pragma unroll
+    for (int i = 1; i < LIST_HW; ++i) {
+      const int cntb = __builtin_popcountll(kept_word(max(t - i, 0)));
+      base += t - i >= 0 ? cntb : 0;
+    }
     const long long id = (long long)rid[t & (LIST_RING - 1)][lane];
     HSTAMP(3);
     if (more) {
