@@ -11,9 +11,17 @@
 //      first, survivors queued in LDS, then the full polygon-clipping predicate with the live lanes packed densely;
 //      per-thread polygon vertices live in LDS [slot][thread] (12 KiB per wave).  VALU-throughput-bound integer+fp32
 //      work (no HBM roofline: N=4096 reads 256 KB, writes 1 MB).
-//   3. nms_scan_kernel: the greedy scan as ONE 10-wave workgroup that never leaves the device: a resolver wave solves
-//      each 64-box diagonal block wave-parallel from an LDS ring, three phase-shifted groups of loader waves OR the
-//      mask rows of the boxes just kept into the removed-set (LDS); one LDS-only barrier per block.
+//      From 768 boxes on (rotated): the QUEUED form — nms_circle_queue_kernel (circle tests only, survivors to a queue in HBM) and
+//      nms_clip_queue_kernel (the full predicate, every pass full), which also appends each positive pair of different blocks to the
+//      earlier box's near / far VICTIM LIST.
+//   3. the greedy scan, ONE 16-wave workgroup per group that never leaves the device:
+//      nms_list_or_scan_kernel (groups of <= 16384 boxes): the LIST scan — one state byte per box in LDS, a resolver wave per block
+//      (alive bytes -> in-block fixed point -> kept; marks the kept boxes' near victims through addresses from an LDS ring), twelve
+//      helper waves (far victims, ring fill, kept ids); no mask rows, no barrier in the loop.  A full victim list makes the same
+//      launch run the classic scan:
+//      nms_scan_kernel (classic; also beyond 16384 boxes, two-level with nms_propagate_kernel): a resolver wave solves each block
+//      from an LDS ring, three phase-shifted groups of row waves OR the mask rows of the boxes just kept into the removed-set (LDS);
+//      one LDS-only barrier per block.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
