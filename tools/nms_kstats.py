@@ -1,3 +1,4 @@
+"""Per-kernel averages of the rbox:: kernels from a rocprofv3 --kernel-trace --stats output directory.  usage: tools/nms_kstats.py DIR"""
 import csv, glob, sys
 for p in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(p)):

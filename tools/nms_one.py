@@ -1,5 +1,7 @@
+"""One NMS problem, 60 calls of rnms_bev (pre-sorted C ABI entry): the workload tools/nms_ab.sh puts under rocprofv3.
+usage: tools/nms_one.py n thresh clutter(0|1)   (GD3D_LIB selects a library variant from tools/build_variants.py)"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import mmdet3d_gaussian_amd as amd
