@@ -937,6 +937,57 @@ def test_list_scan_long_far_lists(amd):
     assert np.array_equal(o[keep[:int(num.item())]].cpu().numpy(), want)
 
 
+def test_list_scan_structured_rank_distances(amd):
+    """Disjoint little gadgets on a grid, placed at chosen RANK distances around the near / far boundary of the list scan (8 blocks):
+    pairs (A suppresses B) and chains (A suppresses B, B would suppress C, A and C do not touch: C stays because B is not kept).  A
+    suppressed box must not mark anybody, and a victim must be marked in time whether the resolver wave (near) or a helper wave
+    (far) does it."""
+    n = 6144
+    dists = [1, 63, 64, 65, 127, 8 * 64 - 1, 8 * 64, 8 * 64 + 1, 9 * 64 - 1, 9 * 64, 9 * 64 + 1, 10 * 64 + 7, 20 * 64 + 3, 40 * 64 + 11]
+    rng = np.random.default_rng(11)
+    gx, gy = np.meshgrid(np.arange(80) * 10.0, np.arange(80) * 10.0)
+    cells = np.stack([gx.ravel(), gy.ravel()], -1)[:n]          # one box per cell by default: nothing overlaps
+    ctr = cells.copy()
+    size = np.tile(np.array([[3.0, 1.5]]), (n, 1))
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    used = set()                                                # boxes are laid out IN RANK ORDER (scores descend with the index)
+    cursor = 100
+    for rep in range(3):
+        for d in dists:
+            for d2 in (None, 1, 64 * 8, 64 * 9 + 5):
+                offs = (0, d) if d2 is None else (0, d, d + d2)
+                a_ = cursor
+                while any(a_ + o in used for o in offs):
+                    a_ += 1
+                if a_ + offs[-1] >= n:
+                    continue
+                used.update(a_ + o for o in offs)
+                cursor += 2
+                b_ = a_ + d
+                if d2 is None:
+                    ctr[b_] = ctr[a_] + 0.05; yaw[b_] = yaw[a_]                # B on top of A
+                else:
+                    c_ = b_ + d2
+                    ctr[b_] = ctr[a_] + np.array([1.6, 0.0]); yaw[a_] = yaw[b_] = 0.0   # A-B overlap 47 %: IoU 0.30
+                    ctr[c_] = ctr[b_] + np.array([1.6, 0.0]); yaw[c_] = 0.0             # B-C the same, A-C apart
+    boxes = np.concatenate([ctr - size / 2, ctr + size / 2, yaw[:, None]], -1).astype(np.float32)
+    scores = np.linspace(1.0, 0.01, n).astype(np.float32)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    for thr in (0.25, 0.6):
+        want = oracle.nms_gpu_oracle(boxes, scores, thr)
+        assert 0 < n - len(want) < n // 2
+        assert np.array_equal(amd.nms_gpu(b, s, thr).cpu().numpy(), want)
+    lib = amd.load_library()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    assert lib.rnms_bev(b.data_ptr(), n, 0.25, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0   # (already in rank order)
+    torch.cuda.synchronize()
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0          # the list scan itself ran
+    assert np.array_equal(keep[:int(num.item())].cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, 0.25))
+
+
 def test_list_scan_falls_back_when_a_victim_list_overflows(amd):
     """A hundred near-duplicates of one box spread over many 64-blocks: the best of them has > 64 later-block victims, the clip kernel
     sets the failure word, and the same launch runs the classic scan instead."""
