@@ -1276,17 +1276,21 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
         }
         SCAN_STAMP(2);
         const bool mine = __builtin_amdgcn_inverse_ballot_w64(kept);
-        kw[u * 64] = mine ? 0x80 : 0x02;   // (also what the helper waves poll)
-        if ((flag & 7u) != 0u && mine) {   // near victims: read back by THIS wave for later blocks — LDS runs a wave's accesses in order
+        // near victims first (read back by THIS wave for later blocks — LDS runs a wave's accesses in order), the block's own state
+        // bytes LAST: they are what the helper waves poll, and a helper that sees the block resolved will refill this block's ring
+        // slot — from which entries 8..15 (rare) are still being read here
+        if ((flag & 7u) != 0u && mine) {
           mark4(l0);
           if ((flag & 6u) != 0u) {         // more than one 4-entry chunk (the count is 0..4)
             mark4(l1);
-            if ((flag & 7u) > 2u) {        // rare: the block's own slot still holds them
+            if ((flag & 7u) > 2u) {
               mark4(ring4(rl + cslot * SLOT_DW, 2));
               if ((flag & 7u) > 3u) mark4(ring4(rl + cslot * SLOT_DW, 3));
             }
           }
         }
+        COMPILER_FENCE();
+        kw[u * 64] = mine ? 0x80 : 0x02;
         COMPILER_FENCE();
         nflag = lds_peek(&rflag[fslot]);   // flag first, then the fields it vouches for
         COMPILER_FENCE();

@@ -912,6 +912,34 @@ def test_list_scan_box_with_many_near_victims(amd):
     assert np.array_equal(o[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(boxes, scores, 0.5))
 
 
+@pytest.mark.parametrize('first,count', [(60, 13), (55, 20), (120, 24)])
+def test_list_scan_nine_to_sixteen_near_victims(amd, first, count):
+    """Near-duplicates at consecutive ranks across a block boundary: the best of them has 9..16 victims inside the next blocks — the
+    third and fourth 4-entry chunks of a ring slot, which the resolver reads from the block's own slot — and no list overflows."""
+    rng = np.random.default_rng(first)
+    n = 3000
+    boxes, scores = nms_boxes(n, seed=93, clutter=False)
+    order = _ranked(boxes, scores)
+    dup = order[first:first + count]
+    boxes[dup] = boxes[dup[0]] + rng.normal(0, 1e-3, (count, 5)).astype(np.float32)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    lib = amd.load_library()
+    want = oracle.nms_gpu_oracle(boxes, scores, 0.5)
+    assert np.array_equal(amd.nms_gpu(b, s, 0.5).cpu().numpy(), want)
+    o = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[o].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    assert lib.rnms_bev(sb.data_ptr(), n, 0.5, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    nearest = min(64 - first % 64, count) - 1                       # victims of the first duplicate inside its own block: colm, not a list
+    assert 8 < count - 1 - nearest <= 16
+    assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0          # the list scan itself ran
+    assert np.array_equal(o[keep[:int(num.item())]].cpu().numpy(), want)
+
+
 def test_list_scan_long_far_lists(amd):
     """Fifty near-duplicates spread over the whole ranking: the best of them has ~49 FAR victims (several uint4 of far list per
     box, the rolled far loop runs more than once) and no list overflows."""
