@@ -1047,3 +1047,23 @@ def test_list_scan_falls_back_when_a_victim_list_overflows(amd):
     torch.cuda.synchronize()
     assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
     assert np.array_equal(o2[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(b2, s2, 0.5))
+
+
+def test_classic_scan_bit_exact_with_the_list_scan_switched_off(amd):
+    """The classic scan (mask rows, two-level above 8448 boxes) is the list scan's fallback and the path above 16384 boxes: with
+    RNMS_LIST_MIN_THR=2 (read once per process: a child process) every call takes it; same keep lists as the CPU oracle."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import mmdet3d_gaussian_amd as amd, oracle\n"
+        "from rbox_inputs import nms_boxes\n"
+        "for n, thr, clutter in ((1000, 0.2, True), (4096, 0.25, True), (4096, 0.25, False), (9000, 0.7, True)):\n"
+        "    b, s = nms_boxes(n, seed=n, clutter=clutter)\n"
+        "    got = amd.nms_gpu(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), thr).cpu().numpy()\n"
+        "    assert np.array_equal(got, oracle.nms_gpu_oracle(b, s, thr)), (n, thr)\n"
+        "print('classic ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, RNMS_LIST_MIN_THR='2')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'classic ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
