@@ -182,6 +182,44 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   }
 }
 
+// Victim lists of the LIST scan (round 5; one group of known size, n <= LIST_MAX_N: nms_list_body below).  Per box i two lists of
+// 16-bit ids of boxes of LATER 64-blocks whose IoU with i exceeds the threshold, in any order, with a counter each (nothing is
+// initialised but the counters; readers mask by the count):
+//   near list: victims in the next LIST_K blocks (<= LIST_NEAR entries): marked by the scan's resolver wave itself;
+//   far list : victims beyond (<= LIST_FAR entries): marked by helper waves.
+constexpr int LIST_K = 8;
+constexpr int LIST_NEAR = 16;
+constexpr int LIST_FAR = 64;
+constexpr unsigned LIST_MAX_N = 16384;          // the list scan keeps one state BYTE per box in LDS
+constexpr unsigned short LIST_DUMMY = 0x4040u;  // first of 64 scratch state bytes (never boxes), four bytes apart, one per lane
+struct QueueArgs {
+  unsigned* queue;   // (G, QUEUE_SHARDS, scap)
+  unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
+  unsigned* ovl;     // (G, npairs) overflowed block pair ids
+  unsigned scap, npairs;   // scap: entries per shard
+  unsigned short* lists;   // per group: (cap, LIST_NEAR) near lists, then (cap, LIST_FAR) far lists — or nullptr: no lists wanted
+  unsigned* lcnt;          // per group a block of `lblock` words: (cap, 2) entries appended per box to its near / far list (may exceed the
+                           // capacity: the list is then incomplete), then the group's FAILURE WORD (+ padding): set when the lists cannot
+                           // be used — a full list, or block pairs that went to the overflow list
+  unsigned lblock;
+};
+__device__ __forceinline__ unsigned* list_counts(const QueueArgs& q, int g) { return q.lcnt + (size_t)g * q.lblock; }
+__device__ __forceinline__ unsigned* list_fail(const QueueArgs& q, const NmsArgs&, int g) { return list_counts(q, g) + (q.lblock - 64u); }
+
+// one more entry of box i's near or far victim list (j: a box of a LATER 64-block that i suppresses if i is kept); `pos` from the
+// counter (the caller's atomicAdd: per pair, or wave-aggregated)
+__device__ __forceinline__ void list_put(const QueueArgs& q, const NmsArgs& a, int g, int i, int j, bool far, unsigned pos) {
+  unsigned short* const glists = q.lists + (size_t)g * a.cap * (LIST_NEAR + LIST_FAR);
+  if (far) {
+    if (pos < (unsigned)LIST_FAR) glists[(size_t)a.cap * LIST_NEAR + (size_t)i * LIST_FAR + pos] = (unsigned short)j;
+    else *list_fail(q, a, g) = 1u;   // the list is incomplete: the list scan must not run (the classic scan does)
+  } else {
+    if (pos < (unsigned)LIST_NEAR) glists[(size_t)i * LIST_NEAR + pos] = (unsigned short)j;
+    else *list_fail(q, a, g) = 1u;
+  }
+}
+
+
 // Axis-aligned and circle NMS (cheap predicates, no polygon scratch): one WAVE per (row box i, 64-box column block
 // c >= block of i): lane l tests box i against box 64c + l and the wave-wide ballot IS the 64-bit mask word — no partial
 // words, no barrier.  A wave walks `rows` (1, 2, 4 or 8; host-chosen) consecutive row boxes against the same 64 column
@@ -196,7 +234,7 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
 template <int MODE>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
                                                       unsigned long long* __restrict__ mask_,
-                                                      unsigned long long* __restrict__ colm_) {
+                                                      unsigned long long* __restrict__ colm_, const QueueArgs q) {
   static_assert(MODE == MODE_NORMAL || MODE == MODE_CIRCLE, "rotated boxes: nms_mask_compact_kernel");
   const int lane = threadIdx.x;
   const int g = blockIdx.y;
@@ -229,6 +267,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
       braw[1] = a.boxes[sj * 2 + 1];
     }
   }
+  unsigned hits = 0u;   // bit r: this lane's box is a hit of row r (rows <= 8)
+  int total = 0;        // lane r: hits of row r
   for (int r = 0; r < rows; ++r) {
     const int i = rb * 64 + r0 + r;  // wave-uniform
     if (i >= n) break;
@@ -261,6 +301,30 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a, const OBo
         colm_[(size_t)g * a.cap + i] = word & below;
       } else {
         mask[(size_t)i * a.cbs + c] = word;
+      }
+    }
+    // the list scan's victim lists: remembered per row (bit r of `hits`, the row's hit count in lane r), appended after the loop
+    if (r < 8) {
+      hits |= hit ? (1u << r) : 0u;
+      if (lane == r) total = __popcll(word);
+    }
+  }
+  // the list scan's victim lists (q.lists: counters and failure word were zeroed before this kernel): the hits of a LATER block go
+  // to the row boxes' near or far lists.  ONE returning atomic for all of the wave's rows (lane r reserves row r's entries): a
+  // counter update per row inside the loop above put a memory round trip between the rows (20 -> 25 us at n = 4096)
+  if (q.lists != nullptr && rb != c) {   // uniform
+    const bool far = c - rb > LIST_K;
+    const int irow = rb * 64 + r0 + lane;   // lane r: row r of this wave
+    unsigned base = 0u;
+    if (lane < min(rows, 8) && total > 0) base = atomicAdd(&list_counts(q, g)[2 * irow + (far ? 1 : 0)], (unsigned)total);
+    if (__ballot(hits != 0u) != 0ull) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < rows) {
+          const unsigned long long word = __ballot((hits >> r) & 1u);
+          const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)base, r);
+          if ((hits >> r) & 1u) list_put(q, a, g, rb * 64 + r0 + r, j, far, b + (unsigned)__popcll(word & ((1ull << lane) - 1ull)));
+        }
       }
     }
   }
@@ -457,26 +521,6 @@ constexpr unsigned QUEUE_SENTINEL = 0xffffffffu;   // (65535, 65535): never a qu
 constexpr unsigned QUEUE_SHARDS = 64;
 constexpr unsigned CTL_STRIDE = 32;                                  // words: one 128-byte line per counter
 constexpr unsigned CTL_WORDS = (QUEUE_SHARDS + 1) * CTL_STRIDE;      // per group: shard counters, then the overflow counter
-// Victim lists of the LIST scan (round 5; one group of known size, n <= LIST_MAX_N: nms_list_body below).  Per box i two lists of
-// 16-bit ids of boxes of LATER 64-blocks whose IoU with i exceeds the threshold, in any order, with a counter each (nothing is
-// initialised but the counters; readers mask by the count):
-//   near list: victims in the next LIST_K blocks (<= LIST_NEAR entries): marked by the scan's resolver wave itself;
-//   far list : victims beyond (<= LIST_FAR entries): marked by helper waves.
-constexpr int LIST_K = 8;
-constexpr int LIST_NEAR = 16;
-constexpr int LIST_FAR = 64;
-constexpr unsigned LIST_MAX_N = 16384;          // the list scan keeps one state BYTE per box in LDS
-constexpr unsigned short LIST_DUMMY = 0x4040u;  // first of 64 scratch state bytes (never boxes), four bytes apart, one per lane
-struct QueueArgs {
-  unsigned* queue;   // (G, QUEUE_SHARDS, scap)
-  unsigned* ctl;     // (G, CTL_WORDS): [s * CTL_STRIDE] entries reserved in shard s (may exceed scap); [QUEUE_SHARDS * CTL_STRIDE] overflowed block pairs
-  unsigned* ovl;     // (G, npairs) overflowed block pair ids
-  unsigned scap, npairs;   // scap: entries per shard
-  unsigned short* lists;   // per group: (cap, LIST_NEAR) near lists, then (cap, LIST_FAR) far lists — or nullptr: no lists wanted
-  unsigned* lcnt;          // (G, cap, 2) entries appended per box to its near / far list (may exceed the capacity: the list is then incomplete)
-  unsigned* lfail;         // (G) set when a group's lists cannot be used: a full list, or block pairs that went to the overflow list
-};
-
 __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, const OBox* __restrict__ ob_,
                                                               unsigned long long* __restrict__ mask_,
                                                               unsigned long long* __restrict__ colm_, const QueueArgs q) {
@@ -511,10 +555,10 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     if (rb == c) {
       colm_[(size_t)g * a.cap + i0 + lane] = 0ull;
       if (q.lists != nullptr)   // the list scan's victim lists of this box: empty (the clip kernel appends)
-        reinterpret_cast<uint2*>(q.lcnt)[(size_t)g * a.cap + i0 + lane] = make_uint2(0u, 0u);
+        reinterpret_cast<uint2*>(list_counts(q, g))[i0 + lane] = make_uint2(0u, 0u);
     }
   }
-  if (q.lists != nullptr && pair == 0 && lane == 0) q.lfail[g] = 0u;
+  if (q.lists != nullptr && pair == 0 && lane == 0) *list_fail(q, a, g) = 0u;
   // circle tests, straight-line as in compact_pair: lane l (column box j) against the 64 row boxes; bit r of `cand` = the
   // pair (row i0 + r, column j) survives.  On the diagonal block only the pairs with the column box AFTER the row box.
   unsigned long long cand = 0ull;
@@ -606,22 +650,14 @@ __global__ __launch_bounds__(64) void nms_clip_queue_kernel(const NmsArgs a, con
           atomicOr(&colm[j], 1ull << (i & 63));
         } else if (q.lists != nullptr) {   // i suppresses j of a later block: one more entry of i's near or far victim list
           const bool far = (j >> 6) - (i >> 6) > LIST_K;
-          unsigned short* const glists = q.lists + (size_t)g * a.cap * (LIST_NEAR + LIST_FAR);
-          const unsigned pos = atomicAdd(&q.lcnt[((size_t)g * a.cap + i) * 2 + (far ? 1 : 0)], 1u);
-          if (far) {
-            if (pos < (unsigned)LIST_FAR) glists[(size_t)a.cap * LIST_NEAR + (size_t)i * LIST_FAR + pos] = (unsigned short)j;
-            else q.lfail[g] = 1u;          // the list is incomplete: the list scan must not run (the classic scan does)
-          } else {
-            if (pos < (unsigned)LIST_NEAR) glists[(size_t)i * LIST_NEAR + pos] = (unsigned short)j;
-            else q.lfail[g] = 1u;
-          }
+          list_put(q, a, g, i, j, far, atomicAdd(&list_counts(q, g)[2 * i + (far ? 1 : 0)], 1u));
         }
       }
     }
   }
   unsigned novf = __hip_atomic_load(&ctl[QUEUE_SHARDS * CTL_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (novf == 0u) return;
-  if (q.lists != nullptr && lane == 0) q.lfail[g] = 1u;   // pairs served by compact_pair() below write mask words only: no lists
+  if (q.lists != nullptr && lane == 0) *list_fail(q, a, g) = 1u;   // pairs served by compact_pair() below write mask words only: no lists
   const int cb = (n + 63) >> 6;
   const unsigned npairs_now = (unsigned)(cb * (cb + 1) / 2);
   novf = novf < npairs_now ? novf : npairs_now;
@@ -1099,7 +1135,7 @@ struct RingFields {      // what a ring slot is made of, as loaded
 // returns false — before anything was written — when the clip kernel's failure word says that the lists are unusable
 __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned long long* __restrict__ colm_,
                                               const unsigned short* __restrict__ lists_, const unsigned* __restrict__ lcnt_,
-                                              const unsigned* __restrict__ lfail_,
+                                              unsigned lblock,
                                               long long* __restrict__ keep_, long long* __restrict__ num_keep_,
                                               [[maybe_unused]] long long* __restrict__ dbg) {
   constexpr int SB = (int)LIST_MAX_N + 384;
@@ -1117,8 +1153,8 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
   const long long* order = a.order != nullptr ? a.order + (size_t)g * a.cap : nullptr;
   const unsigned long long* const colm = colm_ + (size_t)g * a.cap;
   const unsigned short* const lists = lists_ + (size_t)g * a.cap * (LIST_NEAR + LIST_FAR);
-  const unsigned* const lcnt = lcnt_ + (size_t)g * a.cap * 2;
-  const unsigned* const lfail = lfail_ + g;
+  const unsigned* const lcnt = lcnt_ + (size_t)g * lblock;   // the group's counters, then (last 64 words of the block) its failure word
+  const unsigned* const lfail = lcnt + (lblock - 64u);
   long long* const keep = keep_ + (size_t)g * a.cap;
   long long* const num_keep = num_keep_ + g;
   const unsigned short* const flists = lists + (size_t)a.cap * LIST_NEAR;
@@ -1396,10 +1432,10 @@ template <int CH>
 __global__ __launch_bounds__(SCAN_T) void nms_list_or_scan_kernel(const NmsArgs a, const unsigned long long* __restrict__ mask,
                                                                   const unsigned long long* __restrict__ colm,
                                                                   const unsigned short* __restrict__ lists,
-                                                                  const unsigned* __restrict__ lcnt, const unsigned* __restrict__ lfail,
+                                                                  const unsigned* __restrict__ lcnt, unsigned lblock,
                                                                   long long* __restrict__ keep, long long* __restrict__ num_keep,
                                                                   long long* __restrict__ dbg, const ScanWindow win) {
-  if (!nms_list_body(a, colm, lists, lcnt, lfail, keep, num_keep, dbg)) nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
+  if (!nms_list_body(a, colm, lists, lcnt, lblock, keep, num_keep, dbg)) nms_scan_body<SCAN_U, CH>(a, mask, colm, keep, num_keep, dbg, win);
 }
 
 // Second level of the two-level scan: after super-block [c_begin, c_end) has been resolved, every box it KEPT suppresses
@@ -1525,8 +1561,8 @@ extern "C" {
 //   candidate queue of the queued mask form (QUEUE_PER_BOX entries per box) | its control words | overflowed block pairs
 constexpr size_t QUEUE_PER_BOX = 128;
 struct WsLayout {
-  size_t mask, colm, gremv, queue, qctl, ovl, lists, lcnt, lfail, total;
-  unsigned scap, npairs;
+  size_t mask, colm, gremv, queue, qctl, ovl, lists, lcnt, total;
+  unsigned scap, npairs, lblock;
 };
 static WsLayout ws_layout(size_t G, size_t cap) {
   const size_t cb = (cap + 63) / 64;
@@ -1539,13 +1575,14 @@ static WsLayout ws_layout(size_t G, size_t cap) {
   L.npairs = (unsigned)(cb * (cb + 1) / 2);
   L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
   L.ovl = L.qctl + align_up(G * CTL_WORDS * sizeof(unsigned), 256);
-  // victim lists of the list scan (groups of at most LIST_MAX_N boxes only): ids, counts, one failure word per group (the LAST bytes
-  // of the workspace: tests read them)
-  const size_t lboxes = cap <= LIST_MAX_N ? G * cap : 0;
+  // victim lists of the list scan (groups of at most LIST_MAX_N boxes only): ids, then per group one block of `lblock` words: the
+  // (cap, 2) counters followed by the group's failure word in a 256-byte tail (group 0's — with one group: THE — failure word is
+  // found 256 bytes before the end of the workspace: tests read it).  One zero fill per group clears counters and failure word.
+  const bool wl = cap <= LIST_MAX_N;
   L.lists = L.ovl + align_up(G * L.npairs * sizeof(unsigned), 256);
-  L.lcnt = L.lists + align_up(lboxes * (LIST_NEAR + LIST_FAR) * sizeof(unsigned short), 256);
-  L.lfail = L.lcnt + align_up(lboxes * 2 * sizeof(unsigned), 256);
-  L.total = L.lfail + align_up(G * sizeof(unsigned), 256);
+  L.lcnt = L.lists + align_up(wl ? G * cap * (LIST_NEAR + LIST_FAR) * sizeof(unsigned short) : 0, 256);
+  L.lblock = wl ? (unsigned)(align_up(cap * 2 * sizeof(unsigned), 256) / sizeof(unsigned) + 64) : 64u;
+  L.total = L.lcnt + G * (size_t)L.lblock * sizeof(unsigned);
   return L;
 }
 
@@ -1601,7 +1638,33 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     return e != nullptr ? atoll(e) : (long long)QUEUE_MIN_N;
   }();
   const bool queued = mode == MODE_ROT && cap >= queue_min_n && pairs <= 0x7fffffffLL && (thresh_dev != nullptr || thresh >= 0.0f);   // (per-group device thresholds are checked in the kernel)
+  // list scan (victim lists and state bytes instead of mask-row propagation): groups of QUEUE_MIN_N .. LIST_MAX_N boxes, rotated and
+  // axis-aligned boxes;
+  // a full list or an overflowed block pair (a negative / NaN device threshold included) falls back to the classic scan on the
+  // device, per group
+  static const float list_min_thr = [] {
+    const char* e = getenv("RNMS_LIST_MIN_THR");   // measurement / test override (a value > 1 switches the list scan off)
+    return e != nullptr ? (float)atof(e) : 0.0f;
+  }();
+  // (not for circle NMS: its mask kernel is so cheap that building the lists — 15.8 -> 21.9 us at n = 4096 — and clearing the
+  // counters in a launch of their own — 4.4 us — cost what the list scan saves, 29.5 -> 18.0 us; axis-aligned: 62 -> 55 us)
+  const bool lists_wanted = list_min_thr <= 1.0f && cap >= queue_min_n && cap <= (int64_t)LIST_MAX_N && mode != MODE_CIRCLE &&
+                            (mode != MODE_ROT || thresh_dev != nullptr || thresh >= list_min_thr);
   bool use_lists = false;
+  QueueArgs ql;   // the list part alone: what the axis-aligned / circle mask kernel takes
+  ql.queue = ql.ctl = ql.ovl = nullptr;
+  ql.scap = ql.npairs = 0u;
+  ql.lists = nullptr;
+  ql.lcnt = nullptr;
+  ql.lblock = W.lblock;
+  if (mode != MODE_ROT && lists_wanted) {
+    use_lists = true;
+    ql.lists = (unsigned short*)((char*)workspace + W.lists);
+    ql.lcnt = (unsigned*)((char*)workspace + W.lcnt);
+    // counters and failure words start at zero: the scored paths' rank_place_kernel cleared them (`ctl_zeroed`), otherwise a fill
+    // kernel in the stream (a kernel, not a memset node)
+    if (!ctl_zeroed) hipLaunchKernelGGL(zero_words_kernel, dim3(1, (unsigned)G), dim3(256), 0, s, ql.lcnt, (int)W.lblock);
+  }
   if (mode == MODE_ROT && queued) {
     QueueArgs q;
     q.queue = (unsigned*)((char*)workspace + W.queue);
@@ -1609,16 +1672,10 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
     q.ovl = (unsigned*)((char*)workspace + W.ovl);
     q.scap = W.scap;
     q.npairs = W.npairs;
-    // list scan (victim lists and state bytes instead of mask-row propagation): groups of at most LIST_MAX_N boxes; a full list or
-    // an overflowed block pair (a negative / NaN device threshold included) falls back to the classic scan on the device, per group
-    static const float list_min_thr = [] {
-      const char* e = getenv("RNMS_LIST_MIN_THR");   // measurement / test override (a value > 1 switches the list scan off)
-      return e != nullptr ? (float)atof(e) : 0.0f;
-    }();
-    use_lists = list_min_thr <= 1.0f && (thresh_dev != nullptr || thresh >= list_min_thr) && cap <= (int64_t)LIST_MAX_N;
+    use_lists = lists_wanted;
     q.lists = use_lists ? (unsigned short*)((char*)workspace + W.lists) : nullptr;
     q.lcnt = use_lists ? (unsigned*)((char*)workspace + W.lcnt) : nullptr;
-    q.lfail = use_lists ? (unsigned*)((char*)workspace + W.lfail) : nullptr;
+    q.lblock = W.lblock;
     // the control words start at zero: cleared by whichever prep kernel ran (this one, or the scored paths' rank_place_kernel:
     // `ctl_zeroed`); only a caller that prepared the records itself pays a fill in the stream (4.4 us in the trace)
     const int zero_n = (int)CTL_WORDS;   // per group
@@ -1639,9 +1696,9 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
       hipLaunchKernelGGL(obox_prep_kernel, dim3(((unsigned)cap + 255) / 256, (unsigned)G), dim3(256), 0, s, a, ob, (unsigned*)nullptr, 0);
     hipLaunchKernelGGL(nms_mask_compact_kernel, mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
   } else if (mode == MODE_NORMAL) {
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_NORMAL>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm, ql);
   } else {
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm);
+    hipLaunchKernelGGL((nms_mask_kernel<MODE_CIRCLE>), mgrid, dim3(64), 0, s, a, (const OBox*)ob, mask, colm, ql);
   }
   const dim3 sgrid((unsigned)G), sblk(SCAN_T);
   const size_t slds = (size_t)a.cbs * sizeof(unsigned long long);
@@ -1650,15 +1707,14 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   win.c_end = a.cbs;
   win.gremv = win.gkept = nullptr;
   if (use_lists) {   // ONE launch: list scan, or — decided on the device from the clip kernel's failure word — the classic one
-    const unsigned* const lfail = (const unsigned*)((char*)workspace + W.lfail);
     const unsigned short* const lists = (const unsigned short*)((char*)workspace + W.lists);
     const unsigned* const lcnt = (const unsigned*)((char*)workspace + W.lcnt);
     if (a.cbs <= 64 + 1 + SCAN_NU)
       hipLaunchKernelGGL((nms_list_or_scan_kernel<1>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                         (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+                         (const unsigned long long*)colm, lists, lcnt, W.lblock, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     else
       hipLaunchKernelGGL((nms_list_or_scan_kernel<2>), sgrid, sblk, slds, s, a, (const unsigned long long*)mask,
-                         (const unsigned long long*)colm, lists, lcnt, lfail, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
+                         (const unsigned long long*)colm, lists, lcnt, W.lblock, (long long*)keep, (long long*)num_keep, (long long*)ob, win);
     return (int)hipGetLastError();
   }
   // n <= 8448: one launch resolves everything.  Beyond that the single workgroup's row propagation (three 64-word chunks
@@ -1754,16 +1810,18 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
   const dim3 sg((unsigned)((n_all + 63) / 64));   // one 16-wave workgroup per 64 boxes: counts their ranks and places them
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout(1, (size_t)n).qctl);   // control words of the queued mask form
-  if (normal)
+  const WsLayout W1 = ws_layout(1, (size_t)n);
+  if (normal)   // (axis-aligned: no queue; the list scan's counters and failure word are cleared instead)
     hipLaunchKernelGGL((rank_place_kernel<false>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)nullptr,
-                       (const int*)nullptr, (int)n_all, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, (unsigned*)nullptr, 0);
+                       (const int*)nullptr, (int)n_all, (int)n, order, (OBox*)workspace, (int*)nullptr, 0,
+                       (unsigned*)((char*)workspace + W1.lcnt), (int)W1.lblock);
   else
     hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)nullptr,
                        (const int*)nullptr, (int)n_all, (int)n, order, (OBox*)workspace, (int*)nullptr, 0, qctl, (int)CTL_WORDS);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(normal ? MODE_NORMAL : MODE_ROT, boxes, (const int64_t*)order, nullptr, 1, n, thresh, 0.0, nullptr, keep,
-                     num_keep, workspace, stream, /*prepped=*/true, /*ctl_zeroed=*/!normal);
+                     num_keep, workspace, stream, /*prepped=*/true, /*ctl_zeroed=*/true);
 }
 
 size_t rnms_batched_scored_workspace_bytes(int32_t groups, int64_t n, int64_t cap) {
@@ -1795,13 +1853,15 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   if (mode == MODE_ROT)
     hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
                        (int)n, (int)cap, order, (OBox*)workspace, counts, gps, qctl, (int)CTL_WORDS);
-  else
+  else {
+    const WsLayout WG = ws_layout((size_t)groups, (size_t)cap);
     hipLaunchKernelGGL((rank_place_kernel<false>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
-                       (int)n, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)nullptr, 0);
+                       (int)n, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)((char*)workspace + WG.lcnt), (int)WG.lblock);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return rnms_launch(mode, boxes, (const int64_t*)order, (const int32_t*)counts, groups, cap, 0.0f, 0.0, thresh, keep, num_keep,
-                     workspace, stream, /*prepped=*/mode == MODE_ROT, /*ctl_zeroed=*/mode == MODE_ROT);
+                     workspace, stream, /*prepped=*/mode == MODE_ROT, /*ctl_zeroed=*/true);
 }
 
 int rnms_batched_scored(int32_t mode, const float* boxes, const float* scores, const uint8_t* valid, int32_t groups, int64_t n,

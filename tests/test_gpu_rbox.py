@@ -863,7 +863,7 @@ def test_list_scan_keep_indices_bit_exact(amd, n, thr):
     keep = torch.empty(n, dtype=torch.int64, device='cuda')
     num = torch.zeros(1, dtype=torch.int64, device='cuda')
     nbytes = lib.rnms_workspace_bytes(n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    ws = torch.full((nbytes,), 0xff, dtype=torch.uint8, device='cuda')   # garbage: nothing in the workspace may need initialising
     for _ in range(2):   # the second call reuses the workspace (lists, counts and the failure word are reset by the call itself)
         assert lib.rnms_bev(sb.data_ptr(), n, thr, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
         k = int(num.item())
@@ -1047,6 +1047,29 @@ def test_list_scan_falls_back_when_a_victim_list_overflows(amd):
     torch.cuda.synchronize()
     assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
     assert np.array_equal(o2[keep[:int(num.item())]].cpu().numpy(), oracle.nms_gpu_oracle(b2, s2, 0.5))
+
+
+@pytest.mark.parametrize('n,thr', [(768, 0.3), (4096, 0.25), (4096, 0.6), (9000, 0.5), (16384, 0.4)])
+def test_list_scan_axis_aligned_boxes(amd, n, thr):
+    """nms_normal_gpu from 768 boxes on: the mask kernel also fills the victim lists (wave-aggregated appends) and the list scan
+    runs; keep lists equal the CPU oracle's, through the scored entry (rank_place clears the counters) and the pre-sorted one (a
+    fill kernel does); the failure word stays clear."""
+    boxes, scores = nms_boxes(n, seed=n + 9, clutter=True)
+    b, s = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    want = oracle.nms_gpu_oracle(boxes, scores, thr, normal=True)
+    assert np.array_equal(amd.nms_normal_gpu(b, s, thr).cpu().numpy(), want)
+    lib = amd.load_library()
+    order = torch.sort(s, dim=0, descending=True, stable=True)[1]
+    sb = b[order].contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    num = torch.zeros(1, dtype=torch.int64, device='cuda')
+    nbytes = lib.rnms_workspace_bytes(n)
+    ws = torch.full((nbytes,), 0xff, dtype=torch.uint8, device='cuda')     # garbage counters: the call must clear them itself
+    for _ in range(2):
+        assert lib.rnms_normal_bev(sb.data_ptr(), n, thr, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), None) == 0
+        assert np.array_equal(order[keep[:int(num.item())]].cpu().numpy(), want)
+    if thr >= 0.25:
+        assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
 
 
 def test_classic_scan_bit_exact_with_the_list_scan_switched_off(amd):
