@@ -1241,6 +1241,14 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
       unsigned char* const kw = stb + c0 * 64 + lane;
       const unsigned int* const fdp = fdone + c0;
       const int s0 = c0 & (LIST_RING - 1), s4 = (c0 + 4) & (LIST_RING - 1);   // slots of blocks c0 and c0 + 4
+      // ring addresses of the group's own slots and of the next group's (blocks c0 + 2 .. c0 + 5 are fetched here): computed once
+      // per group, so that every access of a block is base register + instruction offset
+      const unsigned int* const rl0 = rl + s0 * SLOT_DW;
+      const unsigned int* const rl4 = rl + s4 * SLOT_DW;
+      const unsigned long long* const rc0 = rc + s0 * 64;
+      const unsigned long long* const rc4 = rc + s4 * 64;
+      const unsigned int* const rf0 = rflag + s0;
+      const unsigned int* const rf4 = rflag + s4;
       const unsigned int gen1 = (unsigned int)(c0 >> 4) + 1u;   // what the flag of every block of this group carries
       auto block = [&](auto U) {
         constexpr int u = decltype(U)::value;
@@ -1249,8 +1257,11 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
 #ifdef SCAN_PROFILE
         if (lane == 0) dbg[(size_t)c * 16 + 6] = dbg[(size_t)c * 16 + 7] = 0;
 #endif
-        const int cslot = s0 + u;                                   // this block's slot
-        const int fslot = u < 2 ? s0 + u + 2 : s4 + u - 2;          // the slot fetched in this block: block c + 2
+        const unsigned int* const crl = rl0 + u * SLOT_DW;          // this block's slot
+        // the slot fetched in this block: block c + 2
+        const unsigned int* const frl = u < 2 ? rl0 + (u + 2) * SLOT_DW : rl4 + (u - 2) * SLOT_DW;
+        const unsigned long long* const frc = u < 2 ? rc0 + (u + 2) * 64 : rc4 + (u - 2) * 64;
+        const unsigned int* const frf = u < 2 ? rf0 + (u + 2) : rf4 + (u - 2);
         Near& l0 = (u & 1) ? l0B : l0A;
         Near& l1 = (u & 1) ? l1B : l1A;
         unsigned long long& col = (u & 1) ? colB : colA;
@@ -1268,11 +1279,11 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
 #ifdef SCAN_PROFILE
             if (lane == 0) dbg[(size_t)c * 16 + 6] = spins + 1;
 #endif
-            const unsigned int fl = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_peek(&rflag[cslot]));
+            const unsigned int fl = (unsigned int)__builtin_amdgcn_readfirstlane((int)lds_peek(rf0 + u));
             COMPILER_FENCE();
-            l0 = ring4(rl + cslot * SLOT_DW, 0);
-            l1 = ring4(rl + cslot * SLOT_DW, 1);
-            col = rc[cslot * 64];
+            l0 = ring4(crl, 0);
+            l1 = ring4(crl, 1);
+            col = rc0[u * 64];
             if ((fl >> 8) == gen1) {
               flag = fl;
               got = true;
@@ -1320,19 +1331,19 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
           if ((flag & 6u) != 0u) {         // more than one 4-entry chunk (the count is 0..4)
             mark4(l1);
             if ((flag & 7u) > 2u) {
-              mark4(ring4(rl + cslot * SLOT_DW, 2));
-              if ((flag & 7u) > 3u) mark4(ring4(rl + cslot * SLOT_DW, 3));
+              mark4(ring4(crl, 2));
+              if ((flag & 7u) > 3u) mark4(ring4(crl, 3));
             }
           }
         }
         COMPILER_FENCE();
         kw[u * 64] = mine ? 0x80 : 0x02;
         COMPILER_FENCE();
-        nflag = lds_peek(&rflag[fslot]);   // flag first, then the fields it vouches for
+        nflag = lds_peek(frf);             // flag first, then the fields it vouches for
         COMPILER_FENCE();
-        l0 = ring4(rl + fslot * SLOT_DW, 0);
-        l1 = ring4(rl + fslot * SLOT_DW, 1);
-        col = rc[fslot * 64];
+        l0 = ring4(frl, 0);
+        l1 = ring4(frl, 1);
+        col = frc[0];
         fd = lds_peek(&fdp[u + 2]);
         COMPILER_FENCE();
         SCAN_STAMP(3);
