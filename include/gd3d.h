@@ -414,9 +414,12 @@ int rnms_normal_bev_cpu(const float* boxes_sorted, int64_t n, float thresh, int6
  * (call sites gd_centerpoint_head.py:340-345, pvrcnn_bbox_head.py:463-464).
  *   boxes_sorted : (n,5) fp32 [x1,y1,x2,y2,ry], ALREADY sorted by descending score
  *   keep         : (n) int64, receives indices into boxes_sorted, ascending
- *   num_keep     : (1) int64
+ *   num_keep     : (1) int64; -1 (every rnms_* entry, per group): the device-side scan gave
+ *                  up — a wave of the list scan stopped making progress and its bounded
+ *                  polling loop ended (never observed; the host layer raises on it)
  * Greedy: box i is kept iff no kept j < i has IoU_bev(j,i) > thresh.  The suppression
- * bit-mask (n x ceil(n/64) uint64) and the greedy scan both stay on the device.
+ * bit-mask (n x ceil(n/64) uint64), from 768 boxes on also per-box victim lists, and the
+ * greedy scan all stay on the device; nothing in the workspace needs initialising.
  * rnms_normal_bev: same with axis-aligned IoU (mmdet3d nms_normal_gpu; angle ignored).
  * ---------------------------------------------------------------------------------- */
 size_t rnms_workspace_bytes(int64_t n);

@@ -423,6 +423,8 @@ def nms_scored(boxes, scores, thresh, n_keep, normal, padded, post_max):
     if padded:
         return keep, num
     k = int(num.item())   # the one unavoidable sync: the result length is data dependent
+    if k < 0:             # the scan kernel's failure mark (a bounded polling loop gave up: never observed)
+        raise RuntimeError(f'nms_gpu: the device-side NMS scan gave up (num_keep = {k}); the result is void')
     if post_max >= 0 and k > post_max:
         k = post_max
     return keep[:k], None

@@ -577,6 +577,7 @@ std::tuple<Tensor, Tensor> nms_scored(const Tensor& boxes, const Tensor& scores,
        normal ? "nms_normal_gpu" : "nms_gpu");
   if (padded) return {keep, num};
   int64_t k = num.item<int64_t>();   // the one unavoidable sync: the result length is data dependent
+  TORCH_CHECK(k >= 0, "nms_gpu: the device-side NMS scan gave up (num_keep = ", k, "); the result is void");   // failure mark of the list scan
   if (post_max >= 0 && k > post_max) k = post_max;
   return {keep.narrow(0, 0, k), Tensor()};
 }

@@ -127,7 +127,7 @@ def _nms(boxes, scores, thresh, pre_max_size, post_max_size, normal, padded=Fals
         if post_max_size is not None:
             keep, num = keep[:post_max_size], num.clamp(max=max(int(post_max_size), 0))
         return keep, num
-    k = int(num.item())  # the one unavoidable sync: the result length is data dependent
+    k = _kept_count(int(num.item()), 'nms_gpu')  # the one unavoidable sync: the result length is data dependent
     keep = keep[:k]
     if post_max_size is not None:
         keep = keep[:post_max_size]
@@ -173,6 +173,14 @@ def nms_gpu(boxes, scores, thresh, pre_max_size=None, post_max_size=None, pre_ma
 def nms_normal_gpu(boxes, scores, thresh):
     """Axis-aligned BEV NMS (angle ignored), mmdet3d `nms_normal_gpu`."""
     return _nms(boxes, scores, thresh, None, None, normal=True)
+
+
+def _kept_count(k, name):
+    """A negative count is the scan kernel's failure mark (a wave of the list scan stopped making progress and its bounded polling
+    loop gave up: never observed; a bug must surface as an error, not as a hang or a wrong list)."""
+    if k < 0:
+        raise RuntimeError(f'{name}: the device-side NMS scan gave up (num_keep = {k}); the result is void')
+    return k
 
 
 _THRESH_CACHE = {}
@@ -245,7 +253,7 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
             _lib.check(lib.rnms_batched_scored(mode, boxes.data_ptr(), sc.data_ptr(), None if vb is None else vb.data_ptr(), G, N,
                                                cap, th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), name)
-        nums = num.tolist()  # the one sync: G data-dependent result lengths
+        nums = [_kept_count(k, name) for k in num.tolist()]  # the one sync: G data-dependent result lengths
         out = []
         for g in range(G):
             k = keep[g, :nums[g]]
@@ -275,7 +283,7 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
         _lib.check(lib.rnms_batched(mode, boxes.data_ptr(), order.data_ptr(), counts.data_ptr(), G, cap, th.data_ptr(),
                                     keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), name)
-    nums = num.tolist()  # the one sync: G data-dependent result lengths
+    nums = [_kept_count(k, 'nms (batched)') for k in num.tolist()]  # the one sync: G data-dependent result lengths
     out = []
     for g in range(G):
         k = keep[g, :nums[g]]
@@ -332,7 +340,7 @@ def nms_gpu_multi(boxes_list, scores_list, thresh, pre_max_size=None, post_max_s
                                              th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream), 'nms_gpu_multi')
         keep = keep - seg[:G].to(torch.int64).unsqueeze(1)          # indices local to each entry
-    nums = num.tolist()  # the one sync: G data-dependent result lengths
+    nums = [_kept_count(k, 'nms (batched)') for k in num.tolist()]  # the one sync: G data-dependent result lengths
     out = []
     for g in range(G):
         k = keep[g, :nums[g]]
@@ -433,7 +441,7 @@ def circle_nms(dets, thresh, post_max_size=83):
         _lib.check(lib.rnms_circle_ordered(xy.data_ptr(), order.data_ptr(), n, float(thresh), keep.data_ptr(),
                                            num.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    'circle_nms')
-    keep = keep[:int(num.item())]
+    keep = keep[:_kept_count(int(num.item()), 'circle_nms')]
     return keep if post_max_size is None else keep[:post_max_size]
 
 
