@@ -97,14 +97,15 @@ __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
 }
 
-// rank_place_kernel: a 16-wave workgroup owns 64 boxes (lanes) of a group and ALL of the group's keys — wave w counts, for the
-// workgroup's 64 boxes, the keys of the w-th sixteenth that are greater: lane l builds key jb + l in registers, the 64 of them are
-// broadcast by v_readlane (a loop over an LDS copy paid one dependent LDS round trip per key; rotating the keys through the lanes
-// with v_mov_b32_dpp wave_ror:1 instead: 15.1 vs 13.2 us at n = 4096, 29.4 vs 25.8 at 9000 — slower); the sixteen partial ranks meet in
-// LDS and wave 0 places its boxes right away: order[r] = i and, for rotated NMS, the OBox record of box i in slot r (this IS the
-// prep kernel, scattered).  No atomics, deterministic.  (Rounds 2-3 ran it as two launches — partial counts per 256-key slice in
-// HBM, then a scatter kernel: n = 1000 4.0 + 3.6 us -> 5.8-7.0 us as one; equal from 4096 boxes on, where 64 workgroups of 16
-// waves keep only a quarter of the CUs busy.)
+// rank_place_kernel: a 16-wave workgroup owns SIXTEEN boxes of a group and ALL of the group's keys — wave w counts, for the
+// workgroup's boxes, the keys of the w-th sixteenth that are greater.  A wave is four DPP rows of 16 lanes: lane (row q, b) holds the
+// workgroup's box b; of every 64 keys the wave loads (lane l builds key jb + l in registers) row q owns keys 16 q .. 16 q + 15 and
+// rotates them through its lanes (v_mov_b32_dpp row_ror:1): sixteen steps show every box all 64 keys, one compare per lane and step.
+// The four rows' counts meet by two lane exchanges, the sixteen waves' in LDS, and wave 0 places its boxes right away: order[r] = i
+// and, for rotated NMS, the OBox record of box i in slot r (this IS the prep kernel, scattered).  No atomics, deterministic.
+// (Until round 5 a workgroup owned 64 boxes, one per lane, the 64 keys broadcast by v_readlane: the same number of compare
+// instructions, but n / 64 workgroups — 64 at n = 4096 — kept a quarter of the CUs busy; with n / 16 workgroups the kernel covers
+// the chip: 14.9 -> 12.0 us averaged over n = 1000 / 4096 / 9000 (6.5 -> 5.2, 31.1 -> 26.4 at the ends).  Rounds 2-3 ran it as two launches — partial counts per 256-key slice in HBM, then a scatter kernel.)
 // counts[g] (nullable) = min(#valid boxes of the group, n_keep): every workgroup sees all of the group's valid flags while it
 // counts, so workgroup 0 WRITES the number — nothing is cleared and then added to (the round-3 form cleared counts with a memset
 // that a captured hipGraph did not order reliably: profiles/r04_nms_queue_ab.txt).
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
                                                           int n, int n_keep, long long* __restrict__ order_,
                                                           OBox* __restrict__ ob_, int* __restrict__ counts, int gps,
                                                           unsigned* zero_words, int zero_n) {
-  __shared__ int spart[16][64];
+  __shared__ int spart[16][16];
   __shared__ int svalid[16];
   zero_control_words(zero_words, zero_n);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -131,11 +132,11 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
     if (counts != nullptr && blockIdx.x == 0 && tid == 0) counts[g] = 0;
     return;
   }
-  if ((int)blockIdx.x * 64 >= ng) return;                              // uniform: no box of this group in this lane block
+  if ((int)blockIdx.x * 16 >= ng) return;                              // uniform: no box of this group in this workgroup
   const size_t grow = (size_t)g * n;
   const float* scores = seg != nullptr ? scores_ + sbase : scores_ + grow;
   const unsigned char* valid = (valid_ != nullptr && seg == nullptr) ? valid_ + grow : nullptr;
-  const int i = blockIdx.x * 64 + lane;
+  const int i = blockIdx.x * 16 + (lane & 15);
   const unsigned long long mine = i < ng ? score_key(scores[i], (unsigned)i) : ~0ull;
   const int q = (((ng + 15) >> 4) + 63) & ~63;                         // keys per wave: a sixteenth, in whole chunks of 64
   const int b = wave * q, e = min(b + q, ng);
@@ -145,15 +146,19 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
     const bool use = j < e && (valid == nullptr || valid[j] != 0);
     nvalid += __popcll(__ballot(use));
     const unsigned long long kj = use ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
-    const unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
+    unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
 #pragma unroll
-    for (int t = 0; t < 64; ++t) {
-      const unsigned long long kk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, t) << 32) |
-                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)klo, t);
-      cnt += kk > mine ? 1 : 0;
+    for (int t = 0; t < 16; ++t) {
+      cnt += (((unsigned long long)khi << 32) | klo) > mine ? 1 : 0;
+      klo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)klo, 0x121, 0xf, 0xf, false);   // row_ror:1 — inside the lane's row of 16
+      khi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)khi, 0x121, 0xf, 0xf, false);
     }
   }
-  spart[wave][lane] = cnt;
+  // (loading every score of the slice before the first compare changed nothing: 12.1 -> 12.0 us on average — the kernel is bound by
+  // its VALU instructions, 4 per 64 compares plus the DPP wait states: n = 9000: 7.8 M wave instructions = 12.7 us on 1024 SIMDs)
+  cnt += __shfl_xor(cnt, 16);   // the four rows hold the same boxes
+  cnt += __shfl_xor(cnt, 32);
+  if (lane < 16) spart[wave][lane] = cnt;
   if (lane == 0) svalid[wave] = nvalid;
   __syncthreads();
   if (wave != 0) return;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
     for (int w = 0; w < 16; ++w) total += svalid[w];
     counts[g] = min(total, n_keep);
   }
-  if (i < ng && (valid == nullptr || valid[i] != 0)) {
+  if (lane < 16 && i < ng && (valid == nullptr || valid[i] != 0)) {
     int r = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) r += spart[w][lane];
@@ -1819,7 +1824,7 @@ int rnms_scored(int32_t normal, const float* boxes, const float* scores, int64_t
   if (n == 0) return fill_words(num_keep, sizeof(int64_t), 0u, s);
   if (boxes == nullptr || scores == nullptr || keep == nullptr || workspace == nullptr) return GD3D_E_BADARG;
   long long* order = (long long*)((char*)workspace + align_up(rnms_workspace_bytes(n), 256));
-  const dim3 sg((unsigned)((n_all + 63) / 64));   // one 16-wave workgroup per 64 boxes: counts their ranks and places them
+  const dim3 sg((unsigned)((n_all + 15) / 16));   // one 16-wave workgroup per 16 boxes: counts their ranks and places them
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout(1, (size_t)n).qctl);   // control words of the queued mask form
   const WsLayout W1 = ws_layout(1, (size_t)n);
   if (normal)   // (axis-aligned: no queue; the list scan's counters and failure word are cleared instead)
@@ -1859,7 +1864,7 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   p += align_up((size_t)groups * cap * sizeof(int64_t), 256);
   int* counts = (int*)p;
   hipError_t e;
-  const dim3 sg((unsigned)((n + 63) / 64), (unsigned)groups);
+  const dim3 sg((unsigned)((n + 15) / 16), (unsigned)groups);
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout((size_t)groups, (size_t)cap).qctl);
   if (mode == MODE_ROT)
     hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
