@@ -564,19 +564,40 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     }
   }
   if (q.lists != nullptr && pair == 0 && lane == 0) *list_fail(q, a, g) = 0u;
-  // circle tests, straight-line as in compact_pair: lane l (column box j) against the 64 row boxes; bit r of `cand` = the
-  // pair (row i0 + r, column j) survives.  On the diagonal block only the pairs with the column box AFTER the row box.
-  unsigned long long cand = 0ull;
+  // circle tests, straight-line: lane l (column box j) against the 64 row boxes; bit r of `cand` = the pair (row i0 + r, column j)
+  // survives.  On the diagonal block only the pairs with the column box AFTER the row box.  TWO ROWS PER INSTRUCTION (float2 ->
+  // v_pk_add / v_pk_mul: the same IEEE operations per component as box_overlap's early-out, in its order), and the mask built by
+  // shifting the compare's result in as a carry (w = w + w + carry: one instruction per row; rows descend so that row r ends in
+  // bit r).  Left to itself the compiler packed the x / y components of ONE row and repacked between rows: 953 VALU instructions
+  // per wave, more than the clipping kernel's 693 (profiles/r05_nms_pmc_counters.txt).
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 bcx2 = {bcx, bcx}, bcy2 = {bcy, bcy}, bext2 = {bext, bext};
+  auto shift_in = [](unsigned w, unsigned long long carry) -> unsigned {
+    unsigned out;
+    unsigned long long co;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(co) : "v"(w), "s"(carry));
+    return out;
+  };
+  unsigned wlo = 0u, whi = 0u;
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    const float acx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r));
-    const float acy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r));
-    const float aext = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r));
-    const float ddx = acx - bcx, ddy = acy - bcy;   // box_overlap's early-out, same operations (symmetric in the boxes)
-    const float reach = 0.5f * (aext + bext) + 1e-2f;
-    const bool near = !(ddx * ddx + ddy * ddy > reach * reach * 1.0001f);
-    cand |= near ? (1ull << r) : 0ull;
+  for (int r = 62; r >= 0; r -= 2) {   // rows r + 1 and r
+    const f2 acx = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r))};
+    const f2 acy = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r))};
+    const f2 aext = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r))};
+    const f2 ddx = acx - bcx2, ddy = acy - bcy2;   // box_overlap's early-out, same operations (symmetric in the boxes)
+    const f2 d2 = ddx * ddx + ddy * ddy;
+    const f2 reach = 0.5f * (aext + bext2) + 1e-2f;
+    const f2 lim = reach * reach * 1.0001f;
+    const unsigned long long n1 = __ballot(!(d2.x > lim.x)), n0 = __ballot(!(d2.y > lim.y));
+    if (r >= 32) {
+      whi = shift_in(whi, n1);
+      whi = shift_in(whi, n0);
+    } else {
+      wlo = shift_in(wlo, n1);
+      wlo = shift_in(wlo, n0);
+    }
   }
+  unsigned long long cand = ((unsigned long long)whi << 32) | (unsigned long long)wlo;
   cand &= nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
   if (rb == c) cand &= (1ull << lane) - 1ull;        // rows r < lane only: i = i0 + r < j = i0 + lane
   if (!jv) cand = 0ull;
