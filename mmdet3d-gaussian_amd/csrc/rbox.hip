@@ -1257,12 +1257,12 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
     auto ring4 = [&](const unsigned int* r, int chunk) -> Near { return Near{r[chunk * 256], r[chunk * 256 + 64], r[chunk * 256 + 128], r[chunk * 256 + 192]}; };
     auto mark4 = [&](const Near& e) { lds_mark_at(e.x); lds_mark_at(e.y); lds_mark_at(e.z); lds_mark_at(e.w); };
     constexpr int SLOT_DW = LIST_NEAR * 64;   // dwords per ring slot
-    // two register sets, blocks of even / odd index: block c's fields are fetched while block c - 2 is worked on, so that neither
-    // the flag nor the entries are waited for
-    unsigned long long colA = rc[0], colB = rc[64];
-    Near l0A = ring4(rl, 0), l1A = ring4(rl, 1), l0B = ring4(rl + SLOT_DW, 0), l1B = ring4(rl + SLOT_DW, 1);
-    unsigned int nflagA = rflag[0], nflagB = rflag[1];   // (cbp >= 4 here: blocks 0 and 1 are in the ring since the prologue)
-    unsigned int fdA = 1u, fdB = 1u;                     // (blocks 0 and 1 wait for nobody)
+    // two register sets, blocks of even / odd index: block c's fields are fetched while block c - 1 waits for its state bytes, so
+    // that neither the flag nor the entries are waited for
+    unsigned long long colA = rc[0], colB = 0ull;
+    Near l0A = ring4(rl, 0), l1A = ring4(rl, 1), l0B = {}, l1B = {};
+    unsigned int nflagA = rflag[0], nflagB = 0u;         // (block 0 is in the ring since the prologue; set B is fetched during block 0)
+    unsigned int fdA = 1u, fdB = 1u;                     // (block 0 waits for nobody)
     for (int c0 = 0; c0 < cbp; c0 += 4) {
       unsigned char* const kw = stb + c0 * 64 + lane;
       const unsigned int* const fdp = fdone + c0;
@@ -1284,15 +1284,49 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
         if (lane == 0) dbg[(size_t)c * 16 + 6] = dbg[(size_t)c * 16 + 7] = 0;
 #endif
         const unsigned int* const crl = rl0 + u * SLOT_DW;          // this block's slot
-        // the slot fetched in this block: block c + 2
-        const unsigned int* const frl = u < 2 ? rl0 + (u + 2) * SLOT_DW : rl4 + (u - 2) * SLOT_DW;
-        const unsigned long long* const frc = u < 2 ? rc0 + (u + 2) * 64 : rc4 + (u - 2) * 64;
-        const unsigned int* const frf = u < 2 ? rf0 + (u + 2) : rf4 + (u - 2);
+        // the slot fetched in this block: block c + 1
+        const unsigned int* const frl = u < 3 ? rl0 + (u + 1) * SLOT_DW : rl4;
+        const unsigned long long* const frc = u < 3 ? rc0 + (u + 1) * 64 : rc4;
+        const unsigned int* const frf = u < 3 ? rf0 + (u + 1) : rf4;
         Near& l0 = (u & 1) ? l0B : l0A;
         Near& l1 = (u & 1) ? l1B : l1A;
         unsigned long long& col = (u & 1) ? colB : colA;
         unsigned int& nflag = (u & 1) ? nflagB : nflagA;
         unsigned int& fd = (u & 1) ? fdB : fdA;
+        // 1. nothing of block c may be read before the far victims of block c - LIST_K - 1 are marked (flag fetched a block ago)
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)fd) == 0, 0)) {
+          bool got = false;
+          for (int spins = 0; spins < LIST_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+#ifdef SCAN_PROFILE
+            if (lane == 0) dbg[(size_t)c * 16 + 7] = spins + 1;
+#endif
+            if (__builtin_amdgcn_readfirstlane((int)lds_peek(&fdp[u])) != 0) {
+              got = true;
+              break;
+            }
+          }
+          if (!got) lds_poke(&failed, 1u);
+        }
+        COMPILER_FENCE();
+        // 2. the block's state bytes: THE round trip of the block.  Everything that does not depend on it is issued in its shadow:
+        //    block c + 1's fields into the other register set (its last user, block c - 1, is done), this block's ring flag check
+        const unsigned char state = kw[u * 64];
+        COMPILER_FENCE();
+        {
+          Near& l0n = (u & 1) ? l0A : l0B;
+          Near& l1n = (u & 1) ? l1A : l1B;
+          unsigned long long& coln = (u & 1) ? colA : colB;
+          unsigned int& nflagn = (u & 1) ? nflagA : nflagB;
+          unsigned int& fdn = (u & 1) ? fdA : fdB;
+          nflagn = lds_peek(frf);          // flag first, then the fields it vouches for
+          COMPILER_FENCE();
+          l0n = ring4(frl, 0);
+          l1n = ring4(frl, 1);
+          coln = frc[0];
+          fdn = lds_peek(&fdp[u + 1]);
+          COMPILER_FENCE();
+        }
         unsigned int flag = (unsigned int)__builtin_amdgcn_readfirstlane((int)nflag);
         if (__builtin_expect((flag >> 8) != gen1, 0)) {
           // the block is not in the ring yet (never in steady state): re-read flag and fields.  Gives up after LIST_SPIN_MAX polls,
@@ -1318,22 +1352,7 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
           }
           if (!got) lds_poke(&failed, 1u);
         }
-        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)fd) == 0, 0)) {   // the far victims of block c - LIST_K - 1 are still being marked
-          bool got = false;
-          for (int spins = 0; spins < LIST_SPIN_MAX && lds_peek(&failed) == 0u; ++spins) {
-            __builtin_amdgcn_s_sleep(1);
-#ifdef SCAN_PROFILE
-            if (lane == 0) dbg[(size_t)c * 16 + 7] = spins + 1;
-#endif
-            if (__builtin_amdgcn_readfirstlane((int)lds_peek(&fdp[u])) != 0) {
-              got = true;
-              break;
-            }
-          }
-          if (!got) lds_poke(&failed, 1u);
-        }
-        COMPILER_FENCE();
-        unsigned long long kept = __ballot(kw[u * 64] == 0);   // nobody kept so far suppresses the lane's box
+        unsigned long long kept = __ballot(state == 0);   // nobody kept so far suppresses the lane's box
         SCAN_STAMP(1);
         if (__builtin_expect((flag & 0x80u) != 0u, 0)) {   // some box of the block has an earlier box of the block on its column word
           const unsigned long long alive = kept;
@@ -1364,13 +1383,6 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
         }
         COMPILER_FENCE();
         kw[u * 64] = mine ? 0x80 : 0x02;
-        COMPILER_FENCE();
-        nflag = lds_peek(frf);             // flag first, then the fields it vouches for
-        COMPILER_FENCE();
-        l0 = ring4(frl, 0);
-        l1 = ring4(frl, 1);
-        col = frc[0];
-        fd = lds_peek(&fdp[u + 2]);
         COMPILER_FENCE();
         SCAN_STAMP(3);
       };
