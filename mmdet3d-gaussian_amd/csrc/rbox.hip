@@ -578,12 +578,23 @@ __global__ __launch_bounds__(64) void nms_circle_queue_kernel(const NmsArgs a, c
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(co) : "v"(w), "s"(carry));
     return out;
   };
+  // the row boxes' (cx, cy, extent) go through LDS, laid out per PAIR of rows as the packed operands want them — [cx of row r + 1,
+  // cx of row r, cy.., cy.., ext.., ext..] — and come back as broadcast reads (a uniform address: 2 LDS instructions per row pair
+  // instead of 6 v_readlane, which are vector instructions: a quarter of the loop's)
+  __shared__ __attribute__((aligned(16))) float srow[32][8];
+  {
+    float* const mypair = &srow[lane >> 1][1 - (lane & 1)];   // odd rows first
+    mypair[0] = rcx;
+    mypair[2] = rcy;
+    mypair[4] = rext;
+  }
+  __syncthreads();
   unsigned wlo = 0u, whi = 0u;
 #pragma unroll
   for (int r = 62; r >= 0; r -= 2) {   // rows r + 1 and r
-    const f2 acx = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcx), r))};
-    const f2 acy = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rcy), r))};
-    const f2 aext = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r + 1)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rext), r))};
+    const float4 xy = *reinterpret_cast<const float4*>(&srow[r >> 1][0]);
+    const float2 ex = *reinterpret_cast<const float2*>(&srow[r >> 1][4]);
+    const f2 acx = {xy.x, xy.y}, acy = {xy.z, xy.w}, aext = {ex.x, ex.y};
     const f2 ddx = acx - bcx2, ddy = acy - bcy2;   // box_overlap's early-out, same operations (symmetric in the boxes)
     const f2 d2 = ddx * ddx + ddy * ddy;
     const f2 reach = 0.5f * (aext + bext2) + 1e-2f;
