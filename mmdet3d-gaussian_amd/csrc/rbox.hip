@@ -1745,11 +1745,13 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
       hipLaunchKernelGGL(zero_words_kernel, dim3(1, (unsigned)G), dim3(256), 0, s, q.ctl, zero_n);   // (a kernel, not a memset node)
     }
     hipLaunchKernelGGL(nms_circle_queue_kernel, dim3((unsigned)pairs, (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
-    // clipping waves: a multiple of the shard count, about one per block pair, at most 2048 (two per SIMD) and at least 8 per
-    // shard: with few block pairs few shards are in use, and one wave per shard walked its ~90 entries in two passes one after
-    // the other (n = 256: 25 us for 900 candidates; waves that find their shard empty leave after one load)
+    // clipping waves: a multiple of the shard count, about one per block pair, at most 4096 and at least 8 per shard: with few
+    // block pairs few shards are in use, and one wave per shard walked its ~90 entries in two passes one after the other (n = 256:
+    // 25 us for 900 candidates; waves that find their shard empty leave after one load).  The kernel is as long as a wave's passes
+    // (memory round trips + one clipping pass each, vector units 27 % busy): more waves with one pass each beat 2048 waves with
+    // three to four (n = 9000: 20.3 -> 18.0 us at 64 per shard; 128: the same — LDS holds ten waves per CU).
     long long per = (pairs + QUEUE_SHARDS - 1) / QUEUE_SHARDS;
-    per = per < 8 ? 8 : (per > 32 ? 32 : per);
+    per = per < 8 ? 8 : (per > 64 ? 64 : per);
     hipLaunchKernelGGL(nms_clip_queue_kernel, dim3((unsigned)(per * QUEUE_SHARDS), (unsigned)G), dim3(64), 0, s, a, (const OBox*)ob, mask, colm, q);
   } else if (mode == MODE_ROT) {
     if (!prepped)
