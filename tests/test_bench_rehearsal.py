@@ -33,9 +33,13 @@ def _env(**extra):
 
 
 def _torchrun(n, args, **env):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(_port()), BENCH, '--gpus', str(n)] + COMMON + args
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(**env), cwd=ROOT)
+    for attempt in range(2):   # (a port found free a moment ago can be taken by the time the launcher binds it: one more try)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+               '--master-port', str(_port()), BENCH, '--gpus', str(n)] + COMMON + args
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(**env), cwd=ROOT)
+        if r.returncode == 0 or not any(m in r.stderr for m in ('Address already in use', 'EADDRINUSE', 'address already in use')):
+            break
+    return r
 
 
 def _result_lines(stdout):
