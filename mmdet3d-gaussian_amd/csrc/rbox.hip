@@ -192,7 +192,7 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
 // initialised but the counters; readers mask by the count):
 //   near list: victims in the next LIST_K blocks (<= LIST_NEAR entries): marked by the scan's resolver wave itself;
 //   far list : victims beyond (<= LIST_FAR entries): marked by helper waves.
-constexpr int LIST_K = 8;
+constexpr int LIST_K = 8;   // (measured, scan kernel: n = 4096 thr 0.25: 17.9 / 16.5 / 16.2 / 16.4 us at 4 / 6 / 8 / 12; n = 9000 thr 0.7: 30.7 / 29.7 / 28.8 at 4 / 8 / 12)
 constexpr int LIST_NEAR = 16;
 constexpr int LIST_FAR = 64;
 constexpr unsigned LIST_MAX_N = 16384;          // the list scan keeps one state BYTE per box in LDS
