@@ -214,6 +214,12 @@ __global__ __launch_bounds__(64) void match_coco_small_kernel(const float* __res
         anyn |= ok[u] & nonign[u];
         anyo |= ok[u];
       }
+      if (anyo == 0ull) {   // uniform, and the usual case in an evaluation (most detections touch no ground truth within the
+        // threshold): unmatched, nothing else changes — ~10 instructions instead of the ~100 of the selection below (the
+        // block-wise prefetch does not mind the branch: its single wait is at the end of the block)
+        mreg = (live && lane == (d & 63)) ? -1 : mreg;
+        continue;
+      }
       unsigned int ord[KBT], best = 0xffffffffu;
 #pragma unroll
       for (int u = 0; u < KBT; ++u) {
