@@ -139,9 +139,11 @@ __global__ __launch_bounds__(64) void match_coco_kernel(const float* __restrict_
         for (int u = 0; u < KB; ++u)
           best = consider<REG>(best, v[u], fl[u], g0 + u * 64 + lane, ng, thr, mytaken, (g0 >> 6) + u, taken);
       }
-      best = wave_min_u64(best);
       int m = -1;
-      if (best != KEY_NONE) m = (int)(0x7fffffffu - (unsigned int)(best & 0x7fffffffull));
+      if (__ballot(best != KEY_NONE) != 0ull) {   // (uniform) nobody eligible — the usual detection of an evaluation: no reduction
+        best = wave_min_u64(best);
+        m = (int)(0x7fffffffu - (unsigned int)(best & 0x7fffffffull));
+      }
       mreg = lane == (d & 63) ? m : mreg;  // results leave in coalesced 64-detection stores, not one store per step
       if (m >= 0) {
         if (REG) {
