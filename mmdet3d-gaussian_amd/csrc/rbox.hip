@@ -137,6 +137,10 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   const float* scores = seg != nullptr ? scores_ + sbase : scores_ + grow;
   const unsigned char* valid = (valid_ != nullptr && seg == nullptr) ? valid_ + grow : nullptr;
   const int i = blockIdx.x * 16 + (lane & 15);
+  // dense form with a validity mask (multi-class NMS over shared boxes): a workgroup none of whose boxes takes part in this group
+  // has nothing to place (workgroup 0 stays: it counts the group's valid boxes), and below a chunk of 64 keys without a valid one
+  // is skipped — the work follows the group's own size, not the size of the shared box array
+  if (valid != nullptr && blockIdx.x != 0 && __ballot(i < ng && valid[min(i, ng - 1)] != 0) == 0ull) return;   // uniform over the workgroup
   const unsigned long long mine = i < ng ? score_key(scores[i], (unsigned)i) : ~0ull;
   const int q = (((ng + 15) >> 4) + 63) & ~63;                         // keys per wave: a sixteenth, in whole chunks of 64
   const int b = wave * q, e = min(b + q, ng);
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   for (int jb = b; jb < e; jb += 64) {
     const int j = jb + lane;
     const bool use = j < e && (valid == nullptr || valid[j] != 0);
-    nvalid += __popcll(__ballot(use));
+    const unsigned long long usem = __ballot(use);
+    nvalid += __popcll(usem);
+    if (usem == 0ull) continue;   // (uniform) nothing to compare with
     const unsigned long long kj = use ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
     unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
 #pragma unroll
