@@ -416,8 +416,14 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay a hipGraph of the step (4-20 us per step slower than eager launches for the plain-backward step, with or without the collective)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly (the default)')
     ap.add_argument('--separate-inputs', action='store_true',
-                    help='one torch allocation per input array (target + one prediction leaf per loss) instead of row ranges of '
-                         'ONE allocation: exposes the placement lottery of DESIGN.md 5.3')
+                    help='(the default since round 6) one torch allocation per input array — target + one prediction leaf per loss — '
+                         'as a caller of the reference has them (pred and target are separate torch.cat outputs)')
+    ap.add_argument('--arena', action='store_true',
+                    help="rounds 4-5's headline form: the four input arrays are row ranges of ONE allocation (never collides in the "
+                         'memory system, DESIGN.md 5.3); by default that form is timed in the third region and reported as '
+                         '`value_one_allocation`')
+    ap.add_argument('--no-standins', action='store_true',
+                    help='skip the parity / nms / head keys (bench_standins.py: ~10 s after the timed regions, N = 1 only)')
     ap.add_argument('--unit-grad', action='store_true',
                     help="main region = rounds 3-4's step: one torch.autograd.backward over the three losses with the library's unit "
                          'gradient (gd_loss.unit_grad) instead of the plain (l0 + l1 + l2).backward() every reference caller runs')
@@ -437,6 +443,7 @@ def main():
     args = ap.parse_args()
     for k, v in RCCL_ENV_DEFAULTS.items():   # before anything touches the GPU, on every launch path
         os.environ.setdefault(k, v)
+    args.separate_inputs = not args.arena
     on_gpu = args.device == 'cuda'
     backend = args.backend or ('nccl' if on_gpu else 'gloo')
 
@@ -674,6 +681,12 @@ def main():
         device_sync()
         return tt.item()
     elapsed = max_over_ranks(elapsed)
+    # rows of the gradients the LAST TIMED STEP left in HBM, for the parity key (bench_standins.parity): taken now, before the
+    # later regions and the copy probe write those buffers again
+    grad_rows = None
+    if on_gpu and rank == 0 and world == 1 and not args.no_standins and not args.strong and n > 0:
+        sample_idx = torch.arange(0, n, max(1, n // 200_000), device=dev)
+        grad_rows = {lt: preds[lt].grad.index_select(0, sample_idx) for lt in LOSSES}
     timing = (f'HIP event pair bound to the fused dispatches of every {every}-th step inside the timed region '
               '(hipExtLaunchKernel start/stop events: begin/end timestamps of the dispatch itself, no marker packets)')
     replay_ms = None
@@ -729,16 +742,26 @@ def main():
             last['pending'].result()
         plain_elapsed = max_over_ranks(time.perf_counter() - tp)
 
-    # Third region (N = 1, eager, GPU): the same unit-gradient step on inputs that are one torch allocation EACH — the form of
-    # rounds 1-3 and of a caller who does not carve its arrays from one allocation.  Its value moves with the physical placement
-    # the process draws (70-74 G pairs/s); reported beside `value`, never as it.
+    # Third region (N = 1, eager, GPU): the headline step again on the OTHER input allocation form.  Main region = one torch
+    # allocation per array (what a caller of the reference has; its value moves with the physical placement the process draws,
+    # DESIGN.md 5.3) -> here the four arrays are row ranges of one allocation (`value_one_allocation`); with --arena the roles swap.
     sep_elapsed = None
-    if graph is None and not use_dist and on_gpu and plain_steps > 0 and not args.separate_inputs:
+    if graph is None and not use_dist and on_gpu and plain_steps > 0:
         held = (cur['tgt'], dict(preds))
-        cur['tgt'] = held[0].clone()
-        for lt in LOSSES:
-            preds[lt].grad = None
-            preds[lt] = held[1][lt].detach().clone().requires_grad_(True)
+        if args.separate_inputs:
+            arena = torch.empty((len(LOSSES) + 1) * n, 7, dtype=torch.float32, device=dev)
+            arena[:n].copy_(held[0])
+            cur['tgt'] = arena[:n]
+            for k, lt in enumerate(LOSSES):
+                preds[lt].grad = None
+                view = arena[(k + 1) * n:(k + 2) * n]
+                view.copy_(held[1][lt].detach())
+                preds[lt] = view.detach().requires_grad_(True)
+        else:
+            cur['tgt'] = held[0].clone()
+            for lt in LOSSES:
+                preds[lt].grad = None
+                preds[lt] = held[1][lt].detach().clone().requires_grad_(True)
         for _ in range(5):
             step(False)
         sync_all()
@@ -747,10 +770,11 @@ def main():
             step(False)
         device_sync()
         sep_elapsed = time.perf_counter() - tp
-        for lt in LOSSES:     # back to the arrays of the main region (the copy probe below runs on them)
+        for lt in LOSSES:     # back to the arrays of the main region (the copy probe and the parity check below run on them)
             preds[lt].grad = None
             preds[lt] = held[1][lt]
         cur['tgt'] = held[0]
+        arena = None
         step(False)
         device_sync()
 
@@ -833,6 +857,8 @@ def main():
         other_frac = (round(BYTES_PER_PAIR * n * len(LOSSES) / (plain_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
                       if plain_elapsed else None)
         main_ms, main_frac = round(elapsed / args.steps * 1e3, 4), round(step_gbps / HBM_PEAK_GBPS, 4)
+        other_alloc_value = round(job_value(args.pairs, world, args.strong, plain_steps, sep_elapsed), 2) if sep_elapsed else None
+        other_alloc_ms = round(sep_elapsed / plain_steps * 1e3, 4) if sep_elapsed else None
         by_form = {'plain': (round(value, 2), main_ms, main_frac, args.steps), 'unit': (other_value, other_ms, other_frac, plain_steps if plain_elapsed else 0)}
         if not main_plain:
             by_form = {'plain': by_form['unit'], 'unit': by_form['plain']}
@@ -850,9 +876,12 @@ def main():
             'plain_backward_steps': by_form['plain'][3],
             # the same step with the library's unit gradient handed to torch.autograd.backward (backward launches nothing)
             'value_unit_grad': by_form['unit'][0], 'ms_per_step_unit_grad': by_form['unit'][1], 'unit_grad_steps': by_form['unit'][3],
-            # the unit-gradient step again on inputs that are one torch allocation each (third region, N = 1): placement lottery
-            'value_separate_inputs': round(job_value(args.pairs, world, args.strong, plain_steps, sep_elapsed), 2) if sep_elapsed else None,
-            'ms_per_step_separate_inputs': round(sep_elapsed / plain_steps * 1e3, 4) if sep_elapsed else None,
+            # the two input allocation forms: one torch allocation per array (the main region unless --arena) and row ranges of ONE
+            # allocation (third region, N = 1; with --arena the roles swap)
+            'value_separate_inputs': round(value, 2) if args.separate_inputs else other_alloc_value,
+            'ms_per_step_separate_inputs': main_ms if args.separate_inputs else other_alloc_ms,
+            'value_one_allocation': other_alloc_value if args.separate_inputs else round(value, 2),
+            'ms_per_step_one_allocation': other_alloc_ms if args.separate_inputs else main_ms,
             'config': {'workload': (f'{args.pairs} synthetic anchor x gt 7-dof box pairs in total, row ranges of {n} per GPU '
                                     if args.strong else
                                     f'{n} synthetic anchor x gt 7-dof box pairs per GPU ') + '(BASELINE configs[2]); '
@@ -866,6 +895,9 @@ def main():
                        'host_glue': host_glue,
                        'launch': 'hipGraph replay' if graph is not None else (graph_note or 'eager'),
                        'prewarm_s': round(sum(prewarm_blocks), 2),
+                       # Python's cyclic collector is OFF across the timed regions (one collect() before the pre-warm; reference
+                       # counting still frees every tensor): a generation-2 pass inside a region stalls the host for ~0.14 s
+                       'gc_disabled': True,
                        'input_allocation': 'one torch allocation per array' if args.separate_inputs else
                                            'target and the three prediction leaves are row ranges of one allocation',
                        'device': 'MI355X (HIP kernels)' if on_gpu else f'cpu (rehearsal: GDLoss _cpu twins, {torch.get_num_threads()} threads per rank; not the metric)',
@@ -884,6 +916,8 @@ def main():
                          # the whole timed step priced like the kernel (reduce launches and backward included)
                          'achieved_step': round(step_gbps, 1), 'frac_step': round(step_gbps / HBM_PEAK_GBPS, 4),
                          'frac_step_plain_backward': by_form['plain'][2], 'frac_step_unit_grad': by_form['unit'][2],
+                         # the whole step priced on the bytes the kernels really move (84 B/pair: no per-pair loss store under 'mean')
+                         'frac_step_moved_bytes': round(step_gbps / HBM_PEAK_GBPS * MOVED_BYTES_PER_PAIR / BYTES_PER_PAIR, 4),
                          'traffic': traffic,
                          'traffic_source': traffic_note, 'traffic_by_loss': traffic_by_loss or None,
                          'kernel': f'gd3d::fused_kernel<{dom}>', 'bytes_per_pair': BYTES_PER_PAIR,
@@ -906,6 +940,18 @@ def main():
         }
         if not on_gpu:   # a rehearsal of the rank loop on host memory: no roofline claim
             line['roofline'] = None
+        if grad_rows is not None:
+            # SURVEY.md §8d "plus max-abs-error vs oracle" and BASELINE.md's NMS boxes/s, and the other BASELINE configs' stand-ins:
+            # after the timed regions, outside them (bench_standins.py)
+            import bench_standins
+            t_st = time.perf_counter()
+            for key, fn in (('parity', lambda: bench_standins.parity(amd, LOSSES, preds, cur['tgt'], n, 5.0, sample_idx, grad_rows)),
+                            ('nms', lambda: bench_standins.nms(amd, dev)), ('head', lambda: bench_standins.head(amd, dev))):
+                try:
+                    line[key] = fn()
+                except Exception as e:  # noqa: BLE001 — a failed stand-in must not cost the headline line; it is reported as failed
+                    line[key] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            line['standins_s'] = round(time.perf_counter() - t_st, 2)
         if args.cpu_sample > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, seed=0)
         sys.stdout.flush()

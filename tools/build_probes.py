@@ -2,6 +2,7 @@
 """Compile the stand-alone measurement programs under tools/ for gfx950 (plain hipcc, no torch):
    hbm_probe   measured HBM ceilings for the fused kernel's access mix
    hbm_probe2  the fused kernel's tile mechanics without its math, flat copies by shape, the occupancy cap
+   launch_floor  what a tiny dependent kernel costs behind a streaming kernel (the floor of the loss sum's second stage)
 The binaries are built in-tree (git-ignored; they travel to the GPU box with the snapshot)."""
 import os
 import subprocess
@@ -11,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PROBES = {
     'hbm_probe': ['-O3'],
     'hbm_probe2': ['-O3'],
+    'launch_floor': ['-O3'],
 }
 
 
