@@ -416,7 +416,11 @@ int rnms_normal_bev_cpu(const float* boxes_sorted, int64_t n, float thresh, int6
  *   keep         : (n) int64, receives indices into boxes_sorted, ascending
  *   num_keep     : (1) int64; -1 (every rnms_* entry, per group): the device-side scan gave
  *                  up — a wave of the list scan stopped making progress and its bounded
- *                  polling loop ended (never observed; the host layer raises on it)
+ *                  polling loop ended (never observed; the host layer raises on it).
+ *                  Every rnms_* entry writes each num_keep word EXACTLY ONCE, with the kernel
+ *                  that resolves the group's last box: the pointer may be device-visible PINNED
+ *                  HOST memory that the caller pre-sets to a sentinel and polls instead of
+ *                  copying the count back (what nms_gpu does: iou3d.py, _pynode.count_mailbox).
  * Greedy: box i is kept iff no kept j < i has IoU_bev(j,i) > thresh.  The suppression
  * bit-mask (n x ceil(n/64) uint64), from 768 boxes on also per-box victim lists, and the
  * greedy scan all stay on the device; nothing in the workspace needs initialising.

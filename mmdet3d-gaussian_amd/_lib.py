@@ -306,6 +306,10 @@ def register_unit_grad(device_index, address):
         _node.set_unit_grad(int(device_index), int(address))
 
 
+class NodeBuildFailed(RuntimeError):
+    """csrc/torch_node.cpp did not compile (as opposed to: no compiler, no binary) — a defect worth an ERROR-level log line."""
+
+
 def _load_cpp_node():
     """_gd3d_node.so, bound to the loaded libgd3d.so.  Raises when it is missing or stale and cannot be rebuilt; never loads a
     binary whose hash (sources + flags + torch version) differs: it would have been compiled against another libtorch."""
@@ -313,7 +317,27 @@ def _load_cpp_node():
         if _build.host_cxx_path() is None:
             what = 'does not match its sources / this torch' if os.path.isfile(_build.NODE_PATH) else 'is missing'
             raise RuntimeError(f'_gd3d_node.so {what} and the ROCm clang++ is not available to build it')
-        _build.build_node()
+        # a build of exactly these sources + flags + torch that already FAILED is not tried again by every new process (each rank
+        # of a torchrun job would spend ~25 s compiling the same error): the failure is stamped with the hash it belongs to
+        want = _build.node_source_hash()
+        stamp = _build.NODE_PATH + '.buildfailed'
+        try:
+            with open(stamp) as f:
+                failed_hash, _, failed_why = f.read().partition('\n')
+        except OSError:
+            failed_hash, failed_why = '', ''
+        if failed_hash.strip() == want:
+            raise NodeBuildFailed(f'an earlier build of csrc/torch_node.cpp at this source hash failed and is not retried '
+                                  f'(delete {stamp} to retry): {failed_why.strip()[:300]}')
+        try:
+            _build.build_node()
+        except Exception as e:
+            try:
+                with open(stamp, 'w') as f:
+                    f.write(want + '\n' + str(e)[-2000:])
+            except OSError:
+                pass
+            raise NodeBuildFailed(str(e)) from e
     import importlib.util
     import torch  # noqa: F401  (libtorch must be loaded before the node is)
     spec = importlib.util.spec_from_file_location('_gd3d_node', _build.NODE_PATH)
@@ -351,7 +375,10 @@ def load_node():
             _node, _glue = _load_cpp_node(), 'cpp'
         except Exception as e:   # missing compiler, torch headers this compiler rejects, an unloadable binary ...
             import logging
-            logging.getLogger('mmdet3d_gaussian_amd').warning(
+            log = logging.getLogger('mmdet3d_gaussian_amd')
+            # a COMPILE error in the node's source is a defect, not an environment property: error level (and stamped, so that
+            # later processes neither retry the build nor hide it)
+            (log.error if isinstance(e, NodeBuildFailed) else log.warning)(
                 'host glue: the optional C++ autograd node is unavailable (%s); using the Python glue (torch.autograd.Function '
                 '+ ctypes over the same C ABI and kernels: identical results, 7-30 us more host time per training-size call). '
                 'Set GD3D_HOST=python to silence this, GD3D_HOST=cpp to make it an error.', str(e).splitlines()[0][:300])

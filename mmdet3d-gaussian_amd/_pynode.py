@@ -18,6 +18,8 @@ Surface (argument for argument that of csrc/torch_node.cpp):
   set_unit_grad / finish_calls / bind: bookkeeping the C++ module also exports.
 """
 import ctypes
+import threading
+import time
 
 import torch
 
@@ -393,6 +395,42 @@ def scatter_reduce(feats, point2voxel_map, voxel_points_count, reduce, order, se
 # ---- nms_gpu's scored path --------------------------------------------------------------------------------------------------------------
 
 _NMS_WS = {}
+_PENDING = -(1 << 62)
+_MAILBOX = threading.local()
+
+
+def count_mailbox(g):
+    """This thread's mailbox: (pinned int64 tensor, its numpy view) of at least g words.  nms_gpu's result length is data
+    dependent; instead of a blocking 8-byte device-to-host copy (a copy call + a stream synchronisation, ~10 us on this stack) the
+    scan kernel writes its count straight into pinned host memory — every NMS entry point takes `num_keep` as a plain pointer —
+    and the host polls the word: 55.0 -> 49.8 us per nms_gpu-sized call (n = 4096; profiles/r06_nms_batched.txt).  The kept
+    ids stay on the device, stream-ordered as before.  One mailbox per thread: a call blocks until its words arrive."""
+    cur = getattr(_MAILBOX, 'box', None)
+    if cur is None or cur[0].numel() < g:
+        t = torch.empty(max(64, g), dtype=torch.int64).pin_memory()
+        cur = _MAILBOX.box = (t, t.numpy())
+    return cur
+
+
+def wait_counts(words, g, dev):
+    """Poll the first g mailbox words until the kernels have written them all; returns them as ints.  After 0.2 s without them
+    the device is synchronised and the words are read once more (a word still pending then raises)."""
+    spins, deadline = 0, None
+    while True:
+        vals = [int(words[i]) for i in range(g)]
+        if _PENDING not in vals:
+            return vals
+        spins += 1
+        if (spins & 0x3ff) == 0:
+            now = time.perf_counter()
+            if deadline is None:
+                deadline = now + 0.2
+            elif now > deadline:
+                torch.cuda.synchronize(dev)
+                vals = [int(words[i]) for i in range(g)]
+                if _PENDING in vals:
+                    raise RuntimeError('nms_gpu: the NMS kernels finished without reporting a count')
+                return vals
 
 
 def nms_scored(boxes, scores, thresh, n_keep, normal, padded, post_max):
@@ -414,15 +452,21 @@ def nms_scored(boxes, scores, thresh, n_keep, normal, padded, post_max):
     dev = boxes.device
     with _on_device(dev) as stream:
         keep = torch.empty(n_keep, dtype=torch.int64, device=dev)
-        num = torch.empty(1, dtype=torch.int64, device=dev)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if padded:
+            num = torch.empty(1, dtype=torch.int64, device=dev)
+            dst = num.data_ptr()
+        else:   # the count goes straight into pinned host memory and is polled there (see count_mailbox)
+            box, words = count_mailbox(1)
+            words[0] = _PENDING
+            dst = box.data_ptr()
         rc = lib.rnms_scored(int(normal), boxes.data_ptr(), scores.data_ptr(), n_all, n_keep, float(thresh), keep.data_ptr(),
-                             num.data_ptr(), ws.data_ptr(), stream)
+                             dst, ws.data_ptr(), stream)
     if rc != 0:
         _lib.check(rc, 'nms_normal_gpu' if normal else 'nms_gpu')
     if padded:
         return keep, num
-    k = int(num.item())   # the one unavoidable sync: the result length is data dependent
+    k = wait_counts(words, 1, dev)[0]   # the one unavoidable wait: the result length is data dependent
     if k < 0:             # the scan kernel's failure mark (a bounded polling loop gave up: never observed)
         raise RuntimeError(f'nms_gpu: the device-side NMS scan gave up (num_keep = {k}); the result is void')
     if post_max >= 0 and k > post_max:

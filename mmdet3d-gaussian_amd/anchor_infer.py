@@ -28,7 +28,8 @@ def anchor_head_get_bboxes(cls_scores, bbox_preds, dir_cls_preds, mlvl_anchors, 
     cfg            : the head's test_cfg: nms_pre, score_thr, nms_thr, max_num, use_rotate_nms;
     dir_offset, dir_limit_offset : the head's attributes (KITTI configs: 0.7854 / 0).
     Returns per sample (bboxes (n,7), scores (n,), labels (n,) int64) — wrapped by input_metas[i]['box_type_3d'](bboxes, box_dim=7)
-    when metas are given.  padded=True: no read-back, dict(bboxes (B,max_num,7), scores, labels, counts) on the device."""
+    when metas are given.  padded=True: no read-back, dict(bboxes (B,max_num,7), scores, labels, counts) on the device
+    (counts[b] = -1: a device-side NMS scan gave up, the sample's rows are void)."""
     if box_code_size != 7:
         raise RuntimeError('anchor_head_get_bboxes: box code size 7 only')
     L = len(cls_scores)
@@ -87,6 +88,8 @@ def anchor_head_get_bboxes(cls_scores, bbox_preds, dir_cls_preds, mlvl_anchors, 
         out = dict(bboxes=boxes, scores=scores, labels=labels, counts=count)
         return (out, cands) if return_candidates else out
     ns = count.tolist()          # the one sync: B data-dependent detection counts
+    if min(ns, default=0) < 0:   # a device-side NMS scan gave up (include/gd3d.h: num_keep = -1): the result is void
+        raise RuntimeError('anchor_infer: a device-side NMS scan gave up (count -1); the result is void')
     out = []
     for i in range(B):
         bx = boxes[i, :ns[i]]

@@ -106,7 +106,8 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
     Returns, per sample, [bboxes (n, 7 + vel) with z at the box bottom, scores (n,), labels (n,) int32]; with `img_metas`
     given the boxes are wrapped by img_metas[i]['box_type_3d'](bboxes, bbox_coder.code_size) as the reference does.
     padded=True: no read-back at all — returns dict(bboxes (B, R, co), scores (B, R), labels (B, R) int32, counts (B,) int64) on
-    the device, rows beyond counts[b] undefined: the whole slice is then stream-ordered and can sit inside a captured hipGraph
+    the device, rows beyond counts[b] undefined (counts[b] = -1: a device-side NMS scan gave up, the sample's rows are void — the
+    caller of the padded form checks it where it next reads the counts): the whole slice is then stream-ordered and can sit inside a captured hipGraph
     (tests/test_gpu_center_infer.py::test_get_bboxes_replays_as_a_hipgraph) or feed a tracker without a host round trip.
     return_candidates: also return what went INTO the NMS, per task a dict(boxes (B,K,co), scores (B,K), labels (B,K) int32,
     counts (B,) int32): the survivors of the score / range mask in score order (rows beyond counts[b] are undefined)."""
@@ -220,6 +221,8 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
     if padded:
         return dict(bboxes=boxes, scores=scores, labels=labels, counts=count)
     ns = count.tolist()          # the one sync: B data-dependent detection counts
+    if min(ns, default=0) < 0:   # a device-side NMS scan gave up (include/gd3d.h: num_keep = -1): the result is void
+        raise RuntimeError('center_infer: a device-side NMS scan gave up (count -1); the result is void')
     out = []
     for i in range(B):
         bx = boxes[i, :ns[i]]

@@ -130,12 +130,14 @@ struct CollectArgs {
 
 __global__ __launch_bounds__(T) void anchor_collect_kernel(const CollectArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ssc[];   // (C, max_num) the classes' best kept scores, descending
-  __shared__ int s_n[MAXC], s_off[MAXC + 1];
+  __shared__ int s_n[MAXC], s_off[MAXC + 1], s_failed;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
     int off = 0;
+    s_failed = 0;
     for (int c = 0; c < a.C; ++c) {
       const long long nk = a.num[(size_t)b * a.C + c];
+      if (nk < 0) s_failed = 1;   // a class's NMS scan gave up (num_keep = -1, include/gd3d.h): no rows from it, the count says so
       s_n[c] = (int)(nk < 0 ? 0 : nk);
       s_off[c] = off;
       off += s_n[c];
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(T) void anchor_collect_kernel(const CollectArgs a) 
       a.out_labels[(size_t)b * a.max_num + pos] = c;
     }
   }
-  if (tid == 0) a.out_count[b] = cut ? a.max_num : total;
+  if (tid == 0) a.out_count[b] = s_failed ? -1 : (cut ? a.max_num : total);
 }
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -634,14 +634,16 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeArgs a) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int t = slot / a.post, r = slot - t * a.post;
   int off = 0, mine = 0, total = 0;
+  bool failed = false;   // a group's NMS scan gave up (num_keep = -1, include/gd3d.h): no rows from it, and the sample's count says so
   for (int q = 0; q < a.Tn; ++q) {
     const long long nk = a.num_keep[q * a.B + b];
-    const int n = (int)(nk < a.post ? nk : a.post);
+    failed |= nk < 0;
+    const int n = (int)(nk < 0 ? 0 : (nk < a.post ? nk : a.post));
     off += q < t ? n : 0;
     mine = q == t ? n : mine;
     total += n;
   }
-  if (slot == 0) a.out_count[b] = total;
+  if (slot == 0) a.out_count[b] = failed ? -1 : total;
   if (t >= a.Tn || r >= mine) return;
   const int G = t * a.B + b;
   const size_t src = (size_t)a.keep[(size_t)G * a.cap + r];

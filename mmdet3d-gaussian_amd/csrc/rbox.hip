@@ -87,14 +87,47 @@ __global__ __launch_bounds__(256) void obox_prep_kernel(const NmsArgs a, OBox* _
 // rank_place_kernel below.
 constexpr int RANK_MAX = 16384;
 
+
 __device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
   unsigned u = __float_as_uint(s);
-  if (s != s) u = 0xffffffffu;              // any NaN: greatest
+  if (s != s) u = 0xfffffffeu;              // any NaN: greatest (+inf maps to 0xff800000); NOT 0xffffffff: rank_place forms u + 1
   else {
     if (u == 0x80000000u) u = 0u;           // -0.0 == +0.0 for the comparison torch.sort makes
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   }
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+
+// lt += #{keys of the lane's row of 16 that are < m}, two instructions per step: step T subtracts m from the key T places away
+// in the row — row_ror:T as a DPP operand of v_sub_co_u32 (VOP2 takes DPP on gfx9, VOPC does not) — the borrow (key < m) lands in
+// VCC and v_addc adds it.  Sixteen independent rotations of ONE register, no dependent chain, no wait states between the pairs
+// (a VCC written by one VALU instruction may be the next one's carry-in).  The leading s_nop covers both DPP hazards (source
+// VGPR written by the VALU instruction before: 2 wait states; EXEC written by a VALU instruction: 5) for whatever code the
+// compiler puts in front of the block.  Measured on the chip before use (profiles/r06_nms_batched.txt): v_sub_co_u32_dpp
+// computes dpp(src0) - src1 as written; v_subREV_co_u32_dpp does NOT compute src1 - dpp(src0): the rotation goes to the
+// MINUEND there too (it gives dpp(src1) - src0), which pairs every key with the wrong box.
+__device__ __forceinline__ void count_row_keys_below(unsigned ku, unsigned m, int& lt) {
+  unsigned tmp;
+  asm("s_nop 4\n"
+      "v_sub_co_u32 %1, vcc, %2, %3\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:3 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:5 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:6 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:7 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:9 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:10 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:11 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:12 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:13 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:14 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      "v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:15 row_mask:0xf bank_mask:0xf\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+      : "+v"(lt), "=&v"(tmp)
+      : "v"(ku), "v"(m)
+      : "vcc");
 }
 
 // rank_place_kernel: a 16-wave workgroup owns SIXTEEN boxes of a group and ALL of the group's keys — wave w counts, for the
@@ -125,6 +158,7 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   zero_control_words(zero_words, zero_n);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = (int)(blockDim.x >> 6);                               // waves per workgroup: 16; 4 in the masked dense form (below)
   const int g = blockIdx.y;
   const int sbase = seg != nullptr ? seg[g] : 0;                       // first score / box of the group in the flat arrays
   const int ng = seg != nullptr ? seg[g + 1] - sbase : n;
@@ -141,27 +175,92 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   // has nothing to place (workgroup 0 stays: it counts the group's valid boxes), and below a chunk of 64 keys without a valid one
   // is skipped — the work follows the group's own size, not the size of the shared box array
   if (valid != nullptr && blockIdx.x != 0 && __ballot(i < ng && valid[min(i, ng - 1)] != 0) == 0ull) return;   // uniform over the workgroup
+  // The compares (round 6).  A key is (order-preserving 32-bit image u of the score, ~index): box i's rank = #{u_j > u_i} +
+  // #{u_j == u_i, j < i}.  The workgroup's sixteen boxes lie in ONE chunk of 64 keys, C0; for every other chunk the index part is
+  // decided by the chunk alone — keys of an EARLIER chunk count from u_j >= u_i, keys of a LATER chunk from u_j > u_i, i.e.
+  // u_j >= u_i + 1 (images end at 0xfffffffe: nothing wraps) — so one 32-bit compare against a per-chunk uniform choice of
+  // threshold m decides, counted as its complement: every lane sees 16 keys per chunk, #{u_j >= m} = 16 - #{u_j < m} (the 0 of
+  // an unused key is below every m: real images start at 0x007fffff, the image of -inf).  v_sub + v_addc per 64 pairs where the
+  // 64-bit keys cost a 64-bit compare, a select, an add and two dependent rotations: 2 against ~6 instructions and their wait
+  // states per step.  Only chunk C0 compares whole keys.  (One class alone, 4096 keys: 7.4 -> 7.7 us, unchanged — 4.2 us of that
+  // is the dispatch floor; the masked three-class form needed it together with fewer waves: profiles/r06_nms_batched.txt.)
+  const int C0 = (int)(blockIdx.x * 16u) >> 6;
   const unsigned long long mine = i < ng ? score_key(scores[i], (unsigned)i) : ~0ull;
-  const int q = (((ng + 15) >> 4) + 63) & ~63;                         // keys per wave: a sixteenth, in whole chunks of 64
-  const int b = wave * q, e = min(b + q, ng);
-  int cnt = 0, nvalid = 0;
-  for (int jb = b; jb < e; jb += 64) {
-    const int j = jb + lane;
-    const bool use = j < e && (valid == nullptr || valid[j] != 0);
-    const unsigned long long usem = __ballot(use);
-    nvalid += __popcll(usem);
-    if (usem == 0ull) continue;   // (uniform) nothing to compare with
-    const unsigned long long kj = use ? score_key(scores[j], (unsigned)j) : 0ull;  // 0 is below every real key
-    unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
+  const unsigned mu = (unsigned)(mine >> 32);
+  int cnt = 0, nvalid = 0, lt = 0, n32 = 0;
+  auto compare = [&](int c, bool use, float sc, int j) {
+    if (c != C0) {   // uniform
+      const unsigned ku = use ? (unsigned)(score_key(sc, 0u) >> 32) : 0u;
+      const unsigned m = c < C0 ? mu : mu + 1u;
+      count_row_keys_below(ku, m, lt);
+      ++n32;
+    } else {
+      const unsigned long long kj = use ? score_key(sc, (unsigned)j) : 0ull;   // 0 is below every real key
+      unsigned klo = (unsigned)kj, khi = (unsigned)(kj >> 32);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      cnt += (((unsigned long long)khi << 32) | klo) > mine ? 1 : 0;
-      klo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)klo, 0x121, 0xf, 0xf, false);   // row_ror:1 — inside the lane's row of 16
-      khi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)khi, 0x121, 0xf, 0xf, false);
+      for (int t = 0; t < 16; ++t) {
+        cnt += (((unsigned long long)khi << 32) | klo) > mine ? 1 : 0;
+        klo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)klo, 0x121, 0xf, 0xf, false);   // row_ror:1
+        khi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)khi, 0x121, 0xf, 0xf, false);
+      }
+    }
+  };
+  if (valid == nullptr) {
+    const int q = (((ng + nw - 1) / nw) + 63) & ~63;                     // keys per wave: a sixteenth, in whole chunks of 64
+    const int b = wave * q, e = min(b + q, ng);
+    for (int jb0 = b; jb0 < e; jb0 += 4 * 64) {   // four chunks' scores in flight together (a lane past the end re-reads the last key)
+      float sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sc[u] = scores[min(jb0 + 64 * u + lane, ng - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jb = jb0 + 64 * u;
+        if (jb >= e) break;   // (uniform)
+        const int j = jb + lane;
+        const bool use = j < e;
+        nvalid += __popcll(__ballot(use));
+        compare(jb >> 6, use, sc[u], j);
+      }
+    }
+  } else {
+    // Dense form with a validity mask: the group's valid keys are a SUBSET of the shared array (multi-class NMS: class c's 4096
+    // candidates among 12 288 boxes).  Round 6 (profiles/r06_nms_batched.txt): 25.6 -> 16.9 us for 3 x 4096 of 12 288 —
+    //  * the chunks are dealt INTERLEAVED (wave w: chunks w, w + nw, ...: any run of valid boxes spreads over all waves) and
+    //    eight at a time, all sixteen loads independent: one memory round trip per eight chunks where the contiguous sixteenth
+    //    per wave paid two per chunk (flag byte, then score) and left ten of sixteen waves without a valid key;
+    //  * the launch uses FOUR waves per workgroup in this form: two thirds of the workgroups have no valid box of their group and
+    //    leave after one byte load, but every wave of theirs costs dispatch (sweep: 128 threads 23.5 us, 256: 16.9, 512: 16.4,
+    //    1024: 22.8; without the 32-bit compares below the busy workgroups were VALU-bound and four waves gained nothing);
+    //  * a chunk without a valid key is skipped.
+    constexpr int RU = 8;
+    const int nchunk = (ng + 63) >> 6;
+    for (int c0 = wave; c0 < nchunk; c0 += nw * RU) {
+      // sixteen independent loads (eight flag bytes, eight scores; a lane past the end re-reads the group's last key): ONE memory
+      // round trip per eight chunks — a score load that waits for its flag serialises the chunks (measured: 0.7 us per chunk)
+      unsigned char fb[RU];
+      float sc[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int j = min(((c0 + nw * u) << 6) + lane, ng - 1);
+        fb[u] = valid[j];
+        sc[u] = scores[j];
+      }
+      bool use[RU];
+      unsigned long long usem[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        use[u] = ((c0 + nw * u) << 6) + lane < ng && fb[u] != 0;
+        usem[u] = __ballot(use[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        nvalid += __popcll(usem[u]);
+        if (usem[u] == 0ull) continue;   // (uniform)
+        compare(c0 + nw * u, use[u], sc[u], ((c0 + nw * u) << 6) + lane);
+      }
     }
   }
-  // (loading every score of the slice before the first compare changed nothing: 12.1 -> 12.0 us on average — the kernel is bound by
-  // its VALU instructions, 4 per 64 compares plus the DPP wait states: n = 9000: 7.8 M wave instructions = 12.7 us on 1024 SIMDs)
+  cnt += 16 * n32 - lt;         // chunks compared through the 32-bit images: 16 keys each per lane, less those below the threshold
   cnt += __shfl_xor(cnt, 16);   // the four rows hold the same boxes
   cnt += __shfl_xor(cnt, 32);
   if (lane < 16) spart[wave][lane] = cnt;
@@ -170,14 +269,12 @@ __global__ __launch_bounds__(1024) void rank_place_kernel(const float* __restric
   if (wave != 0) return;
   if (counts != nullptr && blockIdx.x == 0 && lane == 0) {
     int total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) total += svalid[w];
+    for (int w = 0; w < nw; ++w) total += svalid[w];
     counts[g] = min(total, n_keep);
   }
   if (lane < 16 && i < ng && (valid == nullptr || valid[i] != 0)) {
     int r = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) r += spart[w][lane];
+    for (int w = 0; w < nw; ++w) r += spart[w][lane];
     if (r < n_keep) {
       const int bbase = seg != nullptr ? sbase : (gps > 0 ? (g / gps) * n : 0);
       order_[(size_t)g * n_keep + r] = (long long)(bbase + i);
@@ -805,6 +902,7 @@ struct ScanWindow {
   int c_begin, c_end;               // blocks; c_end is clamped to the group's block count
   unsigned long long* gremv;        // (G, cbs) global removed-set, nullptr = single-level scan over all blocks
   unsigned long long* gkept;        // (G, cbs) kept word per block
+  long long* gcount;                // (G) running keep count between the launches of a two-level scan
 };
 constexpr int SCAN_SB = 64;         // blocks per super-block (4096 boxes): rows inside it fit the one-chunk scan variant
 
@@ -843,7 +941,9 @@ __device__ __forceinline__ void nms_scan_body(const NmsArgs& a, const unsigned l
   if (windowed && c_begin == 0)   // the first super-block opens the global removed-set for everything right of it
     for (int w = cb + tid; w < cb_all; w += SCAN_T) gremv[w] = 0ull;
   if (tid < 4) skept[tid] = 0ull;
-  if (tid == 0) scount = (windowed && c_begin > 0) ? (int)num_keep[g] : 0;
+  // (windowed: the running count travels from launch to launch in the workspace word gcount[g]; num_keep[g] is written ONCE, by
+  //  the launch that resolves the group's last block — a caller may point num_keep at pinned host memory and poll it)
+  if (tid == 0) scount = (windowed && c_begin > 0) ? (int)win.gcount[g] : 0;
   lds_barrier();
   const int NB = cb - c_begin;  // intervals = barriers every wave executes in the main phase
 
@@ -959,7 +1059,10 @@ __device__ __forceinline__ void nms_scan_body(const NmsArgs& a, const unsigned l
           const int total = count + __builtin_popcountll(kept);
           scount = total;
           if (windowed) gkept[c] = kept;
-          if (c == cb - 1) num_keep[g] = total;
+          if (c == cb - 1) {
+            if (windowed) win.gcount[g] = total;
+            if (cb == cb_all) num_keep[g] = total;
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ds_or_b64 above are inline asm: the compiler does not count them
       };
@@ -1440,7 +1543,11 @@ __device__ __forceinline__ bool nms_list_body(const NmsArgs& a, const unsigned l
     if (t + LIST_HW < cb) fcnt_next = cnt2[min((t + LIST_HW) * 64 + lane, n - 1)].y;
     int spins = 0;
     while ((__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u8*)(size_t)(sb0 + (unsigned int)t * 64u)) & 0x82) == 0) {
-      if (++spins > LIST_SPIN_MAX) return true;
+      if (++spins > LIST_SPIN_MAX) {   // a helper gives up: the scan is void — say so (nobody may be left to notice otherwise:
+        lds_poke(&failed, 1u);         // the blocks after this one have no waiter) and report it in the count
+        if (lane == 0) num_keep[0] = -1;
+        return true;
+      }
       __builtin_amdgcn_s_sleep(LIST_POLL_SLEEP);
     }
     COMPILER_FENCE();
@@ -1636,7 +1743,7 @@ static WsLayout ws_layout(size_t G, size_t cap) {
   L.mask = align_up(G * cap * sizeof(OBox), 256);
   L.colm = L.mask + align_up(G * cap * cb * sizeof(unsigned long long), 256);
   L.gremv = L.colm + align_up(G * cap * sizeof(unsigned long long), 256);
-  L.queue = L.gremv + align_up(2 * G * cb * sizeof(unsigned long long), 256);
+  L.queue = L.gremv + align_up((2 * G * cb + G) * sizeof(unsigned long long), 256);   // gremv | gkept | one running count per group
   L.scap = (unsigned)((cap * QUEUE_PER_BOX + QUEUE_SHARDS - 1) / QUEUE_SHARDS);   // entries per shard
   L.npairs = (unsigned)(cb * (cb + 1) / 2);
   L.qctl = L.queue + align_up(G * QUEUE_SHARDS * L.scap * sizeof(unsigned), 256);
@@ -1774,6 +1881,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   win.c_begin = 0;
   win.c_end = a.cbs;
   win.gremv = win.gkept = nullptr;
+  win.gcount = nullptr;
   if (use_lists) {   // ONE launch: list scan, or — decided on the device from the clip kernel's failure word — the classic one
     const unsigned short* const lists = (const unsigned short*)((char*)workspace + W.lists);
     const unsigned* const lcnt = (const unsigned*)((char*)workspace + W.lcnt);
@@ -1802,6 +1910,7 @@ static int rnms_launch(int mode, const float* boxes, const int64_t* order, const
   // the super-block: one chunk), the rows of the kept boxes spread to everything right of it by nms_propagate_kernel
   win.gremv = (unsigned long long*)((char*)workspace + W.gremv);
   win.gkept = win.gremv + (size_t)G * a.cbs;
+  win.gcount = (long long*)(win.gkept + (size_t)G * a.cbs);
   for (int c0 = 0; c0 < a.cbs; c0 += SCAN_SB) {
     win.c_begin = c0;
     win.c_end = c0 + SCAN_SB < a.cbs ? c0 + SCAN_SB : a.cbs;
@@ -1917,13 +2026,19 @@ static int batched_scored_impl(int32_t mode, const float* boxes, const float* sc
   int* counts = (int*)p;
   hipError_t e;
   const dim3 sg((unsigned)((n + 15) / 16), (unsigned)groups);
+  static const unsigned masked_threads = [] {
+    const char* e = getenv("RNMS_RANK_MASKED_THREADS");   // measurement override (tools/nms_batched_ab.sh)
+    const unsigned v = e != nullptr ? (unsigned)atoi(e) : 256u;
+    return (v == 64u || v == 128u || v == 256u || v == 512u || v == 1024u) ? v : 256u;
+  }();
+  const dim3 sb(valid != nullptr && seg == nullptr ? masked_threads : 1024u);   // masked dense form: four waves per workgroup
   unsigned* const qctl = (unsigned*)((char*)workspace + ws_layout((size_t)groups, (size_t)cap).qctl);
   if (mode == MODE_ROT)
-    hipLaunchKernelGGL((rank_place_kernel<true>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
+    hipLaunchKernelGGL((rank_place_kernel<true>), sg, sb, 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
                        (int)n, (int)cap, order, (OBox*)workspace, counts, gps, qctl, (int)CTL_WORDS);
   else {
     const WsLayout WG = ws_layout((size_t)groups, (size_t)cap);
-    hipLaunchKernelGGL((rank_place_kernel<false>), sg, dim3(1024), 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
+    hipLaunchKernelGGL((rank_place_kernel<false>), sg, sb, 0, s, boxes, scores, (const unsigned char*)valid, (const int*)seg,
                        (int)n, (int)cap, order, (OBox*)workspace, counts, gps, (unsigned*)((char*)workspace + WG.lcnt), (int)WG.lblock);
   }
   e = hipGetLastError();

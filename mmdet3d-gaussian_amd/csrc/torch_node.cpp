@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 
@@ -570,13 +571,39 @@ std::tuple<Tensor, Tensor> nms_scored(const Tensor& boxes, const Tensor& scores,
   const int64_t n_all = boxes.size(0);
   c10::DeviceGuard device_guard(boxes.device());
   const auto longs = boxes.options().dtype(at::kLong);
-  Tensor keep = at::empty({n_keep}, longs), num = at::empty({1}, longs);
+  Tensor keep = at::empty({n_keep}, longs), num;
   Tensor ws = at::empty({(int64_t)abi.nms_scored_workspace_bytes(n_all, n_keep)}, boxes.options().dtype(at::kByte));
+  // The one unavoidable wait: the result length is data dependent.  Unpadded calls let the scan kernel write the count straight
+  // into PINNED HOST memory (a thread's own mailbox word) and poll it — no copy call, no stream synchronisation: 55.0 -> 49.8 us
+  // per call at n = 4096 against the blocking 8-byte copy (profiles/r06_nms_batched.txt).  The kept ids stay on the device and
+  // are stream-ordered as before; if the word does not arrive within 0.2 s the stream is synchronised and the word read once more.
+  static thread_local Tensor mailbox;
+  volatile int64_t* word = nullptr;
+  constexpr int64_t PENDING = -(int64_t(1) << 62);
+  if (padded) {
+    num = at::empty({1}, longs);
+  } else {
+    if (!mailbox.defined()) mailbox = at::empty({8}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    word = mailbox.data_ptr<int64_t>();
+    *word = PENDING;
+  }
   fail(abi.nms_scored(normal ? 1 : 0, boxes.data_ptr<float>(), scores.data_ptr<float>(), n_all, n_keep, (float)thresh,
-                      keep.data_ptr<int64_t>(), num.data_ptr<int64_t>(), ws.data_ptr(), current_stream(boxes)),
+                      keep.data_ptr<int64_t>(), padded ? num.data_ptr<int64_t>() : (int64_t*)word, ws.data_ptr(), current_stream(boxes)),
        normal ? "nms_normal_gpu" : "nms_gpu");
   if (padded) return {keep, num};
-  int64_t k = num.item<int64_t>();   // the one unavoidable sync: the result length is data dependent
+  int64_t k = PENDING;
+  {
+    pybind11::gil_scoped_release nogil;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; (k = *word) == PENDING; ++spins) {
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        c10::hip::getCurrentHIPStream(boxes.device().index()).synchronize();
+        k = *word;
+        break;
+      }
+    }
+  }
+  TORCH_CHECK(k != PENDING, "nms_gpu: the NMS kernels finished without reporting a count");
   TORCH_CHECK(k >= 0, "nms_gpu: the device-side NMS scan gave up (num_keep = ", k, "); the result is void");   // failure mark of the list scan
   if (post_max >= 0 && k > post_max) k = post_max;
   return {keep.narrow(0, 0, k), Tensor()};

@@ -57,7 +57,11 @@ class _HeatFocal(torch.autograd.Function):
         need = [bool(ctx.needs_input_grad[2 + t]) for t in range(len(logits))]
         xs = [x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous() for x in logits]
         grads, out = _HeatFocal._launch(cfg, xs, targets, need)
-        ctx.state = (cfg, xs, targets, grads, out, need, [x.dtype for x in logits], [x.shape for x in logits])
+        # the fp32 logits and targets a retain_graph replay re-launches from go through save_for_backward: version-checked (an
+        # in-place edit between forward and that backward raises instead of returning another input's gradients) and released
+        # with the graph; ctx.state holds no input tensor
+        ctx.save_for_backward(*xs, *targets)
+        ctx.state = (cfg, grads, out, need, [x.dtype for x in logits], [x.shape for x in logits])
         ctx.used = False
         losses, num_pos = out[0], out[2]
         ctx.mark_non_differentiable(num_pos)
@@ -67,13 +71,15 @@ class _HeatFocal(torch.autograd.Function):
     @guard_double_backward
     def backward(ctx, grad_losses, _grad_num_pos):
         lib = _lib.load()
-        cfg, xs, targets, grads, out, need, dtypes, shapes = ctx.state
+        cfg, grads, out, need, dtypes, shapes = ctx.state
+        saved = ctx.saved_tensors
+        T = len(saved) // 2
+        xs, targets = list(saved[:T]), list(saved[T:])
         if ctx.used:   # retain_graph replay: the maps of the first backward were scaled in place and handed over: launch again,
             grads, out = _HeatFocal._launch(cfg, xs, targets, need)   # as the loss / anchor-head / centre-head nodes do
         else:
-            ctx.state = (cfg, xs, targets, None, None, need, dtypes, shapes)
+            ctx.state = (cfg, None, None, need, dtypes, shapes)
         ctx.used = True
-        T = len(xs)
         with torch.cuda.device(xs[0].device):
             up = grad_losses.to(torch.float32).contiguous()
             _lib.check(lib.gd3d_heat_focal_scale(_tasks(xs, targets, grads), T, out[1].data_ptr(), up.data_ptr(),

@@ -20,7 +20,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, _pynode
 
 
 def _ptr(t):
@@ -152,6 +152,19 @@ def _ws_bytes(lib, scored, n_all, n):
     return b
 
 
+_BATCHED_WS = {}
+
+
+def _batched_ws_bytes(lib, G, N, cap):
+    key = (G, N, cap)
+    b = _BATCHED_WS.get(key)
+    if b is None:
+        if len(_BATCHED_WS) > 4096:
+            _BATCHED_WS.clear()
+        b = _BATCHED_WS[key] = int(lib.rnms_batched_scored_workspace_bytes(G, N, cap))
+    return b
+
+
 def _scored_max(lib):
     global _SCORED_MAX
     if _SCORED_MAX is None:
@@ -248,12 +261,15 @@ def nms_gpu_batched(boxes, scores, thresh, valid=None, pre_max_size=None, post_m
             vb = None if valid is None else valid.to(torch.bool).contiguous()   # 1 byte per flag
             th = _thresh_tensor(thresh, G, dev)
             keep = torch.empty((G, cap), dtype=torch.int64, device=dev)
-            num = torch.empty(G, dtype=torch.int64, device=dev)
-            ws = torch.empty(lib.rnms_batched_scored_workspace_bytes(G, N, cap), dtype=torch.uint8, device=dev)
+            ws = torch.empty(_batched_ws_bytes(lib, G, N, cap), dtype=torch.uint8, device=dev)
+            # the G data-dependent result lengths arrive in pinned host memory, written by the scan kernels themselves, and are
+            # polled there: no copy call, no stream synchronisation (_pynode.count_mailbox)
+            box, words = _pynode.count_mailbox(G)
+            words[:G] = _pynode._PENDING
             _lib.check(lib.rnms_batched_scored(mode, boxes.data_ptr(), sc.data_ptr(), None if vb is None else vb.data_ptr(), G, N,
-                                               cap, th.data_ptr(), keep.data_ptr(), num.data_ptr(), ws.data_ptr(),
-                                               torch.cuda.current_stream().cuda_stream), name)
-        nums = [_kept_count(k, name) for k in num.tolist()]  # the one sync: G data-dependent result lengths
+                                               cap, th.data_ptr(), keep.data_ptr(), box.data_ptr(), ws.data_ptr(),
+                                               _raw_stream(dev.index)), name)
+        nums = [_kept_count(k, name) for k in _pynode.wait_counts(words, G, dev)]  # the one wait
         out = []
         for g in range(G):
             k = keep[g, :nums[g]]

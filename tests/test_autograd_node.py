@@ -291,3 +291,35 @@ except RuntimeError as e:
 '''
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert 'REFUSED' in r.stdout and 'does not match its sources' in r.stdout, r.stdout + r.stderr
+
+
+def test_a_failed_node_build_is_stamped_and_not_retried(tmp_path):
+    """A COMPILE error in csrc/torch_node.cpp (as opposed to: no compiler): the first process tries the build once, stamps the
+    failure with the source hash it belongs to and falls back to the Python glue with an ERROR-level log line; the next
+    process finds the stamp and does not build again (every rank of a torchrun job would otherwise compile the same error);
+    GD3D_HOST=cpp still raises."""
+    code = f'''
+import logging, os, sys
+sys.path.insert(0, {ROOT!r})
+logging.basicConfig(level=logging.INFO, format='%(levelname)s %(message)s')
+from mmdet3d_gaussian_amd import _lib
+b = _lib._build
+b.NODE_PATH = os.path.join({str(tmp_path)!r}, '_gd3d_node.so'); b.NODE_HASH_PATH = b.NODE_PATH + '.srchash'
+calls = []
+def broken(force=False, verbose=False):
+    calls.append(1)
+    raise RuntimeError('compiling torch_node.cpp failed: error: use of undeclared identifier')
+b.build_node = broken
+node = _lib.load_node()
+print('RESULT', node.IMPLEMENTATION if hasattr(node, 'IMPLEMENTATION') else 'cpp', len(calls), os.path.isfile(b.NODE_PATH + '.buildfailed'))
+'''
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k != 'GD3D_HOST'})
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append((r.stdout.strip().splitlines()[-1], r.stderr))
+    assert runs[0][0] == 'RESULT python 1 True' and 'ERROR' in runs[0][1] and 'undeclared identifier' in runs[0][1]
+    assert runs[1][0] == 'RESULT python 0 True' and 'ERROR' in runs[1][1] and 'not retried' in runs[1][1]
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=dict(os.environ, GD3D_HOST='cpp'))
+    assert r.returncode != 0 and 'not retried' in r.stderr

@@ -146,21 +146,25 @@ def test_every_launch_path_gets_the_rccl_environment_defaults():
 
 
 def test_input_allocation_forms_give_the_same_losses_and_say_which_one_ran():
-    """The input arrays are row ranges of ONE allocation by default (separately allocated read streams collide on
-    some draws of their physical placement); `--separate-inputs` restores one torch allocation per array.  Same values, same
-    gradients path; the result line names the form."""
+    """Since round 6 the headline form is one torch allocation per input array (what a caller of the reference has: pred and target
+    are separate torch.cat outputs); `--arena` makes the four arrays row ranges of ONE allocation (rounds 4-5's headline: separately
+    allocated read streams collide on some draws of their physical placement).  `--separate-inputs` is accepted and
+    means the default.  Same values either way; the result line names the form in `config` and in `value_form`."""
     lines = []
-    for extra in ([], ['--separate-inputs']):
+    for extra in ([], ['--separate-inputs'], ['--arena']):
         r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--pairs', '20000'] + COMMON + extra, capture_output=True, text=True,
                            timeout=300, env=_env(), cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         got = _result_lines(r.stdout)
         assert len(got) == 1
         lines.append(got[0])
-    a, b = lines
-    assert 'row ranges of one allocation' in a['config']['input_allocation']
-    assert b['config']['input_allocation'] == 'one torch allocation per array'
-    assert a['loss_values'] == b['loss_values']
+    a, b, c = lines
+    assert a['config']['input_allocation'] == b['config']['input_allocation'] == 'one torch allocation per array'
+    assert 'one allocation per input array' in a['value_form']
+    assert 'row ranges of one allocation' in c['config']['input_allocation'] and 'row ranges of one allocation' in c['value_form']
+    assert a['loss_values'] == b['loss_values'] == c['loss_values']
+    assert a['config']['gc_disabled'] is True
+    assert a['value_separate_inputs'] == a['value'] and c['value_one_allocation'] == c['value']
 
 
 def test_prewarm_with_collectives_leaves_every_rank_with_the_same_step_count():

@@ -1072,6 +1072,51 @@ def test_list_scan_axis_aligned_boxes(amd, n, thr):
         assert int(ws[nbytes - 256:nbytes - 252].view(torch.int32).item()) == 0
 
 
+@pytest.mark.parametrize('n,thr', [(300, 0.3), (4096, 0.25), (9000, 0.7), (20000, 0.5)])
+def test_num_keep_is_written_once_and_may_live_in_pinned_host_memory(amd, n, thr):
+    """include/gd3d.h: every rnms_* entry writes each num_keep word exactly once, with the kernel that resolves the group's last
+    box — so the word may be pinned host memory that the caller polls (nms_gpu's count mailbox, round 6).  Sizes: the compacted
+    one-launch form, the list scan, the list scan at 9000 boxes, and the two-level classic scan (20 000 boxes: five scan launches
+    that used to keep their running count in num_keep).  The host polls WHILE the kernels run and records every value it sees."""
+    import ctypes
+    lib = amd.load_library()
+    b, s = nms_boxes(n, seed=n + 3)
+    order = np.argsort(-s, kind='stable')
+    sb = torch.from_numpy(b[order]).cuda()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    keep = torch.empty(n, dtype=torch.int64, device='cuda')
+    ws = torch.empty(lib.rnms_workspace_bytes(n), dtype=torch.uint8, device='cuda')
+    num_dev = torch.empty(1, dtype=torch.int64, device='cuda')
+    assert lib.rnms_bev(vp(sb), n, thr, vp(keep), vp(num_dev), vp(ws), None) == 0
+    want_k = int(num_dev.item())
+    want = keep[:want_k].clone()
+    box = torch.empty(8, dtype=torch.int64).pin_memory()
+    words = box.numpy()
+    pending = -(1 << 62)
+    for _ in range(5):
+        words[0] = pending
+        keep.fill_(-7)
+        torch.cuda.synchronize()
+        assert lib.rnms_bev(vp(sb), n, thr, vp(keep), ctypes.c_void_p(box.data_ptr()), vp(ws), None) == 0
+        seen = []
+        for _spin in range(20_000_000):
+            v = int(words[0])
+            if v != pending:
+                if not seen or seen[-1] != v:
+                    seen.append(v)
+                if len(seen) > 1 or _spin > 0 and torch.cuda.current_stream().query():
+                    break
+        torch.cuda.synchronize()
+        v = int(words[0])
+        if not seen or seen[-1] != v:
+            seen.append(v)
+        assert seen == [want_k], (seen, want_k)
+        assert torch.equal(keep[:want_k], want)
+    # and the module surface (both glues poll a mailbox of their own) returns the same list
+    got = amd.nms_gpu(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), thr)
+    assert np.array_equal(got.cpu().numpy(), order[want.cpu().numpy()])
+
+
 def test_classic_scan_bit_exact_with_the_list_scan_switched_off(amd):
     """The classic scan (mask rows, two-level above 8448 boxes) is the list scan's fallback and the path above 16384 boxes: with
     RNMS_LIST_MIN_THR=2 (read once per process: a child process) every call takes it; same keep lists as the CPU oracle."""

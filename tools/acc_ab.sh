@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run ON THE GPU BOX: A/B of the loss sum's second stage on one box, processes alternated —
+# Run ON THE GPU BOX, with profiles/r06_acc_experiment.patch APPLIED (the experiment was removed from the product; record:
+# profiles/r06_acc_ab.txt): A/B of the loss sum's second stage on one box, processes alternated —
 #   all    GD3D_ACC=all   (round 6): exact integer accumulation in the fused kernel (512 shards) + reduce_slots_kernel
 #   small  GD3D_ACC=small (round 5): per-tile partial stores + the 1024-thread reduce_partials_kernel
 #   sNNN   the accumulator form built with NNN shards (tools/build_variants.py sNNN="-DGD_ACC_SHARDS=NNN")
