@@ -213,8 +213,41 @@ SYMBOLS = {
 }
 
 
+# the frozen extras' entry points (include/gd3d_extras.h) live in libgd3d_extras.so since round 6: out of the §8 library
+EXTRA_SYMBOLS = {name: SYMBOLS.pop(name) for name in (
+    'center_infer_max_k',
+    'center_infer_rows_per_task',
+    'center_infer_workspace_bytes',
+    'center_infer_candidates',
+    'center_infer_debug_clocks',
+    'center_infer_debug_clock_probe',
+    'center_infer_select_workspace_bytes',
+    'center_infer_select',
+    'center_infer_bboxes',
+    'center_targets_max_boxes',
+    'center_targets_workspace_bytes',
+    'center_targets_build',
+    'gd3d_heat_focal_workspace_bytes',
+    'gd3d_heat_focal_loss',
+    'gd3d_heat_focal_scale',
+    'anchor_infer_workspace_bytes',
+    'anchor_infer_candidates',
+    'anchor_infer_bboxes',
+    'anchor_targets_max_gt',
+    'anchor_targets_workspace_bytes',
+    'anchor_targets_build',
+    'gd3d_anchor_cls_dir_workspace_bytes',
+    'gd3d_anchor_cls_dir_loss',
+    'gd3d_anchor_cls_dir_loss_dyn',
+)}
+
+
 def lib_path():
     return _build.LIB_PATH
+
+
+def extras_path():
+    return _build.EXTRAS_PATH
 
 
 ABI_VERSION = 6
@@ -266,6 +299,25 @@ def _bind(path):
     return L
 
 
+_extras = None
+
+
+def load_extras():
+    """libgd3d_extras.so — the frozen round-3 extras outside SURVEY.md §8 (include/gd3d_extras.h, DESIGN_EXTRAS.md): loaded on
+    first use by mmdet3d_gaussian_amd.extras' modules only.  It resolves the NMS entry points it calls from the libgd3d.so next
+    to it; `load()` runs first so that a stale pair is rebuilt together."""
+    global _extras
+    if _extras is None:
+        load()
+        L = ctypes.CDLL(_build.EXTRAS_PATH)
+        for name, (res, args) in EXTRA_SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _extras = L
+    return _extras
+
+
 def load():
     """Load libgd3d.so, building it first when the in-tree binary is missing or does not match its sources (content hash).
     A binary that does not match is NEVER loaded: it is rebuilt, or — on a machine without hipcc — refused (a library built
@@ -313,7 +365,8 @@ class NodeBuildFailed(RuntimeError):
 def _load_cpp_node():
     """_gd3d_node.so, bound to the loaded libgd3d.so.  Raises when it is missing or stale and cannot be rebuilt; never loads a
     binary whose hash (sources + flags + torch version) differs: it would have been compiled against another libtorch."""
-    if _build.node_is_stale():
+    node_path = os.environ.get('GD3D_NODE_LIB')   # an instrumented build of the node (tools/sanitize.sh), as GD3D_LIB is for the library
+    if not node_path and _build.node_is_stale():
         if _build.host_cxx_path() is None:
             what = 'does not match its sources / this torch' if os.path.isfile(_build.NODE_PATH) else 'is missing'
             raise RuntimeError(f'_gd3d_node.so {what} and the ROCm clang++ is not available to build it')
@@ -340,7 +393,7 @@ def _load_cpp_node():
             raise NodeBuildFailed(str(e)) from e
     import importlib.util
     import torch  # noqa: F401  (libtorch must be loaded before the node is)
-    spec = importlib.util.spec_from_file_location('_gd3d_node', _build.NODE_PATH)
+    spec = importlib.util.spec_from_file_location('_gd3d_node', node_path or _build.NODE_PATH)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     ver = mod.bind(os.environ.get('GD3D_LIB') or _build.LIB_PATH)

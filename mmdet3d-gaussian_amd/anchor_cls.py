@@ -46,7 +46,7 @@ def _i64c(x):
 class _ClsDir(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, targets, cls_score, dir_cls_preds):
-        lib = _lib.load()
+        lib = _lib.load_extras()
         gamma, alpha, cls_scale, dir_scale, C, avg_dev = cfg
         labels, label_weights, dir_targets, dir_weights = targets
         B, AC, H, W = cls_score.shape

@@ -37,7 +37,7 @@ def anchor_head_get_bboxes(cls_scores, bbox_preds, dir_cls_preds, mlvl_anchors, 
         raise RuntimeError('anchor_head_get_bboxes: 1..4 levels, one entry per level in every list')
     if not cls_scores[0].is_cuda:
         raise RuntimeError('anchor_head_get_bboxes: the MI355X implementation has no CPU path')
-    lib = _lib.load()
+    lib = _lib.load_extras()
     dev = cls_scores[0].device
     C = int(num_classes)
     B = cls_scores[0].shape[0]

@@ -77,7 +77,7 @@ def anchor_head_get_targets(anchors, gt_bboxes, gt_labels, assigner, num_classes
         raise RuntimeError('anchor_head_get_targets: at most 16 anchor sizes and 64 samples')
     if any(c[3:] != cfgs[0][3:] for c in cfgs):
         raise RuntimeError('anchor_head_get_targets: match_low_quality / gt_max_assign_all must agree across the assigners')
-    lib = _lib.load()
+    lib = _lib.load_extras()
     dev = anchors.device
     rows = [(b.tensor if (hasattr(b, 'tensor') and not isinstance(b, torch.Tensor)) else b) for b in gt_bboxes]
     sizes = [int(r.shape[0]) for r in rows]

@@ -21,13 +21,18 @@ ARCH = 'gfx950'
 #    (the losses are graded at 1e-5; the kernel must stay HBM-bound, not VALU-bound);
 #  * rbox.hip: correctly-rounded IEEE division/sqrt and NO fma contraction, because the NMS keep
 #    indices must be bit-identical to a CPU evaluation of the same fp32 operation sequence.
-SOURCES = {
+SOURCES = {   # the SURVEY.md §8 surface: libgd3d.so (include/gd3d.h)
     'gd3d_loss.hip': ['-fno-hip-fp32-correctly-rounded-divide-sqrt', '-ffp-contract=fast'],
     'rbox.hip': ['-ffp-contract=off'],
     'voxel_scatter.hip': [],
     'voxel_index.hip': [],                     # rocPRIM radix sort + scan between hand-written kernels
     'eval_match.hip': ['-ffp-contract=off'],
     'coders.hip': ['-ffp-contract=off'],      # same rounding sequence as the torch elementwise ops it replaces
+}
+# The frozen round-3 extras OUTSIDE §8 (DESIGN_EXTRAS.md; include/gd3d_extras.h): a library of their own since round 6,
+# libgd3d_extras.so, linked against libgd3d.so (the inference slices call its rnms_* entry points) and loaded only by
+# mmdet3d_gaussian_amd.extras' modules (_lib.load_extras()).  What ships as libgd3d.so is the §8 translation units only.
+EXTRA_SOURCES = {
     'center_infer.hip': ['-ffp-contract=off'],    # decode as coders.hip; the NMS boxes feed bit-exact keep decisions
     'anchor_targets.hip': ['-ffp-contract=off'],   # IoU and thresholds decide as the torch elementwise ops do
     'anchor_cls.hip': [],                       # elementwise focal + direction loss with gradient, graded at 1e-5
@@ -35,6 +40,7 @@ SOURCES = {
     'anchor_infer.hip': ['-ffp-contract=off'],    # delta decode in the reference's operation order; boxes feed the NMS
     'center_targets.hip': ['-ffp-contract=off'],  # gaussian_radius in the reference's fp32 operation order
 }
+EXTRAS_PATH = os.path.join(PKG_DIR, 'libgd3d_extras.so')
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 # host translation units (the `_cpu` twins of include/gd3d.h): compiled by the ROCm toolchain's own clang++ as plain C++
@@ -89,14 +95,15 @@ def source_hash():
 
 
 def is_stale():
-    if not os.path.isfile(LIB_PATH) or not os.path.isfile(HASH_PATH):
+    if not os.path.isfile(LIB_PATH) or not os.path.isfile(EXTRAS_PATH) or not os.path.isfile(HASH_PATH):
         return True
     with open(HASH_PATH) as f:
         return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link libgd3d.so.  Returns the path."""
+    """Compile every HIP translation unit for gfx950 and link libgd3d.so (the §8 surface) and libgd3d_extras.so (the frozen
+    extras, linked against it).  Returns libgd3d.so's path."""
     if not force and not is_stale():
         return LIB_PATH
     hipcc = hipcc_path()
@@ -105,7 +112,7 @@ def build(force=False, verbose=False):
     objdir = os.path.join(PKG_DIR, 'build', str(os.getpid()))  # per process: ranks may build concurrently
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for src, flags in SOURCES.items():
+    for src, flags in list(SOURCES.items()) + list(EXTRA_SOURCES.items()):
         path = os.path.join(CSRC, src)
         if not os.path.isfile(path):
             continue
@@ -130,13 +137,23 @@ def build(force=False, verbose=False):
     # the translation units are independent: one hipcc per core, at most 8 (each takes 5-25 s and ~1 GB)
     workers = max(1, min(8, os.cpu_count() or 1, len(jobs)))
     with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-        objs = list(pool.map(compile_one, jobs))
+        objs = dict(zip((j[0] for j in jobs), pool.map(compile_one, jobs)))
+    main_objs = [objs[s_] for s_ in list(SOURCES) + list(HOST_SOURCES) if s_ in objs]
+    extra_objs = [objs[s_] for s_ in EXTRA_SOURCES if s_ in objs]
     tmp = f'{LIB_PATH}.{os.getpid()}.tmp'
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', tmp] + objs
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', tmp] + main_objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
     os.replace(tmp, LIB_PATH)  # atomic
+    # the extras: their own image, resolving rnms_* from libgd3d.so next to it ($ORIGIN: the pair travels together)
+    tmp = f'{EXTRAS_PATH}.{os.getpid()}.tmp'
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-pthread', '-o', tmp] + extra_objs + \
+          ['-L' + PKG_DIR, '-l:libgd3d.so', '-Wl,-rpath,$ORIGIN']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link of libgd3d_extras.so failed:\n{r.stderr[-4000:]}')
+    os.replace(tmp, EXTRAS_PATH)
     with open(HASH_PATH + f'.{os.getpid()}', 'w') as f:
         f.write(source_hash())
     os.replace(HASH_PATH + f'.{os.getpid()}', HASH_PATH)

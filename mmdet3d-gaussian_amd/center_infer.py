@@ -45,7 +45,7 @@ def select_best(scores, preds, topk):
     the K best cells over all classes by descending score (equal scores: ascending class, y, x), one launch."""
     if not scores.is_cuda:
         raise RuntimeError('select_best: the MI355X implementation has no CPU path')
-    lib = _lib.load()
+    lib = _lib.load_extras()
     B, C, H, W = scores.shape
     N = preds.shape[1]
     if preds.shape[0] != B or tuple(preds.shape[2:]) != (H, W):
@@ -120,7 +120,7 @@ def center_head_get_bboxes(preds_dicts, bbox_coder, test_cfg, num_classes, img_m
         raise RuntimeError('center_head_get_bboxes: the MI355X implementation has no CPU path')
     if len(num_classes) != len(tasks):
         raise RuntimeError(f'{len(tasks)} tasks but {len(num_classes)} class counts')
-    lib = _lib.load()
+    lib = _lib.load_extras()
     dev = heat0.device
     B, _, H, W = heat0.shape
     kind, names = _coder_kind(bbox_coder, first)

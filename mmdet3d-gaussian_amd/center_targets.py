@@ -37,7 +37,7 @@ def center_head_get_targets(gt_bboxes_3d, gt_labels_3d, class_names, train_cfg, 
     rows = [b.tensor if o else b for b, o in zip(gt_bboxes_3d, objs)]
     if not rows[0].is_cuda:
         raise RuntimeError('center_head_get_targets: the MI355X implementation has no CPU path')
-    lib = _lib.load()
+    lib = _lib.load_extras()
     dev = rows[0].device
     cols = rows[0].shape[1]
     sizes = [int(r.shape[0]) for r in rows]

@@ -38,7 +38,7 @@ class _HeatFocal(torch.autograd.Function):
     @staticmethod
     def _launch(cfg, xs, targets, need):
         """One gd3d_heat_focal_loss launch set -> (per-task gradient maps | None, out (3, T): losses, factors, num_pos)."""
-        lib = _lib.load()
+        lib = _lib.load_extras()
         alpha, gamma, weight = cfg
         T = len(xs)
         dev = xs[0].device
@@ -70,7 +70,7 @@ class _HeatFocal(torch.autograd.Function):
     @staticmethod
     @guard_double_backward
     def backward(ctx, grad_losses, _grad_num_pos):
-        lib = _lib.load()
+        lib = _lib.load_extras()
         cfg, grads, out, need, dtypes, shapes = ctx.state
         saved = ctx.saved_tensors
         T = len(saved) // 2

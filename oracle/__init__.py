@@ -48,8 +48,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_LIB_PATH)
+        override = os.environ.get('GD3D_ORACLE_LIB')   # an instrumented build of the same sources (tools/sanitize.sh)
+        if not override:
+            build()
+        L = ctypes.CDLL(override or _LIB_PATH)
         i64, f32, vp = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
         for sfx, real in (('_f32', ctypes.c_float), ('_f64', ctypes.c_double)):
             fn = getattr(L, 'gd_oracle_loss' + sfx)

@@ -1,7 +1,11 @@
 """pytest configuration: `gpu` marker + repo root on sys.path.
 
 `-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI symbol check, gloo world_size-2.
-`-m gpu`      : parity tests proper — HIP path through the C ABI vs the oracle / golden vectors.
+`-m gpu`      : parity tests proper — HIP path through the C ABI vs the oracle / golden vectors: the SURVEY.md §8 surface
+                (libgd3d.so).
+`-m extras`   : the frozen round-3 extras OUTSIDE §8 (libgd3d_extras.so, DESIGN_EXTRAS.md): need a GPU too, but are NOT part of
+                `-m gpu` (round 6: the default GPU run is the §8 surface; these are kept green once per round).  Without a GPU
+                they are skipped, so `-m "not gpu"` stays CPU-only.
 """
 import os
 import sys
@@ -15,6 +19,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'extras: frozen extras outside SURVEY.md §8 (need a GPU; run with -m extras; not in -m gpu)')
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='extras need an MI355X (pytest -m extras on a GPU box)')
+    for item in items:
+        if 'extras' in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope='session')

@@ -177,3 +177,83 @@ def test_prewarm_with_collectives_leaves_every_rank_with_the_same_step_count():
     assert r.returncode == 0, r.stderr[-3000:]
     got = _result_lines(r.stdout)
     assert len(got) == 1 and got[0]['n_gpus'] == 3 and got[0]['config']['prewarm_s'] >= 0.3
+
+
+# ---- the REAL world size: eight ranks, as the driver's SCALE run starts them -------------------------------------
+
+def _bench_children(marker):
+    """Live processes whose command line carries `marker` (a --pairs value no other test uses)."""
+    import psutil
+    out = []
+    for p in psutil.process_iter(['pid', 'cmdline', 'status']):
+        try:
+            if p.info['status'] != psutil.STATUS_ZOMBIE and marker in ' '.join(p.info['cmdline'] or []):
+                out.append(p.info['pid'])
+        except (psutil.NoSuchProcess, psutil.AccessDenied):
+            pass
+    return out
+
+
+FAST = ['--backend', 'gloo', '--device', 'cpu', '--steps', '2', '--warmup', '1', '--prewarm', '0', '--cpu-sample', '0', '--plain-steps', '1']
+
+
+def test_eight_ranks_strong_scaling_at_the_benchmark_size_under_the_drivers_launcher():
+    """`--strong` at the headline size: 10 M pairs over 8 ranks = 1 250 000 rows each, through
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ...` (the form the driver uses for its
+    SCALE run; reference counterpart tools/dist_train.sh:8-9).  The line must prove all eight ranks from what the collective
+    returned, the row ranges must tile [0, 10 M) and `value` must count the TOTAL once."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+           '--master-port', str(_port()), BENCH, '--gpus', '8', '--pairs', '10000000', '--strong'] + FAST
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _result_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    c = d['config']
+    assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and c['pairs_per_gpu'] == 1_250_000
+    assert c['ranks_seen'] == list(range(8)) and np.array(c['per_rank_loss']).shape == (8, 3)
+    rows = c['per_rank_rows']
+    assert rows[0][0] == 0 and rows[-1][1] == 10_000_000 and all(rows[k][1] == rows[k + 1][0] for k in range(7))
+    assert sum(b - a for a, b in rows) == 10_000_000 and all(b - a == 1_250_000 for a, b in rows)
+    assert abs(d['value'] - 3 * 10_000_000 * 2 / (d['ms_per_step'] * 2e-3) / 1e6) <= 0.02 * d['value']
+    assert 'gloo' in c['collective']
+
+
+def test_eight_ranks_self_launch_weak_and_a_total_that_does_not_divide():
+    """`python bench.py --gpus 8` with no launcher around it starts its eight ranks itself (children, never a re-exec): weak
+    scaling keeps --pairs per rank; a strong total of 100 003 pairs splits into the contiguous ranges [r N / 8, (r + 1) N / 8)."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--pairs', '6007'] + FAST, capture_output=True, text=True, timeout=600,
+                       env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _result_lines(r.stdout)
+    assert len(lines) == 1 and r.stdout.count('\n') == 1
+    d = lines[0]
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['config']['ranks_seen'] == list(range(8))
+    assert d['config']['per_rank_rows'] == [[6007 * k, 6007 * (k + 1)] for k in range(8)]
+    assert abs(d['value'] - 3 * 6007 * 8 * 2 / (d['ms_per_step'] * 2e-3) / 1e6) <= 0.02 * d['value']
+    want = _expected_losses(8, lambda rank: 6007)
+    got = np.array([d['loss_values'][k] for k in ('gwd3d', 'kld3d', 'bd3d')])
+    assert np.all(np.abs(got - want) <= 1e-5 * (1 + np.abs(want))), (got, want)
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--pairs', '100003', '--strong'] + FAST, capture_output=True, text=True,
+                       timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _result_lines(r.stdout)[0]
+    rows = d['config']['per_rank_rows']
+    assert rows == [[100003 * k // 8, 100003 * (k + 1) // 8] for k in range(8)] and sum(b - a for a, b in rows) == 100003
+    assert d['config']['ranks_seen'] == list(range(8))
+
+
+def test_eight_ranks_one_dies_nonzero_exit_and_every_child_reaped():
+    """Rank 5 of 8 dies after its warm-up steps: the job exits non-zero, prints no result line, and leaves no rank process behind
+    (seven ranks sit in a collective their peer will never join: the launcher must end them)."""
+    marker = '7919'
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--pairs', marker] + FAST, capture_output=True, text=True, timeout=600,
+                       env=_env(GD3D_BENCH_FAIL_RANK='5'), cwd=ROOT)
+    assert r.returncode != 0 and _result_lines(r.stdout) == []
+    import time
+    for _ in range(50):
+        left = _bench_children('--pairs ' + marker)
+        if not left:
+            break
+        time.sleep(0.2)
+    assert left == [], left

@@ -11,7 +11,7 @@ import torch
 import mmdet3d_gaussian_amd as amd
 from oracle import anchor_infer_torch as ait
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 
 
 def distinct_logits(shape, g, lo=0.001, hi=0.6):

@@ -6,7 +6,7 @@ import torch
 
 import mmdet3d_gaussian_amd as amd
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 
 
 def test_train_a_toy_center_head_then_detect():

@@ -12,7 +12,7 @@ import torch
 import mmdet3d_gaussian_amd as amd
 from oracle import center_infer_torch as cit
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'center_infer.npz')
 NUS = dict(pc_range=[-51.2, -51.2], out_size_factor=4, voxel_size=[0.2, 0.2], norm_bbox=True)
 

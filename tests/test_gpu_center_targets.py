@@ -9,7 +9,7 @@ import torch
 import mmdet3d_gaussian_amd as amd
 from oracle import center_targets_torch as ct
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 NUS = dict(grid_size=[512, 512, 1], point_cloud_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], voxel_size=[0.2, 0.2, 8],
            out_size_factor=4, gaussian_overlap=0.1, min_radius=2)
 TASKS = [['car'], ['truck', 'construction_vehicle'], ['bus', 'trailer'], ['barrier'], ['motorcycle', 'bicycle'],

@@ -8,7 +8,7 @@ import torch
 import mmdet3d_gaussian_amd as amd
 from oracle import heat_focal_torch as hf
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 
 
 def targets_like(g, shape, peaks):

@@ -8,7 +8,7 @@ import math
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.extras   # frozen extras outside SURVEY.md §8: `pytest -m extras` on a GPU box (conftest.py), not part of `-m gpu`
 
 pkg = importlib.import_module('mmdet3d-gaussian_amd')
 from oracle import pvrcnn_torch as ORA  # noqa: E402

@@ -14,20 +14,29 @@ from mmdet3d_gaussian_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    # gd3d.h: the hot path's boundary; gd3d_extras.h: the frozen extras (DESIGN_EXTRAS.md).  One library exports both.
-    txt = open(os.path.join(ROOT, 'include', 'gd3d.h')).read() + open(os.path.join(ROOT, 'include', 'gd3d_extras.h')).read()
+def _header_functions(header):
+    txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(?:int|size_t|int64_t|int32_t)\s+((?:gd3d|rnms|riou|vox|eval|coder|center_infer|center_targets|anchor_infer|anchor_targets)_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
-    names = _header_functions()
+    """gd3d.h is the hot path's boundary and libgd3d.so exports exactly it; gd3d_extras.h is the frozen extras'
+    (DESIGN_EXTRAS.md), exported by libgd3d_extras.so (round 6: two libraries; the extras are out of the §8 image)."""
+    names = _header_functions('gd3d.h')
     assert len(names) >= 10, names
     lib = ctypes.CDLL(amd.lib_path())           # built by __graft_entry__.build() / first import
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/gd3d.h but not exported by libgd3d.so'
     assert sorted(_lib.SYMBOLS) == names, 'ctypes table and header disagree'
+    extra = _header_functions('gd3d_extras.h')
+    assert len(extra) >= 10 and not set(extra) & set(names)
+    xlib = ctypes.CDLL(_lib.extras_path())
+    for n in extra:
+        assert hasattr(xlib, n), f'{n} declared in include/gd3d_extras.h but not exported by libgd3d_extras.so'
+        assert not hasattr(lib, n), f'{n} is an extra: it must not be part of libgd3d.so'
+    assert sorted(_lib.EXTRA_SYMBOLS) == extra, 'ctypes table and gd3d_extras.h disagree'
+    assert _lib.load_extras() is not None      # binds: every EXTRA_SYMBOLS entry resolves, the §8 library next to it is found
 
 
 def test_abi_version_and_queries_without_gpu():
@@ -195,7 +204,7 @@ def test_center_infer_struct_layouts_match_the_header():
 
 
 def test_center_infer_queries_and_argument_checks_without_gpu():
-    lib = amd.load_library()
+    lib = _lib.load_extras()   # the frozen extras: libgd3d_extras.so
     assert lib.center_infer_max_k() == 4096
     task = _lib.CenterInferTask()
     task.heatmap = 4096          # never dereferenced: the checks below fail (or only size things) before any launch
@@ -242,7 +251,7 @@ def test_center_targets_struct_layout_and_argument_checks():
     D = _lib.CenterTargetsDesc
     assert got == [ctypes.sizeof(D), D.classes.offset, D.sample_start.offset, D.pc_range.offset, D.out_size_factor.offset,
                    D.gaussian_overlap.offset], got
-    lib = amd.load_library()
+    lib = _lib.load_extras()   # the frozen extras: libgd3d_extras.so
     assert lib.center_targets_max_boxes() == 8192 and lib.center_targets_workspace_bytes(100) % 256 == 0
     d = D()
     d.num_tasks, d.batch, d.height, d.width, d.total, d.box_cols = 1, 1, 8, 8, 9000, 9
@@ -285,7 +294,7 @@ def test_anchor_targets_struct_layout_and_argument_checks():
         got = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     D = _lib.AnchorTargetsDesc
     assert got == [ctypes.sizeof(D), D.num_dir_bins.offset, D.gt_start.offset, D.pos_iou_thr.offset, D.min_pos_iou.offset, D.dir_offset.offset], got
-    lib = amd.load_library()
+    lib = _lib.load_extras()   # the frozen extras: libgd3d_extras.so
     assert lib.anchor_targets_max_gt() == 1024 and lib.anchor_targets_workspace_bytes(3, 100) % 256 == 0
     d = D()
     d.batch, d.cells, d.num_sizes, d.num_rots, d.num_classes, d.num_assigners, d.num_dir_bins = 1, 16, 3, 2, 3, 2, 2
