@@ -295,7 +295,11 @@ class _GDPerPair(torch.autograd.Function):
 @LOSSES.register_module()
 class GDLoss(nn.Module):
     """Gaussian-distance box regression loss (GWD / KLD / BCD / JD / sym-KLD / KFIoU), reference
-    signature (gaussian_distance_loss.py:261-264, :280-286)."""
+    signature (gaussian_distance_loss.py:261-264, :280-286).
+
+    Precision: inputs are EVALUATED IN FP32 regardless of their dtype (cast in, result cast back to pred's dtype); the
+    reference follows the input dtype (gaussian_distance_loss.py:8-21), so an fp64 caller of it gets fp64 arithmetic and here
+    an fp64 label with fp32 accuracy.  The heads call the loss under @force_fp32."""
 
     BAG_GD_LOSS = tuple(LOSS_TYPES)
 

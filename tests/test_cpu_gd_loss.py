@@ -285,3 +285,32 @@ def test_module_survives_deepcopy_pickle_and_torch_save(tmp_path):
     torch.save(holder, path)
     assert torch.equal(torch.load(path, weights_only=False).loss(p, t), a)
     assert len(m.state_dict()) == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float16, torch.bfloat16])
+def test_non_fp32_inputs_are_evaluated_in_fp32_and_cast_back(dtype):
+    """INTEGRATION.md §5 / the GDLoss docstring: the reference follows the dtype of its inputs
+    (gaussian_distance_loss.py:8-21); this package evaluates in fp32 whatever the dtype and casts the result back.  Pinned: an
+    fp64 (fp16, bf16) call returns EXACTLY the fp32 call's value and gradients on the fp32 image of its inputs, carrying the
+    input's dtype — i.e. an fp64 label with fp32 accuracy, which is stated, not hidden."""
+    g = torch.Generator().manual_seed(5)
+    t32 = torch.rand(300, 7, generator=g) * torch.tensor([70, 80, 4, 2, 4, 1.5, 6.28]) + torch.tensor([0, -40, -3, .5, .5, .5, -3.14])
+    p32 = t32 + 0.1 * torch.randn(300, 7, generator=g)
+    w32 = torch.rand(300, generator=g)
+    for lt in ('gwd3d', 'kld3d', 'bd3d'):
+        mod = amd.GDLoss(lt, loss_weight=5.0)
+        p = p32.to(dtype).requires_grad_(True)
+        out = mod(p, t32.to(dtype), w32.to(dtype), avg_factor=77.0)
+        out.backward()
+        assert out.dtype == dtype and p.grad.dtype == dtype
+        q = p32.to(dtype).float().requires_grad_(True)             # the fp32 image of the same inputs
+        ref = mod(q, t32.to(dtype).float(), w32.to(dtype).float(), avg_factor=77.0)
+        ref.backward()
+        assert torch.equal(out, ref.to(dtype)) and torch.equal(p.grad, q.grad.to(dtype))
+        per = mod(p32.to(dtype), t32.to(dtype), reduction_override='none')
+        assert per.dtype == dtype and torch.equal(per, mod(p32.to(dtype).float(), t32.to(dtype).float(), reduction_override='none').to(dtype))
+    if dtype == torch.float64:   # and what that means: the fp64-labelled value is fp32-accurate against the fp64 oracle, not fp64-accurate
+        mod = amd.GDLoss('kld3d', reduction='sum')
+        got = mod(p32.double(), t32.double()).item()
+        want = oracle.gd_loss(p32.numpy(), t32.numpy(), oracle.make_params('kld3d', fun='log1p', tau=1.0), scale=1.0)['loss_sum']
+        assert 1e-12 < abs(got - want) <= 1e-5 * (1 + abs(want))
