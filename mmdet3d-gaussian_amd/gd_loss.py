@@ -193,6 +193,54 @@ def unit_grad(device):
     return t
 
 
+# `loss.backward()` without an explicit gradient makes torch FILL a ones tensor (one launch) that each GDLoss node then has to
+# read on the device to learn that nothing needs scaling (one early-exit launch per node): four tiny dispatches at a 4.1 us
+# floor each per three-loss step (profiles/r06_acc_ab.txt), 3 % of the 10 M-pair step.  The reduced forms therefore return their
+# scalar as a LossValue — a torch.Tensor subclass that changes ONE thing: `.backward()` with no gradient on a 0-dim fp32 value
+# passes the library's unit constant (`unit_grad`) as the root gradient instead of letting torch fill a fresh one.  Sums and
+# products of LossValues with anything are LossValues (torch's subclass propagation), so `(l0 + l1 + l2).backward()`, mmdet's
+# `_parse_losses` sum and an AMP `(loss * scale).backward()` all start from the constant; an `Add` node hands the same tensor on
+# and the nodes recognise it by address (no launch), a `Mul` node hands on a new tensor and the nodes scale on the device as
+# before.  Values and gradients are bit-identical to the plain path (a finish launch at g == 1 touches nothing).
+# `torch.autograd.backward(loss)`, `torch.autograd.grad`, an explicit `gradient=` and non-fp32 values take torch's own path.
+# GD3D_UNIT_ROOT=0 switches the subclass off (the reduced forms then return plain tensors, as through round 5).
+_UNIT_ROOT = os.environ.get('GD3D_UNIT_ROOT', '1') != '0'
+_TENSOR_BACKWARD = torch.Tensor.backward
+
+
+class LossValue(torch.Tensor):
+    """A loss scalar of this package: a plain tensor in every respect but `.backward()` (see the note above)."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func is _TENSOR_BACKWARD and _UNIT_ROOT:
+            kw = dict(kwargs) if kwargs else {}
+            self = args[0]
+            gradient = kw.pop('gradient', args[1] if len(args) > 1 else None)
+            if (gradient is None and self.dim() == 0 and self.dtype == torch.float32 and self.requires_grad and
+                    (self.is_cuda or self.device.type == 'cpu')):
+                names = ('retain_graph', 'create_graph', 'inputs')
+                for k, v in zip(names, args[2:]):
+                    kw.setdefault(k, v)
+                with torch._C.DisableTorchFunctionSubclass():
+                    return torch.autograd.backward(self, unit_grad(self.device), kw.get('retain_graph'),
+                                                   kw.get('create_graph', False), inputs=kw.get('inputs'))
+        return super().__torch_function__(func, types, args, kwargs)
+
+
+    def __deepcopy__(self, memo):
+        # (torch's default deepcopy of a subclass instance runs new_empty() with subclass dispatch off and then rejects the result)
+        return self.as_subclass(torch.Tensor).__deepcopy__(memo).as_subclass(LossValue)
+
+
+def _as_loss_value(t):
+    """The freshly produced loss scalar as a LossValue — by class assignment (the object is ours alone; torch itself does this in
+    nn.parameter.UninitializedParameter.materialize): `as_subclass` would put an AliasBackward node behind every loss."""
+    if _UNIT_ROOT and type(t) is torch.Tensor:
+        t.__class__ = LossValue
+    return t
+
+
 def _is_unit_grad(g):
     t = _UNIT_GRAD.get(g.device.index if g.is_cuda else 'cpu')
     return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0 and g.dtype == torch.float32
@@ -408,6 +456,7 @@ class GDLoss(nn.Module):
                 out = out / post_div
             if n == 0 and reduction == 'mean' and avg_factor is None and not select:
                 out = out + float('nan')  # torch: mean of an empty tensor is nan
+            out = _as_loss_value(out)      # `.backward()` on it (or on sums of it) starts from the unit constant: see LossValue
         return out if out_dtype == torch.float32 else out.to(out_dtype)
 
     def extra_repr(self):

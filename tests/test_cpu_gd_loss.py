@@ -314,3 +314,52 @@ def test_non_fp32_inputs_are_evaluated_in_fp32_and_cast_back(dtype):
         got = mod(p32.double(), t32.double()).item()
         want = oracle.gd_loss(p32.numpy(), t32.numpy(), oracle.make_params('kld3d', fun='log1p', tau=1.0), scale=1.0)['loss_sum']
         assert 1e-12 < abs(got - want) <= 1e-5 * (1 + abs(want))
+
+
+def test_loss_value_backward_starts_from_the_unit_constant_and_changes_nothing_else():
+    """gd_loss.LossValue (round 6) on CPU tensors: the reduced forms return it, sums / products with anything stay LossValues,
+    `.backward()` without a gradient starts from the library's unit constant (seen by a hook on the summed loss), gradients are
+    bit-identical to torch's own path (flag off, functional form, explicit ones), scaled losses and explicit gradients scale,
+    other losses in the sum get their gradients, retain_graph replays, non-fp32 values take torch's path, 'none' stays plain."""
+    from mmdet3d_gaussian_amd import gd_loss as gdl
+    pred, tgt = _synthetic(900, seed=12)
+    mods = [amd.GDLoss(lt, loss_weight=5.0) for lt in ('gwd3d', 'kld3d', 'bd3d')]
+    unit_ptr = gdl.unit_grad('cpu').data_ptr()
+
+    def step(how, flag=True, extra=False):
+        gdl._UNIT_ROOT = flag
+        try:
+            ps = [pred.clone().requires_grad_(True) for _ in mods]
+            q = torch.linspace(-1, 1, 7).requires_grad_(True)
+            ls = [m(p, tgt) for m, p in zip(mods, ps)]
+            tot = sum(ls) + ((q ** 2).sum() if extra else 0.0)
+            seen = []
+            tot.register_hook(lambda g: seen.append(g.data_ptr()))
+            how(tot)
+            return [p.grad.clone() for p in ps], seen[0], q.grad, type(tot), type(ls[0])
+        finally:
+            gdl._UNIT_ROOT = True
+    base, root0, _, ty_tot0, ty_l0 = step(lambda x: x.backward(), flag=False)
+    assert ty_tot0 is torch.Tensor and ty_l0 is torch.Tensor and root0 != unit_ptr
+    got, root, _, ty_tot, ty_l = step(lambda x: x.backward())
+    assert ty_tot is gdl.LossValue and ty_l is gdl.LossValue and root == unit_ptr
+    assert all(torch.equal(a, b) for a, b in zip(got, base))
+    got, root, *_ = step(lambda x: torch.autograd.backward(x))
+    assert root != unit_ptr and all(torch.equal(a, b) for a, b in zip(got, base))
+    got, *_ = step(lambda x: (x * 3.0).backward())
+    assert all(torch.allclose(a, 3.0 * b, rtol=1e-6, atol=0) for a, b in zip(got, base))
+    got, *_ = step(lambda x: x.backward(torch.tensor(0.5)))
+    assert all(torch.equal(a, 0.5 * b) for a, b in zip(got, base))
+    got, root, qg, *_ = step(lambda x: x.backward(), extra=True)
+    assert root == unit_ptr and torch.equal(qg, 2 * torch.linspace(-1, 1, 7)) and all(torch.equal(a, b) for a, b in zip(got, base))
+    got, *_ = step(lambda x: (x.backward(retain_graph=True), x.backward()))
+    assert all(torch.equal(a, 2 * b) for a, b in zip(got, base))
+    assert gdl.unit_grad('cpu').item() == 1.0
+    p64 = pred.double().requires_grad_(True)
+    out = mods[1](p64, tgt.double())
+    out.backward()                                                     # fp64 value: torch's own ones_like path
+    assert out.dtype == torch.float64 and torch.equal(p64.grad, base[1].double())
+    assert type(mods[0](pred, tgt, reduction_override='none')) is torch.Tensor
+    import copy, pickle
+    v = mods[0](pred, tgt)
+    assert float(copy.deepcopy(v.detach())) == float(v) == float(pickle.loads(pickle.dumps(v.detach())))
