@@ -512,21 +512,6 @@ def main():
             view = arena[(k + 1) * n:(k + 2) * n]
             view.copy_(pred0)
             preds[lt] = view.detach().requires_grad_(True)
-    # the OTHER allocation form's arrays (third region, N = 1 on the GPU), made NOW: an allocation of 1.1 GB between two timed regions
-    # stalls the host for milliseconds, the GPU idles and drops its clocks, and the region that follows runs slow
-    alt = None
-    if on_gpu and world == 1 and not ('RANK' in os.environ and 'MASTER_PORT' in os.environ) and not args.graph:
-        if args.separate_inputs:
-            arena2 = torch.empty((len(LOSSES) + 1) * n, 7, dtype=torch.float32, device=dev)
-            arena2[:n].copy_(tgt)
-            alt_preds = {}
-            for k, lt in enumerate(LOSSES):
-                view = arena2[(k + 1) * n:(k + 2) * n]
-                view.copy_(pred0)
-                alt_preds[lt] = view.detach().requires_grad_(True)
-            alt = (arena2[:n], alt_preds)
-        else:
-            alt = (tgt.clone(), {lt: pred0.clone().requires_grad_(True) for lt in LOSSES})
     del pred0
     cur = {'tgt': tgt}   # the arrays the step reads (the third region swaps in the other allocation form's)
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
@@ -562,6 +547,26 @@ def main():
         # N > 1: the per-step payload is (4,): the three shard losses and THIS RANK'S ID — so that what the collective returns
         # names the ranks that took part (`config.ranks_seen` is read from the last step's gather, not from WORLD_SIZE)
         return torch.stack(outs + [rank_id]) if use_dist else outs
+
+    def make_alt():
+        """The OTHER allocation form's arrays (third region, N = 1 on the GPU).  Made before the clocks are ramped (an allocation of
+        1.1 GB between two timed regions stalls the host for milliseconds, the GPU idles, drops its clocks, and the region that
+        follows runs slow) but AFTER the headline form's own first steps: the bench's extra arrays must not sit between the
+        headline form's inputs and its gradient buffers in the allocator's sequence (measured: with them in between, every box
+        drew the slow placement for the one-allocation-per-array form, 135-140 us per fused kernel against 129-133)."""
+        if not (on_gpu and world == 1 and not use_dist and not args.graph):
+            return None
+        src_p, src_t = preds[LOSSES[0]].detach(), cur['tgt']
+        if args.separate_inputs:
+            arena2 = torch.empty((len(LOSSES) + 1) * n, 7, dtype=torch.float32, device=dev)
+            arena2[:n].copy_(src_t)
+            alt_preds = {}
+            for k, lt in enumerate(LOSSES):
+                view = arena2[(k + 1) * n:(k + 2) * n]
+                view.copy_(src_p)
+                alt_preds[lt] = view.detach().requires_grad_(True)
+            return arena2[:n], alt_preds
+        return src_t.clone(), {lt: src_p.clone().requires_grad_(True) for lt in LOSSES}
 
     graph = None
     graph_note = None
@@ -641,19 +646,21 @@ def main():
     # Both backward forms once, BEFORE the clocks are ramped: the first torch.autograd.backward(..., grad_tensors=...) of a process
     # spends ~0.14 s of host time in one-time work inside torch (measured, round 5); left to happen in the second region's warm-up
     # steps it idles the GPU, the clocks drop, and that region and the next run 10-20 % slow (0.46-0.49 ms per step instead of 0.41).
+    alt = None
     if graph is None:
+        for form in (not main_plain, main_plain):
+            for _ in range(2):
+                step(False, plain=form)
+        device_sync()
+        alt = make_alt()
         if alt is not None:   # one step on the other allocation form's arrays too: its gradient buffers exist before the clocks ramp
-            held0 = (cur['tgt'], dict(preds))
-            cur['tgt'] = alt[0]
+            held0 = (cur['tgt'], dict(preds))   # (AFTER the main form's first steps: the bench's extra arrays must not change what the
+            cur['tgt'] = alt[0]                 #  headline form's own allocations draw)
             preds.update(alt[1])
             step(False)
             device_sync()
             cur['tgt'] = held0[0]
             preds.update(held0[1])
-        for form in (not main_plain, main_plain):
-            for _ in range(2):
-                step(False, plain=form)
-        device_sync()
         if use_dist and not on_gpu:
             last['pending'].result()
     prewarm_blocks = []
@@ -934,6 +941,11 @@ def main():
                          # the whole timed step priced like the kernel (reduce launches and backward included)
                          'achieved_step': round(step_gbps, 1), 'frac_step': round(step_gbps / HBM_PEAK_GBPS, 4),
                          'frac_step_plain_backward': by_form['plain'][2], 'frac_step_unit_grad': by_form['unit'][2],
+                         # the same step on the two input allocation forms (main region / third region; see value_separate_inputs)
+                         'frac_step_separate_inputs': main_frac if args.separate_inputs else (
+                             round(BYTES_PER_PAIR * n * len(LOSSES) / (sep_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4) if sep_elapsed else None),
+                         'frac_step_one_allocation': (round(BYTES_PER_PAIR * n * len(LOSSES) / (sep_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
+                                                      if sep_elapsed else None) if args.separate_inputs else main_frac,
                          # the whole step priced on the bytes the kernels really move (84 B/pair: no per-pair loss store under 'mean')
                          'frac_step_moved_bytes': round(step_gbps / HBM_PEAK_GBPS * MOVED_BYTES_PER_PAIR / BYTES_PER_PAIR, 4),
                          'traffic': traffic,

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence for the round into gpurun_out/<round>/.
-#   tools/collect_profiles.sh r05
+#   tools/collect_profiles.sh r06
 # Hot path only; the frozen extras (DESIGN_EXTRAS.md) are not measured any more.
 # kernel-trace/stats and each PMC set are separate runs (gpurun refuses --pmc combined with trace domains,
 # and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
-R=${1:-r05}
+R=${1:-r06}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
@@ -14,6 +14,10 @@ SHORT="python3 bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-traffic --plain
 # the plain bench line first, on the fresh box: the defaults (100 steps / 20 warmup), then the driver's own N = 1 command
 python3 bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${R}_bench_driver_form.json 2> $OUT/bench_driver_form.err
+# rounds 4-5's headline form (the four input arrays are row ranges of one allocation), and the plain step without the LossValue
+# (GD3D_UNIT_ROOT=0: torch fills a ones tensor, every node launches its early-exit finish — the step of round 5)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --arena --cpu-sample 0 --no-traffic --no-standins > $OUT/${R}_bench_driver_form_arena.json 2>> $OUT/bench_driver_form.err
+GD3D_UNIT_ROOT=0 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-standins > $OUT/${R}_bench_driver_form_no_loss_value.json 2>> $OUT/bench_driver_form.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_kernel_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SHORT > $OUT/pmc_$c.log 2>&1
@@ -31,6 +35,8 @@ $RUN1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0
 $RUN1 --master-port 29512 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --graph --strong > $OUT/${R}_rccl_rehearsal_strong.json 2> $OUT/rehearsal_strong.err
 $RUN1 --master-port 29513 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-graph > $OUT/${R}_rccl_rehearsal_weak_eager.json 2> $OUT/rehearsal_weak_eager.err
 python3 tests/perf/nms_time.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_time.txt
+FORMS="single batched batched_c multi" tools/nms_batched_ab.sh product 2>&1 | grep -v amdgpu.ids > $OUT/${R}_nms_batched_kernels.txt
+[ -x tools/launch_floor ] && ./tools/launch_floor > $OUT/${R}_launch_floor.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_nms -- python3 tests/perf/nms_time.py > /dev/null 2>&1
 cp $OUT/kt_nms/*/*kernel_stats.csv $OUT/${R}_nms_kernel_stats.csv 2>/dev/null
 python3 tests/perf/small_p_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_small_p_latency.jsonl
