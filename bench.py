@@ -517,6 +517,8 @@ def main():
     mods = {lt: amd.build_loss(dict(type='GDLoss', loss_type=lt, fun='log1p', tau=1.0, alpha=1.0,
                                     reduction='mean', loss_weight=5.0)) for lt in LOSSES}
     events = {lt: [] for lt in LOSSES}
+    events_alt = {lt: [] for lt in LOSSES}   # fused-dispatch timers of the third region (the other allocation form)
+    ev_sink = {'d': events}
     last = {}
 
     unit = [gdl.unit_grad(dev)] * len(LOSSES)
@@ -535,7 +537,7 @@ def main():
             plain = main_plain
         losses_ = []
         for lt in LOSSES:
-            gdl.PROFILE_EVENTS = events[lt] if (record and on_gpu) else None
+            gdl.PROFILE_EVENTS = ev_sink['d'][lt] if (record and on_gpu) else None
             preds[lt].grad = None
             losses_.append(mods[lt](preds[lt], cur['tgt']))
         gdl.PROFILE_EVENTS = None
@@ -791,11 +793,14 @@ def main():
         for _ in range(5):
             step(False)
         sync_all()
+        ev_sink['d'] = events_alt      # every `--event-every`-th step of this region carries event pairs too
+        tick[0] = -1 if every > 0 else 0
         tp = time.perf_counter()
         for _ in range(plain_steps):
-            step(False)
+            step(sampled())
         device_sync()
         sep_elapsed = time.perf_counter() - tp
+        ev_sink['d'] = events
         for lt in LOSSES:     # back to the arrays of the main region (the copy probe and the parity check below run on them)
             preds[lt].grad = None
             preds[lt] = held[1][lt]
@@ -803,6 +808,11 @@ def main():
         step(False)
         device_sync()
 
+    kern_ms_alt = {}
+    for lt in LOSSES:
+        d = [tm.elapsed_ms() for tm in events_alt[lt]]
+        if d:
+            kern_ms_alt[lt] = sum(d) / len(d)
     first_row, _ = shard_rows(args.pairs, rank, world, args.strong)
     mine = torch.tensor([float(rank), float(first_row), float(n)] + [kern_ms[lt] for lt in LOSSES], dtype=torch.float64, device=dev)
     gc.enable()
@@ -946,6 +956,10 @@ def main():
                              round(BYTES_PER_PAIR * n * len(LOSSES) / (sep_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4) if sep_elapsed else None),
                          'frac_step_one_allocation': (round(BYTES_PER_PAIR * n * len(LOSSES) / (sep_elapsed / plain_steps) / 1e9 / HBM_PEAK_GBPS, 4)
                                                       if sep_elapsed else None) if args.separate_inputs else main_frac,
+                         # the dominant kernel on the other allocation form (event pairs of the third region), priced like `frac`
+                         'kernel_ms_other_allocation': {k: round(v, 4) for k, v in kern_ms_alt.items()} or None,
+                         ('frac_one_allocation' if args.separate_inputs else 'frac_separate_inputs'):
+                             (round(BYTES_PER_PAIR * n / (max(kern_ms_alt.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kern_ms_alt else None),
                          # the whole step priced on the bytes the kernels really move (84 B/pair: no per-pair loss store under 'mean')
                          'frac_step_moved_bytes': round(step_gbps / HBM_PEAK_GBPS * MOVED_BYTES_PER_PAIR / BYTES_PER_PAIR, 4),
                          'traffic': traffic,
