@@ -39,3 +39,18 @@ res = [M[i][j] - (row[i] + col[j] - g) for i in range(NB) for j in range(NB) if 
 print('additive-model residual: max |r|', round(max(abs(r) for r in res), 2), 'rms', round((sum(r * r for r in res) / len(res)) ** 0.5, 2))
 # single-stream reads: copy x -> z only (y = x)
 print('x alone (y = x):', [round(run(b, b, z), 1) for b in bufs])
+# does a SKEW between the two read streams help a slow pair?  thread i reads x[i] and y[i + S]: the same two buffers, the same
+# bytes per stream (n - S floats), another relation between the addresses read at the same time
+flat = [(M[i][j], i, j) for i in range(NB) for j in range(NB) if i != j]
+slow, fast = max(flat), min(flat)
+for name, (t0, i, j) in (('slow pair', slow), ('fast pair', fast)):
+    line = []
+    for S_mb in (0, 1, 7, 64, 128):
+        S = S_mb * (1 << 20) // 4
+        m = (N - S) & ~3
+        ts = []
+        for _ in range(5):
+            assert lib.gd3d_probe_stream(bufs[i].data_ptr(), bufs[j].data_ptr() + 4 * S, z.data_ptr(), m, stream, tm.start, tm.stop) == 0
+            torch.cuda.synchronize(); ts.append(tm.elapsed_ms() * 1e3)
+        line.append(f'S={S_mb:3d} MiB: {statistics.median(ts) * N / m:6.1f}')
+    print(f'{name} ({i},{j}) scaled to the full size, y skewed by S: ' + '  '.join(line))
