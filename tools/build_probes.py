@@ -2,6 +2,7 @@
 """Compile the stand-alone measurement programs under tools/ for gfx950 (plain hipcc, no torch):
    hbm_probe   measured HBM ceilings for the fused kernel's access mix
    hbm_probe2  the fused kernel's tile mechanics without its math, flat copies by shape, the occupancy cap
+   pair_variants  does the access mode change what a cross-class pair of read streams costs
    launch_floor  what a tiny dependent kernel costs behind a streaming kernel (the floor of the loss sum's second stage)
 The binaries are built in-tree (git-ignored; they travel to the GPU box with the snapshot)."""
 import os
@@ -13,6 +14,7 @@ PROBES = {
     'hbm_probe': ['-O3'],
     'hbm_probe2': ['-O3'],
     'launch_floor': ['-O3'],
+    'pair_variants': ['-O3'],
 }
 
 
