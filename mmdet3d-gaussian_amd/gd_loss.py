@@ -237,6 +237,13 @@ def _as_loss_value(t):
     """The freshly produced loss scalar as a LossValue — by class assignment (the object is ours alone; torch itself does this in
     nn.parameter.UninitializedParameter.materialize): `as_subclass` would put an AliasBackward node behind every loss."""
     if _UNIT_ROOT and type(t) is torch.Tensor:
+        if (t.device.index if t.is_cuda else 'cpu') not in _UNIT_GRAD:
+            # the constant is made HERE, eagerly, at the first reduced call on a device — never inside `.backward()`, which may run
+            # under a hipGraph capture (its allocation would then belong to that graph's private pool); a first call that is
+            # itself being captured returns a plain tensor (torch's own ones-fill is captured instead)
+            if t.is_cuda and _capturing():
+                return t
+            unit_grad(t.device)
         t.__class__ = LossValue
     return t
 
